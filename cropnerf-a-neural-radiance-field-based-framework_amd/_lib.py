@@ -1,0 +1,120 @@
+"""ctypes binding of libcropnerf_hip.so (declarations mirror include/cropnerf_hip.h one to one).
+
+The library is the product: there is no Python/CPU fallback.  If it is missing or a call fails, an exception is
+raised (``CropNerfHipError``) -- nothing silently degrades to PyTorch ops.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+CN_MAX_LEVELS = 16
+CN_MAX_LAYERS = 4
+
+SPACING_UNIFORM, SPACING_PIECEWISE = 0, 1
+APP_ZEROS, APP_MEAN, APP_PER_CAMERA = 0, 1, 2
+BG_LAST_SAMPLE, BG_COLOR = 0, 1
+
+CN_ERR_INVALID, CN_ERR_UNSUPPORTED, CN_ERR_LAUNCH, CN_ERR_WORKSPACE = -1, -2, -3, -4
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libcropnerf_hip.so"
+
+
+class CropNerfHipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libcropnerf_hip error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+class Grid(C.Structure):
+    _fields_ = [("table", C.c_void_p), ("num_levels", C.c_int32), ("log2_table_size", C.c_int32),
+                ("scalings", C.c_float * CN_MAX_LEVELS)]
+
+
+class Mlp(C.Structure):
+    _fields_ = [("num_layers", C.c_int32), ("dims", C.c_int32 * (CN_MAX_LAYERS + 1)),
+                ("weight", C.c_void_p * CN_MAX_LAYERS), ("bias", C.c_void_p * CN_MAX_LAYERS)]
+
+
+class FieldParams(C.Structure):
+    _fields_ = [("grid", Grid), ("base", Mlp), ("semantics", Mlp), ("sem_head_weight", C.c_void_p),
+                ("sem_head_bias", C.c_void_p), ("color", Mlp), ("appearance", C.c_void_p),
+                ("num_images", C.c_int32), ("app_dim", C.c_int32), ("geo_feat_dim", C.c_int32)]
+
+
+class DensityParams(C.Structure):
+    _fields_ = [("grid", Grid), ("mlp", Mlp)]
+
+
+class Scene(C.Structure):
+    _fields_ = [("aabb", C.c_float * 6), ("contraction", C.c_int32)]
+
+
+class RenderOpts(C.Structure):
+    _fields_ = [("num_samples", C.c_int32), ("spacing", C.c_int32), ("bg_mode", C.c_int32),
+                ("bg_color", C.c_float * 3), ("app_mode", C.c_int32), ("sh_unit_dir", C.c_int32),
+                ("eval_clamp", C.c_int32), ("density_only", C.c_int32)]
+
+
+_P = C.c_void_p
+_I32, _I64, _F = C.c_int32, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); the not-gpu test checks every symbol of the header is exported and listed here
+SIGNATURES = {
+    "cn_last_error": (C.c_char_p, []),
+    "cn_version": (C.c_int, []),
+    "cn_raygen_pinhole": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P]),
+    "cn_intersect_aabb": (C.c_int, [_P, _P, C.POINTER(_F), _I64, _P, _P, _P]),
+    "cn_raygen_ortho": (C.c_int, [_P, C.POINTER(_F), _I64, _I64, _P, _P, _P, _P, _P, _P]),
+    "cn_surface_grid": (C.c_int, [_F, _F, _I32, _F, _F, _I32, _F, _P, _P]),
+    "cn_apply_pose_adjustment": (C.c_int, [_P, _P, _I64, _P, _P, _P]),
+    "cn_sample_spaced": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _I32, _P, _P, _P, _P, _P]),
+    "cn_sample_pdf": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _F, _I32, _P, _I32, _P, _P, _P]),
+    "cn_proposal_density": (C.c_int, [C.POINTER(DensityParams), C.POINTER(Scene), _P, _P, _P, _P, _I64, _I32, _P, _P]),
+    "cn_field_eval": (C.c_int, [C.POINTER(FieldParams), C.POINTER(Scene), _I32, _I32, _P, _P, _P, _P, _P, _I64, _I32,
+                                _P, _P, _P, _P, _P]),
+    "cn_composite": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, C.POINTER(_F), _I32, _P, _P, _P, _P, _P, _P, _P]),
+    "cn_render_workspace_bytes": (C.c_size_t, [C.POINTER(FieldParams)]),
+    "cn_render_rays": (C.c_int, [C.POINTER(FieldParams), C.POINTER(Scene), C.POINTER(RenderOpts), _P, _P, _P, _P, _P,
+                                 _P, _I64, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cn_render_samples": (C.c_int, [C.POINTER(FieldParams), C.POINTER(Scene), C.POINTER(RenderOpts), _P, _P, _P, _P,
+                                    _P, _P, _I64, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cn_proposal_sample_workspace_bytes": (C.c_size_t, [_I64, C.POINTER(_I32), _I32, _I32]),
+    "cn_proposal_sample": (C.c_int, [C.POINTER(C.POINTER(DensityParams)), _I32, C.POINTER(Scene), _P, _P, _P, _P, _I64,
+                                     C.POINTER(_I32), _I32, _F, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cn_export_compact": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _I64, C.POINTER(_P), C.POINTER(_P), _P, _P]),
+    "cn_pointcloud_compact": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
+    "cn_embedding_mean": (C.c_int, [_P, _I32, _I32, _P, _P]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (built in-tree by build.py).  Raises if it is absent: no fallback path exists."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("CROPNERF_HIP_LIB", LIB_PATH))
+    if not path.exists():
+        raise FileNotFoundError(
+            f"{path} not found: build it with `python {(_HERE / 'build.py')}` (hipcc --offload-arch=gfx950). "
+            "The HIP library is required; there is no CPU or PyTorch fallback."
+        )
+    lib = C.CDLL(str(path))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load().cn_last_error()
+        raise CropNerfHipError(rc, msg.decode() if msg else "")

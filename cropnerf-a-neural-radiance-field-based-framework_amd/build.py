@@ -1,0 +1,73 @@
+"""Build libcropnerf_hip.so (gfx950) in-tree with hipcc.
+
+    python cropnerf-a-neural-radiance-field-based-framework_amd/build.py [--force]
+
+The shared library is written next to this file (``libcropnerf_hip.so``); it is git-ignored but travels with
+the tree.  hipcc cross-compiles for gfx950 without a GPU.
+"""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+OUT = HERE / "libcropnerf_hip.so"
+BUILD = HERE / "build"
+ARCH = "gfx950"
+
+SOURCES = ["api_common.cpp", "raygen.hip", "sampler.hip", "field_simple.hip", "composite.hip", "render_fused.hip",
+           "proposal.hip", "export.hip"]
+HEADERS = ["cn_common.hpp", "wave_ops.hpp", "sampler_dev.hpp", "composite_dev.hpp", "../../include/cropnerf_hip.h"]
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found (need ROCm >= 7.0 for gfx950)")
+    return exe
+
+
+def _stale(target: Path, deps) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(Path(d).stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    hipcc = _hipcc()
+    BUILD.mkdir(exist_ok=True)
+    headers = [CSRC / h for h in HEADERS]
+    flags = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-x", "hip", "-Wno-unused-result"]
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        s = CSRC / src
+        o = BUILD / (src.rsplit(".", 1)[0] + ".o")
+        objs.append(o)
+        if force or _stale(o, [s, *headers]):
+            jobs.append([hipcc, *flags, "-c", str(s), "-o", str(o)])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        p = subprocess.run(cmd, capture_output=True, text=True)
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{' '.join(cmd)}\n{p.stdout}\n{p.stderr}")
+
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(OUT, objs):
+        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(OUT), *map(str, objs)])
+    return OUT
+
+
+if __name__ == "__main__":
+    path = build(force="--force" in sys.argv, verbose=True)
+    print(path)

@@ -1,0 +1,321 @@
+// cn_field_eval / cn_proposal_density: the straightforward evaluation of FruitField / HashMLPDensityField,
+// one lane per sample, fp32 VALU, activations staged in LDS as [feature][lane] (conflict-free), weights read through
+// wave-uniform (scalar) loads.  Handles every layer shape the reference configs can produce
+// (fruit_nerf/fruit_nerf_config.py:29-172).  This is the general, obviously-correct path; the throughput path is
+// render_fused.hip, which is checked against both the CPU oracle and this kernel.
+//
+// Reference: fruit_nerf/fruit_field.py:169-302 (FruitField), fruit_nerf/fruit_nerf.py:118-142 (proposal nets).
+#include "cn_common.hpp"
+#include "wave_ops.hpp"
+
+namespace cn {
+
+constexpr int KMAX = 176;   // widest activation vector (16 + geo 30 + app 128 = 174)
+constexpr int GMAX = 32;    // 1 + geo_feat_dim
+
+struct MlpDev {
+  int num_layers;
+  int dims[CN_MAX_LAYERS + 1];
+  const float* w[CN_MAX_LAYERS];
+  const float* b[CN_MAX_LAYERS];
+};
+
+inline MlpDev make_mlp_dev(const cn_mlp& m) {
+  MlpDev d;
+  d.num_layers = m.num_layers;
+  for (int i = 0; i <= CN_MAX_LAYERS; ++i) d.dims[i] = m.dims[i];
+  for (int i = 0; i < CN_MAX_LAYERS; ++i) {
+    d.w[i] = m.weight[i];
+    d.b[i] = m.bias[i];
+  }
+  return d;
+}
+
+// y[n][lane] = act(b[n] + sum_k W[n][k] x[k][lane]);  x, y: LDS [.][64]
+__device__ __forceinline__ void dense_layer(const float* __restrict__ W, const float* __restrict__ b, int K, int N,
+                                            const float* x, float* y, bool relu, int lane) {
+  for (int n0 = 0; n0 < N; n0 += 8) {
+    float acc[8];
+    int nn[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      nn[j] = min(n0 + j, N - 1);
+      acc[j] = b[nn[j]];
+    }
+    for (int k = 0; k < K; ++k) {
+      float xk = x[k * 64 + lane];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaf(W[nn[j] * K + k], xk, acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (n0 + j < N) y[(n0 + j) * 64 + lane] = relu ? fmaxf(acc[j], 0.f) : acc[j];
+    }
+  }
+}
+
+// runs all layers of `m`; input in `in` (LDS), ping-pongs between a and b; returns pointer to the output rows
+__device__ __forceinline__ float* run_mlp(const MlpDev& m, const float* in, float* a, float* b, int lane) {
+  const float* x = in;
+  float* y = a;
+  for (int l = 0; l < m.num_layers; ++l) {
+    y = (l & 1) ? b : a;
+    dense_layer(m.w[l], m.b[l], m.dims[l], m.dims[l + 1], x, y, l < m.num_layers - 1, lane);
+    x = y;
+  }
+  return y;
+}
+
+__device__ __forceinline__ void encode_grid(const GridDev& g, float px, float py, float pz, float* out, int lane) {
+  for (int l = 0; l < g.num_levels; ++l) {
+    float2 f = hash_level(g.table, (unsigned)l * g.level_stride, g.mask, g.scale[l], px, py, pz);
+    out[(2 * l) * 64 + lane] = f.x;
+    out[(2 * l + 1) * 64 + lane] = f.y;
+  }
+}
+
+struct FieldDev {
+  GridDev grid;
+  MlpDev base, sem, color;
+  const float* sem_head_w;
+  const float* sem_head_b;
+  const float* appearance;
+  int num_images, app_dim, geo;
+};
+
+__global__ void __launch_bounds__(64)
+field_eval_kernel(FieldDev fp, SceneDev sc, int app_mode, int sh_unit, const float* __restrict__ origins,
+                  const float* __restrict__ directions, const int64_t* __restrict__ cam_idx,
+                  const float* __restrict__ starts, const float* __restrict__ ends, long long num_rays, int S,
+                  float* __restrict__ density, float* __restrict__ rgb, float* __restrict__ semantics,
+                  float* __restrict__ positions) {
+  extern __shared__ __align__(16) float lds[];
+  float* bufG = lds;                   // [GMAX][64] base output (density logit + geo)
+  float* bufA = bufG + GMAX * 64;      // [KMAX][64]
+  float* bufB = bufA + KMAX * 64;      // [KMAX][64]
+  float* app_mean = bufB + KMAX * 64;  // [app_dim]
+  const int lane = threadIdx.x;
+  if (app_mode == CN_APP_MEAN) {
+    for (int j = lane; j < fp.app_dim; j += 64) {
+      float s = 0.f;
+      for (int i = 0; i < fp.num_images; ++i) s += fp.appearance[(long long)i * fp.app_dim + j];
+      app_mean[j] = s / (float)fp.num_images;
+    }
+  }
+  __syncthreads();
+  const long long total = num_rays * (long long)S;
+  const long long nblk = (total + 63) / 64;
+  for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    long long i = blk * 64 + lane;
+    bool valid = i < total;
+    long long ic = valid ? i : total - 1;
+    long long r = ic / S;
+    float ox = origins[3 * r], oy = origins[3 * r + 1], oz = origins[3 * r + 2];
+    float dx = directions[3 * r], dy = directions[3 * r + 1], dz = directions[3 * r + 2];
+    float mid = (starts[ic] + ends[ic]) / 2.f;
+    float px = ox + dx * mid, py = oy + dy * mid, pz = oz + dz * mid;
+    if (positions && valid) {
+      positions[3 * i + 0] = px;
+      positions[3 * i + 1] = py;
+      positions[3 * i + 2] = pz;
+    }
+    bool sel = normalize_position(sc, px, py, pz);
+    encode_grid(fp.grid, px, py, pz, bufA, lane);
+    // base MLP: input bufA, layers alternate bufB / bufG so that the final output lands in bufG
+    {
+      const float* x = bufA;
+      for (int l = 0; l < fp.base.num_layers; ++l) {
+        bool last = l == fp.base.num_layers - 1;
+        float* y = last ? bufG : ((x == bufA) ? bufB : bufA);
+        dense_layer(fp.base.w[l], fp.base.b[l], fp.base.dims[l], fp.base.dims[l + 1], x, y, !last, lane);
+        x = y;
+      }
+    }
+    float den = expf(bufG[lane]) * (sel ? 1.f : 0.f);
+    if (density && valid) density[i] = den;
+    // semantics: mlp_semantics(geo) -> Linear(Ht,1)
+    {
+      float* out = run_mlp(fp.sem, bufG + 64, bufA, bufB, lane);
+      int ht = fp.sem.dims[fp.sem.num_layers];
+      float s = fp.sem_head_b[0];
+      for (int k = 0; k < ht; ++k) s = fmaf(fp.sem_head_w[k], out[k * 64 + lane], s);
+      if (semantics && valid) semantics[i] = s;
+    }
+    // colour: [SH16 | geo | appearance] -> mlp_head -> sigmoid
+    if (rgb) {
+      float sx = dx, sy = dy, sz = dz;
+      if (!sh_unit) {
+        sx = (dx + 1.f) / 2.f;
+        sy = (dy + 1.f) / 2.f;
+        sz = (dz + 1.f) / 2.f;
+      }
+      float sh[16];
+      sh_deg4(sx, sy, sz, sh);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) bufA[k * 64 + lane] = sh[k];
+      for (int k = 0; k < fp.geo; ++k) bufA[(16 + k) * 64 + lane] = bufG[(1 + k) * 64 + lane];
+      const float* emb = nullptr;
+      if (app_mode == CN_APP_PER_CAMERA) emb = fp.appearance + cam_idx[r] * (long long)fp.app_dim;
+      for (int k = 0; k < fp.app_dim; ++k) {
+        float a = app_mode == CN_APP_MEAN ? app_mean[k] : (emb ? emb[k] : 0.f);
+        bufA[(16 + fp.geo + k) * 64 + lane] = a;
+      }
+      // layers: bufA -> bufB -> bufA -> ...
+      const float* x = bufA;
+      float* y = bufB;
+      for (int l = 0; l < fp.color.num_layers; ++l) {
+        y = (x == bufA) ? bufB : bufA;
+        dense_layer(fp.color.w[l], fp.color.b[l], fp.color.dims[l], fp.color.dims[l + 1], x, y,
+                    l < fp.color.num_layers - 1, lane);
+        x = y;
+      }
+      if (valid) {
+        rgb[3 * i + 0] = sigmoidf(y[0 * 64 + lane]);
+        rgb[3 * i + 1] = sigmoidf(y[1 * 64 + lane]);
+        rgb[3 * i + 2] = sigmoidf(y[2 * 64 + lane]);
+      }
+    }
+  }
+}
+
+struct DensityDev {
+  GridDev grid;
+  MlpDev mlp;
+};
+
+__global__ void __launch_bounds__(64)
+proposal_density_kernel(DensityDev dp, SceneDev sc, const float* __restrict__ origins,
+                        const float* __restrict__ directions, const float* __restrict__ starts,
+                        const float* __restrict__ ends, long long num_rays, int S, float* __restrict__ density) {
+  __shared__ float bufA[64 * 64];
+  __shared__ float bufB[64 * 64];
+  const int lane = threadIdx.x;
+  const long long total = num_rays * (long long)S;
+  const long long nblk = (total + 63) / 64;
+  for (long long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    long long i = blk * 64 + lane;
+    bool valid = i < total;
+    long long ic = valid ? i : total - 1;
+    long long r = ic / S;
+    float mid = (starts[ic] + ends[ic]) / 2.f;
+    float px = origins[3 * r] + directions[3 * r] * mid;
+    float py = origins[3 * r + 1] + directions[3 * r + 1] * mid;
+    float pz = origins[3 * r + 2] + directions[3 * r + 2] * mid;
+    bool sel = normalize_position(sc, px, py, pz);
+    encode_grid(dp.grid, px, py, pz, bufA, lane);
+    const float* x = bufA;
+    float* y = bufB;
+    for (int l = 0; l < dp.mlp.num_layers; ++l) {
+      y = (x == bufA) ? bufB : bufA;
+      dense_layer(dp.mlp.w[l], dp.mlp.b[l], dp.mlp.dims[l], dp.mlp.dims[l + 1], x, y, l < dp.mlp.num_layers - 1, lane);
+      x = y;
+    }
+    if (valid) density[i] = expf(y[lane]) * (sel ? 1.f : 0.f);
+  }
+}
+
+static int validate_mlp(const cn_mlp& m, const char* name, int in_dim, int out_dim, int max_width) {
+  CN_REQUIRE(m.num_layers >= 1 && m.num_layers <= CN_MAX_LAYERS, CN_ERR_INVALID, "%s: num_layers %d", name,
+             m.num_layers);
+  CN_REQUIRE(m.dims[0] == in_dim, CN_ERR_INVALID, "%s: in_dim %d, expected %d", name, m.dims[0], in_dim);
+  if (out_dim > 0)
+    CN_REQUIRE(m.dims[m.num_layers] == out_dim, CN_ERR_INVALID, "%s: out_dim %d, expected %d", name,
+               m.dims[m.num_layers], out_dim);
+  for (int i = 0; i <= m.num_layers; ++i)
+    CN_REQUIRE(m.dims[i] >= 1 && m.dims[i] <= max_width, CN_ERR_UNSUPPORTED, "%s: layer width %d > %d", name, m.dims[i],
+               max_width);
+  for (int i = 0; i < m.num_layers; ++i)
+    CN_REQUIRE(m.weight[i] && m.bias[i], CN_ERR_INVALID, "%s: null weight/bias in layer %d", name, i);
+  return CN_OK;
+}
+
+int validate_grid(const cn_grid& g, const char* name) {
+  CN_REQUIRE(g.table, CN_ERR_INVALID, "%s: null hash table", name);
+  CN_REQUIRE(g.num_levels >= 1 && g.num_levels <= CN_MAX_LEVELS, CN_ERR_UNSUPPORTED, "%s: %d levels", name,
+             g.num_levels);
+  CN_REQUIRE(g.log2_table_size >= 1 && g.log2_table_size <= 24, CN_ERR_UNSUPPORTED, "%s: log2_table_size %d", name,
+             g.log2_table_size);
+  // gathers use 32-bit byte offsets from the table base
+  CN_REQUIRE(((unsigned long long)g.num_levels << g.log2_table_size) * 8ull <= (1ull << 31), CN_ERR_UNSUPPORTED,
+             "%s: table larger than 2 GiB", name);
+  return CN_OK;
+}
+
+int validate_field(const cn_field_params& p) {
+  int rc = validate_grid(p.grid, "field grid");
+  if (rc) return rc;
+  CN_REQUIRE(p.geo_feat_dim >= 1 && p.geo_feat_dim < GMAX, CN_ERR_UNSUPPORTED, "geo_feat_dim %d", p.geo_feat_dim);
+  CN_REQUIRE(p.app_dim >= 0 && 16 + p.geo_feat_dim + p.app_dim <= KMAX, CN_ERR_UNSUPPORTED, "app_dim %d", p.app_dim);
+  if ((rc = validate_mlp(p.base, "mlp_base_mlp", 2 * p.grid.num_levels, 1 + p.geo_feat_dim, KMAX))) return rc;
+  if ((rc = validate_mlp(p.semantics, "mlp_semantics", p.geo_feat_dim, 0, KMAX))) return rc;
+  if ((rc = validate_mlp(p.color, "mlp_head", 16 + p.geo_feat_dim + p.app_dim, 3, KMAX))) return rc;
+  CN_REQUIRE(p.sem_head_weight && p.sem_head_bias, CN_ERR_INVALID, "null semantic head");
+  CN_REQUIRE(p.app_dim == 0 || (p.appearance && p.num_images > 0), CN_ERR_INVALID, "null appearance embedding");
+  return CN_OK;
+}
+
+FieldDev make_field_dev(const cn_field_params& p) {
+  FieldDev f;
+  f.grid = make_grid_dev(p.grid);
+  f.base = make_mlp_dev(p.base);
+  f.sem = make_mlp_dev(p.semantics);
+  f.color = make_mlp_dev(p.color);
+  f.sem_head_w = p.sem_head_weight;
+  f.sem_head_b = p.sem_head_bias;
+  f.appearance = p.appearance;
+  f.num_images = p.num_images;
+  f.app_dim = p.app_dim;
+  f.geo = p.geo_feat_dim;
+  return f;
+}
+
+}  // namespace cn
+
+extern "C" int cn_field_eval(const cn_field_params* params, const cn_scene* scene, int32_t app_mode,
+                             int32_t sh_unit_dir, const float* origins, const float* directions,
+                             const int64_t* camera_indices, const float* starts, const float* ends, int64_t num_rays,
+                             int32_t num_samples, float* density, float* rgb, float* semantics, float* positions,
+                             cn_stream_t stream) {
+  CN_REQUIRE(params && scene && origins && directions && starts && ends, CN_ERR_INVALID, "cn_field_eval: null input");
+  CN_REQUIRE(num_samples > 0, CN_ERR_INVALID, "cn_field_eval: num_samples must be > 0");
+  CN_REQUIRE(app_mode >= CN_APP_ZEROS && app_mode <= CN_APP_PER_CAMERA, CN_ERR_INVALID, "cn_field_eval: app_mode %d",
+             app_mode);
+  // fruit_field.py:241-242 raises AttributeError when camera indices are missing
+  CN_REQUIRE(app_mode != CN_APP_PER_CAMERA || camera_indices, CN_ERR_INVALID, "Camera indices are not provided.");
+  int rc = cn::validate_field(*params);
+  if (rc) return rc;
+  if (num_rays <= 0) return CN_OK;
+  size_t lds = (size_t)(cn::GMAX + 2 * cn::KMAX) * 64 * sizeof(float) + 256 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::field_eval_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  long long nblk = (num_rays * (long long)num_samples + 63) / 64;
+  hipLaunchKernelGGL(cn::field_eval_kernel, dim3(cn::grid_for(nblk, 1, 256 * 8)), dim3(64), lds, cn::as_stream(stream),
+                     cn::make_field_dev(*params), cn::make_scene_dev(*scene), app_mode, sh_unit_dir, origins,
+                     directions, camera_indices, starts, ends, (long long)num_rays, num_samples, density, rgb,
+                     semantics, positions);
+  return cn::check_launch("cn_field_eval");
+}
+
+extern "C" int cn_proposal_density(const cn_density_params* params, const cn_scene* scene, const float* origins,
+                                   const float* directions, const float* starts, const float* ends, int64_t num_rays,
+                                   int32_t num_samples, float* density, cn_stream_t stream) {
+  CN_REQUIRE(params && scene && origins && directions && starts && ends && density, CN_ERR_INVALID,
+             "cn_proposal_density: null argument");
+  CN_REQUIRE(num_samples > 0, CN_ERR_INVALID, "cn_proposal_density: num_samples must be > 0");
+  int rc = cn::validate_grid(params->grid, "proposal grid");
+  if (rc) return rc;
+  if ((rc = cn::validate_mlp(params->mlp, "proposal mlp", 2 * params->grid.num_levels, 1, 64))) return rc;
+  if (num_rays <= 0) return CN_OK;
+  cn::DensityDev dp;
+  dp.grid = cn::make_grid_dev(params->grid);
+  dp.mlp = cn::make_mlp_dev(params->mlp);
+  long long nblk = (num_rays * (long long)num_samples + 63) / 64;
+  hipLaunchKernelGGL(cn::proposal_density_kernel, dim3(cn::grid_for(nblk, 1, 256 * 16)), dim3(64), 0,
+                     cn::as_stream(stream), dp, cn::make_scene_dev(*scene), origins, directions, starts, ends,
+                     (long long)num_rays, num_samples, density);
+  return cn::check_launch("cn_proposal_density");
+}

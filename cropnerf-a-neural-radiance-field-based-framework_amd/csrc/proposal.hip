@@ -1,0 +1,189 @@
+// cn_proposal_sample: the whole ProposalNetworkSampler of fruit_nerf (fruit_nerf/fruit_nerf.py:157-164, called at
+// :549,501,429,337) in one launch, eval mode: piecewise-in-disparity initial bins -> proposal net 0 -> weights ->
+// PDF resample -> proposal net 1 -> weights -> PDF resample -> final bins.  One wavefront per ray; the per-ray
+// bins / weights / cdf live in LDS, nothing [R,S]-shaped goes to HBM except the final bins ((S+1)*4 B per ray) and
+// the two median depths.  Proposal nets are small (L levels x 8 gathers, 2L->16->1): plain VALU with the MLP
+// weights in wave-uniform (scalar) registers.
+//
+// Built for the proposal shapes the reference configs use: 5 or 7 levels, hidden 16
+// (nerfacto defaults / fruit_nerf_config.py:143-146); other shapes return CN_ERR_UNSUPPORTED and the caller
+// composes cn_sample_spaced + cn_proposal_density + cn_composite + cn_sample_pdf instead.
+#include "composite_dev.hpp"
+#include "sampler_dev.hpp"
+
+namespace cn {
+
+constexpr int PROP_MAX_LEVELS = 3;   // proposal iterations
+constexpr int PROP_MAX_SAMPLES = 512;
+
+struct PropNet {
+  GridDev grid;
+  const float *w0, *b0, *w1, *b1;
+};
+
+struct PropArgs {
+  PropNet net[PROP_MAX_LEVELS];
+  int num_levels;
+  int s_prop[PROP_MAX_LEVELS];
+  int s_final;
+  int smax;
+  float anneal;
+  SceneDev scene;
+  const float* origins;
+  const float* directions;
+  const float* nears;
+  const float* fars;
+  long long num_rays;
+  float* out_eu;
+  float* out_sp;
+  float* out_depth;  // [num_levels][R]
+};
+
+template <int L, int H>
+__device__ __forceinline__ float prop_density(const PropNet& n, const SceneDev& sc, float px, float py, float pz) {
+  bool sel = normalize_position(sc, px, py, pz);
+  float enc[2 * L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    float2 f = hash_level(n.grid.table, (unsigned)l * n.grid.level_stride, n.grid.mask, n.grid.scale[l], px, py, pz);
+    enc[2 * l] = f.x;
+    enc[2 * l + 1] = f.y;
+  }
+  float out = n.b1[0];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    float a = n.b0[h];
+#pragma unroll
+    for (int k = 0; k < 2 * L; ++k) a = fmaf(n.w0[h * 2 * L + k], enc[k], a);
+    out = fmaf(n.w1[h], fmaxf(a, 0.f), out);
+  }
+  return expf(out) * (sel ? 1.f : 0.f);
+}
+
+__device__ __forceinline__ float prop_density_dispatch(const PropNet& n, const SceneDev& sc, float px, float py,
+                                                       float pz) {
+  if (n.grid.num_levels == 5) return prop_density<5, 16>(n, sc, px, py, pz);
+  return prop_density<7, 16>(n, sc, px, py, pz);
+}
+
+__global__ void __launch_bounds__(256) proposal_sample_kernel(PropArgs A) {
+  extern __shared__ __align__(16) float lds[];
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int stride = 4 * A.smax + 4;
+  float* bins_a = lds + wave * stride;    // [smax+1] spacing bins of the current level
+  float* bins_b = bins_a + A.smax + 1;    // [smax+1] next level
+  float* wts = bins_b + A.smax + 1;       // [smax]
+  float* cdf = wts + A.smax;              // [smax+1]
+  const long long waves = (long long)gridDim.x * 4;
+  for (long long rr = blockIdx.x * 4LL + wave; rr < A.num_rays; rr += waves) {
+    const long long r = __builtin_amdgcn_readfirstlane((int)rr);
+    const float ox = A.origins[3 * r], oy = A.origins[3 * r + 1], oz = A.origins[3 * r + 2];
+    const float dx = A.directions[3 * r], dy = A.directions[3 * r + 1], dz = A.directions[3 * r + 2];
+    const float sn = spacing_fn(CN_SPACING_PIECEWISE, A.nears[r]), sf = spacing_fn(CN_SPACING_PIECEWISE, A.fars[r]);
+    float* cur = bins_a;
+    float* nxt = bins_b;
+    // level 0 bins: linspace(0,1,S0+1) in the spacing domain
+    {
+      const int s0 = A.s_prop[0];
+      for (int e = lane; e <= s0; e += 64) cur[e] = linspace01(e, s0 + 1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int lvl = 0; lvl < A.num_levels; ++lvl) {
+      const int S = A.s_prop[lvl];
+      const PropNet& net = A.net[lvl];
+      CompositeState st;
+      for (int c0 = 0; c0 < S; c0 += 64) {
+        const int i = c0 + lane;
+        const bool valid = i < S;
+        const int ic = valid ? i : S - 1;
+        const float t0 = spacing_to_euclid(CN_SPACING_PIECEWISE, cur[ic], sn, sf);
+        const float t1 = spacing_to_euclid(CN_SPACING_PIECEWISE, cur[ic + 1], sn, sf);
+        const float mid = (t0 + t1) / 2.f;
+        const float den = prop_density_dispatch(net, A.scene, ox + dx * mid, oy + dy * mid, oz + dz * mid);
+        const float w = composite_chunk(st, valid, i == S - 1, t1 - t0, den, mid, 0.f, 0.f, 0.f, 0.f, false);
+        if (valid) wts[i] = w;
+      }
+      if (A.out_depth && lane == 0) A.out_depth[lvl * A.num_rays + r] = st.found ? st.depth : st.last_mid;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      wave_cdf_from_weights(wts, S, A.anneal, cdf);
+      const int s_next = lvl + 1 < A.num_levels ? A.s_prop[lvl + 1] : A.s_final;
+      const int nb = s_next + 1;
+      const bool last = lvl + 1 == A.num_levels;
+      for (int b = lane; b < nb; b += 64) {
+        float bin = pdf_invert(cdf, cur, S, pdf_u(b, nb, nullptr, 0));
+        nxt[b] = bin;
+        if (last) {
+          if (A.out_sp) A.out_sp[r * nb + b] = bin;
+          A.out_eu[r * nb + b] = spacing_to_euclid(CN_SPACING_PIECEWISE, bin, sn, sf);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      float* t = cur;
+      cur = nxt;
+      nxt = t;
+    }
+  }
+}
+
+int validate_grid(const cn_grid& g, const char* name);  // field_simple.hip
+
+}  // namespace cn
+
+extern "C" size_t cn_proposal_sample_workspace_bytes(int64_t, const int32_t*, int32_t, int32_t) { return 0; }
+
+extern "C" int cn_proposal_sample(const cn_density_params* const* props, int32_t num_levels, const cn_scene* scene,
+                                  const float* origins, const float* directions, const float* nears, const float* fars,
+                                  int64_t num_rays, const int32_t* s_prop, int32_t s_final, float anneal,
+                                  float* euclidean_bins, float* spacing_bins, float* prop_depth, void*, size_t,
+                                  cn_stream_t stream) {
+  CN_REQUIRE(props && scene && origins && directions && nears && fars && s_prop && euclidean_bins, CN_ERR_INVALID,
+             "cn_proposal_sample: null argument");
+  CN_REQUIRE(num_levels >= 1 && num_levels <= cn::PROP_MAX_LEVELS, CN_ERR_UNSUPPORTED,
+             "cn_proposal_sample: %d proposal iterations (max %d)", num_levels, cn::PROP_MAX_LEVELS);
+  CN_REQUIRE(s_final >= 1 && s_final <= cn::PROP_MAX_SAMPLES, CN_ERR_UNSUPPORTED, "cn_proposal_sample: s_final %d",
+             s_final);
+  CN_REQUIRE(num_rays < (1LL << 31), CN_ERR_INVALID, "cn_proposal_sample: at most 2^31-1 rays per call");
+  cn::PropArgs A{};
+  A.smax = s_final;
+  for (int l = 0; l < num_levels; ++l) {
+    CN_REQUIRE(props[l], CN_ERR_INVALID, "cn_proposal_sample: null proposal net %d", l);
+    CN_REQUIRE(s_prop[l] >= 1 && s_prop[l] <= cn::PROP_MAX_SAMPLES, CN_ERR_UNSUPPORTED,
+               "cn_proposal_sample: %d samples at level %d (max %d)", s_prop[l], l, cn::PROP_MAX_SAMPLES);
+    const cn_density_params& p = *props[l];
+    int rc = cn::validate_grid(p.grid, "proposal grid");
+    if (rc) return rc;
+    bool ok = (p.grid.num_levels == 5 || p.grid.num_levels == 7) && p.mlp.num_layers == 2 &&
+              p.mlp.dims[0] == 2 * p.grid.num_levels && p.mlp.dims[1] == 16 && p.mlp.dims[2] == 1;
+    CN_REQUIRE(ok, CN_ERR_UNSUPPORTED,
+               "cn_proposal_sample: proposal net %d is not {5|7 levels, 2L->16->1}; compose the unfused calls", l);
+    CN_REQUIRE(p.mlp.weight[0] && p.mlp.bias[0] && p.mlp.weight[1] && p.mlp.bias[1], CN_ERR_INVALID,
+               "cn_proposal_sample: null MLP parameter in net %d", l);
+    A.net[l].grid = cn::make_grid_dev(p.grid);
+    A.net[l].w0 = p.mlp.weight[0];
+    A.net[l].b0 = p.mlp.bias[0];
+    A.net[l].w1 = p.mlp.weight[1];
+    A.net[l].b1 = p.mlp.bias[1];
+    A.s_prop[l] = s_prop[l];
+    if (s_prop[l] > A.smax) A.smax = s_prop[l];
+  }
+  if (num_rays <= 0) return CN_OK;
+  A.num_levels = num_levels;
+  A.s_final = s_final;
+  A.anneal = anneal;
+  A.scene = cn::make_scene_dev(*scene);
+  A.origins = origins;
+  A.directions = directions;
+  A.nears = nears;
+  A.fars = fars;
+  A.num_rays = num_rays;
+  A.out_eu = euclidean_bins;
+  A.out_sp = spacing_bins;
+  A.out_depth = prop_depth;
+  size_t lds = (size_t)4 * (4 * A.smax + 4) * sizeof(float);
+  hipLaunchKernelGGL(cn::proposal_sample_kernel, dim3(cn::grid_for(num_rays, 4, 256 * 8)), dim3(256), lds,
+                     cn::as_stream(stream), A);
+  return cn::check_launch("cn_proposal_sample");
+}

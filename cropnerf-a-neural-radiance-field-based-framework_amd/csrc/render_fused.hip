@@ -1,0 +1,609 @@
+// render_fused.hip -- the hot path: sampler + FruitField + alpha compositing in ONE launch, nothing [R,S,.]-shaped
+// ever touches HBM.  Replaces fruit_nerf/fruit_nerf.py:551-597 (get_outputs after sampling), :503-539
+// (get_inference_outputs), :337-342 (get_density_for_camera_ray_bundle) and :476-494 (get_export_outputs).
+//
+// Mapping (gfx950, wave64):
+//   * one wavefront owns one ray at a time and walks its samples in chunks of 64;
+//   * hash-grid phase: lane (g = lane>>4, j = lane&15) gathers levels 4g..4g+3 for the four samples 16c+j (c=0..3) of
+//     the chunk, so a lane's 8 features per sample are exactly the B-operand rows it must feed to the first MFMA
+//     (k = g per step) -- no transpose, no LDS round trip for activations;
+//   * MLPs: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains).  Weights are the A operand (rows = output neurons),
+//     the 16 samples of a column tile are the B operand / the accumulator columns, so a layer's accumulator
+//     registers ARE the next layer's B operands: step (t,r) of the next layer consumes register r of row tile t,
+//     and the weight image in LDS is pre-permuted to that k order (prep kernel below);
+//   * algebra done once per launch in the prep kernel: the last Linear of mlp_semantics is folded into the
+//     Linear(64,1) head (no activation between them, fruit_field.py:146-157); per ray, the SH and appearance
+//     columns of mlp_head's first layer collapse into a 64-vector bias (they are constant along a ray);
+//   * compositing: lane l takes sample l of the chunk, wave-level scans give transmittance and the median depth.
+//
+// Supported field shape: the default `fruit_nerf_method` (fruit_nerf_config.py:29-65): 16 levels x 2 features,
+// 32->64->16, 15->64->64->1, 63->64->64->3, appearance 32.  Other shapes return CN_ERR_UNSUPPORTED (the caller
+// then uses cn_field_eval + cn_composite, which are shape-generic).
+#include "composite_dev.hpp"
+
+namespace cn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- weight image ("blob") layout, in floats -------------------------------------------------------------------
+constexpr int OFF_A0 = 0;       // base L0   [mt 4][sq 2][lane 64][4]   W0[16mt+j][8g + 4sq + e]
+constexpr int OFF_A1 = 2048;    // base L1   [sq 4][lane 64][4]         W1[j][16sq + 4g + e]
+constexpr int OFF_AS0 = 3072;   // sem L0    [mt 4][lane 64][4]         Ws0[16mt+j][4g+e-1] (0 for base neuron 0)
+constexpr int OFF_AC0 = 4096;   // colour L0 [mt 4][lane 64][4]         Wc0[16mt+j][16 + 4g+e-1]
+constexpr int OFF_AC1 = 5120;   // colour L1 [mt 4][sq 4][lane 64][4]   Wc1[16mt+j][16sq + 4g + e]
+constexpr int OFF_B0 = 9216;    // [64]
+constexpr int OFF_B1 = 9280;    // [16]
+constexpr int OFF_BS0 = 9296;   // [64]
+constexpr int OFF_BC1 = 9360;   // [64]
+constexpr int OFF_WF = 9424;    // [64] folded semantic head  Wh . Ws1
+constexpr int OFF_WRGB = 9488;  // [3][64]
+constexpr int OFF_MISC = 9680;  // [0] folded semantic bias, [1..3] rgb bias
+constexpr int OFF_WSH = 9688;   // [64][16] Wc0[:, 0:16]
+constexpr int OFF_SCALE = 10712;  // [16] hash-grid level scalings (lane group g reads [4g, 4g+4))
+constexpr int BLOB_FLOATS = 10712 + 16;
+static_assert(BLOB_FLOATS % 4 == 0, "blob is copied as float4");
+constexpr int WAVE_SCRATCH = 160;  // floats of per-wave LDS scratch
+
+struct PrepArgs {
+  const float *w0, *b0, *w1, *b1;        // base
+  const float *ws0, *bs0, *ws1, *bs1;    // semantics
+  const float *wh, *bh;                  // semantic head
+  const float *wc0, *bc0, *wc1, *bc1, *wc2, *bc2;  // colour
+  const float* emb;
+  int num_images;
+  int app_mode;
+  int app_rows;
+  float scale[CN_MAX_LEVELS];
+};
+
+__global__ void __launch_bounds__(256) prep_kernel(PrepArgs p, float* __restrict__ blob, float* __restrict__ app_bias) {
+  const int total = BLOB_FLOATS + p.app_rows * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (i < OFF_A1) {
+      int q = i - OFF_A0;
+      int mt = q >> 9, sq = (q >> 8) & 1, lane = (q >> 2) & 63, e = q & 3;
+      int g = lane >> 4, j = lane & 15;
+      v = p.w0[(16 * mt + j) * 32 + 8 * g + 4 * sq + e];
+    } else if (i < OFF_AS0) {
+      int q = i - OFF_A1;
+      int sq = q >> 8, lane = (q >> 2) & 63, e = q & 3;
+      int g = lane >> 4, j = lane & 15;
+      v = p.w1[j * 64 + 16 * sq + 4 * g + e];
+    } else if (i < OFF_AC0) {
+      int q = i - OFF_AS0;
+      int mt = q >> 8, lane = (q >> 2) & 63, e = q & 3;
+      int g = lane >> 4, j = lane & 15;
+      int m = 4 * g + e;  // base output neuron feeding this k slot; neuron 0 is the density logit, not a geo feature
+      v = m == 0 ? 0.f : p.ws0[(16 * mt + j) * 15 + (m - 1)];
+    } else if (i < OFF_AC1) {
+      int q = i - OFF_AC0;
+      int mt = q >> 8, lane = (q >> 2) & 63, e = q & 3;
+      int g = lane >> 4, j = lane & 15;
+      int m = 4 * g + e;
+      v = m == 0 ? 0.f : p.wc0[(16 * mt + j) * 63 + 16 + (m - 1)];
+    } else if (i < OFF_B0) {
+      int q = i - OFF_AC1;
+      int mt = q >> 10, sq = (q >> 8) & 3, lane = (q >> 2) & 63, e = q & 3;
+      int g = lane >> 4, j = lane & 15;
+      v = p.wc1[(16 * mt + j) * 64 + 16 * sq + 4 * g + e];
+    } else if (i < OFF_B1) {
+      v = p.b0[i - OFF_B0];
+    } else if (i < OFF_BS0) {
+      v = p.b1[i - OFF_B1];
+    } else if (i < OFF_BC1) {
+      v = p.bs0[i - OFF_BS0];
+    } else if (i < OFF_WF) {
+      v = p.bc1[i - OFF_BC1];
+    } else if (i < OFF_WRGB) {
+      int k = i - OFF_WF;
+      for (int m = 0; m < 64; ++m) v = fmaf(p.wh[m], p.ws1[m * 64 + k], v);
+    } else if (i < OFF_MISC) {
+      v = p.wc2[i - OFF_WRGB];
+    } else if (i < OFF_WSH) {
+      int k = i - OFF_MISC;
+      if (k == 0) {
+        v = p.bh[0];
+        for (int m = 0; m < 64; ++m) v = fmaf(p.wh[m], p.bs1[m], v);
+      } else if (k <= 3) {
+        v = p.bc2[k - 1];
+      }
+    } else if (i < OFF_SCALE) {
+      int q = i - OFF_WSH;
+      v = p.wc0[(q >> 4) * 63 + (q & 15)];
+    } else if (i < BLOB_FLOATS) {
+      int q = i - OFF_SCALE;  // static selects: a dynamically indexed kernarg array would go to scratch
+      v = p.scale[0];
+#pragma unroll
+      for (int k = 1; k < CN_MAX_LEVELS; ++k) v = q == k ? p.scale[k] : v;
+    } else {
+      int q = i - BLOB_FLOATS;
+      int row = q >> 6, n = q & 63;
+      v = p.bc0[n];
+      if (p.app_mode != CN_APP_ZEROS) {
+        for (int k = 0; k < 32; ++k) {
+          float a;
+          if (p.app_mode == CN_APP_PER_CAMERA) {
+            a = p.emb[row * 32 + k];
+          } else {
+            float s = 0.f;
+            for (int im = 0; im < p.num_images; ++im) s += p.emb[im * 32 + k];
+            a = s / (float)p.num_images;
+          }
+          v = fmaf(p.wc0[n * 63 + 31 + k], a, v);
+        }
+      }
+      app_bias[q] = v;
+      continue;
+    }
+    blob[i] = v;
+  }
+}
+
+struct FusedArgs {
+  GridDev grid;
+  SceneDev scene;
+  const float* blob;
+  const float* app_bias;  // [rows][64]
+  const float* origins;
+  const float* directions;
+  const float* nears;
+  const float* fars;
+  const int64_t* cam_idx;
+  const float* bins;  // [R,S+1] or null
+  long long num_rays;
+  int S;
+  int spacing;
+  int bg_mode;
+  float bg[3];
+  int app_per_camera;
+  int sh_unit;
+  int eval_clamp;
+  // composited outputs
+  float *out_rgb, *out_acc, *out_depth, *out_sem, *out_cmap, *out_w;
+  // per-sample outputs
+  float *s_density, *s_rgb, *s_sem, *s_pos;
+};
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+  f32x4 r;
+  r.x = fmaxf(v.x, 0.f);
+  r.y = fmaxf(v.y, 0.f);
+  r.z = fmaxf(v.z, 0.f);
+  r.w = fmaxf(v.w, 0.f);
+  return r;
+}
+
+__device__ __forceinline__ float dot4(f32x4 a, f32x4 b, float acc) {
+  acc = fmaf(a.x, b.x, acc);
+  acc = fmaf(a.y, b.y, acc);
+  acc = fmaf(a.z, b.z, acc);
+  acc = fmaf(a.w, b.w, acc);
+  return acc;
+}
+
+__device__ __forceinline__ float group_sum(float v) { return rows_sum(v); }  // lanes j, j+16, j+32, j+48
+
+__device__ __forceinline__ float pick4(int g, float a, float b, float c, float d) {
+  return g == 0 ? a : (g == 1 ? b : (g == 2 ? c : d));
+}
+
+template <bool PER_SAMPLE, bool DENSITY_ONLY>
+__global__ void __launch_bounds__(256, 2) render_fused_kernel(FusedArgs A) {
+  __shared__ __align__(16) float lds[BLOB_FLOATS + 4 * WAVE_SCRATCH];
+  {
+    const float4* src = reinterpret_cast<const float4*>(A.blob);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    for (int i = threadIdx.x; i < BLOB_FLOATS / 4; i += 256) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int g = lane >> 4, j = lane & 15;
+  float* scratch = lds + BLOB_FLOATS + wave * WAVE_SCRATCH;  // [0,64): per-ray colour bias, [64,129): chunk bin edges
+  float* tbuf = scratch + 64;
+  const int S = A.S;
+
+  // XCD-aware ray ownership: blocks b, b+8, ... share an XCD (round-robin dispatch), so give each XCD one
+  // contiguous ray range and let its blocks sweep it together -> neighbouring rays share L2-resident grid cells.
+  const int xcd = blockIdx.x & 7;
+  const int slot = blockIdx.x >> 3;
+  const long long per_xcd = (A.num_rays + 7) >> 3;
+  const long long ray_lo = xcd * per_xcd;
+  const long long ray_hi = min(ray_lo + per_xcd, A.num_rays);
+  const long long stride = (long long)(gridDim.x >> 3) * 4;
+
+  for (long long rr = ray_lo + slot * 4 + wave; rr < ray_hi; rr += stride) {
+    const long long r = __builtin_amdgcn_readfirstlane((int)rr);  // wave-uniform -> scalar loads below
+    const float ox = A.origins[3 * r], oy = A.origins[3 * r + 1], oz = A.origins[3 * r + 2];
+    const float dx = A.directions[3 * r], dy = A.directions[3 * r + 1], dz = A.directions[3 * r + 2];
+    const float near = A.nears[r], far = A.fars[r];
+    const float sn = spacing_fn(A.spacing, near), sf = spacing_fn(A.spacing, far);
+    const float* bins = A.bins ? A.bins + r * (long long)(S + 1) : nullptr;
+    auto edge = [&](int i) -> float {
+      i = min(i, S);
+      return bins ? bins[i] : spacing_to_euclid(A.spacing, linspace01(i, S + 1), sn, sf);
+    };
+
+    // ---- per-ray colour bias: bc0 + Wc0[:, sh].SH(d) + Wc0[:, app].app  (lane n = neuron n) ------------------
+    f32x4 cbias[4];
+    if (!DENSITY_ONLY) {
+      float sx = dx, sy = dy, sz = dz;
+      if (!A.sh_unit) {
+        sx = (dx + 1.f) / 2.f;
+        sy = (dy + 1.f) / 2.f;
+        sz = (dz + 1.f) / 2.f;
+      }
+      float sh[16];
+      sh_deg4(sx, sy, sz, sh);
+      long long row = A.app_per_camera ? A.cam_idx[r] : 0;
+      float bias = A.app_bias[row * 64 + lane];
+      const f32x4* wsh = reinterpret_cast<const f32x4*>(lds + OFF_WSH + lane * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 w = wsh[q];
+        bias = fmaf(w.x, sh[4 * q + 0], bias);
+        bias = fmaf(w.y, sh[4 * q + 1], bias);
+        bias = fmaf(w.z, sh[4 * q + 2], bias);
+        bias = fmaf(w.w, sh[4 * q + 3], bias);
+      }
+      __builtin_amdgcn_wave_barrier();
+      scratch[lane] = bias;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) cbias[mt] = *reinterpret_cast<const f32x4*>(scratch + 16 * mt + 4 * g);
+    }
+
+    CompositeState st;
+    const f32x4 lvl_scale = *reinterpret_cast<const f32x4*>(lds + OFF_SCALE + 4 * g);
+    for (int c0 = 0; c0 < S; c0 += 64) {
+      // ---- bin edges of the chunk: lane l owns edge c0+l, edge c0+64 is wave-uniform; staged in LDS so that the
+      //      gather lanes (sample 16c+j) and the compositing lanes (sample l) read the same values -------------
+      const float e_lo = edge(c0 + lane);
+      const float e_top = edge(c0 + 64);
+      __builtin_amdgcn_wave_barrier();
+      tbuf[lane] = e_lo;
+      if (lane == 0) tbuf[64] = e_top;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // ---- positions of this lane's four gather samples (rows past S sit at the far plane and are discarded) ---
+      float px[4], py[4], pz[4];
+      bool sel[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float mid = (tbuf[16 * c + j] + tbuf[16 * c + j + 1]) / 2.f;
+        px[c] = ox + dx * mid;
+        py[c] = oy + dy * mid;
+        pz[c] = oz + dz * mid;
+        sel[c] = normalize_position(A.scene, px[c], py[c], pz[c]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- hash grid: levels 4g..4g+3 for the four samples ------------------------------------------------
+      f32x4 feat[4][2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int l = 4 * g + q;
+        const unsigned level_off = (unsigned)l * A.grid.level_stride;
+        const float scale = lvl_scale[q];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float2 f = hash_level(A.grid.table, level_off, A.grid.mask, scale, px[c], py[c], pz[c]);
+          if (q == 0) { feat[c][0].x = f.x; feat[c][0].y = f.y; }
+          if (q == 1) { feat[c][0].z = f.x; feat[c][0].w = f.y; }
+          if (q == 2) { feat[c][1].x = f.x; feat[c][1].y = f.y; }
+          if (q == 3) { feat[c][1].z = f.x; feat[c][1].w = f.y; }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep at most one level (32 gathers, 64 VGPRs) in flight per lane
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- base MLP layer 0: 32 -> 64, ReLU -------------------------------------------------------------------
+      f32x4 h[4][4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B0 + 16 * mt + 4 * g);
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(lds + OFF_A0 + ((mt * 2 + 0) * 64 + lane) * 4);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(lds + OFF_A0 + ((mt * 2 + 1) * 64 + lane) * 4);
+        f32x4 acc[4] = {b, b, b, b};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] = MFMA(a0[e], feat[c][0][e], acc[c]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] = MFMA(a1[e], feat[c][1][e], acc[c]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) h[mt][c] = relu4(acc[c]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- base MLP layer 1: 64 -> 16 (neuron 0 = density logit, 1..15 = geo features) ----------------------------
+      f32x4 o16[4];
+      {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B1 + 4 * g);
+        f32x4 acc[4] = {b, b, b, b};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_A1 + (t * 64 + lane) * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = MFMA(a[e], h[t][c][e], acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o16[c] = acc[c];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      float sem_part[4] = {0.f, 0.f, 0.f, 0.f};
+      float rgb_part[4][3];
+      if (!DENSITY_ONLY) {
+        // ---- semantics: relu(Ws0 geo + bs0) . (Wh Ws1) + folded bias --------------------------------------------
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_BS0 + 16 * mt + 4 * g);
+          const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_AS0 + (mt * 64 + lane) * 4);
+          const f32x4 wf = *reinterpret_cast<const f32x4*>(lds + OFF_WF + 16 * mt + 4 * g);
+          f32x4 acc[4] = {b, b, b, b};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = MFMA(a[e], o16[c][e], acc[c]);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) sem_part[c] = dot4(wf, relu4(acc[c]), sem_part[c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- colour layer 0: geo columns on the MFMA, SH + appearance columns pre-summed in cbias ---------------
+        f32x4 c1[4][4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_AC0 + (mt * 64 + lane) * 4);
+          f32x4 acc[4] = {cbias[mt], cbias[mt], cbias[mt], cbias[mt]};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = MFMA(a[e], o16[c][e], acc[c]);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) c1[mt][c] = relu4(acc[c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- colour layer 1 (64 -> 64, ReLU) with the 64 -> 3 head folded into the row-tile loop -------------------
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rgb_part[c][0] = rgb_part[c][1] = rgb_part[c][2] = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_BC1 + 16 * mt + 4 * g);
+          f32x4 acc[4] = {b, b, b, b};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_AC1 + ((mt * 4 + t) * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) acc[c] = MFMA(a[e], c1[t][c][e], acc[c]);
+          }
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(lds + OFF_WRGB + 0 * 64 + 16 * mt + 4 * g);
+          const f32x4 w1 = *reinterpret_cast<const f32x4*>(lds + OFF_WRGB + 1 * 64 + 16 * mt + 4 * g);
+          const f32x4 w2 = *reinterpret_cast<const f32x4*>(lds + OFF_WRGB + 2 * 64 + 16 * mt + 4 * g);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            f32x4 v = relu4(acc[c]);
+            rgb_part[c][0] = dot4(w0, v, rgb_part[c][0]);
+            rgb_part[c][1] = dot4(w1, v, rgb_part[c][1]);
+            rgb_part[c][2] = dot4(w2, v, rgb_part[c][2]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- hand each lane l the sample c0 + l (column tile c = g, column j) ----------------------------------
+      float dl0 = row0_broadcast(o16[0].x), dl1 = row0_broadcast(o16[1].x);
+      float dl2 = row0_broadcast(o16[2].x), dl3 = row0_broadcast(o16[3].x);
+      float dlogit = pick4(g, dl0, dl1, dl2, dl3);
+      bool msel = pick4(g, sel[0] ? 1.f : 0.f, sel[1] ? 1.f : 0.f, sel[2] ? 1.f : 0.f, sel[3] ? 1.f : 0.f) != 0.f;
+      float density = expf(dlogit) * (msel ? 1.f : 0.f);
+      float sem = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+      if (!DENSITY_ONLY) {
+        float s0 = group_sum(sem_part[0]), s1 = group_sum(sem_part[1]);
+        float s2 = group_sum(sem_part[2]), s3 = group_sum(sem_part[3]);
+        sem = pick4(g, s0, s1, s2, s3) + lds[OFF_MISC + 0];
+        float ch[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          float v0 = group_sum(rgb_part[0][k]), v1 = group_sum(rgb_part[1][k]);
+          float v2 = group_sum(rgb_part[2][k]), v3 = group_sum(rgb_part[3][k]);
+          ch[k] = sigmoidf(pick4(g, v0, v1, v2, v3) + lds[OFF_MISC + 1 + k]);
+        }
+        cr = ch[0];
+        cg = ch[1];
+        cb = ch[2];
+      }
+      const int i = c0 + lane;
+      const bool valid = i < S;
+      const float e0 = e_lo, e1 = tbuf[lane + 1];
+      const float mid = (e0 + e1) / 2.f;
+      if (PER_SAMPLE) {
+        if (valid) {
+          const long long o = r * (long long)S + i;
+          if (A.s_density) A.s_density[o] = density;
+          if (A.s_sem) A.s_sem[o] = sem;
+          if (A.s_rgb) {
+            A.s_rgb[3 * o + 0] = cr;
+            A.s_rgb[3 * o + 1] = cg;
+            A.s_rgb[3 * o + 2] = cb;
+          }
+          if (A.s_pos) {
+            A.s_pos[3 * o + 0] = ox + dx * mid;
+            A.s_pos[3 * o + 1] = oy + dy * mid;
+            A.s_pos[3 * o + 2] = oz + dz * mid;
+          }
+        }
+      } else {
+        float w = composite_chunk(st, valid, i == S - 1, e1 - e0, density, mid, cr, cg, cb, sem, A.eval_clamp != 0);
+        if (A.out_w && valid) A.out_w[r * (long long)S + i] = w;
+      }
+    }
+    if (!PER_SAMPLE) {
+      CompositeOut o = composite_finish(st, A.bg_mode, A.bg[0], A.bg[1], A.bg[2], A.eval_clamp != 0);
+      if (lane == 0) {
+        if (A.out_acc) A.out_acc[r] = o.acc;
+        if (A.out_depth) A.out_depth[r] = o.depth;
+        if (!DENSITY_ONLY) {
+          if (A.out_rgb) {
+            A.out_rgb[3 * r + 0] = o.r;
+            A.out_rgb[3 * r + 1] = o.g;
+            A.out_rgb[3 * r + 2] = o.b;
+          }
+          if (A.out_sem) A.out_sem[r] = o.sem;
+          if (A.out_cmap) {
+            float l = semantics_label(o.sem);
+            A.out_cmap[3 * r + 0] = l;
+            A.out_cmap[3 * r + 1] = l;
+            A.out_cmap[3 * r + 2] = l;
+          }
+        }
+      }
+    }
+  }
+}
+
+int validate_field(const cn_field_params& p);  // field_simple.hip
+
+static int check_fused_shape(const cn_field_params& p) {
+  int rc = validate_field(p);
+  if (rc) return rc;
+  bool ok = p.grid.num_levels == 16 && p.geo_feat_dim == 15 && p.app_dim == 32 && p.base.num_layers == 2 &&
+            p.base.dims[0] == 32 && p.base.dims[1] == 64 && p.base.dims[2] == 16 && p.semantics.num_layers == 2 &&
+            p.semantics.dims[0] == 15 && p.semantics.dims[1] == 64 && p.semantics.dims[2] == 64 &&
+            p.color.num_layers == 3 && p.color.dims[0] == 63 && p.color.dims[1] == 64 && p.color.dims[2] == 64 &&
+            p.color.dims[3] == 3;
+  CN_REQUIRE(ok, CN_ERR_UNSUPPORTED,
+             "fused renderer is built for the default fruit_nerf_method field shape "
+             "(16 levels, 32->64->16, 15->64->64->1, 63->64->64->3, appearance 32); use cn_field_eval + cn_composite");
+  return CN_OK;
+}
+
+static size_t fused_workspace_bytes(const cn_field_params* p) {
+  int rows = p && p->num_images > 0 ? p->num_images : 1;
+  return (size_t)(BLOB_FLOATS + rows * 64) * sizeof(float);
+}
+
+template <bool PER_SAMPLE>
+static int launch_fused(const cn_field_params* params, const cn_scene* scene, const cn_render_opts* opts,
+                        const float* origins, const float* directions, const float* nears, const float* fars,
+                        const int64_t* cam_idx, const float* bins, int64_t num_rays, FusedArgs& A, void* workspace,
+                        size_t workspace_bytes, cn_stream_t stream, const char* who) {
+  CN_REQUIRE(params && scene && opts && origins && directions && nears && fars, CN_ERR_INVALID, "%s: null input", who);
+  CN_REQUIRE(opts->num_samples > 0, CN_ERR_INVALID, "%s: num_samples must be > 0", who);
+  CN_REQUIRE(opts->spacing == CN_SPACING_UNIFORM || opts->spacing == CN_SPACING_PIECEWISE, CN_ERR_INVALID,
+             "%s: unknown spacing %d", who, opts->spacing);
+  CN_REQUIRE(opts->app_mode >= CN_APP_ZEROS && opts->app_mode <= CN_APP_PER_CAMERA, CN_ERR_INVALID, "%s: app_mode %d",
+             who, opts->app_mode);
+  CN_REQUIRE(opts->app_mode != CN_APP_PER_CAMERA || cam_idx, CN_ERR_INVALID, "Camera indices are not provided.");
+  CN_REQUIRE(opts->bg_mode == CN_BG_LAST_SAMPLE || opts->bg_mode == CN_BG_COLOR, CN_ERR_INVALID, "%s: bg_mode %d", who,
+             opts->bg_mode);
+  int rc = check_fused_shape(*params);
+  if (rc) return rc;
+  CN_REQUIRE(workspace && workspace_bytes >= fused_workspace_bytes(params), CN_ERR_WORKSPACE,
+             "%s: workspace %zu B < %zu B", who, workspace_bytes, fused_workspace_bytes(params));
+  CN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, CN_ERR_INVALID, "%s: workspace must be 16-B aligned",
+             who);
+  if (num_rays <= 0) return CN_OK;
+  CN_REQUIRE(num_rays < (1LL << 31), CN_ERR_INVALID, "%s: at most 2^31-1 rays per call", who);
+  hipStream_t s = as_stream(stream);
+  float* blob = static_cast<float*>(workspace);
+  float* app_bias = blob + BLOB_FLOATS;
+  PrepArgs P;
+  P.w0 = params->base.weight[0];
+  P.b0 = params->base.bias[0];
+  P.w1 = params->base.weight[1];
+  P.b1 = params->base.bias[1];
+  P.ws0 = params->semantics.weight[0];
+  P.bs0 = params->semantics.bias[0];
+  P.ws1 = params->semantics.weight[1];
+  P.bs1 = params->semantics.bias[1];
+  P.wh = params->sem_head_weight;
+  P.bh = params->sem_head_bias;
+  P.wc0 = params->color.weight[0];
+  P.bc0 = params->color.bias[0];
+  P.wc1 = params->color.weight[1];
+  P.bc1 = params->color.bias[1];
+  P.wc2 = params->color.weight[2];
+  P.bc2 = params->color.bias[2];
+  P.emb = params->appearance;
+  P.num_images = params->num_images;
+  P.app_mode = opts->app_mode;
+  P.app_rows = opts->app_mode == CN_APP_PER_CAMERA ? params->num_images : 1;
+  for (int i = 0; i < CN_MAX_LEVELS; ++i) P.scale[i] = params->grid.scalings[i];
+  hipLaunchKernelGGL(prep_kernel, dim3(48), dim3(256), 0, s, P, blob, app_bias);
+  rc = check_launch("cn_render prep");
+  if (rc) return rc;
+
+  A.grid = make_grid_dev(params->grid);
+  A.scene = make_scene_dev(*scene);
+  A.blob = blob;
+  A.app_bias = app_bias;
+  A.origins = origins;
+  A.directions = directions;
+  A.nears = nears;
+  A.fars = fars;
+  A.cam_idx = cam_idx;
+  A.bins = bins;
+  A.num_rays = num_rays;
+  A.S = opts->num_samples;
+  A.spacing = opts->spacing;
+  A.bg_mode = opts->bg_mode;
+  A.bg[0] = opts->bg_color[0];
+  A.bg[1] = opts->bg_color[1];
+  A.bg[2] = opts->bg_color[2];
+  A.app_per_camera = opts->app_mode == CN_APP_PER_CAMERA;
+  A.sh_unit = opts->sh_unit_dir;
+  A.eval_clamp = opts->eval_clamp;
+  // persistent-style grid: a multiple of 8 (XCD groups), at most 3 blocks per CU, never more waves than rays
+  long long want = (num_rays + 3) / 4;
+  long long blocks = want < 768 ? ((want + 7) / 8) * 8 : 768;
+  if (PER_SAMPLE) {
+    hipLaunchKernelGGL((render_fused_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, A);
+  } else if (opts->density_only) {
+    hipLaunchKernelGGL((render_fused_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, s, A);
+  } else {
+    hipLaunchKernelGGL((render_fused_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, s, A);
+  }
+  return check_launch(who);
+}
+
+}  // namespace cn
+
+extern "C" size_t cn_render_workspace_bytes(const cn_field_params* params) { return cn::fused_workspace_bytes(params); }
+
+extern "C" int cn_render_rays(const cn_field_params* params, const cn_scene* scene, const cn_render_opts* opts,
+                              const float* origins, const float* directions, const float* nears, const float* fars,
+                              const int64_t* camera_indices, const float* bins, int64_t num_rays, float* out_rgb,
+                              float* out_accumulation, float* out_depth, float* out_semantics,
+                              float* out_semantics_colormap, float* out_weights, void* workspace,
+                              size_t workspace_bytes, cn_stream_t stream) {
+  cn::FusedArgs A{};
+  A.out_rgb = out_rgb;
+  A.out_acc = out_accumulation;
+  A.out_depth = out_depth;
+  A.out_sem = out_semantics;
+  A.out_cmap = out_semantics_colormap;
+  A.out_w = out_weights;
+  return cn::launch_fused<false>(params, scene, opts, origins, directions, nears, fars, camera_indices, bins, num_rays,
+                                 A, workspace, workspace_bytes, stream, "cn_render_rays");
+}
+
+extern "C" int cn_render_samples(const cn_field_params* params, const cn_scene* scene, const cn_render_opts* opts,
+                                 const float* origins, const float* directions, const float* nears, const float* fars,
+                                 const int64_t* camera_indices, const float* bins, int64_t num_rays, float* density,
+                                 float* rgb, float* semantics, float* positions, void* workspace,
+                                 size_t workspace_bytes, cn_stream_t stream) {
+  cn::FusedArgs A{};
+  A.s_density = density;
+  A.s_rgb = rgb;
+  A.s_sem = semantics;
+  A.s_pos = positions;
+  return cn::launch_fused<true>(params, scene, opts, origins, directions, nears, fars, camera_indices, bins, num_rays, A,
+                                workspace, workspace_bytes, stream, "cn_render_samples");
+}

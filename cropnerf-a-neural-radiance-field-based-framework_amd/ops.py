@@ -1,0 +1,417 @@
+"""Tensor-level wrappers over the C ABI (``include/cropnerf_hip.h``).
+
+PyTorch is plumbing here: device memory, the current HIP stream and nothing else -- every value these functions
+return was computed by a kernel of libcropnerf_hip.so.  Inputs must be contiguous float32 (int64 for indices)
+tensors on the ROCm device; a missing library or a failed call raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib as L
+from .config import FieldSpec, GridSpec, ProposalSpec
+
+
+def _stream(t: Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("cropnerf_amd ops need tensors on the ROCm device (no CPU fallback exists)")
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _f32(t: Optional[Tensor], name: str) -> Optional[Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+        raise TypeError(f"{name}: expected a contiguous float32 device tensor, got {t.dtype} {t.device} "
+                        f"contiguous={t.is_contiguous()}")
+    return t
+
+
+def _i64(t: Optional[Tensor], name: str) -> Optional[Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.int64 or not t.is_contiguous() or not t.is_cuda:
+        raise TypeError(f"{name}: expected a contiguous int64 device tensor")
+    return t
+
+
+def _p(t: Optional[Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _farr(vals: Sequence[float]):
+    return (C.c_float * len(vals))(*[float(v) for v in vals])
+
+
+# --------------------------------------------------------------------------------------------------------------
+# parameter handles
+# --------------------------------------------------------------------------------------------------------------
+
+def _grid_struct(table: Tensor, spec: GridSpec) -> L.Grid:
+    _f32(table, "hash_table")
+    if tuple(table.shape) != (spec.table_size * spec.num_levels, 2):
+        raise ValueError(f"hash table shape {tuple(table.shape)} != {(spec.table_size * spec.num_levels, 2)}")
+    g = L.Grid()
+    g.table = table.data_ptr()
+    g.num_levels = spec.num_levels
+    g.log2_table_size = spec.log2_hashmap_size
+    sc = spec.scalings()
+    for i in range(L.CN_MAX_LEVELS):
+        g.scalings[i] = sc[i] if i < len(sc) else 0.0
+    return g
+
+
+def _mlp_struct(params: Dict[str, Tensor], prefix: str, num_layers: int) -> L.Mlp:
+    m = L.Mlp()
+    m.num_layers = num_layers
+    for i in range(num_layers):
+        w = _f32(params[f"{prefix}.layers.{i}.weight"], f"{prefix}.layers.{i}.weight")
+        b = _f32(params[f"{prefix}.layers.{i}.bias"], f"{prefix}.layers.{i}.bias")
+        m.dims[i] = w.shape[1]
+        m.dims[i + 1] = w.shape[0]
+        m.weight[i] = w.data_ptr()
+        m.bias[i] = b.data_ptr()
+    return m
+
+
+class FieldHandle:
+    """cn_field_params for a parameter dict (keeps the tensors alive)."""
+
+    def __init__(self, params: Dict[str, Tensor], spec: FieldSpec):
+        self.params = params
+        self.spec = spec
+        p = L.FieldParams()
+        p.grid = _grid_struct(params["field.mlp_base_grid.hash_table"], spec.grid)
+        p.base = _mlp_struct(params, "field.mlp_base_mlp", 2)
+        p.semantics = _mlp_struct(params, "field.mlp_semantics", spec.num_layers_semantic)
+        p.sem_head_weight = _f32(params["field.field_head_semantics.net.weight"], "sem head w").data_ptr()
+        p.sem_head_bias = _f32(params["field.field_head_semantics.net.bias"], "sem head b").data_ptr()
+        p.color = _mlp_struct(params, "field.mlp_head", spec.num_layers_color)
+        emb = _f32(params["field.embedding_appearance.embedding.weight"], "appearance embedding")
+        p.appearance = emb.data_ptr()
+        p.num_images = emb.shape[0]
+        p.app_dim = emb.shape[1]
+        p.geo_feat_dim = spec.geo_feat_dim
+        self.struct = p
+        self.device = emb.device
+        self._workspace: Optional[Tensor] = None
+
+    def workspace(self) -> Tensor:
+        n = int(L.load().cn_render_workspace_bytes(C.byref(self.struct)))
+        if self._workspace is None or self._workspace.numel() < n:
+            self._workspace = torch.empty(n + 16, dtype=torch.uint8, device=self.device)
+        return self._workspace
+
+
+class DensityHandle:
+    def __init__(self, params: Dict[str, Tensor], level: int, spec: ProposalSpec):
+        self.params = params
+        self.spec = spec
+        p = L.DensityParams()
+        p.grid = _grid_struct(params[f"proposal_networks.{level}.encoding.hash_table"], spec.grid)
+        p.mlp = _mlp_struct(params, f"proposal_networks.{level}.mlp", 2)
+        self.struct = p
+
+
+def scene_struct(aabb: Tensor, contraction: bool) -> L.Scene:
+    s = L.Scene()
+    flat = [float(v) for v in aabb.reshape(-1).tolist()]
+    for i in range(6):
+        s.aabb[i] = flat[i]
+    s.contraction = 1 if contraction else 0
+    return s
+
+
+def render_opts(num_samples: int, spacing: int = L.SPACING_UNIFORM, bg_mode: int = L.BG_LAST_SAMPLE,
+                bg_color: Sequence[float] = (0.0, 0.0, 0.0), app_mode: int = L.APP_MEAN, sh_unit_dir: bool = True,
+                eval_clamp: bool = True, density_only: bool = False) -> L.RenderOpts:
+    o = L.RenderOpts()
+    o.num_samples = int(num_samples)
+    o.spacing = spacing
+    o.bg_mode = bg_mode
+    for i in range(3):
+        o.bg_color[i] = float(bg_color[i])
+    o.app_mode = app_mode
+    o.sh_unit_dir = 1 if sh_unit_dir else 0
+    o.eval_clamp = 1 if eval_clamp else 0
+    o.density_only = 1 if density_only else 0
+    return o
+
+
+# --------------------------------------------------------------------------------------------------------------
+# ray generation
+# --------------------------------------------------------------------------------------------------------------
+
+def raygen_pinhole(c2w: Tensor, intrinsics: Tensor, *, ray_indices: Optional[Tensor] = None, cam: int = 0,
+                   height: int = 0, width: int = 0, pixel_start: int = 0, num_rays: Optional[int] = None,
+                   camera_index_value: int = -1) -> Dict[str, Tensor]:
+    lib = L.load()
+    c2w = _f32(c2w, "c2w")
+    intrinsics = _f32(intrinsics, "intrinsics")
+    if ray_indices is not None:
+        ray_indices = _i64(ray_indices, "ray_indices")
+        R = ray_indices.shape[0]
+    else:
+        R = height * width - pixel_start if num_rays is None else num_rays
+    dev = c2w.device
+    out = {
+        "origins": torch.empty(R, 3, device=dev), "directions": torch.empty(R, 3, device=dev),
+        "pixel_area": torch.empty(R, 1, device=dev), "camera_indices": torch.empty(R, 1, dtype=torch.int64, device=dev),
+        "directions_norm": torch.empty(R, 1, device=dev),
+    }
+    L.check(lib.cn_raygen_pinhole(_p(c2w), _p(intrinsics), _p(ray_indices), cam, height, width, pixel_start, R,
+                                  camera_index_value, _p(out["origins"]), _p(out["directions"]),
+                                  _p(out["pixel_area"]), _p(out["camera_indices"]), _p(out["directions_norm"]),
+                                  _stream(c2w)))
+    return out
+
+
+def intersect_aabb(origins: Tensor, directions: Tensor, aabb6: Sequence[float]) -> Tuple[Tensor, Tensor]:
+    lib = L.load()
+    R = origins.shape[0]
+    nears = torch.empty(R, 1, device=origins.device)
+    fars = torch.empty(R, 1, device=origins.device)
+    L.check(lib.cn_intersect_aabb(_p(_f32(origins, "origins")), _p(_f32(directions, "directions")), _farr(aabb6), R,
+                                  _p(nears), _p(fars), _stream(origins)))
+    return nears, fars
+
+
+def surface_grid(x0: float, x1: float, nx: int, y0: float, y1: float, ny: int, z: float, device) -> Tensor:
+    lib = L.load()
+    pts = torch.empty(nx * ny, 3, device=device)
+    L.check(lib.cn_surface_grid(x0, x1, nx, y0, y1, ny, z, _p(pts), _stream(pts)))
+    return pts
+
+
+def raygen_ortho(surface_points: Tensor, plane_vector: Sequence[float], start: int, num_rays: int) -> Dict[str, Tensor]:
+    lib = L.load()
+    dev = surface_points.device
+    out = {"origins": torch.empty(num_rays, 3, device=dev), "directions": torch.empty(num_rays, 3, device=dev),
+           "pixel_area": torch.empty(num_rays, 1, device=dev), "nears": torch.empty(num_rays, 1, device=dev),
+           "fars": torch.empty(num_rays, 1, device=dev)}
+    L.check(lib.cn_raygen_ortho(_p(_f32(surface_points, "surface_points")), _farr(plane_vector), start, num_rays,
+                                _p(out["origins"]), _p(out["directions"]), _p(out["pixel_area"]), _p(out["nears"]),
+                                _p(out["fars"]), _stream(surface_points)))
+    return out
+
+
+def apply_pose_adjustment(pose_adjustment: Tensor, camera_indices: Tensor, origins: Tensor, directions: Tensor) -> None:
+    """In place, like ``camera_optimizer.apply_to_raybundle``."""
+    lib = L.load()
+    L.check(lib.cn_apply_pose_adjustment(_p(_f32(pose_adjustment, "pose_adjustment")),
+                                         _p(_i64(camera_indices, "camera_indices")), origins.shape[0],
+                                         _p(_f32(origins, "origins")), _p(_f32(directions, "directions")),
+                                         _stream(origins)))
+
+
+def embedding_mean(embedding: Tensor) -> Tensor:
+    lib = L.load()
+    out = torch.empty(embedding.shape[1], device=embedding.device)
+    L.check(lib.cn_embedding_mean(_p(_f32(embedding, "embedding")), embedding.shape[0], embedding.shape[1], _p(out),
+                                  _stream(embedding)))
+    return out
+
+
+# --------------------------------------------------------------------------------------------------------------
+# samplers
+# --------------------------------------------------------------------------------------------------------------
+
+def sample_spaced(nears: Tensor, fars: Tensor, num_samples: int, spacing: int = L.SPACING_UNIFORM,
+                  t_rand: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    lib = L.load()
+    R = nears.shape[0]
+    dev = nears.device
+    out = {k: torch.empty(R, num_samples, device=dev) for k in ("starts", "ends", "spacing_starts", "spacing_ends")}
+    stride = 0 if t_rand is None else t_rand.shape[1]
+    L.check(lib.cn_sample_spaced(_p(_f32(nears, "nears")), _p(_f32(fars, "fars")), R, num_samples, spacing,
+                                 _p(_f32(t_rand, "t_rand")), stride, _p(out["starts"]), _p(out["ends"]),
+                                 _p(out["spacing_starts"]), _p(out["spacing_ends"]), _stream(nears)))
+    return out
+
+
+def sample_pdf(prev_spacing_bins: Tensor, weights: Tensor, nears: Tensor, fars: Tensor, num_samples: int,
+               anneal: float = 1.0, spacing: int = L.SPACING_PIECEWISE, u_rand: Optional[Tensor] = None
+               ) -> Tuple[Tensor, Tensor]:
+    lib = L.load()
+    R, s_in = weights.shape
+    dev = weights.device
+    sp = torch.empty(R, num_samples + 1, device=dev)
+    eu = torch.empty(R, num_samples + 1, device=dev)
+    stride = 0 if u_rand is None else u_rand.shape[1]
+    L.check(lib.cn_sample_pdf(_p(_f32(prev_spacing_bins, "prev_spacing_bins")), _p(_f32(weights, "weights")),
+                              _p(_f32(nears, "nears")), _p(_f32(fars, "fars")), R, s_in, num_samples, anneal, spacing,
+                              _p(_f32(u_rand, "u_rand")), stride, _p(sp), _p(eu), _stream(weights)))
+    return sp, eu
+
+
+def proposal_sample(props: Sequence[DensityHandle], scene: L.Scene, origins: Tensor, directions: Tensor,
+                    nears: Tensor, fars: Tensor, s_prop: Sequence[int], s_final: int, anneal: float = 1.0
+                    ) -> Dict[str, Tensor]:
+    lib = L.load()
+    R = origins.shape[0]
+    dev = origins.device
+    n = len(props)
+    arr = (C.POINTER(L.DensityParams) * n)(*[C.pointer(p.struct) for p in props])
+    sp_arr = (C.c_int32 * n)(*[int(s) for s in s_prop])
+    eu = torch.empty(R, s_final + 1, device=dev)
+    sp = torch.empty(R, s_final + 1, device=dev)
+    depth = torch.empty(n, R, device=dev)
+    L.check(lib.cn_proposal_sample(arr, n, C.byref(scene), _p(_f32(origins, "origins")),
+                                   _p(_f32(directions, "directions")), _p(_f32(nears, "nears")), _p(_f32(fars, "fars")),
+                                   R, sp_arr, s_final, anneal, _p(eu), _p(sp), _p(depth), C.c_void_p(0), 0,
+                                   _stream(origins)))
+    return {"euclidean_bins": eu, "spacing_bins": sp, "prop_depth": depth}
+
+
+# --------------------------------------------------------------------------------------------------------------
+# field / compositing
+# --------------------------------------------------------------------------------------------------------------
+
+def proposal_density(prop: DensityHandle, scene: L.Scene, origins: Tensor, directions: Tensor, starts: Tensor,
+                     ends: Tensor) -> Tensor:
+    lib = L.load()
+    R, S = starts.shape
+    den = torch.empty(R, S, device=starts.device)
+    L.check(lib.cn_proposal_density(C.byref(prop.struct), C.byref(scene), _p(_f32(origins, "origins")),
+                                    _p(_f32(directions, "directions")), _p(_f32(starts, "starts")),
+                                    _p(_f32(ends, "ends")), R, S, _p(den), _stream(starts)))
+    return den
+
+
+def field_eval(fh: FieldHandle, scene: L.Scene, origins: Tensor, directions: Tensor, camera_indices: Optional[Tensor],
+               starts: Tensor, ends: Tensor, app_mode: int = L.APP_MEAN, sh_unit_dir: bool = True,
+               want_positions: bool = False) -> Dict[str, Tensor]:
+    lib = L.load()
+    R, S = starts.shape
+    dev = starts.device
+    out = {"density": torch.empty(R, S, device=dev), "rgb": torch.empty(R, S, 3, device=dev),
+           "semantics": torch.empty(R, S, device=dev)}
+    pos = torch.empty(R, S, 3, device=dev) if want_positions else None
+    L.check(lib.cn_field_eval(C.byref(fh.struct), C.byref(scene), app_mode, 1 if sh_unit_dir else 0,
+                              _p(_f32(origins, "origins")), _p(_f32(directions, "directions")),
+                              _p(_i64(camera_indices, "camera_indices")), _p(_f32(starts, "starts")),
+                              _p(_f32(ends, "ends")), R, S, _p(out["density"]), _p(out["rgb"]), _p(out["semantics"]),
+                              _p(pos), _stream(starts)))
+    if pos is not None:
+        out["positions"] = pos
+    return out
+
+
+def composite(starts: Tensor, ends: Tensor, density: Tensor, rgb: Optional[Tensor] = None,
+              semantics: Optional[Tensor] = None, bg_mode: int = L.BG_LAST_SAMPLE,
+              bg_color: Sequence[float] = (0.0, 0.0, 0.0), eval_clamp: bool = True, want_weights: bool = False
+              ) -> Dict[str, Tensor]:
+    lib = L.load()
+    R, S = starts.shape
+    dev = starts.device
+    out = {"accumulation": torch.empty(R, 1, device=dev), "depth": torch.empty(R, 1, device=dev)}
+    if rgb is not None:
+        out["rgb"] = torch.empty(R, 3, device=dev)
+    if semantics is not None:
+        out["semantics"] = torch.empty(R, 1, device=dev)
+        out["semantics_colormap"] = torch.empty(R, 3, device=dev)
+    if want_weights:
+        out["weights"] = torch.empty(R, S, device=dev)
+    L.check(lib.cn_composite(_p(_f32(starts, "starts")), _p(_f32(ends, "ends")), _p(_f32(density, "density")),
+                             _p(_f32(rgb, "rgb")), _p(_f32(semantics, "semantics")), R, S, bg_mode, _farr(bg_color),
+                             1 if eval_clamp else 0, _p(out.get("rgb")), _p(out["accumulation"]), _p(out["depth"]),
+                             _p(out.get("semantics")), _p(out.get("semantics_colormap")), _p(out.get("weights")),
+                             _stream(starts)))
+    return out
+
+
+def render_rays(fh: FieldHandle, scene: L.Scene, opts: L.RenderOpts, origins: Tensor, directions: Tensor,
+                nears: Tensor, fars: Tensor, camera_indices: Optional[Tensor] = None, bins: Optional[Tensor] = None,
+                want_weights: bool = False) -> Dict[str, Tensor]:
+    """Fused sampler + field + compositor (cn_render_rays)."""
+    lib = L.load()
+    R = origins.shape[0]
+    dev = origins.device
+    S = opts.num_samples
+    if bins is not None and tuple(bins.shape) != (R, S + 1):
+        raise ValueError(f"bins shape {tuple(bins.shape)} != {(R, S + 1)}")
+    out: Dict[str, Tensor] = {"accumulation": torch.empty(R, 1, device=dev)}
+    if not opts.density_only:
+        out.update({"rgb": torch.empty(R, 3, device=dev), "depth": torch.empty(R, 1, device=dev),
+                    "semantics": torch.empty(R, 1, device=dev), "semantics_colormap": torch.empty(R, 3, device=dev)})
+    if want_weights:
+        out["weights"] = torch.empty(R, S, device=dev)
+    ws = fh.workspace()
+    L.check(lib.cn_render_rays(C.byref(fh.struct), C.byref(scene), C.byref(opts), _p(_f32(origins, "origins")),
+                               _p(_f32(directions, "directions")), _p(_f32(nears, "nears")), _p(_f32(fars, "fars")),
+                               _p(_i64(camera_indices, "camera_indices")), _p(_f32(bins, "bins")), R,
+                               _p(out.get("rgb")), _p(out["accumulation"]), _p(out.get("depth")),
+                               _p(out.get("semantics")), _p(out.get("semantics_colormap")), _p(out.get("weights")),
+                               C.c_void_p(ws.data_ptr()), ws.numel(), _stream(origins)))
+    return out
+
+
+def render_samples(fh: FieldHandle, scene: L.Scene, opts: L.RenderOpts, origins: Tensor, directions: Tensor,
+                   nears: Tensor, fars: Tensor, camera_indices: Optional[Tensor] = None,
+                   bins: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """Fused sampler + field with per-sample outputs (cn_render_samples): the export-mode forward."""
+    lib = L.load()
+    R = origins.shape[0]
+    dev = origins.device
+    S = opts.num_samples
+    out = {"density": torch.empty(R, S, device=dev), "rgb": torch.empty(R, S, 3, device=dev),
+           "semantics": torch.empty(R, S, device=dev), "positions": torch.empty(R, S, 3, device=dev)}
+    ws = fh.workspace()
+    L.check(lib.cn_render_samples(C.byref(fh.struct), C.byref(scene), C.byref(opts), _p(_f32(origins, "origins")),
+                                  _p(_f32(directions, "directions")), _p(_f32(nears, "nears")), _p(_f32(fars, "fars")),
+                                  _p(_i64(camera_indices, "camera_indices")), _p(_f32(bins, "bins")), R,
+                                  _p(out["density"]), _p(out["rgb"]), _p(out["semantics"]), _p(out["positions"]),
+                                  C.c_void_p(ws.data_ptr()), ws.numel(), _stream(origins)))
+    return out
+
+
+# --------------------------------------------------------------------------------------------------------------
+# exporters
+# --------------------------------------------------------------------------------------------------------------
+
+def export_compact(positions: Tensor, rgb: Tensor, semantics: Tensor, density: Tensor, capacity: int,
+                   sem_thresh: float = 3.0, den_thresh: float = 70.0,
+                   buffers: Optional[Tuple[List[Tensor], List[Tensor], Tensor]] = None
+                   ) -> Tuple[List[Tensor], List[Tensor], Tensor]:
+    """Appends to three (points [cap,3], colors [cap,4]) sets; returns (points, colors, counts[3] int64 device)."""
+    lib = L.load()
+    dev = positions.device
+    N = semantics.numel()
+    if buffers is None:
+        pts = [torch.empty(capacity, 3, device=dev) for _ in range(3)]
+        cols = [torch.empty(capacity, 4, device=dev) for _ in range(3)]
+        counts = torch.zeros(3, dtype=torch.int64, device=dev)
+    else:
+        pts, cols, counts = buffers
+    parr = (C.c_void_p * 3)(*[t.data_ptr() for t in pts])
+    carr = (C.c_void_p * 3)(*[t.data_ptr() for t in cols])
+    L.check(lib.cn_export_compact(_p(_f32(positions, "positions")), _p(_f32(rgb, "rgb")),
+                                  _p(_f32(semantics, "semantics")), _p(_f32(density, "density")), N, sem_thresh,
+                                  den_thresh, capacity, parr, carr, _p(counts), _stream(positions)))
+    return pts, cols, counts
+
+
+def pointcloud_compact(origins: Tensor, directions: Tensor, depth: Tensor, rgb: Tensor, semantics_colormap: Tensor,
+                       capacity: int, buffers: Optional[Tuple[Tensor, Tensor, Tensor, Tensor]] = None
+                       ) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    lib = L.load()
+    dev = origins.device
+    R = origins.shape[0]
+    if buffers is None:
+        pts = torch.empty(capacity, 3, device=dev)
+        cols = torch.empty(capacity, 3, device=dev)
+        dirs = torch.empty(capacity, 3, device=dev)
+        count = torch.zeros(1, dtype=torch.int64, device=dev)
+    else:
+        pts, cols, dirs, count = buffers
+    L.check(lib.cn_pointcloud_compact(_p(_f32(origins, "origins")), _p(_f32(directions, "directions")),
+                                      _p(_f32(depth, "depth")), _p(_f32(rgb, "rgb")),
+                                      _p(_f32(semantics_colormap, "semantics_colormap")), R, capacity, _p(pts),
+                                      _p(cols), _p(dirs), _p(count), _stream(origins)))
+    return pts, cols, dirs, count

@@ -1,0 +1,274 @@
+/*
+ * cropnerf_hip.h -- C ABI of libcropnerf_hip.so (gfx950 / MI355X)
+ *
+ * Drop-in boundary for the volumetric ray-marching hot path of CropNeRF's `fruit_nerf`
+ * method.  The reference (pure Python, /root/reference/crop_nerf) has no FFI of its own:
+ * every entry point below replaces a Python call site of the reference (cited per
+ * function as file:line under crop_nerf/) whose arithmetic lives in nerfstudio 1.1.3.
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 (CN_OK) or a negative cn_status; cn_last_error() gives a
+ *     thread-local message for the last failure on the calling thread.
+ *   - all array arguments are DEVICE pointers unless marked "host"; fp32 unless noted;
+ *     indices int64 (nerfstudio uses torch.long).  The caller owns every buffer; the
+ *     library never allocates device memory -- scratch comes through `workspace`,
+ *     sized by the matching *_workspace_bytes() query.
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised.
+ *   - re-entrant; no global mutable state.  One process per GPU for multi-GPU use.
+ *   - layouts: rays SoA [R,3]/[R,1] row-major; samples [R,S]; weights of Linear layers in
+ *     torch.nn.Linear layout [out,in]; hash tables in nerfstudio torch HashEncoding layout
+ *     [num_levels * 2^log2_T, 2], level-major.
+ */
+#ifndef CROPNERF_HIP_H
+#define CROPNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum cn_status {
+  CN_OK = 0,
+  CN_ERR_INVALID = -1,      /* bad argument (null pointer, size, enum)            */
+  CN_ERR_UNSUPPORTED = -2,  /* dimensions outside what the kernels are built for  */
+  CN_ERR_LAUNCH = -3,       /* HIP launch / runtime error                          */
+  CN_ERR_WORKSPACE = -4     /* workspace too small                                 */
+} cn_status;
+
+typedef void* cn_stream_t; /* hipStream_t */
+
+#define CN_MAX_LEVELS 16
+#define CN_MAX_LAYERS 4
+
+/* spacing functions of the SpacedSampler family (fruit_nerf/components/ray_samplers.py:46-52) */
+#define CN_SPACING_UNIFORM 0   /* s(x)=x                                                       */
+#define CN_SPACING_PIECEWISE 1 /* s(x)=x/2 (x<1) else 1-1/(2x): UniformLinDispPiecewiseSampler */
+
+/* appearance-embedding modes of FruitField (fruit_nerf/fruit_field.py:218-220,250-261) */
+#define CN_APP_ZEROS 0
+#define CN_APP_MEAN 1
+#define CN_APP_PER_CAMERA 2
+
+/* background modes of RGBRenderer (fruit_nerf/fruit_nerf.py:170; scripts/semantic_projection.py:158,169) */
+#define CN_BG_LAST_SAMPLE 0
+#define CN_BG_COLOR 1
+
+/* One multiresolution hash grid: nerfstudio torch HashEncoding (fruit_nerf/fruit_field.py:125-132). */
+typedef struct cn_grid {
+  const float* table;             /* [num_levels << log2_table_size, 2]                   */
+  int32_t num_levels;             /* <= CN_MAX_LEVELS                                      */
+  int32_t log2_table_size;        /* 2^k entries per level                                 */
+  float scalings[CN_MAX_LEVELS];  /* host values: floor(min_res * growth^l)                */
+} cn_grid;
+
+/* A nerfstudio torch MLP: Linear(+ReLU) x (num_layers-1), Linear. dims[0]=in, dims[num_layers]=out. */
+typedef struct cn_mlp {
+  int32_t num_layers;
+  int32_t dims[CN_MAX_LAYERS + 1];
+  const float* weight[CN_MAX_LAYERS]; /* [dims[i+1], dims[i]] */
+  const float* bias[CN_MAX_LAYERS];   /* [dims[i+1]]          */
+} cn_mlp;
+
+/* FruitField parameters (module graph fruit_nerf/fruit_field.py:109-167). */
+typedef struct cn_field_params {
+  cn_grid grid;                 /* mlp_base_grid: 16 levels, F=2                               */
+  cn_mlp base;                  /* mlp_base_mlp: 32 -> 64 -> 1+geo                             */
+  cn_mlp semantics;             /* mlp_semantics: geo -> Hs (-> Hs) -> Ht, no out activation  */
+  const float* sem_head_weight; /* field_head_semantics: [1, Ht]                               */
+  const float* sem_head_bias;   /* [1]                                                         */
+  cn_mlp color;                 /* mlp_head: 16+geo+app -> 64 -> 64 -> 3, sigmoid              */
+  const float* appearance;      /* embedding_appearance: [num_images, app_dim]                */
+  int32_t num_images;
+  int32_t app_dim;
+  int32_t geo_feat_dim;
+} cn_field_params;
+
+/* A proposal network: HashMLPDensityField (fruit_nerf/fruit_nerf.py:133-142). */
+typedef struct cn_density_params {
+  cn_grid grid; /* 5 levels (7 in fruit_nerf_method_huge) */
+  cn_mlp mlp;   /* 2L -> 16 -> 1                            */
+} cn_density_params;
+
+/* Scene frame: SceneBox aabb + whether SceneContraction(inf) is active
+ * (fruit_nerf/fruit_nerf.py:91-94,189; fruit_nerf/fruit_field.py:171-176). host struct. */
+typedef struct cn_scene {
+  float aabb[6];       /* min xyz, max xyz */
+  int32_t contraction; /* 1: contract then (p+2)/4; 0: AABB-normalise */
+} cn_scene;
+
+/* Options of the fused renderer. host struct. */
+typedef struct cn_render_opts {
+  int32_t num_samples;  /* S: field samples per ray                                          */
+  int32_t spacing;      /* CN_SPACING_* used when `bins` is NULL                             */
+  int32_t bg_mode;      /* CN_BG_*                                                            */
+  float bg_color[3];    /* used with CN_BG_COLOR                                              */
+  int32_t app_mode;     /* CN_APP_*                                                           */
+  int32_t sh_unit_dir;  /* 1: SH of the unit direction (tcnn semantics); 0: SH of (d+1)/2   */
+  int32_t eval_clamp;   /* 1: nan_to_num(rgb) before, clamp[0,1] after (RGBRenderer in eval) */
+  int32_t density_only; /* 1: only accumulation is produced (get_density_for_camera_ray_bundle) */
+} cn_render_opts;
+
+const char* cn_last_error(void);
+int cn_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Ray generation
+ * ------------------------------------------------------------------------------------------- */
+
+/* Pinhole rays.  Replaces Cameras.generate_rays as called at
+ *   fruit_nerf/data/fruit_datamanager.py:188-197 (train_ray_generator(ray_indices)),
+ *   fruit_nerf/fruit_nerf.py:283 (full image, camera_indices=0),
+ *   fruit_nerf/export/exporter_utils_nerfacto.py:266-268.
+ * ray_indices [R,3] = (camera, row, col) or NULL; with NULL the rays are pixels
+ * [pixel_start, pixel_start+R) of camera `cam`, row-major over (H,W).
+ * camera_index_value >= 0 overrides the camera index written to `camera_indices`
+ * (the reference writes 0 at fruit_nerf.py:283). Outputs may be NULL to skip. */
+int cn_raygen_pinhole(const float* c2w /*[C,3,4]*/, const float* intrinsics /*[C,4] fx fy cx cy*/,
+                      const int64_t* ray_indices, int32_t cam, int32_t height, int32_t width,
+                      int64_t pixel_start, int64_t num_rays, int32_t camera_index_value,
+                      float* origins, float* directions, float* pixel_area, int64_t* camera_indices,
+                      float* directions_norm, cn_stream_t stream);
+
+/* Ray / AABB slab test: nerfstudio.utils.math.intersect_aabb as used by generate_rays(aabb_box=...)
+ * at fruit_nerf/fruit_nerf.py:283-286 (misses -> 1e10 in both outputs). aabb: host [6]. */
+int cn_intersect_aabb(const float* origins, const float* directions, const float* aabb_host,
+                      int64_t num_rays, float* nears, float* fars, cn_stream_t stream);
+
+/* Orthographic surface rays: OrthographicRayGenerator.forward
+ * (fruit_nerf/components/ray_generators.py:46-66) over the surface grid of
+ * fruit_nerf/data/fruit_datamanager.py:71-121.  surface_points [P,3] device; rays
+ * [start, start+num_rays). plane_vector: host [3]. */
+int cn_raygen_ortho(const float* surface_points, const float* plane_vector_host, int64_t start,
+                    int64_t num_rays, float* origins, float* directions, float* pixel_area, float* nears,
+                    float* fars, cn_stream_t stream);
+
+/* Dense n x n surface grid (sample_surface_points, fruit_nerf/data/fruit_datamanager.py:71-121):
+ * point i*ny+j = (lerp x, lerp y, z_const). */
+int cn_surface_grid(float x0, float x1, int32_t nx, float y0, float y1, int32_t ny, float z_const,
+                    float* surface_points, cn_stream_t stream);
+
+/* SO3xR3 pose refinement: camera_optimizer.apply_to_raybundle (fruit_nerf/fruit_nerf.py:547).
+ * origins/directions are updated in place. */
+int cn_apply_pose_adjustment(const float* pose_adjustment /*[C,6]*/, const int64_t* camera_indices,
+                             int64_t num_rays, float* origins, float* directions, cn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Samplers
+ * ------------------------------------------------------------------------------------------- */
+
+/* SpacedSampler / UniformSamplerWithNoise.generate_ray_samples
+ * (fruit_nerf/components/ray_samplers.py:54-104).  t_rand: NULL (eval) or stratified jitter with row
+ * stride t_rand_stride (1 = single jitter, S+1 = per-bin).  Outputs [R,S]; any may be NULL. */
+int cn_sample_spaced(const float* nears, const float* fars, int64_t num_rays, int32_t num_samples,
+                     int32_t spacing, const float* t_rand, int32_t t_rand_stride, float* starts,
+                     float* ends, float* spacing_starts, float* spacing_ends, cn_stream_t stream);
+
+/* PDFSampler.generate_ray_samples (nerfstudio; called through ProposalNetworkSampler at
+ * fruit_nerf/fruit_nerf.py:157-164,549).  Inputs: previous spacing bins [R,S_in+1] and weights [R,S_in]
+ * (already annealed by the caller or via `anneal`: w^anneal).  u_rand NULL = eval.
+ * Outputs: spacing bins [R,S_out+1] and euclidean bins [R,S_out+1]. */
+int cn_sample_pdf(const float* prev_spacing_bins, const float* weights, const float* nears, const float* fars,
+                  int64_t num_rays, int32_t s_in, int32_t s_out, float anneal, int32_t spacing,
+                  const float* u_rand, int32_t u_rand_stride, float* spacing_bins, float* euclidean_bins,
+                  cn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Field evaluation (materialised, per-sample outputs)
+ * ------------------------------------------------------------------------------------------- */
+
+/* HashMLPDensityField.density_fn at sample mid-points (fruit_nerf/fruit_nerf.py:135-142). density [R,S]. */
+int cn_proposal_density(const cn_density_params* params, const cn_scene* scene, const float* origins,
+                        const float* directions, const float* starts, const float* ends, int64_t num_rays,
+                        int32_t num_samples, float* density, cn_stream_t stream);
+
+/* FruitField.forward (fruit_nerf/fruit_field.py:284-302) at sample mid-points.
+ * Outputs per sample: density [R,S], rgb [R,S,3], semantics logit [R,S], positions [R,S,3] (NULL to skip).
+ * This is also FruitModel.get_export_outputs' field part (fruit_nerf/fruit_nerf.py:476-494). */
+int cn_field_eval(const cn_field_params* params, const cn_scene* scene, int32_t app_mode, int32_t sh_unit_dir,
+                  const float* origins, const float* directions, const int64_t* camera_indices,
+                  const float* starts, const float* ends, int64_t num_rays, int32_t num_samples,
+                  float* density, float* rgb, float* semantics, float* positions, cn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Compositing
+ * ------------------------------------------------------------------------------------------- */
+
+/* RaySamples.get_weights + RGB/Accumulation/Depth(median)/Semantic renderers + colormap
+ * (fruit_nerf/fruit_nerf.py:556-597).  rgb/semantics inputs may be NULL (then those outputs are skipped:
+ * proposal levels only need weights + depth).  Outputs [R,3],[R,1],[R,1],[R,1],[R,3],[R,S]; any NULL skips. */
+int cn_composite(const float* starts, const float* ends, const float* density, const float* rgb,
+                 const float* semantics, int64_t num_rays, int32_t num_samples, int32_t bg_mode,
+                 const float* bg_color_host, int32_t eval_clamp, float* out_rgb, float* out_accumulation,
+                 float* out_depth, float* out_semantics, float* out_semantics_colormap, float* out_weights,
+                 cn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused renderer (the hot path): sampler + FruitField + compositing in one launch
+ * ------------------------------------------------------------------------------------------- */
+
+/* Replaces, for one chunk of rays, FruitModel.get_outputs / get_inference_outputs after sampling
+ * (fruit_nerf/fruit_nerf.py:551-597, 503-539) and get_density_for_camera_ray_bundle (:337-342).
+ * `bins` = euclidean sample bins [R,S+1] from the proposal sampler, or NULL to sample S bins with
+ * opts->spacing between nears and fars (UniformSamplerWithNoise in eval, fruit_nerf.py:188).
+ * No [R,S,.] tensor is materialised unless out_weights is given.  Outputs as cn_composite. */
+size_t cn_render_workspace_bytes(const cn_field_params* params);
+int cn_render_rays(const cn_field_params* params, const cn_scene* scene, const cn_render_opts* opts,
+                   const float* origins, const float* directions, const float* nears, const float* fars,
+                   const int64_t* camera_indices, const float* bins, int64_t num_rays, float* out_rgb,
+                   float* out_accumulation, float* out_depth, float* out_semantics,
+                   float* out_semantics_colormap, float* out_weights, void* workspace, size_t workspace_bytes,
+                   cn_stream_t stream);
+
+/* Same kernel with per-sample outputs instead of compositing: FruitModel.get_export_outputs
+ * (fruit_nerf/fruit_nerf.py:476-494). density [R,S], rgb [R,S,3], semantics [R,S], positions [R,S,3]. */
+int cn_render_samples(const cn_field_params* params, const cn_scene* scene, const cn_render_opts* opts,
+                      const float* origins, const float* directions, const float* nears, const float* fars,
+                      const int64_t* camera_indices, const float* bins, int64_t num_rays, float* density,
+                      float* rgb, float* semantics, float* positions, void* workspace, size_t workspace_bytes,
+                      cn_stream_t stream);
+
+/* Fused proposal sampler: piecewise initial samples -> proposal net 0 -> PDF -> proposal net 1 -> PDF
+ * (ProposalNetworkSampler as configured at fruit_nerf/fruit_nerf.py:157-164, eval mode).
+ * s_prop: host [num_levels] samples per proposal level (256, 96); s_final: field samples.
+ * Outputs: euclidean bins [R,s_final+1], spacing bins [R,s_final+1] (NULL to skip),
+ * prop_depth [num_levels][R] median depths (NULL to skip). */
+size_t cn_proposal_sample_workspace_bytes(int64_t num_rays, const int32_t* s_prop_host, int32_t num_levels,
+                                          int32_t s_final);
+int cn_proposal_sample(const cn_density_params* const* props_host, int32_t num_levels, const cn_scene* scene,
+                       const float* origins, const float* directions, const float* nears, const float* fars,
+                       int64_t num_rays, const int32_t* s_prop_host, int32_t s_final, float anneal,
+                       float* euclidean_bins, float* spacing_bins, float* prop_depth, void* workspace,
+                       size_t workspace_bytes, cn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Exporters
+ * ------------------------------------------------------------------------------------------- */
+
+/* sample_volume masking + compaction (fruit_nerf/export/exporter_utils.py:100-153) over N samples:
+ *   set 0 "semantic_colormap": label(sigmoid(sem) > 0.9) and density >= den_thresh, 4th colour sigmoid(sem)
+ *   set 1 "semantic":          sem >= sem_thresh and density >= den_thresh,        4th colour sigmoid(sem)
+ *   set 2 "density":           density >= den_thresh,                              4th colour sigmoid(density)
+ * Appends to points[set] ([cap,3]) / colors[set] ([cap,4]) at counts[set] (device int64[3], caller zeroes);
+ * rows beyond `capacity` are counted but not written.  Order within a set is not the reference's
+ * (atomic append); compare as sets. */
+int cn_export_compact(const float* positions, const float* rgb, const float* semantics, const float* density,
+                      int64_t num_samples, float sem_thresh, float den_thresh, int64_t capacity,
+                      float* const* points_host3, float* const* colors_host3, int64_t* counts,
+                      cn_stream_t stream);
+
+/* generate_point_cloud inner step (fruit_nerf/export/exporter_utils_nerfacto.py:156-166):
+ * point = o + d*depth kept where semantics_colormap[:,0] > 0; appends xyz/rgb/view-dir rows. */
+int cn_pointcloud_compact(const float* origins, const float* directions, const float* depth, const float* rgb,
+                          const float* semantics_colormap, int64_t num_rays, int64_t capacity, float* points,
+                          float* colors, float* view_dirs, int64_t* count, cn_stream_t stream);
+
+/* Embedding.mean(dim=0) (fruit_nerf/fruit_field.py:220,257): [num_images, dim] -> [dim]. */
+int cn_embedding_mean(const float* embedding, int32_t num_images, int32_t dim, float* mean, cn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CROPNERF_HIP_H */

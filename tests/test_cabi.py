@@ -1,0 +1,94 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports exactly the symbols
+``include/cropnerf_hip.h`` declares (no compute calls here -- there is no GPU in this tier)."""
+
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+HEADER = ROOT / "include" / "cropnerf_hip.h"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import cropnerf_amd
+    from cropnerf_amd import _lib
+
+    if not _lib.LIB_PATH.exists():
+        cropnerf_amd.build_library()
+    return _lib.load()
+
+
+def _declared():
+    text = HEADER.read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_surface():
+    names = _declared()
+    for must in ("cn_raygen_pinhole", "cn_intersect_aabb", "cn_raygen_ortho", "cn_sample_spaced", "cn_sample_pdf",
+                 "cn_proposal_density", "cn_field_eval", "cn_composite", "cn_render_rays", "cn_render_samples",
+                 "cn_proposal_sample", "cn_export_compact", "cn_pointcloud_compact", "cn_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for name in _declared():
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+
+
+def test_binding_covers_every_declared_symbol(lib):
+    from cropnerf_amd import _lib
+
+    assert sorted(_lib.SIGNATURES) == _declared()
+
+
+def test_struct_layout_matches_header():
+    """sizeof of the by-pointer structs as the C compiler sees them == the ctypes mirrors."""
+    import subprocess
+    import tempfile
+
+    from cropnerf_amd import _lib
+
+    src = f'#include "{HEADER}"\n#include <stdio.h>\nint main(){{printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(cn_grid),' \
+          " sizeof(cn_mlp), sizeof(cn_field_params), sizeof(cn_density_params), sizeof(cn_scene), sizeof(cn_render_opts));}\n"
+    with tempfile.TemporaryDirectory() as d:
+        c = Path(d) / "s.c"
+        c.write_text(src)
+        subprocess.run(["gcc", str(c), "-o", str(Path(d) / "s")], check=True)
+        out = subprocess.run([str(Path(d) / "s")], check=True, capture_output=True, text=True).stdout.split()
+    sizes = [ctypes.sizeof(x) for x in (_lib.Grid, _lib.Mlp, _lib.FieldParams, _lib.DensityParams, _lib.Scene,
+                                        _lib.RenderOpts)]
+    assert [int(v) for v in out] == sizes
+
+
+def test_error_path_without_gpu(lib):
+    """Argument validation happens on the host before any HIP call: a null pointer is CN_ERR_INVALID + message."""
+    rc = lib.cn_intersect_aabb(None, None, None, 4, None, None, None)
+    assert rc == -1
+    assert b"cn_intersect_aabb" in lib.cn_last_error()
+    assert lib.cn_version() >= 100
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+
+    from cropnerf_amd import ops
+
+    with pytest.raises((RuntimeError, TypeError)):
+        ops.intersect_aabb(torch.zeros(4, 3), torch.ones(4, 3), [0, 0, 0, 1, 1, 1])
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from cropnerf_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("CROPNERF_HIP_LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(FileNotFoundError, match="no CPU or PyTorch fallback"):
+        _lib.load()
+    monkeypatch.delenv("CROPNERF_HIP_LIB")
+    monkeypatch.setattr(_lib, "_lib", None)
+    _lib.load()

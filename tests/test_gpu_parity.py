@@ -1,0 +1,462 @@
+"""GPU parity tests: every HIP entry point, called through the C ABI, against the CPU oracle on the same seeded
+inputs.  Stated fp32 tolerance for the field / renderer: rtol 2e-4, atol 2e-5 (fp32 accumulation-order and
+exp/sigmoid differences; the MLPs run on exact-fp32 MFMA chains).  Index-like outputs (median depth, labels)
+may flip on exact ties and are checked on >= 99.5 % of the rays.
+"""
+
+import math
+
+import pytest
+import torch
+
+from _helpers import assert_close, dev_params, make_scene, oracle_model, product_specs, rays_with_box, to_dev
+from oracle import field as OF
+from oracle import model as OM
+from oracle import rays as ORY
+from oracle import render as ORD
+from oracle import samplers as OSM
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 2e-4, 2e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    from cropnerf_amd import ops as _ops
+
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def scene():
+    return make_scene(seed=0)
+
+
+@pytest.fixture(scope="module")
+def handles(scene, ops):
+    fspec, pspecs = product_specs(scene)
+    dp = dev_params(scene)
+    fh = ops.FieldHandle(dp, fspec)
+    dh = [ops.DensityHandle(dp, i, ps) for i, ps in enumerate(pspecs)]
+    return dp, fh, dh
+
+
+# ------------------------------------------------------------------------------------------------ ray generation
+def test_raygen_pinhole_indices_and_image(scene, ops):
+    g = torch.Generator().manual_seed(1)
+    R = 777
+    idx = torch.stack([torch.randint(0, scene.c2w.shape[0], (R,), generator=g),
+                       torch.randint(0, scene.height, (R,), generator=g),
+                       torch.randint(0, scene.width, (R,), generator=g)], -1)
+    ref = ORY.pinhole_rays(scene.c2w, scene.intr, idx[:, 0], idx[:, 1], idx[:, 2])
+    out = ops.raygen_pinhole(to_dev(scene.c2w), to_dev(scene.intr), ray_indices=to_dev(idx))
+    assert_close(out["origins"], ref.origins, 0, 1e-7, "origins")
+    assert_close(out["directions"], ref.directions, 1e-6, 1e-6, "directions")
+    assert_close(out["pixel_area"], ref.pixel_area, 2e-3, 1e-12, "pixel_area")
+    assert torch.equal(out["camera_indices"].cpu(), ref.camera_indices)
+    assert_close(out["directions_norm"], ref.directions_norm, 1e-6, 0, "directions_norm")
+    # full image slice, camera index forced to 0 like fruit_nerf.py:283
+    ref = ORY.image_rays(scene.c2w, scene.intr, 3, scene.height, scene.width, start=100, end=1300, camera_index_value=0)
+    out = ops.raygen_pinhole(to_dev(scene.c2w), to_dev(scene.intr), cam=3, height=scene.height, width=scene.width,
+                             pixel_start=100, num_rays=1200, camera_index_value=0)
+    assert_close(out["directions"], ref.directions, 1e-6, 1e-6, "image directions")
+    assert int(out["camera_indices"].abs().sum()) == 0
+
+
+def test_raygen_empty_and_bad_args(scene, ops):
+    from cropnerf_amd._lib import CropNerfHipError
+
+    out = ops.raygen_pinhole(to_dev(scene.c2w), to_dev(scene.intr), cam=0, height=4, width=4, pixel_start=16, num_rays=0)
+    assert out["origins"].shape == (0, 3)
+    with pytest.raises(CropNerfHipError):
+        ops.raygen_pinhole(to_dev(scene.c2w), to_dev(scene.intr), cam=0, height=4, width=4, pixel_start=10, num_rays=10)
+
+
+def test_intersect_aabb(scene, ops):
+    rb = ORY.image_rays(scene.c2w, scene.intr, 1, scene.height, scene.width)
+    for box in ([-1, -1, -1, 1, 1, 1], [-0.2, -0.1, -0.3, 0.1, 0.2, 0.0], [3, 3, 3, 4, 4, 4]):
+        tmin, tmax = ORY.intersect_aabb(rb.origins, rb.directions, torch.tensor(box, dtype=torch.float32))
+        n, f = ops.intersect_aabb(to_dev(rb.origins), to_dev(rb.directions), box)
+        assert_close(n[:, 0], tmin, 1e-6, 1e-6, "nears")
+        assert_close(f[:, 0], tmax, 1e-6, 1e-6, "fars")
+
+
+def test_ortho_rays_and_surface_grid(ops):
+    aabb = torch.tensor([[-1.0, -1.0, -0.682], [1.0, 1.0, 1.318]])
+    pts, plane = ORY.surface_points(ORY.corners_of_aabb(aabb), 37)
+    dpts = ops.surface_grid(-1.0, 1.0, 37, -1.0, 1.0, 37, -0.682, "cuda")
+    assert_close(dpts, pts, 0, 1e-7, "surface grid")
+    ref = ORY.ortho_rays(pts, plane, batch=512, count=2)
+    out = ops.raygen_ortho(dpts, plane[0].tolist(), 512, len(ref))
+    for k in ("origins", "directions", "nears", "fars", "pixel_area"):
+        assert_close(out[k], getattr(ref, k), 1e-6, 1e-7, k)
+
+
+def test_pose_adjustment(scene, ops):
+    rb = ORY.image_rays(scene.c2w, scene.intr, 2, scene.height, scene.width)
+    g = torch.Generator().manual_seed(5)
+    rb.camera_indices = torch.randint(0, scene.c2w.shape[0], (len(rb), 1), generator=g)
+    adj = (torch.rand(scene.c2w.shape[0], 6, generator=g) - 0.5) * 0.3
+    ref = ORY.apply_pose_adjustment(rb, adj)
+    o, d = to_dev(rb.origins).clone(), to_dev(rb.directions).clone()
+    ops.apply_pose_adjustment(to_dev(adj), to_dev(rb.camera_indices[:, 0]), o, d)
+    assert_close(o, ref.origins, 1e-6, 1e-7, "origins")
+    assert_close(d, ref.directions, 1e-5, 1e-6, "directions")
+
+
+def test_embedding_mean(scene, ops):
+    emb = scene.params["field.embedding_appearance.embedding.weight"]
+    assert_close(ops.embedding_mean(to_dev(emb)), emb.mean(0), 1e-5, 1e-6, "embedding mean")
+
+
+# ------------------------------------------------------------------------------------------------ samplers
+@pytest.mark.parametrize("spacing", ["uniform", "piecewise"])
+@pytest.mark.parametrize("jitter", [None, "single", "full"])
+def test_sample_spaced(scene, ops, spacing, jitter):
+    from cropnerf_amd import _lib as L
+
+    rb = rays_with_box(scene, 0, 300)
+    rb.nears = rb.nears + 0.05
+    S = 50
+    g = torch.Generator().manual_seed(2)
+    t_rand = None if jitter is None else torch.rand(len(rb), 1 if jitter == "single" else S + 1, generator=g)
+    ref = OSM.spaced_sampler(rb, S, spacing, t_rand=t_rand)
+    out = ops.sample_spaced(to_dev(rb.nears), to_dev(rb.fars), S,
+                            L.SPACING_UNIFORM if spacing == "uniform" else L.SPACING_PIECEWISE, to_dev(t_rand))
+    assert_close(out["starts"], ref.starts[..., 0], 2e-6, 1e-6, "starts")
+    assert_close(out["ends"], ref.ends[..., 0], 2e-6, 1e-6, "ends")
+    assert_close(out["spacing_starts"], ref.spacing_starts[..., 0].expand(len(rb), S), 1e-6, 1e-7, "spacing_starts")
+    assert_close(out["spacing_ends"], ref.spacing_ends[..., 0].expand(len(rb), S), 1e-6, 1e-7, "spacing_ends")
+
+
+@pytest.mark.parametrize("anneal", [1.0, 0.35])
+@pytest.mark.parametrize("train", [False, True])
+def test_sample_pdf(scene, ops, anneal, train):
+    rb = rays_with_box(scene, 0, 257)
+    rb.nears = rb.nears + 0.05
+    S_in, S_out = 96, 48
+    prev = OSM.spaced_sampler(rb, S_in, "piecewise")
+    g = torch.Generator().manual_seed(3)
+    w = torch.rand(len(rb), S_in, 1, generator=g) ** 4
+    w[5] = 0.0  # all-zero weights: the eps padding branch
+    w[6, :] = 0.0
+    w[6, 17] = 1.0  # one-hot
+    u_rand = torch.rand(len(rb), 1, generator=g) if train else None
+    ref = OSM.pdf_sampler(prev, torch.pow(w, anneal), S_out, u_rand=u_rand)
+    prev_bins = torch.cat([prev.spacing_starts[..., 0], prev.spacing_ends[:, -1:, 0]], -1).expand(len(rb), S_in + 1)
+    sp, eu = ops.sample_pdf(to_dev(prev_bins.contiguous()), to_dev(w[..., 0]), to_dev(rb.nears), to_dev(rb.fars), S_out,
+                            anneal=anneal, u_rand=to_dev(u_rand))
+    ref_sp = torch.cat([ref.spacing_starts[..., 0], ref.spacing_ends[:, -1:, 0]], -1)
+    ref_eu = torch.cat([ref.starts[..., 0], ref.ends[:, -1:, 0]], -1)
+    assert_close(sp, ref_sp, 1e-4, 2e-6, "spacing bins")
+    assert_close(eu, ref_eu, 2e-4, 2e-6, "euclidean bins")
+
+
+# ------------------------------------------------------------------------------------------------ field
+@pytest.mark.parametrize("contraction", [True, False])
+def test_proposal_density(scene, ops, handles, contraction):
+    dp, fh, dh = handles
+    rb = rays_with_box(scene, 1, 200)
+    rs = OSM.spaced_sampler(rb, 40, "uniform")
+    sc = ops.scene_struct(scene.aabb, contraction)
+    for lvl in range(2):
+        ref = OF.proposal_density(rs.positions(), scene.params, lvl, scene.pspecs[lvl], scene.aabb, contraction)
+        out = ops.proposal_density(dh[lvl], sc, to_dev(rb.origins), to_dev(rb.directions), to_dev(rs.starts[..., 0]),
+                                   to_dev(rs.ends[..., 0]))
+        assert_close(out, ref[..., 0], RTOL, ATOL, f"proposal density {lvl}")
+
+
+@pytest.mark.parametrize("contraction,mode", [(True, "test"), (False, "inference"), (True, "train_app")])
+def test_field_eval_general_kernel(scene, ops, handles, contraction, mode):
+    from cropnerf_amd import _lib as L
+
+    dp, fh, dh = handles
+    rb = rays_with_box(scene, 2, 150)
+    g = torch.Generator().manual_seed(7)
+    rb.camera_indices = torch.randint(0, scene.c2w.shape[0], (len(rb), 1), generator=g)
+    rs = OSM.spaced_sampler(rb, 33, "uniform")
+    training = mode == "train_app"
+    ref = OF.field_forward(rs.positions(), rb.directions, rb.camera_indices, scene.params, scene.fspec, scene.aabb,
+                           contraction, "inference" if mode == "inference" else "test", training=training)
+    sc = ops.scene_struct(scene.aabb, contraction)
+    out = ops.field_eval(fh, sc, to_dev(rb.origins), to_dev(rb.directions), to_dev(rb.camera_indices[:, 0]),
+                         to_dev(rs.starts[..., 0]), to_dev(rs.ends[..., 0]),
+                         app_mode=L.APP_PER_CAMERA if training else L.APP_MEAN, want_positions=True)
+    assert_close(out["positions"], rs.positions(), 1e-6, 1e-6, "positions")
+    assert_close(out["density"], ref["density"][..., 0], RTOL, ATOL, "density")
+    assert_close(out["semantics"], ref["semantics"][..., 0], RTOL, ATOL, "semantics")
+    assert_close(out["rgb"], ref["rgb"], RTOL, ATOL, "rgb")
+
+
+# ------------------------------------------------------------------------------------------------ compositing
+def _depth_match(dev_depth, ref_depth, frac=0.995):
+    ok = (dev_depth.cpu() - ref_depth).abs() <= 1e-5 + 1e-5 * ref_depth.abs()
+    assert ok.float().mean().item() >= frac, f"median depth agrees on {ok.float().mean().item():.4f} of rays"
+
+
+@pytest.mark.parametrize("S", [48, 64, 192, 333])
+def test_composite(ops, S):
+    from cropnerf_amd import _lib as L
+
+    g = torch.Generator().manual_seed(S)
+    R = 500
+    nears = torch.rand(R, 1, generator=g)
+    rb = ORY.RayBundle(torch.zeros(R, 3), torch.zeros(R, 3), torch.zeros(R, 1), None, nears, nears + 1 + torch.rand(R, 1, generator=g))
+    rs = OSM.spaced_sampler(rb, S, "uniform")
+    den = torch.rand(R, S, 1, generator=g) ** 3 * 40
+    den[::7] *= 0.01  # rays that never reach 0.5 accumulated weight
+    rgb = torch.rand(R, S, 3, generator=g)
+    sem = torch.randn(R, S, 1, generator=g) * 4
+    w = OSM.get_weights(rs.deltas, den)
+    for bg_mode, bg in ((L.BG_LAST_SAMPLE, (0, 0, 0)), (L.BG_COLOR, (0.0, 0.0, 0.0)), (L.BG_COLOR, (0.2, 0.5, 1.0))):
+        ref_rgb = ORD.render_rgb(rgb, w, "last_sample" if bg_mode == L.BG_LAST_SAMPLE else torch.tensor(bg, dtype=torch.float32))
+        out = ops.composite(to_dev(rs.starts[..., 0]), to_dev(rs.ends[..., 0]), to_dev(den[..., 0]), to_dev(rgb),
+                            to_dev(sem[..., 0]), bg_mode=bg_mode, bg_color=bg, want_weights=True)
+        assert_close(out["rgb"], ref_rgb, RTOL, ATOL, "rgb")
+    assert_close(out["weights"], w[..., 0], RTOL, 1e-7, "weights")
+    assert_close(out["accumulation"], ORD.render_accumulation(w), RTOL, ATOL, "accumulation")
+    ref_sem = ORD.render_semantics(sem, w)
+    assert_close(out["semantics"], ref_sem, RTOL, 5e-5, "semantics")
+    _depth_match(out["depth"], ORD.render_depth_median(w, rs.starts, rs.ends))
+    cm = ORD.semantics_colormap(ref_sem)
+    far_from_tie = (ref_sem[:, 0] - math.log(9.0)).abs() > 1e-3
+    assert torch.equal(out["semantics_colormap"].cpu()[far_from_tie], cm[far_from_tie])
+
+
+def test_composite_homogeneous_known_answer(ops):
+    S, near, far, sigma = 192, 0.5, 2.5, 3.0
+    R = 8
+    rb = ORY.RayBundle(torch.zeros(R, 3), torch.zeros(R, 3), torch.zeros(R, 1), None, torch.full((R, 1), near), torch.full((R, 1), far))
+    rs = OSM.spaced_sampler(rb, S, "uniform")
+    out = ops.composite(to_dev(rs.starts[..., 0]), to_dev(rs.ends[..., 0]), torch.full((R, S), sigma, device="cuda"))
+    assert abs(out["accumulation"][0, 0].item() - (1 - math.exp(-sigma * (far - near)))) < 1e-5
+    delta = (far - near) / S
+    k = math.ceil(math.log(2) / (sigma * delta)) - 1
+    assert abs(out["depth"][0, 0].item() - (near + (k + 0.5) * delta)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ fused renderer
+def _fused_vs_oracle(scene, ops, handles, S, contraction, n_rays, cam, bg_override=None, density_only=False):
+    from cropnerf_amd import _lib as L
+
+    dp, fh, dh = handles
+    rb = rays_with_box(scene, cam, n_rays)
+    m = oracle_model(scene, "inference", disable_scene_contraction=not contraction)
+    m.uniform_samples = S  # uniform sampler, contraction as configured
+    if bg_override is not None:
+        m.background_override = torch.tensor(bg_override, dtype=torch.float32)
+    ref = m.forward(rb)
+    sc = ops.scene_struct(scene.aabb, contraction)
+    opts = ops.render_opts(S, bg_mode=L.BG_COLOR if bg_override is not None else L.BG_LAST_SAMPLE,
+                           bg_color=bg_override or (0, 0, 0), density_only=density_only)
+    out = ops.render_rays(fh, sc, opts, to_dev(rb.origins), to_dev(rb.directions), to_dev(rb.nears), to_dev(rb.fars),
+                          want_weights=True)
+    return ref, out
+
+
+@pytest.mark.parametrize("S,contraction", [(192, False), (64, True), (48, True), (100, False), (333, False)])
+def test_render_rays_uniform(scene, ops, handles, S, contraction):
+    ref, out = _fused_vs_oracle(scene, ops, handles, S, contraction, 600, 0)
+    assert_close(out["weights"], ref["_weights"][..., 0], RTOL, 1e-6, "weights")
+    assert_close(out["accumulation"], ref["accumulation"], RTOL, ATOL, "accumulation")
+    assert_close(out["rgb"], ref["rgb"], RTOL, ATOL, "rgb")
+    assert_close(out["semantics"], ref["semantics"], RTOL, 5e-5, "semantics")
+    _depth_match(out["depth"], ref["depth"])
+
+
+def test_render_rays_black_background_and_density_only(scene, ops, handles):
+    ref, out = _fused_vs_oracle(scene, ops, handles, 96, True, 300, 3, bg_override=(0.0, 0.0, 0.0))
+    assert_close(out["rgb"], ref["rgb"], RTOL, ATOL, "rgb (black bg)")
+    ref, out = _fused_vs_oracle(scene, ops, handles, 96, True, 300, 3, density_only=True)
+    assert_close(out["accumulation"], ref["accumulation"], RTOL, ATOL, "accumulation (density only)")
+    assert "rgb" not in out
+
+
+def test_render_samples_matches_general_kernel_and_oracle(scene, ops, handles):
+    """Export-mode forward (fruit_nerf.py:476-494): per-sample outputs of the fused kernel vs the oracle AND the
+    shape-generic HIP kernel (two independent device implementations)."""
+    dp, fh, dh = handles
+    aabb = torch.tensor([[-1.0, -1.0, -0.682], [1.0, 1.0, 1.318]])
+    pts, plane = ORY.surface_points(ORY.corners_of_aabb(aabb), 12)
+    rb = ORY.ortho_rays(pts, plane, 100, 1)
+    S = 150
+    m = oracle_model(scene, "export")
+    m.setup_inference(True, S)
+    ref = m.forward(rb)
+    sc = ops.scene_struct(scene.aabb, False)
+    opts = ops.render_opts(S)
+    o, d, n, f = (to_dev(x) for x in (rb.origins, rb.directions, rb.nears, rb.fars))
+    out = ops.render_samples(fh, sc, opts, o, d, n, f)
+    assert_close(out["positions"], ref["point_location"], 1e-6, 1e-6, "positions")
+    assert_close(out["density"], ref["density"], RTOL, ATOL, "density")
+    assert_close(out["semantics"], ref["semantics"], RTOL, ATOL, "semantics")
+    assert_close(out["rgb"], ref["rgb"], RTOL, ATOL, "rgb")
+    sm = ops.sample_spaced(n, f, S)
+    gen = ops.field_eval(fh, sc, o, d, None, sm["starts"], sm["ends"])
+    assert_close(out["density"], gen["density"].cpu(), RTOL, ATOL, "fused vs general: density")
+    assert_close(out["rgb"], gen["rgb"].cpu(), RTOL, ATOL, "fused vs general: rgb")
+    assert_close(out["semantics"], gen["semantics"].cpu(), RTOL, ATOL, "fused vs general: semantics")
+
+
+def test_render_rays_per_camera_appearance(scene, ops, handles):
+    """Training-style appearance (embedding[camera_idx], fruit_field.py:251-252) through the fused kernel."""
+    from cropnerf_amd import _lib as L
+
+    dp, fh, dh = handles
+    rb = rays_with_box(scene, 4, 256)
+    g = torch.Generator().manual_seed(11)
+    rb.camera_indices = torch.randint(0, scene.c2w.shape[0], (len(rb), 1), generator=g)
+    S = 64
+    rs = OSM.spaced_sampler(rb, S, "uniform")
+    fo = OF.field_forward(rs.positions(), rb.directions, rb.camera_indices, scene.params, scene.fspec, scene.aabb,
+                          True, "test", training=True)
+    w = OSM.get_weights(rs.deltas, fo["density"])
+    ref_rgb = ORD.render_rgb(fo["rgb"], w, "last_sample")
+    sc = ops.scene_struct(scene.aabb, True)
+    opts = ops.render_opts(S, app_mode=L.APP_PER_CAMERA)
+    out = ops.render_rays(fh, sc, opts, to_dev(rb.origins), to_dev(rb.directions), to_dev(rb.nears), to_dev(rb.fars),
+                          camera_indices=to_dev(rb.camera_indices[:, 0]))
+    assert_close(out["rgb"], ref_rgb, RTOL, ATOL, "rgb per-camera appearance")
+    from cropnerf_amd._lib import CropNerfHipError
+
+    with pytest.raises(CropNerfHipError, match="Camera indices are not provided"):
+        ops.render_rays(fh, sc, opts, to_dev(rb.origins), to_dev(rb.directions), to_dev(rb.nears), to_dev(rb.fars))
+
+
+# ------------------------------------------------------------------------------------------------ proposal path
+def test_proposal_sample_and_full_forward(scene, ops, handles):
+    """get_outputs in eval (fruit_nerf.py:543-599): pose tweak -> proposal sampler (256, 96) -> 48 field samples."""
+    from cropnerf_amd import _lib as L
+
+    dp, fh, dh = handles
+    rb = ORY.image_rays(scene.c2w, scene.intr, 5, scene.height, scene.width).slice(0, 500)
+    m = oracle_model(scene, "test")
+    ref = m.forward(rb)
+    o, d = to_dev(rb.origins).clone(), to_dev(rb.directions).clone()
+    ops.apply_pose_adjustment(dp["camera_optimizer.pose_adjustment"], to_dev(rb.camera_indices[:, 0]), o, d)
+    R = len(rb)
+    nears = torch.zeros(R, 1, device="cuda")
+    fars = torch.full((R, 1), 1000.0, device="cuda")
+    sc = ops.scene_struct(scene.aabb, True)
+    ps = ops.proposal_sample(dh, sc, o, d, nears, fars, (256, 96), 48)
+    ref_bins = torch.cat([ref["_starts"][..., 0], ref["_ends"][:, -1:, 0]], -1)
+    # bins are a piecewise-linear inverse-cdf of fp32 weights; far-field bins are huge numbers in metric space
+    assert_close(ps["euclidean_bins"], ref_bins, 2e-3, 1e-4, "final euclidean bins", frac_ok=0.999)
+    _depth_match(ps["prop_depth"][0][:, None], ref["prop_depth_0"], 0.99)
+    _depth_match(ps["prop_depth"][1][:, None], ref["prop_depth_1"], 0.99)
+    opts = ops.render_opts(48)
+    out = ops.render_rays(fh, sc, opts, o, d, nears, fars, camera_indices=to_dev(rb.camera_indices[:, 0]),
+                          bins=ps["euclidean_bins"])
+    # end to end (sampler differences feed through): rendered values to 1e-3
+    assert_close(out["rgb"], ref["rgb"], 2e-3, 2e-3, "rgb (proposal path)", frac_ok=0.995)
+    assert_close(out["accumulation"], ref["accumulation"], 2e-3, 2e-3, "accumulation (proposal path)", frac_ok=0.995)
+    # and exactly, given the oracle's own bins
+    out2 = ops.render_rays(fh, sc, opts, o, d, nears, fars, bins=to_dev(ref_bins), want_weights=True)
+    assert_close(out2["weights"], ref["_weights"][..., 0], RTOL, 1e-6, "weights (oracle bins)")
+    assert_close(out2["rgb"], ref["rgb"], RTOL, ATOL, "rgb (oracle bins)")
+    assert_close(out2["semantics"], ref["semantics"], RTOL, 5e-5, "semantics (oracle bins)")
+
+
+def test_unfused_proposal_chain_matches_fused(scene, ops, handles):
+    """cn_sample_spaced + cn_proposal_density + cn_composite + cn_sample_pdf composed == cn_proposal_sample."""
+    from cropnerf_amd import _lib as L
+
+    dp, fh, dh = handles
+    rb = rays_with_box(scene, 1, 200)
+    o, d, n, f = (to_dev(x) for x in (rb.origins, rb.directions, rb.nears + 0.01, rb.fars))
+    sc = ops.scene_struct(scene.aabb, True)
+    fused = ops.proposal_sample(dh, sc, o, d, n, f, (128, 64), 32)
+    sm = ops.sample_spaced(n, f, 128, L.SPACING_PIECEWISE)
+    bins = torch.cat([sm["spacing_starts"], sm["spacing_ends"][:, -1:]], -1).contiguous()
+    starts, ends = sm["starts"], sm["ends"]
+    for lvl, s_next in ((0, 64), (1, 32)):
+        den = ops.proposal_density(dh[lvl], sc, o, d, starts, ends)
+        w = ops.composite(starts, ends, den, want_weights=True)["weights"]
+        bins, eu = ops.sample_pdf(bins, w, n, f, s_next)
+        starts, ends = eu[:, :-1].contiguous(), eu[:, 1:].contiguous()
+    assert_close(eu, fused["euclidean_bins"].cpu(), 1e-5, 1e-6, "fused vs composed bins")
+
+
+# ------------------------------------------------------------------------------------------------ exporters
+def test_export_compact_sets(scene, ops):
+    g = torch.Generator().manual_seed(21)
+    N = 100_003
+    out = {
+        "point_location": torch.rand(N, 3, generator=g),
+        "semantics": torch.randn(N, generator=g) * 3 + 1,
+        "density": torch.rand(N, generator=g) * 140,
+        "rgb": torch.rand(N, 3, generator=g),
+    }
+    out["semantics"][:3] = 3.0
+    out["density"][:3] = 70.0  # inclusive thresholds (exporter_utils.py:111-112)
+    out["semantics_colormap"] = torch.heaviside(torch.sigmoid(out["semantics"]) - 0.9, torch.tensor(0.0)).long()
+    ref = OM.sample_volume_masks(out)
+    pts, cols, counts = ops.export_compact(to_dev(out["point_location"]), to_dev(out["rgb"]), to_dev(out["semantics"]),
+                                           to_dev(out["density"]), capacity=N)
+    counts = counts.cpu().tolist()
+    for k, name in enumerate(("semantic_colormap", "semantic", "density")):
+        assert counts[k] == ref[name]["points"].shape[0], name
+        got = torch.cat([pts[k][: counts[k]].cpu(), cols[k][: counts[k]].cpu()], -1)
+        exp = torch.cat([ref[name]["points"], ref[name]["colors"]], -1)
+        got = got[torch.argsort(got[:, 0])]
+        exp = exp[torch.argsort(exp[:, 0])]
+        assert_close(got, exp, 1e-5, 1e-6, name)
+    # capacity overflow is counted, not written
+    pts, cols, counts2 = ops.export_compact(to_dev(out["point_location"]), to_dev(out["rgb"]), to_dev(out["semantics"]),
+                                            to_dev(out["density"]), capacity=10)
+    assert counts2.cpu().tolist() == counts
+
+
+def test_pointcloud_compact(scene, ops):
+    g = torch.Generator().manual_seed(22)
+    R = 5000
+    o, d = torch.rand(R, 3, generator=g), torch.randn(R, 3, generator=g)
+    rb = ORY.RayBundle(o, d, torch.zeros(R, 1))
+    outputs = {"depth": torch.rand(R, 1, generator=g), "rgb": torch.rand(R, 3, generator=g),
+               "semantics_colormap": (torch.rand(R, 1, generator=g) > 0.7).float().repeat(1, 3)}
+    rp, rc, rd = OM.pointcloud_from_outputs(rb, outputs)
+    pts, cols, dirs, count = ops.pointcloud_compact(to_dev(o), to_dev(d), to_dev(outputs["depth"]), to_dev(outputs["rgb"]),
+                                                    to_dev(outputs["semantics_colormap"]), capacity=R)
+    n = int(count.item())
+    assert n == rp.shape[0]
+    got = torch.cat([pts[:n], cols[:n], dirs[:n]], -1).cpu()
+    exp = torch.cat([rp, rc, rd], -1)
+    assert_close(got[torch.argsort(got[:, 0])], exp[torch.argsort(exp[:, 0])], 1e-6, 1e-6, "pointcloud rows")
+
+
+# ------------------------------------------------------------------------------------------------ full size
+def test_full_size_chunk_properties(ops):
+    """BASELINE config C2 chunk (65 536 rays x 192 samples): size-independent properties instead of the oracle."""
+    sc_ = make_scene(seed=3, height=800, width=800, focal=1111.1, num_images=4)
+    fspec, pspecs = product_specs(sc_)
+    dp = dev_params(sc_)
+    fh = ops.FieldHandle(dp, fspec)
+    R, S = 65536, 192
+    rays = ops.raygen_pinhole(to_dev(sc_.c2w), to_dev(sc_.intr), cam=1, height=800, width=800, pixel_start=800 * 300,
+                              num_rays=R)
+    n, f = ops.intersect_aabb(rays["origins"], rays["directions"], [-1, -1, -1, 1, 1, 1])
+    sc = ops.scene_struct(sc_.aabb, False)
+    opts = ops.render_opts(S)
+    out = ops.render_rays(fh, sc, opts, rays["origins"], rays["directions"], n, f, want_weights=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out["rgb"]).all() and out["rgb"].min() >= 0 and out["rgb"].max() <= 1
+    assert out["accumulation"].min() >= 0 and out["accumulation"].max() <= 1 + 1e-5
+    assert_close(out["weights"].sum(-1, keepdim=True), out["accumulation"].cpu(), 1e-5, 1e-6, "sum w == acc")
+    assert (out["depth"] >= n - 1e-6).all() and (out["depth"] <= f + 1e-6).all()
+    # chunk invariance: any sub-range rendered alone gives bit-identical rows
+    lo, hi = 12345, 23456
+    sub = ops.render_rays(fh, sc, opts, rays["origins"][lo:hi].contiguous(), rays["directions"][lo:hi].contiguous(),
+                          n[lo:hi].contiguous(), f[lo:hi].contiguous())
+    assert torch.equal(sub["rgb"], out["rgb"][lo:hi])
+    assert torch.equal(sub["semantics"], out["semantics"][lo:hi])
+    # and a spot check of 256 rays against the oracle
+    idx = torch.arange(0, R, R // 256)[:256]
+    rb = ORY.RayBundle(rays["origins"].cpu()[idx], rays["directions"].cpu()[idx], torch.zeros(256, 1), None,
+                       n.cpu()[idx], f.cpu()[idx])
+    m = oracle_model(sc_, "inference", disable_scene_contraction=True)
+    m.uniform_samples = S
+    ref = m.forward(rb)
+    assert_close(out["rgb"][idx.cuda()], ref["rgb"], RTOL, ATOL, "rgb spot check")
+    assert_close(out["accumulation"][idx.cuda()], ref["accumulation"], RTOL, ATOL, "acc spot check")
