@@ -39,23 +39,36 @@ __device__ __forceinline__ float wave_read(float v, int src_lane) {
 
 __device__ __forceinline__ float wave_sum(float v) { return wave_read(wave_inclusive_scan(v), 63); }
 
-// sum over lanes {l, l^16, l^32, l^48}: v_permlane16_swap / v_permlane32_swap put the partner row / half beside
-// the own one (gfx950), one add each.
+// v_permlane16_swap / v_permlane32_swap (gfx950) through inline asm: with hipcc (ROCm 7.2) the second result of
+// __builtin_amdgcn_permlaneN_swap comes back as the FIRST result's register (the .s shows `v_add v0, v0, v0` after
+// the swap), so a lo+hi sum silently becomes 2*lo.  The builtin pads the VALU-write -> swap-read hazard with
+// `s_nop 1`; inside asm that is ours to do.
+//   swap16: rows 1,3 of a <-> rows 0,2 of b      swap32: lanes 32..63 of a <-> lanes 0..31 of b
+__device__ __forceinline__ void permlane16_swap(unsigned& a, unsigned& b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void permlane32_swap(unsigned& a, unsigned& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
+// sum over lanes {l, l^16, l^32, l^48}
 __device__ __forceinline__ float rows_sum(float v) {
-  unsigned u = __builtin_bit_cast(unsigned, v);
-  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  float s = __builtin_bit_cast(float, a[0]) + __builtin_bit_cast(float, a[1]);
-  unsigned t = __builtin_bit_cast(unsigned, s);
-  auto b = __builtin_amdgcn_permlane32_swap(t, t, false, false);
-  return __builtin_bit_cast(float, b[0]) + __builtin_bit_cast(float, b[1]);
+  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+  permlane16_swap(a, b);  // a = {r0,r0,r2,r2}, b = {r1,r1,r3,r3}
+  float s = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+  a = __builtin_bit_cast(unsigned, s);
+  b = a;
+  permlane32_swap(a, b);  // a = {lo,lo}, b = {hi,hi}
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
 }
 
 // copy row 0 (lanes 0..15) of v into every row: lane (g, j) <- lane j
 __device__ __forceinline__ float row0_broadcast(float v) {
-  unsigned u = __builtin_bit_cast(unsigned, v);
-  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // a[0] = {r0, r0, r2, r2}
-  auto b = __builtin_amdgcn_permlane32_swap(a[0], a[0], false, false);  // b[0] = {lo, lo} = {r0, r0, r0, r0}
-  return __builtin_bit_cast(float, b[0]);
+  unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+  permlane16_swap(a, b);  // a = {r0, r0, r2, r2}
+  b = a;
+  permlane32_swap(a, b);  // a = {r0, r0, r0, r0}
+  return __builtin_bit_cast(float, a);
 }
 
 }  // namespace cn

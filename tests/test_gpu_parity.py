@@ -380,6 +380,13 @@ def test_unfused_proposal_chain_matches_fused(scene, ops, handles):
 
 
 # ------------------------------------------------------------------------------------------------ exporters
+def _sort_rows(t):
+    """Lexicographic row order on the three position columns (positions are copied bit-exactly)."""
+    for c in (2, 1, 0):
+        t = t[torch.sort(t[:, c], stable=True).indices]
+    return t
+
+
 def test_export_compact_sets(scene, ops):
     g = torch.Generator().manual_seed(21)
     N = 100_003
@@ -400,9 +407,7 @@ def test_export_compact_sets(scene, ops):
         assert counts[k] == ref[name]["points"].shape[0], name
         got = torch.cat([pts[k][: counts[k]].cpu(), cols[k][: counts[k]].cpu()], -1)
         exp = torch.cat([ref[name]["points"], ref[name]["colors"]], -1)
-        got = got[torch.argsort(got[:, 0])]
-        exp = exp[torch.argsort(exp[:, 0])]
-        assert_close(got, exp, 1e-5, 1e-6, name)
+        assert_close(_sort_rows(got), _sort_rows(exp), 1e-5, 1e-6, name)
     # capacity overflow is counted, not written
     pts, cols, counts2 = ops.export_compact(to_dev(out["point_location"]), to_dev(out["rgb"]), to_dev(out["semantics"]),
                                             to_dev(out["density"]), capacity=10)
@@ -423,7 +428,7 @@ def test_pointcloud_compact(scene, ops):
     assert n == rp.shape[0]
     got = torch.cat([pts[:n], cols[:n], dirs[:n]], -1).cpu()
     exp = torch.cat([rp, rc, rd], -1)
-    assert_close(got[torch.argsort(got[:, 0])], exp[torch.argsort(exp[:, 0])], 1e-6, 1e-6, "pointcloud rows")
+    assert_close(_sort_rows(got), _sort_rows(exp), 1e-6, 1e-6, "pointcloud rows")
 
 
 # ------------------------------------------------------------------------------------------------ full size
