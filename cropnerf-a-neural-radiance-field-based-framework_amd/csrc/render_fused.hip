@@ -50,11 +50,21 @@ struct PrepArgs {
   const float *wh, *bh;                  // semantic head
   const float *wc0, *bc0, *wc1, *bc1, *wc2, *bc2;  // colour
   const float* emb;
+  const float* emb_mean;  // [32] (workspace), valid when app_mode == CN_APP_MEAN
   int num_images;
   int app_mode;
   int app_rows;
   float scale[CN_MAX_LEVELS];
 };
+
+// Embedding.mean(dim=0): one thread per column, independent loads
+__global__ void __launch_bounds__(64) prep_mean_kernel(const float* __restrict__ emb, int n, float* __restrict__ mean) {
+  const int k = threadIdx.x;
+  if (k >= 32) return;
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) s += emb[i * 32 + k];
+  mean[k] = s / (float)n;
+}
 
 __global__ void __launch_bounds__(256) prep_kernel(PrepArgs p, float* __restrict__ blob, float* __restrict__ app_bias) {
   const int total = BLOB_FLOATS + p.app_rows * 64;
@@ -121,17 +131,8 @@ __global__ void __launch_bounds__(256) prep_kernel(PrepArgs p, float* __restrict
       int row = q >> 6, n = q & 63;
       v = p.bc0[n];
       if (p.app_mode != CN_APP_ZEROS) {
-        for (int k = 0; k < 32; ++k) {
-          float a;
-          if (p.app_mode == CN_APP_PER_CAMERA) {
-            a = p.emb[row * 32 + k];
-          } else {
-            float s = 0.f;
-            for (int im = 0; im < p.num_images; ++im) s += p.emb[im * 32 + k];
-            a = s / (float)p.num_images;
-          }
-          v = fmaf(p.wc0[n * 63 + 31 + k], a, v);
-        }
+        const float* a = p.app_mode == CN_APP_PER_CAMERA ? p.emb + row * 32 : p.emb_mean;
+        for (int k = 0; k < 32; ++k) v = fmaf(p.wc0[n * 63 + 31 + k], a[k], v);
       }
       app_bias[q] = v;
       continue;
@@ -191,7 +192,7 @@ __device__ __forceinline__ float pick4(int g, float a, float b, float c, float d
 }
 
 template <bool PER_SAMPLE, bool DENSITY_ONLY>
-__global__ void __launch_bounds__(256, 2) render_fused_kernel(FusedArgs A) {
+__global__ void __launch_bounds__(256, 3) render_fused_kernel(FusedArgs A) {
   __shared__ __align__(16) float lds[BLOB_FLOATS + 4 * WAVE_SCRATCH];
   {
     const float4* src = reinterpret_cast<const float4*>(A.blob);
@@ -227,7 +228,6 @@ __global__ void __launch_bounds__(256, 2) render_fused_kernel(FusedArgs A) {
     };
 
     // ---- per-ray colour bias: bc0 + Wc0[:, sh].SH(d) + Wc0[:, app].app  (lane n = neuron n) ------------------
-    f32x4 cbias[4];
     if (!DENSITY_ONLY) {
       float sx = dx, sy = dy, sz = dz;
       if (!A.sh_unit) {
@@ -252,15 +252,12 @@ __global__ void __launch_bounds__(256, 2) render_fused_kernel(FusedArgs A) {
       scratch[lane] = bias;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) cbias[mt] = *reinterpret_cast<const f32x4*>(scratch + 16 * mt + 4 * g);
     }
 
     CompositeState st;
-    const f32x4 lvl_scale = *reinterpret_cast<const f32x4*>(lds + OFF_SCALE + 4 * g);
     for (int c0 = 0; c0 < S; c0 += 64) {
       // ---- bin edges of the chunk: lane l owns edge c0+l, edge c0+64 is wave-uniform; staged in LDS so that the
-      //      gather lanes (sample 16c+j) and the compositing lanes (sample l) read the same values -------------
+      //      gather lanes (sample 32h+16c+j) and the compositing lanes (sample l) read the same values ----------
       const float e_lo = edge(c0 + lane);
       const float e_top = edge(c0 + 64);
       __builtin_amdgcn_wave_barrier();
@@ -268,156 +265,166 @@ __global__ void __launch_bounds__(256, 2) render_fused_kernel(FusedArgs A) {
       if (lane == 0) tbuf[64] = e_top;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      // ---- positions of this lane's four gather samples (rows past S sit at the far plane and are discarded) ---
-      float px[4], py[4], pz[4];
-      bool sel[4];
+
+      // values of "my" sample (lane l <-> sample c0+l), filled by the half that evaluates it
+      float my_dlogit = 0.f, my_sel = 0.f, my_sem = 0.f, my_r = 0.f, my_g = 0.f, my_b = 0.f;
+
+      // The 64 samples go through gather + MLPs as two halves of 2 column tiles (32 samples): half the live
+      // accumulators (h: 32, c1: 32 VGPRs) buys twice the waves per SIMD to hide the gather latency.
+#pragma unroll 1
+      for (int half = 0; half < 2; ++half) {
+        // ---- positions of this lane's two gather samples (rows past S sit at the far plane and are discarded) --
+        float px[2], py[2], pz[2];
+        bool sel[2];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float mid = (tbuf[16 * c + j] + tbuf[16 * c + j + 1]) / 2.f;
-        px[c] = ox + dx * mid;
-        py[c] = oy + dy * mid;
-        pz[c] = oz + dz * mid;
-        sel[c] = normalize_position(A.scene, px[c], py[c], pz[c]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- hash grid: levels 4g..4g+3 for the four samples ------------------------------------------------
-      f32x4 feat[4][2];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int l = 4 * g + q;
-        const unsigned level_off = (unsigned)l * A.grid.level_stride;
-        const float scale = lvl_scale[q];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          float2 f = hash_level(A.grid.table, level_off, A.grid.mask, scale, px[c], py[c], pz[c]);
-          if (q == 0) { feat[c][0].x = f.x; feat[c][0].y = f.y; }
-          if (q == 1) { feat[c][0].z = f.x; feat[c][0].w = f.y; }
-          if (q == 2) { feat[c][1].x = f.x; feat[c][1].y = f.y; }
-          if (q == 3) { feat[c][1].z = f.x; feat[c][1].w = f.y; }
+        for (int c = 0; c < 2; ++c) {
+          const int k = 32 * half + 16 * c + j;
+          float mid = (tbuf[k] + tbuf[k + 1]) / 2.f;
+          px[c] = ox + dx * mid;
+          py[c] = oy + dy * mid;
+          pz[c] = oz + dz * mid;
+          sel[c] = normalize_position(A.scene, px[c], py[c], pz[c]);
         }
-        __builtin_amdgcn_sched_barrier(0);  // keep at most one level (32 gathers, 64 VGPRs) in flight per lane
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- base MLP layer 0: 32 -> 64, ReLU -------------------------------------------------------------------
-      f32x4 h[4][4];
+        // ---- hash grid: levels 4g..4g+3 for the two samples ------------------------------------------------
+        f32x4 feat[2][2];
+        {
+          const f32x4 lvl_scale = *reinterpret_cast<const f32x4*>(lds + OFF_SCALE + 4 * g);
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B0 + 16 * mt + 4 * g);
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(lds + OFF_A0 + ((mt * 2 + 0) * 64 + lane) * 4);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(lds + OFF_A0 + ((mt * 2 + 1) * 64 + lane) * 4);
-        f32x4 acc[4] = {b, b, b, b};
+          for (int q = 0; q < 4; ++q) {
+            const unsigned level_off = (unsigned)(4 * g + q) * A.grid.level_stride;
+            const float scale = lvl_scale[q];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) acc[c] = MFMA(a0[e], feat[c][0][e], acc[c]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) acc[c] = MFMA(a1[e], feat[c][1][e], acc[c]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) h[mt][c] = relu4(acc[c]);
+            for (int c = 0; c < 2; ++c) {
+              float2 f = hash_level(A.grid.table, level_off, A.grid.mask, scale, px[c], py[c], pz[c]);
+              if (q == 0) { feat[c][0].x = f.x; feat[c][0].y = f.y; }
+              if (q == 1) { feat[c][0].z = f.x; feat[c][0].w = f.y; }
+              if (q == 2) { feat[c][1].x = f.x; feat[c][1].y = f.y; }
+              if (q == 3) { feat[c][1].z = f.x; feat[c][1].w = f.y; }
+            }
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- base MLP layer 1: 64 -> 16 (neuron 0 = density logit, 1..15 = geo features) ----------------------------
-      f32x4 o16[4];
-      {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B1 + 4 * g);
-        f32x4 acc[4] = {b, b, b, b};
+        // ---- base MLP layer 0: 32 -> 64, ReLU ----------------------------------------------------------------
+        f32x4 h[4][2];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_A1 + (t * 64 + lane) * 4);
+        for (int mt = 0; mt < 4; ++mt) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B0 + 16 * mt + 4 * g);
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(lds + OFF_A0 + ((mt * 2 + 0) * 64 + lane) * 4);
+          const f32x4 a1 = *reinterpret_cast<const f32x4*>(lds + OFF_A0 + ((mt * 2 + 1) * 64 + lane) * 4);
+          f32x4 acc[2] = {b, b};
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = MFMA(a[e], h[t][c][e], acc[c]);
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) o16[c] = acc[c];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      float sem_part[4] = {0.f, 0.f, 0.f, 0.f};
-      float rgb_part[4][3];
-      if (!DENSITY_ONLY) {
-        // ---- semantics: relu(Ws0 geo + bs0) . (Wh Ws1) + folded bias --------------------------------------------
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_BS0 + 16 * mt + 4 * g);
-          const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_AS0 + (mt * 64 + lane) * 4);
-          const f32x4 wf = *reinterpret_cast<const f32x4*>(lds + OFF_WF + 16 * mt + 4 * g);
-          f32x4 acc[4] = {b, b, b, b};
+            for (int c = 0; c < 2; ++c) acc[c] = MFMA(a0[e], feat[c][0][e], acc[c]);
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = MFMA(a[e], o16[c][e], acc[c]);
+            for (int c = 0; c < 2; ++c) acc[c] = MFMA(a1[e], feat[c][1][e], acc[c]);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) sem_part[c] = dot4(wf, relu4(acc[c]), sem_part[c]);
+          for (int c = 0; c < 2; ++c) h[mt][c] = relu4(acc[c]);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- colour layer 0: geo columns on the MFMA, SH + appearance columns pre-summed in cbias ---------------
-        f32x4 c1[4][4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_AC0 + (mt * 64 + lane) * 4);
-          f32x4 acc[4] = {cbias[mt], cbias[mt], cbias[mt], cbias[mt]};
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = MFMA(a[e], o16[c][e], acc[c]);
-#pragma unroll
-          for (int c = 0; c < 4; ++c) c1[mt][c] = relu4(acc[c]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- colour layer 1 (64 -> 64, ReLU) with the 64 -> 3 head folded into the row-tile loop -------------------
-#pragma unroll
-        for (int c = 0; c < 4; ++c) rgb_part[c][0] = rgb_part[c][1] = rgb_part[c][2] = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_BC1 + 16 * mt + 4 * g);
-          f32x4 acc[4] = {b, b, b, b};
+        // ---- base MLP layer 1: 64 -> 16 (neuron 0 = density logit, 1..15 = geo features) -------------------------
+        f32x4 o16[2];
+        {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B1 + 4 * g);
+          f32x4 acc[2] = {b, b};
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_AC1 + ((mt * 4 + t) * 64 + lane) * 4);
+            const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_A1 + (t * 64 + lane) * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-              for (int c = 0; c < 4; ++c) acc[c] = MFMA(a[e], c1[t][c][e], acc[c]);
+              for (int c = 0; c < 2; ++c) acc[c] = MFMA(a[e], h[t][c][e], acc[c]);
           }
-          const f32x4 w0 = *reinterpret_cast<const f32x4*>(lds + OFF_WRGB + 0 * 64 + 16 * mt + 4 * g);
-          const f32x4 w1 = *reinterpret_cast<const f32x4*>(lds + OFF_WRGB + 1 * 64 + 16 * mt + 4 * g);
-          const f32x4 w2 = *reinterpret_cast<const f32x4*>(lds + OFF_WRGB + 2 * 64 + 16 * mt + 4 * g);
+          o16[0] = acc[0];
+          o16[1] = acc[1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bool mine = (g >> 1) == half;  // this half holds lane l's own sample in column tile g&1
+        const bool odd = (g & 1) != 0;
+        {
+          float d0 = row0_broadcast(o16[0].x), d1 = row0_broadcast(o16[1].x);
+          float dsel = odd ? d1 : d0;
+          float ssel = (odd ? sel[1] : sel[0]) ? 1.f : 0.f;
+          my_dlogit = mine ? dsel : my_dlogit;
+          my_sel = mine ? ssel : my_sel;
+        }
+        if (!DENSITY_ONLY) {
+          // ---- semantics: relu(Ws0 geo + bs0) . (Wh Ws1) + folded bias ------------------------------------------
+          float sem_part[2] = {0.f, 0.f};
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            f32x4 v = relu4(acc[c]);
-            rgb_part[c][0] = dot4(w0, v, rgb_part[c][0]);
-            rgb_part[c][1] = dot4(w1, v, rgb_part[c][1]);
-            rgb_part[c][2] = dot4(w2, v, rgb_part[c][2]);
+          for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_BS0 + 16 * mt + 4 * g);
+            const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_AS0 + (mt * 64 + lane) * 4);
+            const f32x4 wf = *reinterpret_cast<const f32x4*>(lds + OFF_WF + 16 * mt + 4 * g);
+            f32x4 acc[2] = {b, b};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int c = 0; c < 2; ++c) acc[c] = MFMA(a[e], o16[c][e], acc[c]);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) sem_part[c] = dot4(wf, relu4(acc[c]), sem_part[c]);
+          }
+          // ---- colour layer 0: geo columns on the MFMA, SH + appearance columns pre-summed in the ray bias -------
+          f32x4 c1[4][2];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_AC0 + (mt * 64 + lane) * 4);
+            const f32x4 cb = *reinterpret_cast<const f32x4*>(scratch + 16 * mt + 4 * g);
+            f32x4 acc[2] = {cb, cb};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int c = 0; c < 2; ++c) acc[c] = MFMA(a[e], o16[c][e], acc[c]);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) c1[mt][c] = relu4(acc[c]);
           }
           __builtin_amdgcn_sched_barrier(0);
+          // ---- colour layer 1 (64 -> 64, ReLU) with the 64 -> 3 head folded into the row-tile loop ----------------
+          float rgb_part[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_BC1 + 16 * mt + 4 * g);
+            f32x4 acc[2] = {b, b};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_AC1 + ((mt * 4 + t) * 64 + lane) * 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[c] = MFMA(a[e], c1[t][c][e], acc[c]);
+            }
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(lds + OFF_WRGB + 0 * 64 + 16 * mt + 4 * g);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(lds + OFF_WRGB + 1 * 64 + 16 * mt + 4 * g);
+            const f32x4 w2 = *reinterpret_cast<const f32x4*>(lds + OFF_WRGB + 2 * 64 + 16 * mt + 4 * g);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              f32x4 v = relu4(acc[c]);
+              rgb_part[c][0] = dot4(w0, v, rgb_part[c][0]);
+              rgb_part[c][1] = dot4(w1, v, rgb_part[c][1]);
+              rgb_part[c][2] = dot4(w2, v, rgb_part[c][2]);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          // ---- reduce the heads over the four lane groups and keep the column tile this lane owns -------------
+          float s0 = group_sum(sem_part[0]), s1 = group_sum(sem_part[1]);
+          my_sem = mine ? (odd ? s1 : s0) : my_sem;
+          float r0 = group_sum(rgb_part[0][0]), r1 = group_sum(rgb_part[1][0]);
+          my_r = mine ? (odd ? r1 : r0) : my_r;
+          float g0 = group_sum(rgb_part[0][1]), g1 = group_sum(rgb_part[1][1]);
+          my_g = mine ? (odd ? g1 : g0) : my_g;
+          float b0 = group_sum(rgb_part[0][2]), b1 = group_sum(rgb_part[1][2]);
+          my_b = mine ? (odd ? b1 : b0) : my_b;
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- hand each lane l the sample c0 + l (column tile c = g, column j) ----------------------------------
-      float dl0 = row0_broadcast(o16[0].x), dl1 = row0_broadcast(o16[1].x);
-      float dl2 = row0_broadcast(o16[2].x), dl3 = row0_broadcast(o16[3].x);
-      float dlogit = pick4(g, dl0, dl1, dl2, dl3);
-      bool msel = pick4(g, sel[0] ? 1.f : 0.f, sel[1] ? 1.f : 0.f, sel[2] ? 1.f : 0.f, sel[3] ? 1.f : 0.f) != 0.f;
-      float density = expf(dlogit) * (msel ? 1.f : 0.f);
+      // ---- lane l now holds sample c0 + l ------------------------------------------------------------------
+      float density = expf(my_dlogit) * my_sel;
       float sem = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
       if (!DENSITY_ONLY) {
-        float s0 = group_sum(sem_part[0]), s1 = group_sum(sem_part[1]);
-        float s2 = group_sum(sem_part[2]), s3 = group_sum(sem_part[3]);
-        sem = pick4(g, s0, s1, s2, s3) + lds[OFF_MISC + 0];
-        float ch[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          float v0 = group_sum(rgb_part[0][k]), v1 = group_sum(rgb_part[1][k]);
-          float v2 = group_sum(rgb_part[2][k]), v3 = group_sum(rgb_part[3][k]);
-          ch[k] = sigmoidf(pick4(g, v0, v1, v2, v3) + lds[OFF_MISC + 1 + k]);
-        }
-        cr = ch[0];
-        cg = ch[1];
-        cb = ch[2];
+        sem = my_sem + lds[OFF_MISC + 0];
+        cr = sigmoidf(my_r + lds[OFF_MISC + 1]);
+        cg = sigmoidf(my_g + lds[OFF_MISC + 2]);
+        cb = sigmoidf(my_b + lds[OFF_MISC + 3]);
       }
       const int i = c0 + lane;
       const bool valid = i < S;
@@ -486,7 +493,19 @@ static int check_fused_shape(const cn_field_params& p) {
 
 static size_t fused_workspace_bytes(const cn_field_params* p) {
   int rows = p && p->num_images > 0 ? p->num_images : 1;
-  return (size_t)(BLOB_FLOATS + rows * 64) * sizeof(float);
+  return (size_t)(BLOB_FLOATS + rows * 64 + 32) * sizeof(float);  // weight image | appearance bias rows | mean
+}
+
+// Resident blocks of a kernel variant on this device (rounded down to a multiple of 8 = one group per XCD).  A grid
+// larger than the residency would leave a tail running at a fraction of the occupancy.
+template <typename K>
+static int resident_blocks(K kernel) {
+  int dev = 0, cus = 256, per_cu = 2;
+  if (hipGetDevice(&dev) != hipSuccess) return 512;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+  int n = cus * per_cu;
+  return n >= 8 ? (n / 8) * 8 : 8;
 }
 
 template <bool PER_SAMPLE>
@@ -535,6 +554,10 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   P.num_images = params->num_images;
   P.app_mode = opts->app_mode;
   P.app_rows = opts->app_mode == CN_APP_PER_CAMERA ? params->num_images : 1;
+  float* emb_mean = app_bias + (size_t)(params->num_images > 0 ? params->num_images : 1) * 64;
+  P.emb_mean = emb_mean;
+  if (opts->app_mode == CN_APP_MEAN)
+    hipLaunchKernelGGL(prep_mean_kernel, dim3(1), dim3(64), 0, s, params->appearance, params->num_images, emb_mean);
   for (int i = 0; i < CN_MAX_LEVELS; ++i) P.scale[i] = params->grid.scalings[i];
   hipLaunchKernelGGL(prep_kernel, dim3(48), dim3(256), 0, s, P, blob, app_bias);
   rc = check_launch("cn_render prep");
@@ -560,15 +583,19 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   A.app_per_camera = opts->app_mode == CN_APP_PER_CAMERA;
   A.sh_unit = opts->sh_unit_dir;
   A.eval_clamp = opts->eval_clamp;
-  // persistent-style grid: a multiple of 8 (XCD groups), at most 3 blocks per CU, never more waves than rays
-  long long want = (num_rays + 3) / 4;
-  long long blocks = want < 768 ? ((want + 7) / 8) * 8 : 768;
+  // persistent grid: exactly the resident block count (a multiple of 8 = XCD groups), never more waves than rays
+  static const int res_sample = resident_blocks(render_fused_kernel<true, false>);
+  static const int res_density = resident_blocks(render_fused_kernel<false, true>);
+  static const int res_full = resident_blocks(render_fused_kernel<false, false>);
+  const long long cap = PER_SAMPLE ? res_sample : (opts->density_only ? res_density : res_full);
+  const long long want = (((num_rays + 3) / 4) + 7) / 8 * 8;
+  const unsigned blocks = (unsigned)(want < cap ? want : cap);
   if (PER_SAMPLE) {
-    hipLaunchKernelGGL((render_fused_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, A);
+    hipLaunchKernelGGL((render_fused_kernel<true, false>), dim3(blocks), dim3(256), 0, s, A);
   } else if (opts->density_only) {
-    hipLaunchKernelGGL((render_fused_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, s, A);
+    hipLaunchKernelGGL((render_fused_kernel<false, true>), dim3(blocks), dim3(256), 0, s, A);
   } else {
-    hipLaunchKernelGGL((render_fused_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, s, A);
+    hipLaunchKernelGGL((render_fused_kernel<false, false>), dim3(blocks), dim3(256), 0, s, A);
   }
   return check_launch(who);
 }
