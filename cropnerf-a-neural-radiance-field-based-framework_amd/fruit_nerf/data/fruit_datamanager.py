@@ -1,0 +1,103 @@
+"""``FruitDataManager`` -- the ray-source part of ``crop_nerf/fruit_nerf/data/fruit_datamanager.py`` on the HIP ray
+generators: ``next_train`` (pixel sample -> ``train_ray_generator``, ``:188-197``), ``setup_inference`` /
+``next_sample_volume`` (orthographic surface rays for the dense export, ``:157-172,199-204``) and the AABB corner /
+surface-grid helpers (``:42-121``).  Image decoding and dataparsing are out of scope; images and
+masks, when given, are tensors already in memory."""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from ... import ops
+from ...rays import Cameras, RayBundle
+from ..components.ray_generators import OrthographicRayGenerator
+
+
+@dataclass
+class FruitDataManagerConfig:
+    train_num_rays_per_batch: int = 4096
+    eval_num_rays_per_batch: int = 4096
+    camera_res_scale_factor: float = 1.0
+
+
+def get_corners_of_aabb(aabb, device=None) -> Tensor:
+    """``:42-69``: 8 corners, x fastest."""
+    mn, mx = [float(v) for v in aabb[0]], [float(v) for v in aabb[1]]
+    return torch.tensor([
+        [mn[0], mn[1], mn[2]], [mx[0], mn[1], mn[2]], [mn[0], mx[1], mn[2]], [mx[0], mx[1], mn[2]],
+        [mn[0], mn[1], mx[2]], [mx[0], mn[1], mx[2]], [mn[0], mx[1], mx[2]], [mx[0], mx[1], mx[2]],
+    ], dtype=torch.float32)
+
+
+def sample_surface_points(corners: Tensor, n: int, device, noise: bool = False) -> Tuple[Tensor, Tensor]:
+    """``:71-121``: n x n grid on the face through corners 0,1,2; the constant coordinate goes to column 2
+    (reference quirk); plane vector along that column.  Grid parameters on the host, points by ``cn_surface_grid``."""
+    c1, c2, c3 = corners[0], corners[1], corners[2]
+    ext = torch.abs(corners.max(dim=0).values - corners.min(dim=0).values)
+    const = int(torch.argmax(torch.logical_and(c1 == c2, c2 == c3).to(torch.int64)))
+    ax = int(torch.argmax(torch.abs(c1 - c2)))
+    ay = int(torch.argmax(torch.abs(c1 - c3)))
+    nx = int(ext[0] / ext[const] * n)
+    ny = int(ext[1] / ext[const] * n)
+    pts = ops.surface_grid(float(c1[ax]), float(c2[ax]), nx, float(c1[ay]), float(c3[ay]), ny, float(c3[const]), device)
+    c4 = corners[-1]
+    plane = torch.tensor([[0.0, 0.0, float(torch.sign(c4[const]) * torch.abs(c1[const]) + torch.abs(c4[const]))]],
+                         dtype=torch.float32)
+    return pts, plane
+
+
+class FruitDataManager:
+    def __init__(self, config: FruitDataManagerConfig, cameras: Cameras, device="cuda", test_mode: str = "val",
+                 world_size: int = 1, local_rank: int = 0, images: Optional[Tensor] = None,
+                 fruit_masks: Optional[Tensor] = None, seed: int = 0, **kwargs):
+        self.config = config
+        self.device = torch.device(device)
+        self.cameras = cameras.to(self.device)
+        self.test_mode = test_mode
+        self.world_size = world_size
+        self.local_rank = local_rank
+        self.images = images  # [N,H,W,3] float (optional)
+        self.fruit_masks = fruit_masks  # [N,H,W,1] float (optional)
+        self.train_count = 0
+        self.eval_count = 0
+        self._gen = torch.Generator(device="cpu").manual_seed(seed + 1000 * local_rank)
+        self.orthographic_ray_generator: Optional[OrthographicRayGenerator] = None
+
+    # PixelSampler.sample + train_ray_generator (:188-197)
+    def _sample(self, num_rays: int) -> Tuple[RayBundle, Dict]:
+        n, h, w = len(self.cameras), self.cameras.height, self.cameras.width
+        idx = torch.stack([torch.randint(0, n, (num_rays,), generator=self._gen),
+                           torch.randint(0, h, (num_rays,), generator=self._gen),
+                           torch.randint(0, w, (num_rays,), generator=self._gen)], dim=-1)
+        batch: Dict[str, Tensor] = {"indices": idx}
+        if self.images is not None:
+            batch["image"] = self.images[idx[:, 0], idx[:, 1], idx[:, 2]]
+        if self.fruit_masks is not None:
+            batch["fruit_mask"] = self.fruit_masks[idx[:, 0], idx[:, 1], idx[:, 2]]
+        return self.cameras.generate_rays(idx.to(self.device)), batch
+
+    def next_train(self, step: int) -> Tuple[RayBundle, Dict]:
+        self.train_count += 1
+        return self._sample(self.config.train_num_rays_per_batch)
+
+    def next_eval(self, step: int) -> Tuple[RayBundle, Dict]:
+        self.eval_count += 1
+        return self._sample(self.config.eval_num_rays_per_batch)
+
+    def setup_inference(self, aabb, num_points) -> int:
+        """``:157-172``: surface grid on the bottom face + orthographic generator; returns the ray count."""
+        corners = get_corners_of_aabb(aabb)
+        pts, plane = sample_surface_points(corners, n=num_points, device=self.device, noise=False)
+        self.orthographic_ray_generator = OrthographicRayGenerator(
+            surface_points=pts, plane_normal=plane, ray_batch_size=self.config.eval_num_rays_per_batch,
+            device=self.device, aabb=aabb)
+        return pts.shape[0]
+
+    def next_sample_volume(self, step: int) -> Tuple[RayBundle, None]:
+        """``:199-204``."""
+        self.train_count += 1
+        return self.orthographic_ray_generator(count=self.train_count), None

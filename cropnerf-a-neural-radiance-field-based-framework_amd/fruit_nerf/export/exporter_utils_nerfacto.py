@@ -1,0 +1,70 @@
+"""Semantic point-cloud export -- mirror of ``generate_point_cloud``
+(``crop_nerf/fruit_nerf/export/exporter_utils_nerfacto.py:83-227``): random train rays -> model forward ->
+``point = o + d * depth`` kept where ``semantics_colormap[:, 0] > 0`` (``:156-166``) -> optional OBB crop -> accumulate
+until ``num_points``.  Mask, point computation and compaction run in ``cn_pointcloud_compact``; kept points leave the
+device once.  open3d's statistical outlier removal / normal estimation (``:194-225``) are CPU post-processing outside the
+hot path and are applied only when open3d is importable."""
+
+from __future__ import annotations
+
+import sys
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from ... import ops
+
+
+def generate_point_cloud(pipeline, num_points: int = 1000000, remove_outliers: bool = True,
+                         estimate_normals: bool = False, reorient_normals: bool = False, rgb_output_name: str = "rgb",
+                         depth_output_name: str = "depth", normal_output_name: Optional[str] = None, crop_obb=None,
+                         std_ratio: float = 10.0, only_semantics: bool = True, max_batches: Optional[int] = None
+                         ) -> Dict[str, np.ndarray]:
+    model, dm = pipeline.model, pipeline.datamanager
+    cap = int(num_points + dm.config.train_num_rays_per_batch)
+    buffers = None
+    kept = 0
+    batches = 0
+    with torch.no_grad():
+        while kept < num_points:
+            ray_bundle, _ = dm.next_train(0)
+            outputs = model(ray_bundle)
+            for name in (rgb_output_name, depth_output_name):
+                if name not in outputs:  # :133-142
+                    print(f"Could not find {name} in the model outputs; choose one of: {list(outputs.keys())}",
+                          file=sys.stderr)
+                    sys.exit(1)
+            cmap = outputs["semantics_colormap"] if only_semantics else torch.ones_like(outputs["rgb"])
+            buffers = ops.pointcloud_compact(ray_bundle.origins, ray_bundle.directions, outputs[depth_output_name],
+                                             outputs[rgb_output_name], cmap.contiguous(), cap, buffers)
+            kept = int(buffers[3].item())
+            batches += 1
+            if max_batches is not None and batches >= max_batches:
+                break
+    pts, cols, dirs, count = buffers
+    n = min(int(count.item()), cap)
+    points = pts[:n].double().cpu().numpy()
+    colors = cols[:n].double().cpu().numpy()
+    view_dirs = dirs[:n].cpu().numpy()
+    if crop_obb is not None:
+        m = crop_obb.within(torch.from_numpy(points).float()).numpy()
+        points, colors, view_dirs = points[m], colors[m], view_dirs[m]
+    result = {"points": points, "colors": colors, "view_directions": view_dirs}
+    if remove_outliers or estimate_normals:
+        try:
+            import open3d as o3d  # noqa: F401
+        except ImportError:
+            result["note"] = "open3d not installed: statistical outlier removal / normal estimation skipped"
+            return result
+        pcd = o3d.geometry.PointCloud()
+        pcd.points = o3d.utility.Vector3dVector(points)
+        pcd.colors = o3d.utility.Vector3dVector(colors)
+        if remove_outliers:
+            pcd, ind = pcd.remove_statistical_outlier(nb_neighbors=20, std_ratio=std_ratio)
+            view_dirs = view_dirs[ind]
+        if estimate_normals:
+            pcd.estimate_normals()
+            result["normals"] = np.asarray(pcd.normals)
+        result.update(points=np.asarray(pcd.points), colors=np.asarray(pcd.colors), view_directions=view_dirs)
+    return result

@@ -1,0 +1,351 @@
+"""FruitModel -- host-side mirror of the reference's model for the hot path, running on libcropnerf_hip.
+
+Same names, argument meaning, output-dict keys and error behaviour as ``crop_nerf/fruit_nerf/fruit_nerf.py``
+(``FruitModel``: ``forward :617-637``, ``get_outputs :543-599``, ``get_inference_outputs :497-541``,
+``get_export_outputs :476-494``, ``setup_inference :185-189``, ``get_param_groups :191-196``,
+``get_outputs_for_camera_ray_bundle :377-404``, ``get_outputs_for_camera_jagged_ray_bundle :346-374``,
+``get_density_for_camera_ray_bundle :320-344``, ``get_outputs_for_projections :254-318``,
+``get_metrics_dict :639-645``).  Every number comes from a HIP kernel; this file is control flow only.
+
+Differences kept deliberately: outputs stay on the model's device until the caller asks for
+them (one D2H per image instead of one per chunk); ``depth`` is not forced to ``"cuda"``; artefact paths of the
+projection pass are arguments with the reference's values as defaults; ``compat_projection_cam0`` reproduces the
+reference's use of camera index 0 for every projected camera.
+"""
+
+from __future__ import annotations
+
+import contextlib
+import os
+import shutil
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from .. import _lib as L
+from .. import ops
+from ..config import FruitNerfModelConfig, init_params, param_shapes
+from ..rays import Cameras, RayBundle, SceneBox
+
+__all__ = ["FruitNerfModelConfig", "FruitModel", "Semantics", "background_color_override_context"]
+
+_BACKGROUND_COLOR_OVERRIDE: Optional[Tuple[float, float, float]] = None
+
+
+@contextlib.contextmanager
+def background_color_override_context(color):
+    """nerfstudio ``renderers.background_color_override_context`` (used at
+    ``fruit_nerf/scripts/semantic_projection.py:169``)."""
+    global _BACKGROUND_COLOR_OVERRIDE
+    old = _BACKGROUND_COLOR_OVERRIDE
+    _BACKGROUND_COLOR_OVERRIDE = tuple(float(c) for c in (color.tolist() if isinstance(color, Tensor) else color))
+    try:
+        yield
+    finally:
+        _BACKGROUND_COLOR_OVERRIDE = old
+
+
+class Semantics:
+    """``nerfstudio.data.utils.dataparsers...Semantics`` as built at ``data/cotton_nerf_dataparser.py:244-254``."""
+
+    def __init__(self, filenames: Sequence[str] = (), classes: Sequence[str] = ("apple", "stuff"),
+                 colors: Optional[Tensor] = None, mask_classes: Sequence[str] = ()):
+        self.filenames = list(filenames)
+        self.classes = list(classes)
+        self.colors = torch.tensor([0.0, 1.0]) if colors is None else colors
+        self.mask_classes = list(mask_classes)
+
+
+class FruitModel:
+    """Eval / export side of the reference's ``FruitModel`` (training backward is not built in this round)."""
+
+    def __init__(self, config: FruitNerfModelConfig, scene_box: SceneBox, num_train_data: int, metadata: Dict,
+                 device: Union[str, torch.device] = "cuda", grad_scaler=None, test_mode: str = "val",
+                 render_rgb_inference: bool = True, params: Optional[Dict[str, Tensor]] = None, seed: int = 0,
+                 **kwargs) -> None:
+        assert "semantics" in metadata.keys() and isinstance(metadata["semantics"], Semantics)
+        self.semantics = metadata["semantics"]
+        self.test_mode = test_mode
+        self.config = config
+        self.scene_box = scene_box
+        self.num_train_data = num_train_data
+        self.device = torch.device(device)
+        self.training = False
+        self.compat_projection_cam0 = False
+        self.colormap = self.semantics.colors.clone().detach().to(self.device)
+        self._given_params = params
+        self._seed = seed
+        self.populate_modules()
+
+    # ------------------------------------------------------------------------------------------ modules / params
+    def populate_modules(self) -> None:
+        cfg = self.config
+        self.field_spec = cfg.field_spec(self.num_train_data)
+        self.proposal_specs = cfg.proposal_specs()
+        shapes = param_shapes(self.field_spec, self.proposal_specs)
+        if self._given_params is not None:
+            params = {k: v.to(self.device, torch.float32).contiguous() for k, v in self._given_params.items()}
+            for k, shp in shapes.items():
+                if tuple(params[k].shape) != tuple(shp):
+                    raise ValueError(f"parameter {k}: shape {tuple(params[k].shape)} != {tuple(shp)}")
+        else:
+            params = init_params(self.field_spec, self.proposal_specs, seed=self._seed, device=self.device)
+        self.params = params
+        self.field = ops.FieldHandle(params, self.field_spec)
+        self.proposal_networks = [ops.DensityHandle(params, i, ps) for i, ps in enumerate(self.proposal_specs)]
+        self._field_contraction = not cfg.disable_scene_contraction
+        self._prop_contraction = not cfg.disable_scene_contraction
+        self._uniform_samples: Optional[int] = None
+        self._anneal = 1.0
+        self.render_rgb = True
+
+    def state_dict(self) -> Dict[str, Tensor]:
+        return dict(self.params)
+
+    def load_state_dict(self, state: Dict[str, Tensor]) -> None:
+        for k in self.params:
+            self.params[k].copy_(state[k].to(self.device))
+
+    def get_param_groups(self) -> Dict[str, List[Tensor]]:
+        """``fruit_nerf.py:191-196``: groups ``proposal_networks``, ``fields``, ``camera_opt``."""
+        return {
+            "proposal_networks": [v for k, v in self.params.items() if k.startswith("proposal_networks.")],
+            "fields": [v for k, v in self.params.items() if k.startswith("field.")],
+            "camera_opt": [self.params["camera_optimizer.pose_adjustment"]],
+        }
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def setup_inference(self, render_rgb: bool, num_inference_samples: int) -> None:
+        """``fruit_nerf.py:185-189``: uniform sampler with ``num_inference_samples`` and no field contraction."""
+        self.render_rgb = render_rgb
+        self.num_inference_samples = int(num_inference_samples)
+        self._uniform_samples = int(num_inference_samples)
+        self._field_contraction = False
+
+    def set_anneal(self, anneal: float) -> None:
+        self._anneal = float(anneal)
+
+    # ------------------------------------------------------------------------------------------ helpers
+    def _scene(self, contraction: bool) -> L.Scene:
+        return ops.scene_struct(self.scene_box.aabb, contraction)
+
+    def _background(self):
+        if _BACKGROUND_COLOR_OVERRIDE is not None:
+            return L.BG_COLOR, _BACKGROUND_COLOR_OVERRIDE
+        bg = self.config.background_color
+        if isinstance(bg, str):
+            if bg != "last_sample":
+                raise NotImplementedError(f"background_color={bg!r} (eval path supports 'last_sample' or an RGB triple)")
+            return L.BG_LAST_SAMPLE, (0.0, 0.0, 0.0)
+        return L.BG_COLOR, tuple(bg)
+
+    def _app_mode(self) -> int:
+        if self.test_mode in ("inference", "export"):
+            return L.APP_MEAN
+        if self.training:
+            return L.APP_PER_CAMERA
+        return L.APP_MEAN if self.config.use_average_appearance_embedding else L.APP_ZEROS
+
+    def _collide(self, rb: RayBundle) -> RayBundle:
+        """NearFarCollider (``fruit_nerf.py:167,625-626``): only fills missing nears/fars; near plane 0 in eval."""
+        if rb.nears is not None and rb.fars is not None:
+            return rb
+        R = rb.origins.shape[0]
+        near = self.config.near_plane if self.training else 0.0
+        rb.nears = torch.full((R, 1), float(near), device=self.device)
+        rb.fars = torch.full((R, 1), float(self.config.far_plane), device=self.device)
+        return rb
+
+    def _prepared(self, ray_bundle: RayBundle) -> RayBundle:
+        rb = ray_bundle.flatten().to(self.device)
+        rb = rb._map(lambda t: t.contiguous())
+        return self._collide(rb)
+
+    def _cam_idx(self, rb: RayBundle) -> Optional[Tensor]:
+        if rb.camera_indices is None:
+            return None
+        return rb.camera_indices.reshape(-1).to(torch.int64).contiguous()
+
+    def _opts(self, num_samples: int, density_only: bool = False) -> L.RenderOpts:
+        bg_mode, bg = self._background()
+        return ops.render_opts(num_samples, spacing=L.SPACING_UNIFORM, bg_mode=bg_mode, bg_color=bg,
+                               app_mode=self._app_mode(), sh_unit_dir=self.config.sh_input == "unit",
+                               eval_clamp=not self.training, density_only=density_only)
+
+    def _sample_and_render(self, rb: RayBundle, density_only: bool = False) -> Dict[str, Tensor]:
+        """proposal (or uniform) sampler -> field -> renderers, all on device."""
+        o, d, n, f = rb.origins, rb.directions, rb.nears, rb.fars
+        cam = self._cam_idx(rb)
+        if self._app_mode() == L.APP_PER_CAMERA and cam is None:
+            raise AttributeError("Camera indices are not provided.")  # fruit_field.py:241-242
+        if self._uniform_samples is not None:
+            S = self._uniform_samples
+            return ops.render_rays(self.field, self._scene(self._field_contraction), self._opts(S, density_only),
+                                   o, d, n, f, camera_indices=cam)
+        cfg = self.config
+        S = cfg.num_nerf_samples_per_ray
+        ps = ops.proposal_sample(self.proposal_networks, self._scene(self._prop_contraction), o, d, n, f,
+                                 cfg.num_proposal_samples_per_ray, S, anneal=self._anneal)
+        out = ops.render_rays(self.field, self._scene(self._field_contraction), self._opts(S, density_only), o, d, n, f,
+                              camera_indices=cam, bins=ps["euclidean_bins"])
+        for i in range(len(self.proposal_networks)):
+            out[f"prop_depth_{i}"] = ps["prop_depth"][i][:, None]
+        return out
+
+    # ------------------------------------------------------------------------------------------ forward variants
+    def forward(self, ray_bundle: RayBundle) -> Dict[str, Union[Tensor, List]]:
+        """``fruit_nerf.py:617-637``."""
+        rb = self._prepared(ray_bundle)
+        if self.test_mode == "inference":
+            return self.get_inference_outputs(rb)
+        if self.test_mode == "export":
+            return self.get_export_outputs(rb)
+        return self.get_outputs(rb)
+
+    __call__ = forward
+
+    def get_outputs(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:
+        """``fruit_nerf.py:543-599`` (eval): the camera-optimizer tweak is applied also outside training."""
+        if self.training:
+            raise NotImplementedError("training forward (weights_list / ray_samples_list + backward) is not built yet")
+        rb = ray_bundle
+        if rb.camera_indices is None:
+            raise AttributeError("Camera indices are not provided.")
+        rb = RayBundle(rb.origins.clone(), rb.directions.clone(), rb.pixel_area, rb.camera_indices, rb.nears, rb.fars)
+        ops.apply_pose_adjustment(self.params["camera_optimizer.pose_adjustment"], self._cam_idx(rb), rb.origins,
+                                  rb.directions)
+        return self._finish(self._sample_and_render(rb))
+
+    def get_inference_outputs(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:
+        """``fruit_nerf.py:497-541``: no pose tweak, mean appearance."""
+        return self._finish(self._sample_and_render(ray_bundle))
+
+    def _finish(self, out: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        keys = ["rgb", "accumulation", "depth"] + [k for k in out if k.startswith("prop_depth_")] + \
+               ["semantics", "semantics_colormap"]
+        return {k: out[k] for k in keys if k in out}
+
+    def get_export_outputs(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:
+        """``fruit_nerf.py:476-494``: per-sample rgb / position / semantic logit / density / label, no compositing."""
+        if self._uniform_samples is None:
+            raise RuntimeError("export mode needs setup_inference(render_rgb, num_inference_samples) first")
+        rb = ray_bundle
+        out = ops.render_samples(self.field, self._scene(self._field_contraction), self._opts(self._uniform_samples),
+                                 rb.origins, rb.directions, rb.nears, rb.fars, camera_indices=self._cam_idx(rb))
+        labels = ((torch.sigmoid(out["semantics"]) - 0.9) > 0).to(torch.long)  # bookkeeping on 1 value/sample
+        return {"rgb": out["rgb"], "point_location": out["positions"], "semantics": out["semantics"],
+                "density": out["density"], "semantics_colormap": labels}
+
+    # ------------------------------------------------------------------------------------------ chunked renders
+    def _chunked(self, camera_ray_bundle: RayBundle, fn) -> Dict[str, Tensor]:
+        chunk = self.config.eval_num_rays_per_chunk
+        flat = camera_ray_bundle.flatten()
+        n = len(flat)
+        lists: Dict[str, List[Tensor]] = {}
+        for i in range(0, n, chunk):
+            out = fn(flat.get_row_major_sliced_ray_bundle(i, i + chunk))
+            for k, v in out.items():
+                if isinstance(v, Tensor):
+                    lists.setdefault(k, []).append(v)
+        return {k: torch.cat(v) for k, v in lists.items()}
+
+    @torch.no_grad()
+    def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
+        """``fruit_nerf.py:377-404``: [H,W,C] outputs of a full-image bundle."""
+        image_height, image_width = camera_ray_bundle.origins.shape[:2]
+        out = self._chunked(camera_ray_bundle, self.forward)
+        return {k: v.view(image_height, image_width, -1) for k, v in out.items()}
+
+    @torch.no_grad()
+    def get_outputs_for_camera_jagged_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
+        """``fruit_nerf.py:346-374``: same for an arbitrary list of rays ([N,C] outputs)."""
+        return self._chunked(camera_ray_bundle, self.forward)
+
+    @torch.no_grad()
+    def get_density_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Tensor:
+        """``fruit_nerf.py:320-344``: sum_s w per ray (no pose tweak, no collider); density-only kernel variant."""
+        out = self._chunked(camera_ray_bundle,
+                            lambda rb: self._sample_and_render(rb.flatten().to(self.device)._map(lambda t: t.contiguous()),
+                                                               density_only=True))
+        return out["accumulation"][:, 0]
+
+    # ------------------------------------------------------------------------------------------ projection
+    @torch.no_grad()
+    def get_outputs_for_projections(self, train_dataset, camera_optimizer=None,
+                                    pcd_path: str = "/opt/data/artifacts/pear/pcd/all_super_cluster_info_nsub_2.npy",
+                                    output_root: str = "/opt/data/artifacts/pear/projection",
+                                    pcd_data=None, save: bool = True):
+        """``fruit_nerf.py:254-318``: per (super-cluster, camera, sub-cluster AABB) an unoccluded semantic render and an
+        occlusion-masked one, written as PNGs.  Returns {(i_sc, cam_idx, i): (wo_occ, visible)} when ``save`` is False."""
+        cameras: Cameras = train_dataset.cameras
+        segmentation_files = train_dataset.metadata["semantics"].filenames
+        if pcd_data is None:
+            pcd_data = np.load(pcd_path, allow_pickle=True)
+        results = {}
+        for i_sc in range(len(pcd_data)):
+            cluster_aabb = np.asarray(pcd_data[i_sc]["aabb"])
+            save_dir = os.path.join(output_root, f"super_cluster_{i_sc}")
+            if save:
+                os.makedirs(save_dir, exist_ok=True)
+            for cam_idx, cam in enumerate(cameras):
+                cam_dir = os.path.join(save_dir, f"cam_{cam_idx}")
+                if save:
+                    os.makedirs(cam_dir, exist_ok=True)
+                for i in range(cluster_aabb.shape[0]):
+                    aabb = SceneBox(torch.tensor(cluster_aabb[i], dtype=torch.float32))
+                    wo_occ, visible = self.project_cluster(cam, aabb, cam_idx)
+                    if save:
+                        save_image(visible, os.path.join(cam_dir, f"visible_cluster_{i}.png"))
+                        save_image(wo_occ, os.path.join(cam_dir, f"wo_occ_cluster_{i}.png"))
+                    else:
+                        results[(i_sc, cam_idx, i)] = (wo_occ, visible)
+                if save and cam_idx < len(segmentation_files) and os.path.exists(segmentation_files[cam_idx]):
+                    shutil.copy(segmentation_files[cam_idx], cam_dir)
+        return results if not save else None
+
+    def project_cluster(self, cam: Cameras, aabb: SceneBox, cam_idx: int = 0) -> Tuple[Tensor, Tensor]:
+        """One job of the loop above: returns float images [H,W,3] (wo_occ, visible) on the device."""
+        cam = cam.to(self.device)
+        rays = cam.generate_rays(camera_indices=0, keep_shape=True, aabb_box=aabb)  # fruit_nerf.py:283
+        if not self.compat_projection_cam0:
+            rays.camera_indices = torch.full_like(rays.camera_indices, cam_idx)
+        H, W = rays.origins.shape[:2]
+        valid = rays.nears < 1e10  # [H,W,1]
+        img = torch.zeros(H * W, 3, device=self.device)
+        if int(valid.sum()) < 10:  # fruit_nerf.py:293
+            z = img.reshape(H, W, 3)
+            return z, z.clone()
+        vmask = valid.squeeze(-1)
+        sub = rays[vmask]
+        out = self.get_outputs_for_camera_jagged_ray_bundle(sub)
+        img[vmask.reshape(-1)] = out["semantics"]  # logit sum, un-sigmoided (reference quirk, :302)
+        img = img.reshape(H, W, 3)
+        wo_occ = img.clone()
+        occ = rays.clone()
+        occ.fars[valid] = rays.nears[valid]
+        occ.nears[valid] = 0.0
+        weights = torch.zeros(H * W, device=self.device)
+        weights[vmask.reshape(-1)] = self.get_density_for_camera_ray_bundle(occ[vmask])
+        mark = (weights >= 0.5).reshape(H, W)
+        img[mark] = 0.0
+        return wo_occ, img
+
+    # ------------------------------------------------------------------------------------------ metrics
+    def get_metrics_dict(self, outputs, batch) -> Dict[str, Tensor]:
+        """``fruit_nerf.py:639-645`` (PSNR only; the distortion metric needs the training lists)."""
+        image = batch["image"].to(self.device)
+        mse = torch.mean((outputs["rgb"] - image[:, :3]) ** 2)
+        return {"psnr": -10.0 * torch.log10(mse)}
+
+
+def save_image(img_hw3: Tensor, path: str) -> None:
+    """``torchvision.utils.save_image`` semantics for one [H,W,3] image: clamp to [0,1], x255 + 0.5, uint8 PNG."""
+    from PIL import Image
+
+    arr = img_hw3.detach().clamp(0, 1).mul(255).add_(0.5).clamp_(0, 255).to("cpu", torch.uint8).numpy()
+    Image.fromarray(arr).save(path)

@@ -1,0 +1,121 @@
+#!/usr/bin/env python
+"""``semantic_projection.py pointcloud | cameras`` -- mirror of
+``crop_nerf/fruit_nerf/scripts/semantic_projection.py:99-213`` (same sub-commands and flag names; argparse instead
+of tyro, which this image lacks).
+
+    python semantic_projection.py pointcloud --load-config RUN/config.json --output-dir OUT \
+        [--pcd-path all_super_cluster_info_nsub_2.npy] [--num-rays-per-batch 4096]
+    python semantic_projection.py cameras --load-config RUN/config.json --output-dir OUT
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Optional, Tuple
+
+import torch
+
+
+@dataclass
+class Exporter:
+    load_config: Path
+    output_dir: Path
+
+
+@dataclass
+class ExportPointCloud(Exporter):
+    """Fields as ``scripts/semantic_projection.py:99-130``."""
+
+    num_points: int = 1000000
+    remove_outliers: bool = True
+    reorient_normals: bool = True
+    normal_method: str = "model_output"
+    normal_output_name: str = "normals"
+    depth_output_name: str = "depth"
+    rgb_output_name: str = "rgb"
+    obb_center: Optional[Tuple[float, float, float]] = None
+    obb_rotation: Optional[Tuple[float, float, float]] = None
+    obb_scale: Optional[Tuple[float, float, float]] = None
+    num_rays_per_batch: int = 1024 * 4
+    std_ratio: float = 10.0
+    save_world_frame: bool = False
+    pcd_path: str = "/opt/data/artifacts/pear/pcd/all_super_cluster_info_nsub_2.npy"
+    compat_projection_cam0: bool = False
+
+    def main(self) -> None:
+        from cropnerf_amd.fruit_nerf.checkpoint import eval_setup
+        from cropnerf_amd.fruit_nerf.fruit_nerf import Semantics, background_color_override_context
+
+        if not self.output_dir.exists():
+            self.output_dir.mkdir(parents=True)
+        config, pipeline, _, step = eval_setup(self.load_config, eval_num_rays_per_chunk=self.num_rays_per_batch,
+                                               test_mode="test")
+        pipeline.model.eval()
+        pipeline.model.compat_projection_cam0 = self.compat_projection_cam0
+
+        class _Dataset:  # what get_outputs_for_projections reads from train_dataset (fruit_nerf.py:263-264)
+            cameras = pipeline.datamanager.cameras
+            metadata = {"semantics": Semantics()}
+
+        background_color = torch.tensor([0.0, 0.0, 0.0])
+        with background_color_override_context(background_color), torch.no_grad():
+            pipeline.model.get_outputs_for_projections(_Dataset, None, pcd_path=self.pcd_path,
+                                                       output_root=str(self.output_dir / "projection"))
+
+
+@dataclass
+class ExportCameraPoses(Exporter):
+    """``scripts/semantic_projection.py:174-199``: dump the (pose-refined) training cameras."""
+
+    def main(self) -> None:
+        from cropnerf_amd.fruit_nerf.checkpoint import eval_setup
+
+        if not self.output_dir.exists():
+            self.output_dir.mkdir(parents=True)
+        _, pipeline, _, _ = eval_setup(self.load_config)
+        cams = pipeline.datamanager.cameras
+        adj = pipeline.model.params["camera_optimizer.pose_adjustment"].cpu()
+        frames = []
+        for i in range(len(cams)):
+            c2w = cams.camera_to_worlds[i].cpu()
+            frames.append({"file_path": f"frame_{i:05d}", "transform": c2w.tolist(), "pose_adjustment": adj[i].tolist()})
+        path = os.path.join(self.output_dir, "transforms_train.json")
+        with open(path, "w", encoding="UTF-8") as f:
+            json.dump(frames, f, indent=4)
+        print(f"Saved poses to {path}")
+
+
+def _add_common(p):
+    p.add_argument("--load-config", type=Path, required=True)
+    p.add_argument("--output-dir", type=Path, required=True)
+
+
+def entrypoint(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    pc = sub.add_parser("pointcloud")
+    _add_common(pc)
+    pc.add_argument("--num-points", type=int, default=1000000)
+    pc.add_argument("--num-rays-per-batch", type=int, default=4096)
+    pc.add_argument("--std-ratio", type=float, default=10.0)
+    pc.add_argument("--pcd-path", default=ExportPointCloud.pcd_path)
+    pc.add_argument("--compat-projection-cam0", action="store_true")
+    cam = sub.add_parser("cameras")
+    _add_common(cam)
+    a = ap.parse_args(argv)
+    if a.cmd == "pointcloud":
+        ExportPointCloud(a.load_config, a.output_dir, num_points=a.num_points, num_rays_per_batch=a.num_rays_per_batch,
+                         std_ratio=a.std_ratio, pcd_path=a.pcd_path,
+                         compat_projection_cam0=a.compat_projection_cam0).main()
+    else:
+        ExportCameraPoses(a.load_config, a.output_dir).main()
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
+    entrypoint()

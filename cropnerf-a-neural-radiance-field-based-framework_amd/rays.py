@@ -1,0 +1,147 @@
+"""Device-side ray containers with nerfstudio's field names (``RayBundle``, ``RaySamples``/``Frustums``, ``Cameras``,
+``SceneBox``): what the reference's call sites pass around (``fruit_nerf/fruit_nerf.py:283-310,617-637``).  SoA tensors
+on the ROCm device; no nerfstudio import."""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field, replace
+from typing import Dict, Optional, Sequence, Union
+
+import torch
+from torch import Tensor
+
+
+@dataclass
+class SceneBox:
+    aabb: Tensor  # [2,3]
+
+    def flat(self):
+        return [float(v) for v in self.aabb.reshape(-1).tolist()]
+
+
+@dataclass
+class RayBundle:
+    origins: Tensor  # [R,3] or [H,W,3]
+    directions: Tensor
+    pixel_area: Optional[Tensor] = None
+    camera_indices: Optional[Tensor] = None  # [R,1] int64
+    nears: Optional[Tensor] = None
+    fars: Optional[Tensor] = None
+    metadata: Dict[str, Tensor] = field(default_factory=dict)
+
+    _FIELDS = ("origins", "directions", "pixel_area", "camera_indices", "nears", "fars")
+
+    def __len__(self) -> int:
+        n = 1
+        for s in self.origins.shape[:-1]:
+            n *= s
+        return n
+
+    @property
+    def shape(self):
+        return tuple(self.origins.shape[:-1])
+
+    def _map(self, fn) -> "RayBundle":
+        kw = {k: (None if getattr(self, k) is None else fn(getattr(self, k))) for k in self._FIELDS}
+        return RayBundle(**kw, metadata={k: fn(v) for k, v in self.metadata.items()})
+
+    def flatten(self) -> "RayBundle":
+        return self._map(lambda t: t.reshape(-1, t.shape[-1]))
+
+    def to(self, device) -> "RayBundle":
+        return self._map(lambda t: t.to(device))
+
+    def get_row_major_sliced_ray_bundle(self, start_idx: int, end_idx: int) -> "RayBundle":
+        return self.flatten()._map(lambda t: t[start_idx:end_idx])
+
+    def __getitem__(self, idx) -> "RayBundle":
+        """Boolean-mask / index selection over the leading (ray) dimensions, like nerfstudio's TensorDataclass."""
+        if isinstance(idx, Tensor) and idx.dtype == torch.bool:
+            n = idx.dim()
+            return self._map(lambda t: t[idx.to(t.device)] if t.dim() - 1 == n else t.reshape(-1, t.shape[-1])[idx.reshape(-1).to(t.device)])
+        return self._map(lambda t: t[idx])
+
+    def clone(self) -> "RayBundle":
+        return self._map(lambda t: t.clone())
+
+
+@dataclass
+class RaySamples:
+    """Materialised samples ([R,S,1] tensors), only built on the unfused / training-list paths."""
+
+    origins: Tensor  # [R,3]
+    directions: Tensor  # [R,3]
+    starts: Tensor  # [R,S,1]
+    ends: Tensor
+    spacing_starts: Optional[Tensor] = None
+    spacing_ends: Optional[Tensor] = None
+    camera_indices: Optional[Tensor] = None
+
+    @property
+    def deltas(self) -> Tensor:
+        return self.ends - self.starts
+
+    @property
+    def shape(self):
+        return tuple(self.starts.shape[:-1])
+
+
+@dataclass
+class Cameras:
+    """Undistorted perspective cameras (nerfstudio ``Cameras`` subset used by the reference's hot path)."""
+
+    camera_to_worlds: Tensor  # [N,3,4]
+    fx: Tensor  # [N]
+    fy: Tensor
+    cx: Tensor
+    cy: Tensor
+    height: int
+    width: int
+
+    def __len__(self) -> int:
+        return self.camera_to_worlds.shape[0]
+
+    def __getitem__(self, i: int) -> "Cameras":
+        return Cameras(self.camera_to_worlds[i:i + 1], self.fx[i:i + 1], self.fy[i:i + 1], self.cx[i:i + 1],
+                       self.cy[i:i + 1], self.height, self.width)
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    @property
+    def image_height(self):
+        return self.height
+
+    @property
+    def image_width(self):
+        return self.width
+
+    def intrinsics(self) -> Tensor:
+        return torch.stack([self.fx, self.fy, self.cx, self.cy], dim=-1).to(torch.float32).contiguous()
+
+    def to(self, device) -> "Cameras":
+        return Cameras(self.camera_to_worlds.to(device), self.fx.to(device), self.fy.to(device), self.cx.to(device),
+                       self.cy.to(device), self.height, self.width)
+
+    def generate_rays(self, camera_indices: Union[int, Tensor], keep_shape: Optional[bool] = None,
+                      aabb_box: Optional[SceneBox] = None, coords: Optional[Tensor] = None) -> RayBundle:
+        """``Cameras.generate_rays`` for (a) one camera's full image (``camera_indices`` int, ``keep_shape=True`` gives
+        [H,W,.] tensors as at ``fruit_nerf.py:283``) and (b) a [R,3] tensor of (camera,row,col) ray indices
+        (``train_ray_generator``).  ``aabb_box`` fills nears/fars with the slab test (misses: 1e10)."""
+        from . import ops
+
+        dev = self.camera_to_worlds.device
+        c2w = self.camera_to_worlds.to(torch.float32).contiguous()
+        intr = self.intrinsics()
+        if isinstance(camera_indices, int):
+            out = ops.raygen_pinhole(c2w, intr, cam=camera_indices, height=self.height, width=self.width,
+                                     camera_index_value=camera_indices)
+        else:
+            out = ops.raygen_pinhole(c2w, intr, ray_indices=camera_indices.to(dev).to(torch.int64).contiguous())
+        rb = RayBundle(out["origins"], out["directions"], out["pixel_area"], out["camera_indices"],
+                       metadata={"directions_norm": out["directions_norm"]})
+        if aabb_box is not None:
+            rb.nears, rb.fars = ops.intersect_aabb(rb.origins, rb.directions, aabb_box.flat())
+        if isinstance(camera_indices, int) and keep_shape:
+            rb = rb._map(lambda t: t.reshape(self.height, self.width, t.shape[-1]))
+        return rb
