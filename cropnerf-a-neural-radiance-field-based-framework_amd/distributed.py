@@ -1,0 +1,96 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI
+on MI355X; "gloo" in the CPU tests).
+
+Rays are independent, so the path shards with no collective inside the render.  The reference's only collective
+call site is DDP around the model (``crop_nerf/fruit_nerf/fruit_pipeline.py:119-121``); for render / export the
+equivalent is:
+
+* ``render_rays_sharded``  -- contiguous ray ranges per rank, ONE all-gather of the fixed-size per-ray outputs
+  (rgb 3 + accumulation 1 + depth 1 + semantics 1 = 24 B/ray);
+* ``all_gather_points``    -- variable-length exporter output: all-gather of the counts, then one padded all-gather
+  of the rows (xyz + colour), trimmed on arrival;
+* ``shard_jobs``           -- projection jobs (camera x sub-cluster) dealt round-robin, no communication at all.
+
+xGMI is point to point (7 links per GPU); these payloads are 1-2 MB per rank, i.e. latency-bound single-shot
+collectives -- no bucketing is needed and none is done.
+"""
+
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+PACK_KEYS = (("rgb", 3), ("accumulation", 1), ("depth", 1), ("semantics", 1))
+
+
+def world(group=None) -> Tuple[int, int]:
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def shard_range(n: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous balanced split of [0, n): the first n % world ranks get one extra row."""
+    base, rem = divmod(n, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_jobs(jobs: Sequence, rank: int, world_size: int) -> List:
+    return list(jobs[rank::world_size])
+
+
+def _all_gather_rows(local: Tensor, counts: List[int], group=None) -> Tensor:
+    """All-gather of [n_r, k] row blocks of different lengths: pad to the longest, gather once, trim."""
+    rank, ws = world(group)
+    mx = max(counts) if counts else 0
+    k = local.shape[1]
+    padded = torch.zeros(mx, k, dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    out = torch.empty(ws * mx, k, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    out = out.view(ws, mx, k)
+    return torch.cat([out[r, : counts[r]] for r in range(ws)], dim=0)
+
+
+def render_rays_sharded(render_fn: Callable[[int, int], Dict[str, Tensor]], num_rays: int, group=None
+                        ) -> Dict[str, Tensor]:
+    """``render_fn(lo, hi)`` renders rays [lo, hi) on this rank and returns at least the PACK_KEYS tensors
+    ([n,3],[n,1],[n,1],[n,1]).  Returns the full-size tensors on every rank."""
+    rank, ws = world(group)
+    lo, hi = shard_range(num_rays, rank, ws)
+    out = render_fn(lo, hi)
+    if ws == 1:
+        return {k: out[k] for k, _ in PACK_KEYS}
+    packed = torch.cat([out[k].reshape(hi - lo, w) for k, w in PACK_KEYS], dim=-1).contiguous()
+    counts = [shard_range(num_rays, r, ws)[1] - shard_range(num_rays, r, ws)[0] for r in range(ws)]
+    full = _all_gather_rows(packed, counts, group)
+    res, c = {}, 0
+    for k, w in PACK_KEYS:
+        res[k] = full[:, c:c + w].contiguous()
+        c += w
+    return res
+
+
+def all_gather_points(rows: Tensor, group=None) -> Tensor:
+    """Variable-length all-gather of exporter rows ([n_r, k], e.g. xyz+rgb+prob): counts first, then payload."""
+    rank, ws = world(group)
+    if ws == 1:
+        return rows
+    n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
+    all_n = torch.empty(ws, dtype=torch.int64, device=rows.device)
+    dist.all_gather_into_tensor(all_n, n, group=group)
+    return _all_gather_rows(rows.contiguous(), [int(v) for v in all_n.tolist()], group)
+
+
+def all_reduce_mean(value: Tensor, group=None) -> Tensor:
+    """Per-view scalar metrics (loss / PSNR terms): sum-reduce then divide."""
+    rank, ws = world(group)
+    if ws == 1:
+        return value
+    v = value.clone()
+    dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
+    return v / ws

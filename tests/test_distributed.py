@@ -1,0 +1,106 @@
+"""World-size-2 (and 3) gloo tests of the ray-batch sharding layer, on CPU.  The render function is injected, so the
+CPU oracle stands in for the HIP renderer here (tests may use the oracle; the product path cannot)."""
+
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, fn_name, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = globals()[fn_name](rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn_name, world):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fn_name, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    return dict(ret)
+
+
+def _case_render(rank, world):
+    from _helpers import make_scene, oracle_model, rays_with_box
+    from cropnerf_amd import distributed as D
+
+    sc = make_scene(seed=2, log2_T=10, num_images=3, height=9, width=7, focal=10.0, prop_log2_T=8)
+    m = oracle_model(sc, "inference", disable_scene_contraction=True)
+    m.uniform_samples = 16
+    rb = rays_with_box(sc, 0)
+    calls = []
+
+    def render(lo, hi):
+        calls.append((lo, hi))
+        return m.forward(rb.slice(lo, hi))
+
+    full = D.render_rays_sharded(render, len(rb))
+    ref = m.forward(rb)
+    ok = all(torch.allclose(full[k], ref[k], atol=1e-6) for k in ("rgb", "accumulation", "depth", "semantics"))
+    return {"ok": ok, "calls": calls, "n": len(rb)}
+
+
+def _case_points(rank, world):
+    from cropnerf_amd import distributed as D
+
+    g = torch.Generator().manual_seed(rank)
+    n = [5, 0, 11][rank % 3]  # ragged, including an empty rank
+    rows = torch.rand(n, 7, generator=g) + rank
+    out = D.all_gather_points(rows)
+    mean = D.all_reduce_mean(torch.tensor([float(rank)]))
+    return {"shape": tuple(out.shape), "first": [float(out[:, 0].min()), float(out[:, 0].max())], "mean": float(mean)}
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_render_equals_single_rank(world):
+    res = _run("_case_render", world)
+    n = res[0]["n"]
+    assert all(r["ok"] for r in res.values())
+    ranges = sorted(r["calls"][0] for r in res.values())
+    assert ranges[0][0] == 0 and ranges[-1][1] == n
+    assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))  # contiguous, disjoint
+    assert max(hi - lo for lo, hi in ranges) - min(hi - lo for lo, hi in ranges) <= 1  # balanced
+
+
+def test_ragged_point_all_gather():
+    res = _run("_case_points", 2)
+    assert all(r["shape"] == (5, 7) for r in res.values())  # 5 + 0 rows
+    assert abs(res[0]["mean"] - 0.5) < 1e-6
+    res = _run("_case_points", 3)
+    assert all(r["shape"] == (16, 7) for r in res.values())
+    assert all(r["first"][0] < 1.0 and r["first"][1] >= 2.0 for r in res.values())
+
+
+def test_shard_helpers_single_process():
+    from cropnerf_amd import distributed as D
+
+    assert [D.shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert D.shard_range(0, 0, 2) == (0, 0)
+    assert D.shard_jobs(list(range(7)), 1, 3) == [1, 4]
+    t = torch.arange(6.0).reshape(3, 2)
+    assert D.all_gather_points(t) is t  # world size 1: no communication
