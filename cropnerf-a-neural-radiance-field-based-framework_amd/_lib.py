@@ -82,7 +82,7 @@ SIGNATURES = {
     "cn_render_rays": (C.c_int, [C.POINTER(FieldParams), C.POINTER(Scene), C.POINTER(RenderOpts), _P, _P, _P, _P, _P,
                                  _P, _I64, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cn_render_samples": (C.c_int, [C.POINTER(FieldParams), C.POINTER(Scene), C.POINTER(RenderOpts), _P, _P, _P, _P,
-                                    _P, _P, _I64, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+                                    _P, _P, _I64, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cn_proposal_sample_workspace_bytes": (C.c_size_t, [_I64, C.POINTER(_I32), _I32, _I32]),
     "cn_proposal_sample": (C.c_int, [C.POINTER(C.POINTER(DensityParams)), _I32, C.POINTER(Scene), _P, _P, _P, _P, _I64,
                                      C.POINTER(_I32), _I32, _F, _P, _P, _P, _P, C.c_size_t, _P]),

@@ -43,6 +43,15 @@ constexpr int OFF_SCALE = 10712;  // [16] hash-grid level scalings (lane group g
 constexpr int BLOB_FLOATS = 10712 + 16;
 static_assert(BLOB_FLOATS % 4 == 0, "blob is copied as float4");
 constexpr int WAVE_SCRATCH = 160;  // floats of per-wave LDS scratch
+#ifndef CN_FUSED_WAVES
+#define CN_FUSED_WAVES 4
+#endif
+#ifndef CN_FUSED_MIN_WAVES_PER_SIMD
+#define CN_FUSED_MIN_WAVES_PER_SIMD 3
+#endif
+// 4 waves x 3 blocks/CU measured faster than 8 waves x 2 blocks/CU (3.38 vs 3.06 Gsamples/s at C2)
+constexpr int FUSED_WAVES = CN_FUSED_WAVES;  // waves per workgroup (they share one LDS weight image)
+constexpr int FUSED_THREADS = FUSED_WAVES * 64;
 
 struct PrepArgs {
   const float *w0, *b0, *w1, *b1;        // base
@@ -57,13 +66,20 @@ struct PrepArgs {
   float scale[CN_MAX_LEVELS];
 };
 
-// Embedding.mean(dim=0): one thread per column, independent loads
-__global__ void __launch_bounds__(64) prep_mean_kernel(const float* __restrict__ emb, int n, float* __restrict__ mean) {
-  const int k = threadIdx.x;
-  if (k >= 32) return;
+// Embedding.mean(dim=0) for the 32-wide appearance embedding: 8 partial sums per column, combined through LDS
+__global__ void __launch_bounds__(256) prep_mean_kernel(const float* __restrict__ emb, int n, float* __restrict__ mean) {
+  __shared__ float part[8][32];
+  const int k = threadIdx.x & 31, p = threadIdx.x >> 5;
   float s = 0.f;
-  for (int i = 0; i < n; ++i) s += emb[i * 32 + k];
-  mean[k] = s / (float)n;
+  for (int i = p; i < n; i += 8) s += emb[i * 32 + k];
+  part[p][k] = s;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += part[q][k];
+    mean[k] = t / (float)n;
+  }
 }
 
 __global__ void __launch_bounds__(256) prep_kernel(PrepArgs p, float* __restrict__ blob, float* __restrict__ app_bias) {
@@ -164,16 +180,24 @@ struct FusedArgs {
   float *out_rgb, *out_acc, *out_depth, *out_sem, *out_cmap, *out_w;
   // per-sample outputs
   float *s_density, *s_rgb, *s_sem, *s_pos;
+  int64_t* s_label;
 };
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// ReLU as a signed-integer max on the float bits: one v_max_i32 per value.  fmaxf(x, 0) costs two VALU ops here
+// (hipcc inserts a canonicalising v_max_f32 x, x in front); on the bit pattern, every negative float (sign bit set,
+// -0.0 included) is a negative int -> 0, every non-negative float is unchanged.
+__device__ __forceinline__ float relu1(float x) {
+  int i = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, i > 0 ? i : 0);
+}
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
   f32x4 r;
-  r.x = fmaxf(v.x, 0.f);
-  r.y = fmaxf(v.y, 0.f);
-  r.z = fmaxf(v.z, 0.f);
-  r.w = fmaxf(v.w, 0.f);
+  r.x = relu1(v.x);
+  r.y = relu1(v.y);
+  r.z = relu1(v.z);
+  r.w = relu1(v.w);
   return r;
 }
 
@@ -192,12 +216,12 @@ __device__ __forceinline__ float pick4(int g, float a, float b, float c, float d
 }
 
 template <bool PER_SAMPLE, bool DENSITY_ONLY>
-__global__ void __launch_bounds__(256, 3) render_fused_kernel(FusedArgs A) {
-  __shared__ __align__(16) float lds[BLOB_FLOATS + 4 * WAVE_SCRATCH];
+__global__ void __launch_bounds__(FUSED_THREADS, CN_FUSED_MIN_WAVES_PER_SIMD) render_fused_kernel(FusedArgs A) {
+  __shared__ __align__(16) float lds[BLOB_FLOATS + FUSED_WAVES * WAVE_SCRATCH];
   {
     const float4* src = reinterpret_cast<const float4*>(A.blob);
     float4* dst = reinterpret_cast<float4*>(lds);
-    for (int i = threadIdx.x; i < BLOB_FLOATS / 4; i += 256) dst[i] = src[i];
+    for (int i = threadIdx.x; i < BLOB_FLOATS / 4; i += FUSED_THREADS) dst[i] = src[i];
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -213,9 +237,9 @@ __global__ void __launch_bounds__(256, 3) render_fused_kernel(FusedArgs A) {
   const long long per_xcd = (A.num_rays + 7) >> 3;
   const long long ray_lo = xcd * per_xcd;
   const long long ray_hi = min(ray_lo + per_xcd, A.num_rays);
-  const long long stride = (long long)(gridDim.x >> 3) * 4;
+  const long long stride = (long long)(gridDim.x >> 3) * FUSED_WAVES;
 
-  for (long long rr = ray_lo + slot * 4 + wave; rr < ray_hi; rr += stride) {
+  for (long long rr = ray_lo + slot * FUSED_WAVES + wave; rr < ray_hi; rr += stride) {
     const long long r = __builtin_amdgcn_readfirstlane((int)rr);  // wave-uniform -> scalar loads below
     const float ox = A.origins[3 * r], oy = A.origins[3 * r + 1], oz = A.origins[3 * r + 2];
     const float dx = A.directions[3 * r], dy = A.directions[3 * r + 1], dz = A.directions[3 * r + 2];
@@ -435,6 +459,7 @@ __global__ void __launch_bounds__(256, 3) render_fused_kernel(FusedArgs A) {
           const long long o = r * (long long)S + i;
           if (A.s_density) A.s_density[o] = density;
           if (A.s_sem) A.s_sem[o] = sem;
+          if (A.s_label) A.s_label[o] = (int64_t)semantics_label(sem);
           if (A.s_rgb) {
             A.s_rgb[3 * o + 0] = cr;
             A.s_rgb[3 * o + 1] = cg;
@@ -503,7 +528,7 @@ static int resident_blocks(K kernel) {
   int dev = 0, cus = 256, per_cu = 2;
   if (hipGetDevice(&dev) != hipSuccess) return 512;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, FUSED_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 2;
   int n = cus * per_cu;
   return n >= 8 ? (n / 8) * 8 : 8;
 }
@@ -557,7 +582,7 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   float* emb_mean = app_bias + (size_t)(params->num_images > 0 ? params->num_images : 1) * 64;
   P.emb_mean = emb_mean;
   if (opts->app_mode == CN_APP_MEAN)
-    hipLaunchKernelGGL(prep_mean_kernel, dim3(1), dim3(64), 0, s, params->appearance, params->num_images, emb_mean);
+    hipLaunchKernelGGL(prep_mean_kernel, dim3(1), dim3(256), 0, s, params->appearance, params->num_images, emb_mean);
   for (int i = 0; i < CN_MAX_LEVELS; ++i) P.scale[i] = params->grid.scalings[i];
   hipLaunchKernelGGL(prep_kernel, dim3(48), dim3(256), 0, s, P, blob, app_bias);
   rc = check_launch("cn_render prep");
@@ -588,14 +613,14 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   static const int res_density = resident_blocks(render_fused_kernel<false, true>);
   static const int res_full = resident_blocks(render_fused_kernel<false, false>);
   const long long cap = PER_SAMPLE ? res_sample : (opts->density_only ? res_density : res_full);
-  const long long want = (((num_rays + 3) / 4) + 7) / 8 * 8;
+  const long long want = (((num_rays + FUSED_WAVES - 1) / FUSED_WAVES) + 7) / 8 * 8;
   const unsigned blocks = (unsigned)(want < cap ? want : cap);
   if (PER_SAMPLE) {
-    hipLaunchKernelGGL((render_fused_kernel<true, false>), dim3(blocks), dim3(256), 0, s, A);
+    hipLaunchKernelGGL((render_fused_kernel<true, false>), dim3(blocks), dim3(FUSED_THREADS), 0, s, A);
   } else if (opts->density_only) {
-    hipLaunchKernelGGL((render_fused_kernel<false, true>), dim3(blocks), dim3(256), 0, s, A);
+    hipLaunchKernelGGL((render_fused_kernel<false, true>), dim3(blocks), dim3(FUSED_THREADS), 0, s, A);
   } else {
-    hipLaunchKernelGGL((render_fused_kernel<false, false>), dim3(blocks), dim3(256), 0, s, A);
+    hipLaunchKernelGGL((render_fused_kernel<false, false>), dim3(blocks), dim3(FUSED_THREADS), 0, s, A);
   }
   return check_launch(who);
 }
@@ -624,13 +649,14 @@ extern "C" int cn_render_rays(const cn_field_params* params, const cn_scene* sce
 extern "C" int cn_render_samples(const cn_field_params* params, const cn_scene* scene, const cn_render_opts* opts,
                                  const float* origins, const float* directions, const float* nears, const float* fars,
                                  const int64_t* camera_indices, const float* bins, int64_t num_rays, float* density,
-                                 float* rgb, float* semantics, float* positions, void* workspace,
-                                 size_t workspace_bytes, cn_stream_t stream) {
+                                 float* rgb, float* semantics, float* positions, int64_t* semantics_colormap,
+                                 void* workspace, size_t workspace_bytes, cn_stream_t stream) {
   cn::FusedArgs A{};
   A.s_density = density;
   A.s_rgb = rgb;
   A.s_sem = semantics;
   A.s_pos = positions;
+  A.s_label = semantics_colormap;
   return cn::launch_fused<true>(params, scene, opts, origins, directions, nears, fars, camera_indices, bins, num_rays, A,
                                 workspace, workspace_bytes, stream, "cn_render_samples");
 }

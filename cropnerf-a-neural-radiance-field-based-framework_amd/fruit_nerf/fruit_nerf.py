@@ -237,9 +237,8 @@ class FruitModel:
         rb = ray_bundle
         out = ops.render_samples(self.field, self._scene(self._field_contraction), self._opts(self._uniform_samples),
                                  rb.origins, rb.directions, rb.nears, rb.fars, camera_indices=self._cam_idx(rb))
-        labels = ((torch.sigmoid(out["semantics"]) - 0.9) > 0).to(torch.long)  # bookkeeping on 1 value/sample
         return {"rgb": out["rgb"], "point_location": out["positions"], "semantics": out["semantics"],
-                "density": out["density"], "semantics_colormap": labels}
+                "density": out["density"], "semantics_colormap": out["semantics_colormap"]}
 
     # ------------------------------------------------------------------------------------------ chunked renders
     def _chunked(self, camera_ray_bundle: RayBundle, fn) -> Dict[str, Tensor]:

@@ -361,13 +361,15 @@ def render_samples(fh: FieldHandle, scene: L.Scene, opts: L.RenderOpts, origins:
     dev = origins.device
     S = opts.num_samples
     out = {"density": torch.empty(R, S, device=dev), "rgb": torch.empty(R, S, 3, device=dev),
-           "semantics": torch.empty(R, S, device=dev), "positions": torch.empty(R, S, 3, device=dev)}
+           "semantics": torch.empty(R, S, device=dev), "positions": torch.empty(R, S, 3, device=dev),
+           "semantics_colormap": torch.empty(R, S, dtype=torch.int64, device=dev)}
     ws = fh.workspace()
     L.check(lib.cn_render_samples(C.byref(fh.struct), C.byref(scene), C.byref(opts), _p(_f32(origins, "origins")),
                                   _p(_f32(directions, "directions")), _p(_f32(nears, "nears")), _p(_f32(fars, "fars")),
                                   _p(_i64(camera_indices, "camera_indices")), _p(_f32(bins, "bins")), R,
                                   _p(out["density"]), _p(out["rgb"]), _p(out["semantics"]), _p(out["positions"]),
-                                  C.c_void_p(ws.data_ptr()), ws.numel(), _stream(origins)))
+                                  _p(out["semantics_colormap"]), C.c_void_p(ws.data_ptr()), ws.numel(),
+                                  _stream(origins)))
     return out
 
 

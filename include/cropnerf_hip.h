@@ -223,12 +223,13 @@ int cn_render_rays(const cn_field_params* params, const cn_scene* scene, const c
                    cn_stream_t stream);
 
 /* Same kernel with per-sample outputs instead of compositing: FruitModel.get_export_outputs
- * (fruit_nerf/fruit_nerf.py:476-494). density [R,S], rgb [R,S,3], semantics [R,S], positions [R,S,3]. */
+ * (fruit_nerf/fruit_nerf.py:476-494). density [R,S], rgb [R,S,3], semantics [R,S], positions [R,S,3],
+ * semantics_colormap [R,S] int64 labels = heaviside(sigmoid(sem) - 0.9, 0) (:488-492); any output may be NULL. */
 int cn_render_samples(const cn_field_params* params, const cn_scene* scene, const cn_render_opts* opts,
                       const float* origins, const float* directions, const float* nears, const float* fars,
                       const int64_t* camera_indices, const float* bins, int64_t num_rays, float* density,
-                      float* rgb, float* semantics, float* positions, void* workspace, size_t workspace_bytes,
-                      cn_stream_t stream);
+                      float* rgb, float* semantics, float* positions, int64_t* semantics_colormap, void* workspace,
+                      size_t workspace_bytes, cn_stream_t stream);
 
 /* Fused proposal sampler: piecewise initial samples -> proposal net 0 -> PDF -> proposal net 1 -> PDF
  * (ProposalNetworkSampler as configured at fruit_nerf/fruit_nerf.py:157-164, eval mode).

@@ -293,6 +293,8 @@ def test_render_samples_matches_general_kernel_and_oracle(scene, ops, handles):
     assert_close(out["density"], ref["density"], RTOL, ATOL, "density")
     assert_close(out["semantics"], ref["semantics"], RTOL, ATOL, "semantics")
     assert_close(out["rgb"], ref["rgb"], RTOL, ATOL, "rgb")
+    clear = (ref["semantics"] - math.log(9.0)).abs() > 1e-3
+    assert torch.equal(out["semantics_colormap"].cpu()[clear], ref["semantics_colormap"][clear])
     sm = ops.sample_spaced(n, f, S)
     gen = ops.field_eval(fh, sc, o, d, None, sm["starts"], sm["ends"])
     assert_close(out["density"], gen["density"].cpu(), RTOL, ATOL, "fused vs general: density")
