@@ -1,0 +1,557 @@
+// Training, field side: parameter gradients of FruitField and of the proposal HashMLPDensityFields.
+//
+//   cn_field_backward     : given d loss / d (density, rgb, semantics) per sample (train_render.hip), recompute the
+//                           forward of FruitField (fruit_nerf/fruit_field.py:169-282, training branch: per-camera
+//                           appearance, semantic MLP on detached geo features) for a 64-sample tile with all activations
+//                           in LDS, back-propagate, and accumulate gradients of every Linear layer, of the appearance
+//                           embedding and of the hash table.
+//   cn_proposal_backward  : same for a proposal network given d loss / d density (interlevel loss).
+//
+// Layout: a 256-thread workgroup owns a tile of 64 samples; activations and deltas live in LDS as [feature][65]
+// (row pad 1 -> conflict-free both for "lane = sample" sweeps and for the weight-gradient dots).  Forward / delta
+// layers split their output rows over the 4 waves (weights come through scalar loads).  Weight gradients
+// dW[n][k] = sum_samples delta[n] x[k]: thread t owns entries t, t+256, ... of each matrix and keeps the partial sums in
+// registers across all tiles of its (persistent) workgroup, then issues one global_atomic_add_f32 per entry at the end
+// -- atomics per step are (#workgroups x #parameters), not (#samples x #parameters).  Hash-table gradients are
+// scatter-adds (2 floats x 8 corners per level per sample), as in every hash-grid trainer.
+//
+// Shapes: the default fruit_nerf_method field (16 levels, 32->64->16, 15->64->64->1, 63->64->64->3, appearance 32)
+// and {5|7}-level 2L->16->1 proposal nets; other shapes return CN_ERR_UNSUPPORTED.
+#include "cn_common.hpp"
+#include "wave_ops.hpp"
+
+namespace cn {
+
+constexpr int TS = 64;       // samples per tile
+constexpr int LD = TS + 1;   // padded row length
+constexpr int TB = 256;      // threads per workgroup
+
+// y[n][lane] = act(b[n] + sum_k W[n][k] x[k][lane]) for the rows n = wave, wave+4, ...
+template <int K, int N, bool RELU>
+__device__ __forceinline__ void fwd_rows(const float* __restrict__ W, const float* __restrict__ b, const float* x,
+                                         float* y, int wave, int lane) {
+  for (int n = wave; n < N; n += 4) {
+    float acc = b[n];
+#pragma unroll 8
+    for (int k = 0; k < K; ++k) acc = fmaf(W[n * K + k], x[k * LD + lane], acc);
+    y[n * LD + lane] = RELU ? fmaxf(acc, 0.f) : acc;
+  }
+}
+
+// dx[k][lane] = (sum_n W[n][k] dy[n][lane]) * (gate ? act[k][lane] > 0 : 1) for rows k = k0 + wave, +4, ... < k1
+template <int K, int N>
+__device__ __forceinline__ void bwd_rows(const float* __restrict__ W, const float* dy, float* dx, const float* act,
+                                         int k0, int k1, int wave, int lane) {
+  for (int k = k0 + wave; k < k1; k += 4) {
+    float acc = 0.f;
+#pragma unroll 8
+    for (int n = 0; n < N; ++n) acc = fmaf(W[n * K + k], dy[n * LD + lane], acc);
+    if (act) acc = act[k * LD + lane] > 0.f ? acc : 0.f;
+    dx[k * LD + lane] = acc;
+  }
+}
+
+// acc[i] += sum_j dy[n][j] x[k][j] for the entries e = tid + TB*i (n = e / K, k = e % K)
+template <int K, int N>
+struct WGrad {
+  static constexpr int E = (N * K + TB - 1) / TB;
+  float acc[E];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < E; ++i) acc[i] = 0.f;
+  }
+  __device__ __forceinline__ void add(const float* dy, const float* x, int tid) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      int e = tid + TB * i;
+      if (e < N * K) {
+        const float* a = dy + (e / K) * LD;
+        const float* b = x + (e % K) * LD;
+        float s = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < TS; ++j) s = fmaf(a[j], b[j], s);
+        acc[i] += s;
+      }
+    }
+  }
+  __device__ __forceinline__ void flush(float* __restrict__ g, int tid) {
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      int e = tid + TB * i;
+      if (e < N * K) atomicAdd(g + e, acc[i]);
+    }
+  }
+};
+
+// bias gradient: thread n < N owns sum_j dy[n][j]
+template <int N>
+__device__ __forceinline__ void bias_add(float& acc, const float* dy, int tid) {
+  if (tid < N) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < TS; ++j) s += dy[tid * LD + j];
+    acc += s;
+  }
+}
+
+// scatter d(loss)/d(features of one level) into the table gradient with the forward's trilinear weights
+__device__ __forceinline__ void hash_level_backward(float* __restrict__ gtab, unsigned level_off, unsigned mask,
+                                                    float scale, float px, float py, float pz, float g0, float g1) {
+  float sx = px * scale, sy = py * scale, sz = pz * scale;
+  float fx = floorf(sx), fy = floorf(sy), fz = floorf(sz);
+  float ox = sx - fx, oy = sy - fy, oz = sz - fz;
+  unsigned ix = (unsigned)(int)fx, iy = (unsigned)(int)fy, iz = (unsigned)(int)fz;
+  unsigned hx[2] = {ix, ix + 1u};
+  unsigned hy[2] = {iy * CN_P1, iy * CN_P1 + CN_P1};
+  unsigned hz[2] = {iz * CN_P2, iz * CN_P2 + CN_P2};
+  float wx[2] = {1.f - ox, ox}, wy[2] = {1.f - oy, oy}, wz[2] = {1.f - oz, oz};  // index 1 = ceil corner
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int a = c & 1, b = (c >> 1) & 1, d = c >> 2;
+    const float w = wx[a] * wy[b] * wz[d];
+    const unsigned e = ((hx[a] ^ hy[b] ^ hz[d]) & mask) + level_off;
+    if (w != 0.f) {
+      atomicAdd(gtab + 2 * (size_t)e, w * g0);
+      atomicAdd(gtab + 2 * (size_t)e + 1, w * g1);
+    }
+  }
+}
+
+struct FieldPtrs {
+  const float* table;
+  const float *w0, *b0, *w1, *b1;
+  const float *ws0, *bs0, *ws1, *bs1, *wh, *bh;
+  const float *wc0, *bc0, *wc1, *bc1, *wc2, *bc2;
+  const float* emb;
+};
+struct FieldGrads {
+  float* table;
+  float *w0, *b0, *w1, *b1;
+  float *ws0, *bs0, *ws1, *bs1, *wh, *bh;
+  float *wc0, *bc0, *wc1, *bc1, *wc2, *bc2;
+  float* emb;
+};
+
+struct FieldBwdArgs {
+  FieldPtrs p;
+  FieldGrads g;
+  unsigned mask, level_stride;
+  float scale[CN_MAX_LEVELS];
+  SceneDev scene;
+  int sh_unit;
+  int app_per_camera;
+  const float* app_mean;  // [32] when not per-camera (may be null -> zeros)
+  const float *origins, *directions, *starts, *ends;
+  const int64_t* cam_idx;
+  const float *d_density, *d_rgb, *d_sem;
+  long long R;
+  int S;
+};
+
+// LDS rows (each LD floats)
+constexpr int R_ENC = 0;            // 32
+constexpr int R_H1 = R_ENC + 32;    // 64 (post ReLU)
+constexpr int R_O16 = R_H1 + 64;    // 16
+constexpr int R_S1 = R_O16 + 16;    // 64 (post ReLU)
+constexpr int R_S2 = R_S1 + 64;     // 64
+constexpr int R_CIN = R_S2 + 64;    // 63 (+1 pad row)
+constexpr int R_C1 = R_CIN + 64;    // 64
+constexpr int R_C2 = R_C1 + 64;     // 64
+constexpr int R_DA = R_C2 + 64;     // 64 delta buffer A
+constexpr int R_DB = R_DA + 64;     // 64 delta buffer B
+constexpr int R_MISC = R_DB + 64;   // pos xyz(3) sel(1) logit-deriv(1) dsem(1) drgbpre(3) cam(1) = 10 rows
+constexpr int FIELD_ROWS = R_MISC + 10;
+
+__global__ void __launch_bounds__(TB) field_backward_kernel(FieldBwdArgs A) {
+  extern __shared__ __align__(16) float lds[];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  float* enc = lds + R_ENC * LD;
+  float* h1 = lds + R_H1 * LD;
+  float* o16 = lds + R_O16 * LD;
+  float* s1 = lds + R_S1 * LD;
+  float* s2 = lds + R_S2 * LD;
+  float* cin = lds + R_CIN * LD;
+  float* c1 = lds + R_C1 * LD;
+  float* c2 = lds + R_C2 * LD;
+  float* dA = lds + R_DA * LD;
+  float* dB = lds + R_DB * LD;
+  float* misc = lds + R_MISC * LD;
+
+  WGrad<32, 64> gW0;
+  WGrad<64, 16> gW1;
+  WGrad<15, 64> gWs0;
+  WGrad<64, 64> gWs1;
+  WGrad<63, 64> gWc0;
+  WGrad<64, 64> gWc1;
+  WGrad<64, 3> gWc2;
+  WGrad<64, 1> gWh;
+  gW0.zero(); gW1.zero(); gWs0.zero(); gWs1.zero(); gWc0.zero(); gWc1.zero(); gWc2.zero(); gWh.zero();
+  float gb0 = 0.f, gb1 = 0.f, gbs0 = 0.f, gbs1 = 0.f, gbh = 0.f, gbc0 = 0.f, gbc1 = 0.f, gbc2 = 0.f;
+
+  const long long total = A.R * (long long)A.S;
+  const long long ntiles = (total + TS - 1) / TS;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long i = tile * TS + lane;
+    const bool valid = i < total;
+    const long long ic = valid ? i : total - 1;
+    const long long r = ic / A.S;
+    // ---- per-sample inputs (wave 0 fills the shared rows) ------------------------------------------------------
+    if (wave == 0) {
+      const float mid = (A.starts[ic] + A.ends[ic]) / 2.f;
+      float px = A.origins[3 * r] + A.directions[3 * r] * mid;
+      float py = A.origins[3 * r + 1] + A.directions[3 * r + 1] * mid;
+      float pz = A.origins[3 * r + 2] + A.directions[3 * r + 2] * mid;
+      bool sel = normalize_position(A.scene, px, py, pz);
+      misc[0 * LD + lane] = px;
+      misc[1 * LD + lane] = py;
+      misc[2 * LD + lane] = pz;
+      misc[3 * LD + lane] = sel ? 1.f : 0.f;
+      misc[5 * LD + lane] = valid ? A.d_sem[ic] : 0.f;
+      // colour input: SH(16) | geo (filled after the base MLP) | appearance(32)
+      float dx = A.directions[3 * r], dy = A.directions[3 * r + 1], dz = A.directions[3 * r + 2];
+      if (!A.sh_unit) {
+        dx = (dx + 1.f) / 2.f;
+        dy = (dy + 1.f) / 2.f;
+        dz = (dz + 1.f) / 2.f;
+      }
+      float sh[16];
+      sh_deg4(dx, dy, dz, sh);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) cin[k * LD + lane] = sh[k];
+      const float* a = A.app_per_camera ? A.p.emb + A.cam_idx[r] * 32 : A.app_mean;
+      for (int k = 0; k < 32; ++k) cin[(31 + k) * LD + lane] = a ? a[k] : 0.f;
+    }
+    __syncthreads();
+    // ---- forward recompute -------------------------------------------------------------------------------------------
+    {
+      const float px = misc[0 * LD + lane], py = misc[1 * LD + lane], pz = misc[2 * LD + lane];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int l = 4 * wave + q;
+        float2 f = hash_level(A.p.table, (unsigned)l * A.level_stride, A.mask, A.scale[l], px, py, pz);
+        enc[(2 * l) * LD + lane] = f.x;
+        enc[(2 * l + 1) * LD + lane] = f.y;
+      }
+    }
+    __syncthreads();
+    fwd_rows<32, 64, true>(A.p.w0, A.p.b0, enc, h1, wave, lane);
+    __syncthreads();
+    fwd_rows<64, 16, false>(A.p.w1, A.p.b1, h1, o16, wave, lane);
+    __syncthreads();
+    if (wave == 0) {
+      // trunc_exp backward: g * exp(clamp(x, -15, 15)), times the selector; d_density is d loss / d (post-selector density)
+      const float logit = o16[lane];
+      const float dd = valid ? A.d_density[ic] : 0.f;
+      misc[4 * LD + lane] = dd * misc[3 * LD + lane] * expf(fminf(fmaxf(logit, -15.f), 15.f));
+    }
+    for (int k = wave; k < 15; k += 4) cin[(16 + k) * LD + lane] = o16[(1 + k) * LD + lane];
+    fwd_rows<15, 64, true>(A.p.ws0, A.p.bs0, o16 + LD, s1, wave, lane);  // geo = rows 1..15 of o16
+    __syncthreads();
+    fwd_rows<64, 64, false>(A.p.ws1, A.p.bs1, s1, s2, wave, lane);
+    fwd_rows<63, 64, true>(A.p.wc0, A.p.bc0, cin, c1, wave, lane);
+    __syncthreads();
+    fwd_rows<64, 64, true>(A.p.wc1, A.p.bc1, c1, c2, wave, lane);
+    __syncthreads();
+    // ---- colour head: rgb = sigmoid(Wc2 c2 + bc2); delta_pre = d_rgb * rgb (1 - rgb) -> dA rows 0..2 ----------------
+    if (wave < 3) {
+      float acc = A.p.bc2[wave];
+      for (int k = 0; k < 64; ++k) acc = fmaf(A.p.wc2[wave * 64 + k], c2[k * LD + lane], acc);
+      const float s = 1.f / (1.f + expf(-acc));
+      const float up = valid ? A.d_rgb[3 * ic + wave] : 0.f;
+      dA[wave * LD + lane] = up * s * (1.f - s);
+    }
+    __syncthreads();
+    gWc2.add(dA, c2, tid);
+    bias_add<3>(gbc2, dA, tid);
+    bwd_rows<64, 3>(A.p.wc2, dA, dB, c2, 0, 64, wave, lane);  // delta_c2 (ReLU-gated) -> dB
+    __syncthreads();
+    gWc1.add(dB, c1, tid);
+    bias_add<64>(gbc1, dB, tid);
+    bwd_rows<64, 64>(A.p.wc1, dB, dA, c1, 0, 64, wave, lane);  // delta_c1 -> dA
+    __syncthreads();
+    gWc0.add(dA, cin, tid);
+    bias_add<64>(gbc0, dA, tid);
+    // delta of the colour input: geo rows (16..30) feed the base MLP, appearance rows (31..62) the embedding
+    bwd_rows<63, 64>(A.p.wc0, dA, dB, nullptr, 16, 63, wave, lane);  // dB rows 16..62
+    __syncthreads();
+    if (A.app_per_camera && valid) {
+      for (int k = wave; k < 32; k += 4) atomicAdd(A.g.emb + A.cam_idx[r] * 32 + k, dB[(31 + k) * LD + lane]);
+    }
+    // delta_o16 -> dA' : row 0 = density logit, rows 1..15 = geo (from the colour branch only: semantics sees detached geo)
+    // (dA is still needed by nobody: gWc0 has consumed it)
+    __syncthreads();
+    if (wave == 0) dA[lane] = misc[4 * LD + lane];
+    for (int k = wave; k < 15; k += 4) dA[(1 + k) * LD + lane] = dB[(16 + k) * LD + lane];
+    __syncthreads();
+    gW1.add(dA, h1, tid);
+    bias_add<16>(gb1, dA, tid);
+    bwd_rows<64, 16>(A.p.w1, dA, dB, h1, 0, 64, wave, lane);  // delta_h1 -> dB
+    __syncthreads();
+    gW0.add(dB, enc, tid);
+    bias_add<64>(gb0, dB, tid);
+    bwd_rows<32, 64>(A.p.w0, dB, dA, nullptr, 0, 32, wave, lane);  // delta_enc -> dA rows 0..31
+    __syncthreads();
+    if (valid) {
+      const float px = misc[0 * LD + lane], py = misc[1 * LD + lane], pz = misc[2 * LD + lane];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int l = 4 * wave + q;
+        hash_level_backward(A.g.table, (unsigned)l * A.level_stride, A.mask, A.scale[l], px, py, pz,
+                            dA[(2 * l) * LD + lane], dA[(2 * l + 1) * LD + lane]);
+      }
+    }
+    __syncthreads();
+    // ---- semantic branch: sem = Wh s2 + bh; gradients stop at the (detached) geo features ------------------------------
+    // delta_sem (1 row) is misc row 5
+    gWh.add(misc + 5 * LD, s2, tid);
+    bias_add<1>(gbh, misc + 5 * LD, tid);
+    bwd_rows<64, 1>(A.p.wh, misc + 5 * LD, dB, nullptr, 0, 64, wave, lane);  // delta_s2 -> dB
+    __syncthreads();
+    gWs1.add(dB, s1, tid);
+    bias_add<64>(gbs1, dB, tid);
+    bwd_rows<64, 64>(A.p.ws1, dB, dA, s1, 0, 64, wave, lane);  // delta_s1 -> dA
+    __syncthreads();
+    gWs0.add(dA, o16 + LD, tid);
+    bias_add<64>(gbs0, dA, tid);
+    __syncthreads();
+  }
+  gW0.flush(A.g.w0, tid); gW1.flush(A.g.w1, tid); gWs0.flush(A.g.ws0, tid); gWs1.flush(A.g.ws1, tid);
+  gWc0.flush(A.g.wc0, tid); gWc1.flush(A.g.wc1, tid); gWc2.flush(A.g.wc2, tid); gWh.flush(A.g.wh, tid);
+  if (tid < 64) {
+    atomicAdd(A.g.b0 + tid, gb0);
+    atomicAdd(A.g.bs0 + tid, gbs0);
+    atomicAdd(A.g.bs1 + tid, gbs1);
+    atomicAdd(A.g.bc0 + tid, gbc0);
+    atomicAdd(A.g.bc1 + tid, gbc1);
+  }
+  if (tid < 16) atomicAdd(A.g.b1 + tid, gb1);
+  if (tid < 3) atomicAdd(A.g.bc2 + tid, gbc2);
+  if (tid < 1) atomicAdd(A.g.bh + tid, gbh);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// proposal network backward
+// ------------------------------------------------------------------------------------------------------------------------
+struct PropBwdArgs {
+  const float* table;
+  const float *w0, *b0, *w1, *b1;
+  float *g_table, *g_w0, *g_b0, *g_w1, *g_b1;
+  unsigned mask, level_stride;
+  float scale[CN_MAX_LEVELS];
+  SceneDev scene;
+  const float *origins, *directions, *starts, *ends, *d_density;
+  long long R;
+  int S;
+};
+
+template <int L>
+__global__ void __launch_bounds__(TB) proposal_backward_kernel(PropBwdArgs A) {
+  constexpr int K = 2 * L, H = 16;
+  __shared__ float lds[(K + H + H + 1 + 4) * LD];
+  float* enc = lds;                  // [K]
+  float* hid = enc + K * LD;         // [H] post ReLU
+  float* dh = hid + H * LD;          // [H] delta hidden
+  float* dout = dh + H * LD;         // [1] delta logit
+  float* misc = dout + LD;           // pos(3)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  WGrad<K, H> gW0;
+  WGrad<H, 1> gW1;
+  gW0.zero();
+  gW1.zero();
+  float gb0 = 0.f, gb1 = 0.f;
+  const long long total = A.R * (long long)A.S;
+  const long long ntiles = (total + TS - 1) / TS;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long i = tile * TS + lane;
+    const bool valid = i < total;
+    const long long ic = valid ? i : total - 1;
+    const long long r = ic / A.S;
+    float sel_f = 0.f;
+    if (wave == 0) {
+      const float mid = (A.starts[ic] + A.ends[ic]) / 2.f;
+      float px = A.origins[3 * r] + A.directions[3 * r] * mid;
+      float py = A.origins[3 * r + 1] + A.directions[3 * r + 1] * mid;
+      float pz = A.origins[3 * r + 2] + A.directions[3 * r + 2] * mid;
+      bool sel = normalize_position(A.scene, px, py, pz);
+      sel_f = sel ? 1.f : 0.f;
+      misc[0 * LD + lane] = px;
+      misc[1 * LD + lane] = py;
+      misc[2 * LD + lane] = pz;
+      misc[3 * LD + lane] = sel_f;
+    }
+    __syncthreads();
+    for (int l = wave; l < L; l += 4) {
+      float2 f = hash_level(A.table, (unsigned)l * A.level_stride, A.mask, A.scale[l], misc[lane], misc[LD + lane],
+                            misc[2 * LD + lane]);
+      enc[(2 * l) * LD + lane] = f.x;
+      enc[(2 * l + 1) * LD + lane] = f.y;
+    }
+    __syncthreads();
+    fwd_rows<K, H, true>(A.w0, A.b0, enc, hid, wave, lane);
+    __syncthreads();
+    if (wave == 0) {
+      float logit = A.b1[0];
+#pragma unroll
+      for (int k = 0; k < H; ++k) logit = fmaf(A.w1[k], hid[k * LD + lane], logit);
+      const float up = valid ? A.d_density[ic] : 0.f;
+      dout[lane] = up * misc[3 * LD + lane] * expf(fminf(fmaxf(logit, -15.f), 15.f));
+    }
+    __syncthreads();
+    gW1.add(dout, hid, tid);
+    bias_add<1>(gb1, dout, tid);
+    bwd_rows<H, 1>(A.w1, dout, dh, hid, 0, H, wave, lane);
+    __syncthreads();
+    gW0.add(dh, enc, tid);
+    bias_add<H>(gb0, dh, tid);
+    // delta_enc[k] = sum_n W0[n][k] dh[n] -> straight into the table gradient
+    if (valid) {
+      for (int l = wave; l < L; l += 4) {
+        float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+        for (int n = 0; n < H; ++n) {
+          const float d = dh[n * LD + lane];
+          g0 = fmaf(A.w0[n * K + 2 * l], d, g0);
+          g1 = fmaf(A.w0[n * K + 2 * l + 1], d, g1);
+        }
+        hash_level_backward(A.g_table, (unsigned)l * A.level_stride, A.mask, A.scale[l], misc[lane], misc[LD + lane],
+                            misc[2 * LD + lane], g0, g1);
+      }
+    }
+    __syncthreads();
+  }
+  gW0.flush(A.g_w0, tid);
+  gW1.flush(A.g_w1, tid);
+  if (tid < H) atomicAdd(A.g_b0 + tid, gb0);
+  if (tid < 1) atomicAdd(A.g_b1 + tid, gb1);
+}
+
+int validate_field(const cn_field_params& p);  // field_simple.hip
+int validate_grid(const cn_grid& g, const char* name);
+
+static bool is_default_field_shape(const cn_field_params& p) {
+  return p.grid.num_levels == 16 && p.geo_feat_dim == 15 && p.app_dim == 32 && p.base.num_layers == 2 &&
+         p.base.dims[0] == 32 && p.base.dims[1] == 64 && p.base.dims[2] == 16 && p.semantics.num_layers == 2 &&
+         p.semantics.dims[0] == 15 && p.semantics.dims[1] == 64 && p.semantics.dims[2] == 64 &&
+         p.color.num_layers == 3 && p.color.dims[0] == 63 && p.color.dims[1] == 64 && p.color.dims[2] == 64 &&
+         p.color.dims[3] == 3;
+}
+
+}  // namespace cn
+
+extern "C" int cn_field_backward(const cn_field_params* params, const cn_field_params* grads, const cn_scene* scene,
+                                 int32_t app_mode, int32_t sh_unit_dir, const float* app_mean, const float* origins,
+                                 const float* directions, const int64_t* camera_indices, const float* starts,
+                                 const float* ends, const float* d_density, const float* d_rgb, const float* d_semantics,
+                                 int64_t num_rays, int32_t num_samples, cn_stream_t stream) {
+  CN_REQUIRE(params && grads && scene && origins && directions && starts && ends && d_density && d_rgb && d_semantics,
+             CN_ERR_INVALID, "cn_field_backward: null argument");
+  CN_REQUIRE(app_mode != CN_APP_PER_CAMERA || camera_indices, CN_ERR_INVALID, "Camera indices are not provided.");
+  CN_REQUIRE(app_mode != CN_APP_MEAN || app_mean, CN_ERR_INVALID, "cn_field_backward: app_mean required for CN_APP_MEAN");
+  int rc = cn::validate_field(*params);
+  if (rc) return rc;
+  if ((rc = cn::validate_field(*grads))) return rc;
+  CN_REQUIRE(cn::is_default_field_shape(*params) && cn::is_default_field_shape(*grads), CN_ERR_UNSUPPORTED,
+             "cn_field_backward is built for the default fruit_nerf_method field shape");
+  CN_REQUIRE(grads->grid.log2_table_size == params->grid.log2_table_size, CN_ERR_INVALID,
+             "cn_field_backward: gradient table size differs");
+  if (num_rays <= 0) return CN_OK;
+  cn::FieldBwdArgs A{};
+  auto fill = [](auto& dst, const cn_field_params& s) {
+    dst.w0 = (decltype(dst.w0))s.base.weight[0];
+    dst.b0 = (decltype(dst.b0))s.base.bias[0];
+    dst.w1 = (decltype(dst.w1))s.base.weight[1];
+    dst.b1 = (decltype(dst.b1))s.base.bias[1];
+    dst.ws0 = (decltype(dst.ws0))s.semantics.weight[0];
+    dst.bs0 = (decltype(dst.bs0))s.semantics.bias[0];
+    dst.ws1 = (decltype(dst.ws1))s.semantics.weight[1];
+    dst.bs1 = (decltype(dst.bs1))s.semantics.bias[1];
+    dst.wh = (decltype(dst.wh))s.sem_head_weight;
+    dst.bh = (decltype(dst.bh))s.sem_head_bias;
+    dst.wc0 = (decltype(dst.wc0))s.color.weight[0];
+    dst.bc0 = (decltype(dst.bc0))s.color.bias[0];
+    dst.wc1 = (decltype(dst.wc1))s.color.weight[1];
+    dst.bc1 = (decltype(dst.bc1))s.color.bias[1];
+    dst.wc2 = (decltype(dst.wc2))s.color.weight[2];
+    dst.bc2 = (decltype(dst.bc2))s.color.bias[2];
+    dst.emb = (decltype(dst.emb))s.appearance;
+    dst.table = (decltype(dst.table))s.grid.table;
+  };
+  fill(A.p, *params);
+  fill(A.g, *grads);
+  A.level_stride = 1u << params->grid.log2_table_size;
+  A.mask = A.level_stride - 1u;
+  for (int i = 0; i < CN_MAX_LEVELS; ++i) A.scale[i] = params->grid.scalings[i];
+  A.scene = cn::make_scene_dev(*scene);
+  A.sh_unit = sh_unit_dir;
+  A.app_per_camera = app_mode == CN_APP_PER_CAMERA;
+  A.app_mean = app_mode == CN_APP_MEAN ? app_mean : nullptr;
+  A.origins = origins;
+  A.directions = directions;
+  A.starts = starts;
+  A.ends = ends;
+  A.cam_idx = camera_indices;
+  A.d_density = d_density;
+  A.d_rgb = d_rgb;
+  A.d_sem = d_semantics;
+  A.R = num_rays;
+  A.S = num_samples;
+  size_t lds = (size_t)cn::FIELD_ROWS * cn::LD * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::field_backward_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  long long ntiles = (num_rays * (long long)num_samples + cn::TS - 1) / cn::TS;
+  hipLaunchKernelGGL(cn::field_backward_kernel, dim3(cn::grid_for(ntiles, 1, 256)), dim3(cn::TB), lds,
+                     cn::as_stream(stream), A);
+  return cn::check_launch("cn_field_backward");
+}
+
+extern "C" int cn_proposal_backward(const cn_density_params* params, const cn_density_params* grads,
+                                    const cn_scene* scene, const float* origins, const float* directions,
+                                    const float* starts, const float* ends, const float* d_density, int64_t num_rays,
+                                    int32_t num_samples, cn_stream_t stream) {
+  CN_REQUIRE(params && grads && scene && origins && directions && starts && ends && d_density, CN_ERR_INVALID,
+             "cn_proposal_backward: null argument");
+  int rc = cn::validate_grid(params->grid, "proposal grid");
+  if (rc) return rc;
+  const int L = params->grid.num_levels;
+  bool ok = (L == 5 || L == 7) && params->mlp.num_layers == 2 && params->mlp.dims[0] == 2 * L &&
+            params->mlp.dims[1] == 16 && params->mlp.dims[2] == 1 && grads->grid.num_levels == L &&
+            grads->grid.log2_table_size == params->grid.log2_table_size;
+  CN_REQUIRE(ok, CN_ERR_UNSUPPORTED, "cn_proposal_backward: proposal net must be {5|7 levels, 2L->16->1}");
+  CN_REQUIRE(grads->grid.table && grads->mlp.weight[0] && grads->mlp.bias[0] && grads->mlp.weight[1] &&
+                 grads->mlp.bias[1],
+             CN_ERR_INVALID, "cn_proposal_backward: null gradient buffer");
+  if (num_rays <= 0) return CN_OK;
+  cn::PropBwdArgs A{};
+  A.table = params->grid.table;
+  A.w0 = params->mlp.weight[0];
+  A.b0 = params->mlp.bias[0];
+  A.w1 = params->mlp.weight[1];
+  A.b1 = params->mlp.bias[1];
+  A.g_table = const_cast<float*>(grads->grid.table);
+  A.g_w0 = const_cast<float*>(grads->mlp.weight[0]);
+  A.g_b0 = const_cast<float*>(grads->mlp.bias[0]);
+  A.g_w1 = const_cast<float*>(grads->mlp.weight[1]);
+  A.g_b1 = const_cast<float*>(grads->mlp.bias[1]);
+  A.level_stride = 1u << params->grid.log2_table_size;
+  A.mask = A.level_stride - 1u;
+  for (int i = 0; i < CN_MAX_LEVELS; ++i) A.scale[i] = params->grid.scalings[i];
+  A.scene = cn::make_scene_dev(*scene);
+  A.origins = origins;
+  A.directions = directions;
+  A.starts = starts;
+  A.ends = ends;
+  A.d_density = d_density;
+  A.R = num_rays;
+  A.S = num_samples;
+  long long ntiles = (num_rays * (long long)num_samples + cn::TS - 1) / cn::TS;
+  dim3 grid(cn::grid_for(ntiles, 1, 1024));
+  if (L == 5)
+    hipLaunchKernelGGL(cn::proposal_backward_kernel<5>, grid, dim3(cn::TB), 0, cn::as_stream(stream), A);
+  else
+    hipLaunchKernelGGL(cn::proposal_backward_kernel<7>, grid, dim3(cn::TB), 0, cn::as_stream(stream), A);
+  return cn::check_launch("cn_proposal_backward");
+}

@@ -1,0 +1,283 @@
+// Training, ray side: losses + backward of the volume renderer and of the interlevel (proposal) loss.
+//   cn_train_render_backward  : FruitModel.get_loss_dict rgb + semantics terms (fruit_nerf/fruit_nerf.py:601-608) on top of
+//                               get_weights + RGBRenderer("last_sample", training) + SemanticRenderer (:556-591), forward
+//                               and backward in one wave-per-ray kernel.
+//   cn_interlevel_backward    : interlevel_loss term (:609-612; nerfstudio losses.interlevel_loss / lossfun_outer / outer)
+//                               of one proposal level: loss and d(loss)/d(proposal density).
+//   cn_adam_step              : torch.optim.Adam update (fruit_nerf/fruit_nerf_config.py:45-60), elementwise.
+// Gradients w.r.t. per-sample field outputs leave as [R,S] arrays; train_field.hip turns them into parameter gradients.
+#include "composite_dev.hpp"
+
+namespace cn {
+
+constexpr int TRAIN_MAX_S = 512;
+
+// reverse-order helpers: suffix sums are prefix sums of the lane-reversed chunk
+__device__ __forceinline__ float wave_total(float v) { return wave_read(wave_inclusive_scan(v), 63); }
+
+// one wave per ray.  LDS per wave: w[S] | P[S] (exclusive prefix of delta*sigma)
+__global__ void __launch_bounds__(256)
+train_render_backward_kernel(const float* __restrict__ starts, const float* __restrict__ ends,
+                             const float* __restrict__ density, const float* __restrict__ rgb,
+                             const float* __restrict__ sem, const float* __restrict__ image,
+                             const float* __restrict__ mask, long long R, int S, float sem_weight,
+                             float* __restrict__ out_rgb, float* __restrict__ out_sem, float* __restrict__ out_acc,
+                             float* __restrict__ out_w, float* __restrict__ d_density, float* __restrict__ d_rgb,
+                             float* __restrict__ d_sem, float* __restrict__ loss_sums) {
+  extern __shared__ __align__(16) float lds[];
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  float* wbuf = lds + wave * 2 * S;
+  float* pbuf = wbuf + S;
+  const long long waves = (long long)gridDim.x * 4;
+  const float inv_3r = 1.f / (3.f * (float)R), inv_r = 1.f / (float)R;
+  for (long long r = blockIdx.x * 4LL + wave; r < R; r += waves) {
+    const long long base = r * (long long)S;
+    // ---- forward: weights, rgb / accumulation / semantics ------------------------------------------------------
+    float carry = 0.f, ar = 0.f, ag = 0.f, ab = 0.f, aw = 0.f, as = 0.f;
+    for (int c0 = 0; c0 < S; c0 += 64) {
+      const int i = c0 + lane;
+      const bool valid = i < S;
+      const int ic = valid ? i : S - 1;
+      float dd = valid ? (ends[base + ic] - starts[base + ic]) * density[base + ic] : 0.f;
+      float incl = wave_inclusive_scan(dd);
+      float P = carry + (incl - dd);
+      float w = valid ? nan_to_num((1.f - expf(-dd)) * expf(-P)) : 0.f;
+      carry += wave_read(incl, 63);
+      if (valid) {
+        wbuf[i] = w;
+        pbuf[i] = P;
+        if (out_w) out_w[base + i] = w;
+      }
+      ar += w * rgb[3 * (base + ic) + 0];
+      ag += w * rgb[3 * (base + ic) + 1];
+      ab += w * rgb[3 * (base + ic) + 2];
+      aw += w;
+      as += w * sem[base + ic];
+    }
+    const float acc = wave_sum(aw);
+    const float lr_ = rgb[3 * (base + S - 1) + 0], lg_ = rgb[3 * (base + S - 1) + 1], lb_ = rgb[3 * (base + S - 1) + 2];
+    const float cr = wave_sum(ar) + lr_ * (1.f - acc);
+    const float cg = wave_sum(ag) + lg_ * (1.f - acc);
+    const float cb = wave_sum(ab) + lb_ * (1.f - acc);
+    const float so = wave_sum(as);
+    // ---- losses and their derivatives w.r.t. the rendered values ----------------------------------------------------
+    const float e0 = cr - image[3 * r + 0], e1 = cg - image[3 * r + 1], e2 = cb - image[3 * r + 2];
+    const float y = mask[r];
+    const float G0 = 2.f * e0 * inv_3r, G1 = 2.f * e1 * inv_3r, G2 = 2.f * e2 * inv_3r;  // d MSE / d rgb
+    const float gs = sem_weight * (sigmoidf(so) - y) * inv_r;                           // d BCE / d semantics
+    if (lane == 0) {
+      if (out_rgb) {
+        out_rgb[3 * r + 0] = cr;
+        out_rgb[3 * r + 1] = cg;
+        out_rgb[3 * r + 2] = cb;
+      }
+      if (out_sem) out_sem[r] = so;
+      if (out_acc) out_acc[r] = acc;
+      atomicAdd(loss_sums + 0, e0 * e0 + e1 * e1 + e2 * e2);
+      atomicAdd(loss_sums + 1, fmaxf(so, 0.f) - so * y + log1pf(expf(-fabsf(so))));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- backward, chunks in reverse order: d dd_j = gw_j (T_j - w_j) - sum_{i>j} gw_i w_i -----------------------
+    float suffix = 0.f;  // sum over later chunks of gw_i * w_i
+    for (int c0 = ((S - 1) / 64) * 64; c0 >= 0; c0 -= 64) {
+      const int i = c0 + (63 - lane);  // lanes walk the chunk backwards, so a prefix scan is a suffix sum
+      const bool valid = i < S;
+      const int ic = valid ? i : S - 1;
+      const float w = valid ? wbuf[ic] : 0.f;
+      const float c_r = rgb[3 * (base + ic) + 0], c_g = rgb[3 * (base + ic) + 1], c_b = rgb[3 * (base + ic) + 2];
+      const float gw = G0 * (c_r - lr_) + G1 * (c_g - lg_) + G2 * (c_b - lb_);
+      const float term = valid ? gw * w : 0.f;
+      const float incl = wave_inclusive_scan(term);
+      const float later = suffix + (incl - term);  // strictly later samples
+      suffix += wave_read(incl, 63);
+      if (valid) {
+        const float T = expf(-pbuf[ic]);
+        const float delta = ends[base + ic] - starts[base + ic];
+        d_density[base + ic] = delta * (gw * (T - w) - later);
+        const float k = (ic == S - 1) ? w + (1.f - acc) : w;
+        d_rgb[3 * (base + ic) + 0] = G0 * k;
+        d_rgb[3 * (base + ic) + 1] = G1 * k;
+        d_rgb[3 * (base + ic) + 2] = G2 * k;
+        d_sem[base + ic] = gs * w;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// first index in [0,n) with a[idx] > v   (torch.searchsorted side="right")
+__device__ __forceinline__ int upper_bound(const float* a, int n, float v) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (a[mid] <= v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// one wave per ray.  LDS per wave: cp[Sp+1] | wp[Sp] | P[Sp] | cy[Sp+1] | diff[Sp+1]
+__global__ void __launch_bounds__(256)
+interlevel_backward_kernel(const float* __restrict__ c_bins, const float* __restrict__ w_final,
+                           const float* __restrict__ cp_bins, const float* __restrict__ starts_p,
+                           const float* __restrict__ ends_p, const float* __restrict__ density_p, long long R, int Sf,
+                           int Sp, float mult, float* __restrict__ d_density_p, float* __restrict__ loss_sum) {
+  extern __shared__ __align__(16) float lds[];
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int stride = 5 * Sp + 3;
+  float* cp = lds + wave * stride;
+  float* wp = cp + Sp + 1;
+  float* Pp = wp + Sp;
+  float* cy = Pp + Sp;
+  float* diff = cy + Sp + 1;
+  const long long waves = (long long)gridDim.x * 4;
+  const float eps = 1.0e-7f;
+  for (long long r = blockIdx.x * 4LL + wave; r < R; r += waves) {
+    const long long bp = r * (long long)Sp, bf = r * (long long)Sf;
+    for (int e = lane; e <= Sp; e += 64) {
+      cp[e] = cp_bins[r * (Sp + 1) + e];
+      diff[e] = 0.f;
+    }
+    // proposal weights, their exclusive dd prefix and their cumulative sum cy[m] = sum_{k<m} wp_k
+    float carry = 0.f, cw = 0.f;
+    for (int c0 = 0; c0 < Sp; c0 += 64) {
+      const int i = c0 + lane;
+      const bool valid = i < Sp;
+      const int ic = valid ? i : Sp - 1;
+      float dd = valid ? (ends_p[bp + ic] - starts_p[bp + ic]) * density_p[bp + ic] : 0.f;
+      float incl = wave_inclusive_scan(dd);
+      float P = carry + (incl - dd);
+      float w = valid ? nan_to_num((1.f - expf(-dd)) * expf(-P)) : 0.f;
+      carry += wave_read(incl, 63);
+      float wi = wave_inclusive_scan(w);
+      if (valid) {
+        wp[i] = w;
+        Pp[i] = P;
+        cy[i + 1] = cw + wi;
+      }
+      cw += wave_read(wi, 63);
+    }
+    if (lane == 0) cy[0] = 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // loss terms of the final samples; d loss / d wp as range adds on a difference array
+    float lsum = 0.f;
+    for (int i = lane; i < Sf; i += 64) {
+      const float t0s = c_bins[r * (Sf + 1) + i], t0e = c_bins[r * (Sf + 1) + i + 1];
+      const float w = w_final[bf + i];
+      int lo = upper_bound(cp, Sp, t0s) - 1;       // t1_starts = cp[0..Sp)
+      int hi = upper_bound(cp + 1, Sp, t0e);       // t1_ends   = cp[1..Sp]
+      lo = min(max(lo, 0), Sp - 1);
+      hi = min(max(hi, 0), Sp - 1);
+      const float outer = cy[hi + 1] - cy[lo];
+      const float dv = w - outer;
+      if (dv > 0.f) {
+        lsum += dv * dv / (w + eps);
+        const float g = -2.f * dv / (w + eps) * mult;  // d/d outer, scaled by loss_mult / (R*Sf)
+        atomicAdd(diff + lo, g);
+        atomicAdd(diff + hi + 1, -g);
+      }
+    }
+    lsum = wave_sum(lsum);
+    if (lane == 0) atomicAdd(loss_sum, lsum);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // gw[m] = prefix(diff)[m]  (in place, chunked scan)
+    float run = 0.f;
+    for (int c0 = 0; c0 < Sp; c0 += 64) {
+      const int i = c0 + lane;
+      float v = i < Sp ? diff[i] : 0.f;
+      float incl = wave_inclusive_scan(v);
+      if (i < Sp) diff[i] = run + incl;
+      run += wave_read(incl, 63);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // weights backward of the proposal level
+    float suffix = 0.f;
+    for (int c0 = ((Sp - 1) / 64) * 64; c0 >= 0; c0 -= 64) {
+      const int i = c0 + (63 - lane);
+      const bool valid = i < Sp;
+      const int ic = valid ? i : Sp - 1;
+      const float w = valid ? wp[ic] : 0.f;
+      const float gw = valid ? diff[ic] : 0.f;
+      const float term = gw * w;
+      const float incl = wave_inclusive_scan(term);
+      const float later = suffix + (incl - term);
+      suffix += wave_read(incl, 63);
+      if (valid) {
+        const float T = expf(-Pp[ic]);
+        d_density_p[bp + ic] = (ends_p[bp + ic] - starts_p[bp + ic]) * (gw * (T - w) - later);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ void __launch_bounds__(256)
+adam_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                 long long n, float step_size, float beta1, float beta2, float omb1, float omb2, float inv_sqrt_bc2,
+                 float eps, int zero_grad) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = beta1 * m[i] + omb1 * gi;  // 1 - beta rounded from double on the host, like torch
+    const float vi = beta2 * v[i] + omb2 * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    if (zero_grad) g[i] = 0.f;
+  }
+}
+
+}  // namespace cn
+
+extern "C" int cn_train_render_backward(const float* starts, const float* ends, const float* density,
+                                        const float* rgb, const float* semantics, const float* image,
+                                        const float* fruit_mask, int64_t num_rays, int32_t num_samples,
+                                        float semantic_loss_weight, float* out_rgb, float* out_semantics,
+                                        float* out_accumulation, float* out_weights, float* d_density, float* d_rgb,
+                                        float* d_semantics, float* loss_sums, cn_stream_t stream) {
+  CN_REQUIRE(starts && ends && density && rgb && semantics && image && fruit_mask && d_density && d_rgb &&
+                 d_semantics && loss_sums,
+             CN_ERR_INVALID, "cn_train_render_backward: null argument");
+  CN_REQUIRE(num_samples >= 1 && num_samples <= cn::TRAIN_MAX_S, CN_ERR_UNSUPPORTED,
+             "cn_train_render_backward: %d samples per ray (max %d)", num_samples, cn::TRAIN_MAX_S);
+  if (num_rays <= 0) return CN_OK;
+  size_t lds = (size_t)4 * 2 * num_samples * sizeof(float);
+  hipLaunchKernelGGL(cn::train_render_backward_kernel, dim3(cn::grid_for(num_rays, 4, 4096)), dim3(256), lds,
+                     cn::as_stream(stream), starts, ends, density, rgb, semantics, image, fruit_mask,
+                     (long long)num_rays, num_samples, semantic_loss_weight, out_rgb, out_semantics, out_accumulation,
+                     out_weights, d_density, d_rgb, d_semantics, loss_sums);
+  return cn::check_launch("cn_train_render_backward");
+}
+
+extern "C" int cn_interlevel_backward(const float* final_spacing_bins, const float* final_weights,
+                                      const float* prop_spacing_bins, const float* prop_starts, const float* prop_ends,
+                                      const float* prop_density, int64_t num_rays, int32_t s_final, int32_t s_prop,
+                                      float loss_mult, float* d_prop_density, float* loss_sum, cn_stream_t stream) {
+  CN_REQUIRE(final_spacing_bins && final_weights && prop_spacing_bins && prop_starts && prop_ends && prop_density &&
+                 d_prop_density && loss_sum,
+             CN_ERR_INVALID, "cn_interlevel_backward: null argument");
+  CN_REQUIRE(s_final >= 1 && s_prop >= 1 && s_prop <= cn::TRAIN_MAX_S, CN_ERR_UNSUPPORTED,
+             "cn_interlevel_backward: sample counts %d / %d", s_final, s_prop);
+  if (num_rays <= 0) return CN_OK;
+  size_t lds = (size_t)4 * (5 * s_prop + 3) * sizeof(float);
+  float mult = loss_mult / ((float)num_rays * (float)s_final);
+  hipLaunchKernelGGL(cn::interlevel_backward_kernel, dim3(cn::grid_for(num_rays, 4, 4096)), dim3(256), lds,
+                     cn::as_stream(stream), final_spacing_bins, final_weights, prop_spacing_bins, prop_starts, prop_ends,
+                     prop_density, (long long)num_rays, s_final, s_prop, mult, d_prop_density, loss_sum);
+  return cn::check_launch("cn_interlevel_backward");
+}
+
+extern "C" int cn_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
+                            double lr, double beta1, double beta2, double eps, int32_t zero_grad, cn_stream_t stream) {
+  CN_REQUIRE(param && grad && exp_avg && exp_avg_sq, CN_ERR_INVALID, "cn_adam_step: null argument");
+  CN_REQUIRE(step >= 1, CN_ERR_INVALID, "cn_adam_step: step is 1-based");
+  if (n <= 0) return CN_OK;
+  // hyper-parameters arrive as doubles (Python floats) so that 1-beta rounds to fp32 exactly as torch's does
+  double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(cn::adam_step_kernel, dim3(cn::grid_for(n, 256, 4096)), dim3(256), 0, cn::as_stream(stream), param,
+                     grad, exp_avg, exp_avg_sq, (long long)n, (float)(lr / bc1), (float)beta1, (float)beta2,
+                     (float)(1.0 - beta1), (float)(1.0 - beta2), (float)(1.0 / sqrt(bc2)), (float)eps, zero_grad);
+  return cn::check_launch("cn_adam_step");
+}

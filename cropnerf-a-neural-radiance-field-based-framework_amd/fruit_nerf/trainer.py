@@ -1,0 +1,137 @@
+"""Training step of the fruit_nerf method on the HIP kernels.
+
+What the nerfstudio Trainer does around the reference's model per iteration:
+``datamanager.next_train`` -> ``FruitModel.forward`` (training: near 0.05, stratified single-jitter proposal sampling,
+per-camera appearance) -> ``get_loss_dict`` (``fruit_nerf/fruit_nerf.py:601-615``: rgb MSE + semantic BCE + interlevel)
+-> backward -> Adam with exponential LR decay (``fruit_nerf/fruit_nerf_config.py:45-60``) -> anneal callback
+(``fruit_nerf.py:198-232``).
+
+Not trained in this round (stated in DESIGN.md): the camera pose refinement (``camera_opt`` group; the pose tweak is
+applied but frozen) and the camera-optimizer regulariser; no GradScaler / autocast (everything is fp32).
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from .. import _lib as L
+from .. import ops
+from ..rays import RayBundle
+from .fruit_nerf import FruitModel
+
+
+@dataclass
+class OptimGroup:
+    lr: float = 1e-2
+    eps: float = 1e-15
+    lr_final: Optional[float] = 1e-4
+    max_steps: Optional[int] = 200000
+
+    def lr_at(self, step: int) -> float:
+        """nerfstudio ExponentialDecayScheduler (no warm-up)."""
+        if self.lr_final is None or self.max_steps is None:
+            return self.lr
+        t = min(max(step / self.max_steps, 0.0), 1.0)
+        return math.exp(math.log(self.lr) * (1 - t) + math.log(self.lr_final) * t)
+
+
+class FruitTrainer:
+    def __init__(self, model: FruitModel, groups: Optional[Dict[str, OptimGroup]] = None, seed: int = 0):
+        self.model = model
+        self.groups = groups or {"proposal_networks": OptimGroup(), "fields": OptimGroup()}
+        dev = model.device
+        self.trainable = [k for k in model.params if not k.startswith("camera_optimizer.")]
+        self.grads = {k: torch.zeros_like(v) for k, v in model.params.items()}
+        self.exp_avg = {k: torch.zeros_like(model.params[k]) for k in self.trainable}
+        self.exp_avg_sq = {k: torch.zeros_like(model.params[k]) for k in self.trainable}
+        self.grad_field = ops.FieldHandle(self.grads, model.field_spec)
+        self.grad_props = [ops.DensityHandle(self.grads, i, ps) for i, ps in enumerate(model.proposal_specs)]
+        self.step = 0
+        self._gen = torch.Generator(device="cpu").manual_seed(seed)
+        self.loss_sums = torch.zeros(4, device=dev)
+
+    # ------------------------------------------------------------------------------------------------------
+    def set_anneal(self, step: int) -> None:
+        """``set_anneal`` callback (``fruit_nerf.py:206-216``), arXiv 2111.12077 eq. 18."""
+        cfg = self.model.config
+        if not cfg.use_proposal_weight_anneal:
+            return
+        frac = float(np.clip(step / cfg.proposal_weights_anneal_max_num_iters, 0, 1))
+        b = cfg.proposal_weights_anneal_slope
+        self.model.set_anneal(b * frac / ((b - 1) * frac + 1))
+
+    def forward_backward(self, ray_bundle: RayBundle, batch: Dict[str, Tensor],
+                         jitter: Optional[List[Tensor]] = None) -> Dict[str, Tensor]:
+        """One training forward + backward; gradients are ACCUMULATED into ``self.grads``.  ``jitter`` = the three
+        [R,1] uniform randoms of the proposal sampler (drawn here when None)."""
+        m, cfg = self.model, self.model.config
+        dev = m.device
+        rb = ray_bundle.flatten().to(dev)._map(lambda t: t.contiguous())
+        R = rb.origins.shape[0]
+        if rb.camera_indices is None:
+            raise AttributeError("Camera indices are not provided.")
+        cam = rb.camera_indices.reshape(-1).to(torch.int64).contiguous()
+        o, d = rb.origins.clone(), rb.directions.clone()
+        ops.apply_pose_adjustment(m.params["camera_optimizer.pose_adjustment"], cam, o, d)
+        nears = rb.nears if rb.nears is not None else torch.full((R, 1), float(cfg.near_plane), device=dev)
+        fars = rb.fars if rb.fars is not None else torch.full((R, 1), float(cfg.far_plane), device=dev)
+        n_lvl = len(m.proposal_networks)
+        if jitter is None:
+            jitter = [torch.rand(R, 1, generator=self._gen) for _ in range(n_lvl + 1)]
+        jitter = [j.to(dev).contiguous() for j in jitter]
+        scene = m._scene(True)
+        # ---- proposal sampler, level by level (weights and bins are kept for the interlevel loss) ---------------
+        levels = []
+        sm = ops.sample_spaced(nears, fars, cfg.num_proposal_samples_per_ray[0], L.SPACING_PIECEWISE, jitter[0])
+        bins = torch.cat([sm["spacing_starts"], sm["spacing_ends"][:, -1:]], -1).contiguous()
+        starts, ends = sm["starts"], sm["ends"]
+        for lvl in range(n_lvl):
+            den = ops.proposal_density(m.proposal_networks[lvl], scene, o, d, starts, ends)
+            w = ops.composite(starts, ends, den, want_weights=True, eval_clamp=False)["weights"]
+            levels.append({"bins": bins, "starts": starts, "ends": ends, "density": den})
+            s_next = cfg.num_proposal_samples_per_ray[lvl + 1] if lvl + 1 < n_lvl else cfg.num_nerf_samples_per_ray
+            bins, eu = ops.sample_pdf(bins, w, nears, fars, s_next, anneal=m._anneal, u_rand=jitter[lvl + 1])
+            starts, ends = eu[:, :-1].contiguous(), eu[:, 1:].contiguous()
+        # ---- field forward (fused kernel, per-sample outputs) --------------------------------------------------------
+        S = cfg.num_nerf_samples_per_ray
+        opts = ops.render_opts(S, app_mode=L.APP_PER_CAMERA, sh_unit_dir=cfg.sh_input == "unit", eval_clamp=False)
+        fo = ops.render_samples(m.field, scene, opts, o, d, nears, fars, camera_indices=cam, bins=eu.contiguous())
+        # ---- renderer + losses + their backward ------------------------------------------------------------------------
+        self.loss_sums.zero_()
+        image = batch["image"].to(dev)[:, :3].to(torch.float32).contiguous()
+        mask = batch["fruit_mask"].to(dev).to(torch.float32).reshape(R, 1).contiguous()
+        rb_out = ops.train_render_backward(starts, ends, fo["density"], fo["rgb"], fo["semantics"], image, mask,
+                                           cfg.semantic_loss_weight, self.loss_sums)
+        ops.field_backward(m.field, self.grad_field, scene, o, d, cam, starts, ends, rb_out["d_density"],
+                           rb_out["d_rgb"], rb_out["d_semantics"], app_mode=L.APP_PER_CAMERA,
+                           sh_unit_dir=cfg.sh_input == "unit")
+        for lvl, lv in enumerate(levels):
+            dd = ops.interlevel_backward(bins, rb_out["weights"], lv["bins"], lv["starts"], lv["ends"], lv["density"],
+                                         cfg.interlevel_loss_mult, self.loss_sums[2:3])
+            ops.proposal_backward(m.proposal_networks[lvl], self.grad_props[lvl], scene, o, d, lv["starts"], lv["ends"], dd)
+        sums = self.loss_sums
+        loss_dict = {"rgb_loss": sums[0] / (3.0 * R), "semantics_loss": cfg.semantic_loss_weight * sums[1] / R,
+                     "interlevel_loss": cfg.interlevel_loss_mult * sums[2] / (R * S)}
+        return {"loss_dict": loss_dict, "rgb": rb_out["rgb"], "semantics": rb_out["semantics"],
+                "accumulation": rb_out["accumulation"]}
+
+    def optimizer_step(self) -> None:
+        self.step += 1
+        for k in self.trainable:
+            grp = self.groups["proposal_networks" if k.startswith("proposal_networks.") else "fields"]
+            ops.adam_step(self.model.params[k], self.grads[k], self.exp_avg[k], self.exp_avg_sq[k], self.step,
+                          grp.lr_at(self.step - 1), eps=grp.eps, zero_grad=True)
+
+    def train_iteration(self, ray_bundle: RayBundle, batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        self.set_anneal(self.step)
+        out = self.forward_backward(ray_bundle, batch)
+        self.optimizer_step()
+        mse = out["loss_dict"]["rgb_loss"]
+        out["metrics_dict"] = {"psnr": -10.0 * torch.log10(mse)}
+        return out

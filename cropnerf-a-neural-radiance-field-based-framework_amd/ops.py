@@ -417,3 +417,75 @@ def pointcloud_compact(origins: Tensor, directions: Tensor, depth: Tensor, rgb: 
                                       _p(_f32(semantics_colormap, "semantics_colormap")), R, capacity, _p(pts),
                                       _p(cols), _p(dirs), _p(count), _stream(origins)))
     return pts, cols, dirs, count
+
+
+# --------------------------------------------------------------------------------------------------------------
+# training
+# --------------------------------------------------------------------------------------------------------------
+
+def train_render_backward(starts: Tensor, ends: Tensor, density: Tensor, rgb: Tensor, semantics: Tensor,
+                          image: Tensor, fruit_mask: Tensor, semantic_loss_weight: float, loss_sums: Tensor
+                          ) -> Dict[str, Tensor]:
+    """cn_train_render_backward: rendered values, per-sample gradients of rgb_loss + semantics_loss."""
+    lib = L.load()
+    R, S = starts.shape
+    dev = starts.device
+    out = {"rgb": torch.empty(R, 3, device=dev), "semantics": torch.empty(R, 1, device=dev),
+           "accumulation": torch.empty(R, 1, device=dev), "weights": torch.empty(R, S, device=dev),
+           "d_density": torch.empty(R, S, device=dev), "d_rgb": torch.empty(R, S, 3, device=dev),
+           "d_semantics": torch.empty(R, S, device=dev)}
+    L.check(lib.cn_train_render_backward(
+        _p(_f32(starts, "starts")), _p(_f32(ends, "ends")), _p(_f32(density, "density")), _p(_f32(rgb, "rgb")),
+        _p(_f32(semantics, "semantics")), _p(_f32(image, "image")), _p(_f32(fruit_mask, "fruit_mask")), R, S,
+        float(semantic_loss_weight), _p(out["rgb"]), _p(out["semantics"]), _p(out["accumulation"]), _p(out["weights"]),
+        _p(out["d_density"]), _p(out["d_rgb"]), _p(out["d_semantics"]), _p(_f32(loss_sums, "loss_sums")),
+        _stream(starts)))
+    return out
+
+
+def interlevel_backward(final_spacing_bins: Tensor, final_weights: Tensor, prop_spacing_bins: Tensor,
+                        prop_starts: Tensor, prop_ends: Tensor, prop_density: Tensor, loss_mult: float,
+                        loss_sum: Tensor) -> Tensor:
+    lib = L.load()
+    R, Sp = prop_density.shape
+    Sf = final_weights.shape[1]
+    d = torch.empty(R, Sp, device=prop_density.device)
+    L.check(lib.cn_interlevel_backward(
+        _p(_f32(final_spacing_bins, "final_spacing_bins")), _p(_f32(final_weights, "final_weights")),
+        _p(_f32(prop_spacing_bins, "prop_spacing_bins")), _p(_f32(prop_starts, "prop_starts")),
+        _p(_f32(prop_ends, "prop_ends")), _p(_f32(prop_density, "prop_density")), R, Sf, Sp, float(loss_mult), _p(d),
+        _p(_f32(loss_sum, "loss_sum")), _stream(prop_density)))
+    return d
+
+
+def field_backward(fh: FieldHandle, gh: FieldHandle, scene: L.Scene, origins: Tensor, directions: Tensor,
+                   camera_indices: Optional[Tensor], starts: Tensor, ends: Tensor, d_density: Tensor, d_rgb: Tensor,
+                   d_semantics: Tensor, app_mode: int = L.APP_PER_CAMERA, sh_unit_dir: bool = True,
+                   app_mean: Optional[Tensor] = None) -> None:
+    """Accumulates parameter gradients into the tensors behind ``gh`` (a FieldHandle over the gradient dict)."""
+    lib = L.load()
+    R, S = starts.shape
+    L.check(lib.cn_field_backward(
+        C.byref(fh.struct), C.byref(gh.struct), C.byref(scene), app_mode, 1 if sh_unit_dir else 0,
+        _p(_f32(app_mean, "app_mean")), _p(_f32(origins, "origins")), _p(_f32(directions, "directions")),
+        _p(_i64(camera_indices, "camera_indices")), _p(_f32(starts, "starts")), _p(_f32(ends, "ends")),
+        _p(_f32(d_density, "d_density")), _p(_f32(d_rgb, "d_rgb")), _p(_f32(d_semantics, "d_semantics")), R, S,
+        _stream(starts)))
+
+
+def proposal_backward(dh: DensityHandle, gh: DensityHandle, scene: L.Scene, origins: Tensor, directions: Tensor,
+                      starts: Tensor, ends: Tensor, d_density: Tensor) -> None:
+    lib = L.load()
+    R, S = starts.shape
+    L.check(lib.cn_proposal_backward(
+        C.byref(dh.struct), C.byref(gh.struct), C.byref(scene), _p(_f32(origins, "origins")),
+        _p(_f32(directions, "directions")), _p(_f32(starts, "starts")), _p(_f32(ends, "ends")),
+        _p(_f32(d_density, "d_density")), R, S, _stream(starts)))
+
+
+def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step: int, lr: float,
+              beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-15, zero_grad: bool = True) -> None:
+    lib = L.load()
+    L.check(lib.cn_adam_step(_p(_f32(param, "param")), _p(_f32(grad, "grad")), _p(_f32(exp_avg, "exp_avg")),
+                             _p(_f32(exp_avg_sq, "exp_avg_sq")), param.numel(), int(step), float(lr), beta1, beta2,
+                             eps, 1 if zero_grad else 0, _stream(param)))

@@ -269,6 +269,55 @@ int cn_pointcloud_compact(const float* origins, const float* directions, const f
 /* Embedding.mean(dim=0) (fruit_nerf/fruit_field.py:220,257): [num_images, dim] -> [dim]. */
 int cn_embedding_mean(const float* embedding, int32_t num_images, int32_t dim, float* mean, cn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training: losses, backward, optimiser (FruitModel.get_loss_dict fruit_nerf/fruit_nerf.py:601-615,
+ * optimisers fruit_nerf/fruit_nerf_config.py:45-60).  Gradient buffers use the SAME structs as the
+ * parameters (cn_field_params / cn_density_params whose pointers address the gradient arrays) and are
+ * ACCUMULATED into (atomics); the caller zeroes them (cn_adam_step can do it).
+ * ------------------------------------------------------------------------------------------- */
+
+/* Forward + backward of the volume renderer and of the rgb (MSE over R*3) and semantics
+ * (semantic_loss_weight * BCE-with-logits mean over R) losses, training mode (no clamp, "last_sample"
+ * background, semantics rendered with detached weights: fruit_nerf.py:556-591).  Inputs per sample [R,S]:
+ * starts, ends, density, rgb [R,S,3], semantics.  Outputs: rendered rgb [R,3] / semantics [R,1] /
+ * accumulation [R,1] / weights [R,S] (any NULL skips), gradients d_density [R,S], d_rgb [R,S,3],
+ * d_semantics [R,S] of (rgb_loss + semantics_loss), and loss_sums[0] += sum (rgb-image)^2,
+ * loss_sums[1] += sum BCE terms (divide by 3R / R on the host). */
+int cn_train_render_backward(const float* starts, const float* ends, const float* density, const float* rgb,
+                             const float* semantics, const float* image /*[R,3]*/,
+                             const float* fruit_mask /*[R,1]*/, int64_t num_rays, int32_t num_samples,
+                             float semantic_loss_weight, float* out_rgb, float* out_semantics,
+                             float* out_accumulation, float* out_weights, float* d_density, float* d_rgb,
+                             float* d_semantics, float* loss_sums, cn_stream_t stream);
+
+/* nerfstudio interlevel_loss term of ONE proposal level (fruit_nerf.py:609-612): final spacing bins
+ * [R,Sf+1] and (detached) final weights [R,Sf] against the level's spacing bins [R,Sp+1] and density
+ * [R,Sp] (with its euclidean starts/ends).  Writes d loss / d proposal density [R,Sp] for
+ * loss = loss_mult * mean_{R,Sf}(...), and adds the un-normalised sum to *loss_sum. */
+int cn_interlevel_backward(const float* final_spacing_bins, const float* final_weights,
+                           const float* prop_spacing_bins, const float* prop_starts, const float* prop_ends,
+                           const float* prop_density, int64_t num_rays, int32_t s_final, int32_t s_prop,
+                           float loss_mult, float* d_prop_density, float* loss_sum, cn_stream_t stream);
+
+/* Parameter gradients of FruitField (training branch: per-camera appearance, semantic MLP on detached geo
+ * features, fruit_nerf/fruit_field.py:235-282) from per-sample upstream gradients; the forward is recomputed
+ * tile by tile.  app_mean [app_dim] is read with CN_APP_MEAN only. */
+int cn_field_backward(const cn_field_params* params, const cn_field_params* grads, const cn_scene* scene,
+                      int32_t app_mode, int32_t sh_unit_dir, const float* app_mean, const float* origins,
+                      const float* directions, const int64_t* camera_indices, const float* starts,
+                      const float* ends, const float* d_density, const float* d_rgb, const float* d_semantics,
+                      int64_t num_rays, int32_t num_samples, cn_stream_t stream);
+
+/* Parameter gradients of one proposal network from d loss / d density [R,S]. */
+int cn_proposal_backward(const cn_density_params* params, const cn_density_params* grads, const cn_scene* scene,
+                         const float* origins, const float* directions, const float* starts, const float* ends,
+                         const float* d_density, int64_t num_rays, int32_t num_samples, cn_stream_t stream);
+
+/* torch.optim.Adam step (no weight decay / amsgrad) on one flat tensor; `step` is 1-based;
+ * zero_grad != 0 clears the gradient after use. */
+int cn_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step, double lr,
+                 double beta1, double beta2, double eps, int32_t zero_grad, cn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -125,6 +125,7 @@ def pdf_sampler(prev: RaySamples, weights: Tensor, num_samples: int, u_rand: Opt
     bins_g1 = torch.gather(existing, -1, above)
     t = torch.clip(torch.nan_to_num((u - cdf_g0) / (cdf_g1 - cdf_g0), 0), 0, 1)
     bins = bins_g0 + t * (bins_g1 - bins_g0)  # [R,S+1] spacing domain
+    bins = bins.detach()  # upstream: "Stop gradients"
 
     eu = prev.spacing_to_euclidean(bins)
     return RaySamples(

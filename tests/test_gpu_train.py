@@ -1,0 +1,130 @@
+"""GPU tests of the training rows: losses, backward kernels and Adam against the CPU oracle
+with torch autograd as the gradient reference."""
+
+import math
+
+import pytest
+import torch
+
+from _helpers import assert_close, make_scene, to_dev
+from oracle import losses as OL
+from oracle import rays as ORY
+
+pytestmark = pytest.mark.gpu
+
+S_PROP, S_FINAL = (64, 32), 16
+
+
+def _setup(seed=5, R=96):
+    sc = make_scene(seed=seed, log2_T=12, num_images=4, height=20, width=20, focal=28.0, prop_log2_T=10)
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.stack([torch.randint(0, 4, (R,), generator=g), torch.randint(0, 20, (R,), generator=g),
+                       torch.randint(0, 20, (R,), generator=g)], -1)
+    jitter = [torch.rand(R, 1, generator=g) for _ in range(3)]
+    image = torch.rand(R, 3, generator=g)
+    mask = (torch.rand(R, 1, generator=g) > 0.5).float()
+    return sc, idx, jitter, image, mask
+
+
+def _hip_model(sc):
+    from cropnerf_amd.config import FruitNerfModelConfig
+    from cropnerf_amd.fruit_nerf.fruit_nerf import FruitModel, Semantics
+    from cropnerf_amd.rays import SceneBox
+
+    pl = [{"hidden_dim": 16, "log2_hashmap_size": p.grid.log2_hashmap_size, "num_levels": 5, "max_res": p.grid.max_res}
+          for p in sc.pspecs]
+    cfg = FruitNerfModelConfig(log2_hashmap_size=sc.fspec.grid.log2_hashmap_size, proposal_net_args_list=pl,
+                               num_proposal_samples_per_ray=S_PROP, num_nerf_samples_per_ray=S_FINAL)
+    return FruitModel(cfg, SceneBox(sc.aabb), num_train_data=sc.c2w.shape[0], metadata={"semantics": Semantics()},
+                      device="cuda", test_mode="val", params=sc.params)
+
+
+def _oracle_grads(sc, idx, jitter, image, mask, params=None):
+    params = {k: v.clone().requires_grad_(not k.startswith("camera_optimizer")) for k, v in (params or sc.params).items()}
+    rb = ORY.pinhole_rays(sc.c2w, sc.intr, idx[:, 0], idx[:, 1], idx[:, 2])
+    out = OL.train_forward(rb, params, sc.fspec, sc.pspecs, sc.aabb, S_PROP, S_FINAL, jitter)
+    ld = OL.loss_dict(out, image, mask)
+    sum(ld.values()).backward()
+    return {k: float(v) for k, v in ld.items()}, {k: v.grad for k, v in params.items() if v.grad is not None}, out
+
+
+def _hip_rays(sc, idx):
+    from cropnerf_amd.rays import Cameras
+
+    cams = Cameras(sc.c2w, sc.intr[:, 0], sc.intr[:, 1], sc.intr[:, 2], sc.intr[:, 3], sc.height, sc.width).to("cuda")
+    return cams.generate_rays(idx.cuda())
+
+
+def test_gradients_match_autograd():
+    from cropnerf_amd.fruit_nerf.trainer import FruitTrainer
+
+    sc, idx, jitter, image, mask = _setup()
+    ref_loss, ref_grads, ref_out = _oracle_grads(sc, idx, jitter, image, mask)
+    model = _hip_model(sc)
+    model.training = True
+    tr = FruitTrainer(model)
+    out = tr.forward_backward(_hip_rays(sc, idx), {"image": image, "fruit_mask": mask}, jitter=jitter)
+    for k, v in ref_loss.items():
+        got = float(out["loss_dict"][k])
+        assert abs(got - v) <= 2e-4 * abs(v) + 1e-7, f"{k}: {got} vs {v}"
+    assert_close(out["rgb"], ref_out["rgb"].detach(), 2e-4, 2e-5, "train rgb")
+    assert_close(out["semantics"], ref_out["semantics"].detach(), 2e-4, 5e-5, "train semantics")
+    worst = {}
+    for k, g_ref in ref_grads.items():
+        g = tr.grads[k].cpu()
+        denom = g_ref.norm().item() + 1e-12
+        worst[k] = (g - g_ref).norm().item() / denom
+        assert g_ref.abs().sum() > 0, k
+    bad = {k: v for k, v in worst.items() if v > 3e-3}
+    assert not bad, f"relative gradient error too large: {bad}"
+    assert float(tr.grads["camera_optimizer.pose_adjustment"].abs().sum()) == 0.0
+
+
+def test_adam_step_matches_torch_semantics():
+    from cropnerf_amd import ops
+
+    g = torch.Generator().manual_seed(1)
+    p = torch.randn(10007, generator=g)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    dp, dm, dv = to_dev(p).clone(), to_dev(m).clone(), to_dev(v).clone()
+    for step in range(1, 6):
+        grad = torch.randn(10007, generator=g) * (10.0 ** torch.randint(-6, 1, (10007,), generator=g).float())
+        grad[::17] = 0.0
+        lr = OL.exponential_decay_lr(step - 1, 1e-2, 1e-4, 50)
+        OL.adam_step(p, grad, m, v, step, lr)
+        dg = to_dev(grad).clone()
+        ops.adam_step(dp, dg, dm, dv, step, lr)
+        assert float(dg.abs().sum()) == 0.0  # zero_grad
+    assert_close(dp, p, 1e-5, 1e-6, "adam params")
+    assert_close(dv, v, 1e-5, 1e-12, "adam exp_avg_sq")
+
+
+def test_training_reduces_loss_like_the_oracle():
+    """Ten iterations on one fixed batch: the loss trajectory follows the oracle's (autograd + Adam) and goes down."""
+    from cropnerf_amd.fruit_nerf.trainer import FruitTrainer, OptimGroup
+
+    sc, idx, jitter, image, mask = _setup(seed=6, R=128)
+    model = _hip_model(sc)
+    model.training = True
+    groups = {"proposal_networks": OptimGroup(1e-2, 1e-15, 1e-4, 1000), "fields": OptimGroup(1e-2, 1e-15, 1e-4, 1000)}
+    tr = FruitTrainer(model, groups)
+    rays = _hip_rays(sc, idx)
+    hip_losses = []
+    for it in range(10):
+        out = tr.forward_backward(rays, {"image": image, "fruit_mask": mask}, jitter=jitter)
+        hip_losses.append(sum(float(v) for v in out["loss_dict"].values()))
+        tr.optimizer_step()
+    # oracle loop
+    params = {k: v.clone() for k, v in sc.params.items()}
+    ms = {k: torch.zeros_like(v) for k, v in params.items()}
+    vs = {k: torch.zeros_like(v) for k, v in params.items()}
+    ref_losses = []
+    for it in range(10):
+        ld, grads, _ = _oracle_grads(sc, idx, jitter, image, mask, params)
+        ref_losses.append(sum(ld.values()))
+        lr = OL.exponential_decay_lr(it, 1e-2, 1e-4, 1000)
+        for k, gk in grads.items():
+            OL.adam_step(params[k], gk, ms[k], vs[k], it + 1, lr)
+    assert hip_losses[-1] < hip_losses[0] and ref_losses[-1] < ref_losses[0]
+    for a, b in zip(hip_losses, ref_losses):
+        assert abs(a - b) <= 0.03 * abs(b) + 1e-4, (hip_losses, ref_losses)
