@@ -50,6 +50,7 @@ def parse_args():
     ap.add_argument("--mode", choices=["uniform", "proposal"], default="uniform",
                     help="uniform: 192 field evals/ray (headline); proposal: + (256,96) proposal-net evals/ray")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step timing")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -165,9 +166,10 @@ def main():
         avg = sum(durs) / len(durs)
         alg_bytes = R * (S * BYTES_PER_SAMPLE + BYTES_PER_RAY_IO)
         achieved = alg_bytes / avg / 1e9
+        traffic, traffic_note = pmc_traffic()
         roofline = {"bound": "hbm", "kernel": "render_fused_kernel<false,false>", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                    "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                    "traffic": traffic, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": alg_bytes,
                     "avg_launch_ms": round(avg * 1e3, 4),
                     "mlp_tflops_fp32": round(R * S * 2 * 9216 / avg / 1e12, 2)}
         extra["uniform_samples_per_sec_single_launch"] = R * S / avg
@@ -177,6 +179,10 @@ def main():
     psnr = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline, psnr = run_cpu_baseline(args, params, fspec, pspecs, batches, ops, fh, scene_u, opts)
+
+    # ---- secondary numbers (rank 0, N=1): proposal-mode render and training iterations --------------------------------
+    if rank == 0 and world == 1:
+        extra.update(secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, opts))
 
     if rank == 0:
         samples = world * R * S * args.steps
@@ -206,6 +212,81 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic():
+    """Memory-side bytes per launch of render_fused_kernel from the committed rocprofv3 PMC passes of this same
+    command (profiles/*_pmc_render_fused.json: FETCH_SIZE and WRITE_SIZE, KiB, separate passes).  No 2x FETCH_SIZE
+    correction is applied: the guide calibrates that factor for 16-B-per-lane streaming reads only, these are 8-B
+    gathers; the TCC miss count (x64 B) of the same run agrees with the raw value.  Infinity-Cache hits are included,
+    so this is an upper bound on HBM bytes (the 64 MB table is cache-resident)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_render_fused.json")))
+    if not files:
+        return None, "no PMC summary under profiles/"
+    try:
+        with open(files[-1]) as fh_:
+            d = json.load(fh_)
+        val = lambda k: d[k]["avg_per_launch"] if isinstance(d[k], dict) else d[k]
+        return int((val("FETCH_SIZE") + val("WRITE_SIZE")) * 1024), f"from {os.path.basename(files[-1])} (measured on the kernel version named there)"
+    except Exception as e:  # noqa: BLE001
+        return None, f"unreadable PMC summary: {e}"
+
+
+def secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, opts):
+    """Not the headline: M-proposal render (256+96 proposal-net evals + 192 field evals per ray) and the training
+    iteration of the default method config (4096 rays: (256, 96) proposal + 48 field samples, forward + backward + Adam)."""
+    out = {}
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(fn, n):
+        fn(0)
+        torch.cuda.synchronize()
+        ev0.record()
+        for i in range(n):
+            fn(i)
+        ev1.record()
+        ev1.synchronize()
+        return ev0.elapsed_time(ev1) * 1e-3 / n
+
+    def prop(i):
+        o, d, n, f, cam = batches[i % DISTINCT_BATCHES]
+        ps = ops.proposal_sample(dh, scene_c, o, d, n, f, cfg.num_proposal_samples_per_ray, S)
+        ops.render_rays(fh, scene_c, opts, o, d, n, f, bins=ps["euclidean_bins"])
+
+    t = timed(prop, 10)
+    out["proposal_mode"] = {"ms_per_batch": round(t * 1e3, 3), "rays_per_sec": R / t, "field_samples_per_sec": R * S / t,
+                            "network_evals_per_sec": R * (S + sum(cfg.num_proposal_samples_per_ray)) / t}
+    if not args.no_train:
+        from cropnerf_amd import config as PC
+        from cropnerf_amd.fruit_nerf.fruit_nerf import FruitModel, Semantics
+        from cropnerf_amd.fruit_nerf.trainer import FruitTrainer
+        from cropnerf_amd.rays import RayBundle, SceneBox
+
+        tcfg = PC.FruitNerfModelConfig()  # reference defaults: 48 field samples, (256, 96) proposal samples
+        model = FruitModel(tcfg, SceneBox(torch.tensor([[-1.0, -1, -1], [1, 1, 1]])), NUM_CAMERAS,
+                           {"semantics": Semantics()}, device=batches[0][0].device, params=params)
+        model.training = True
+        tr = FruitTrainer(model)
+        g = torch.Generator().manual_seed(0)
+        train = {}
+        from cropnerf_amd import synthetic
+        from cropnerf_amd.rays import Cameras
+
+        c2w, intr = synthetic.orbit_cameras(NUM_CAMERAS, height=H, width=W, focal=FOCAL)
+        cams = Cameras(c2w, intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], H, W).to(batches[0][0].device)
+        for nrays in (4096, 65536):
+            # training batches are random pixels over all images (PixelSampler), not a block of one image
+            idx = torch.stack([torch.randint(0, NUM_CAMERAS, (nrays,), generator=g), torch.randint(0, H, (nrays,), generator=g),
+                               torch.randint(0, W, (nrays,), generator=g)], -1)
+            rb = cams.generate_rays(idx.to(batches[0][0].device))
+            batch = {"image": torch.rand(nrays, 3, generator=g), "fruit_mask": (torch.rand(nrays, 1, generator=g) > 0.5).float()}
+            batch = {k: v.to(batches[0][0].device) for k, v in batch.items()}
+            t = timed(lambda i: tr.train_iteration(rb, batch), 5)
+            train[str(nrays)] = {"ms_per_iter": round(t * 1e3, 3), "rays_per_sec": nrays / t}
+        out["train_iteration"] = train
+    return out
 
 
 def run_cpu_baseline(args, params, fspec, pspecs, batches, ops, fh, scene_u, opts):

@@ -17,6 +17,8 @@
 //
 // Shapes: the default fruit_nerf_method field (16 levels, 32->64->16, 15->64->64->1, 63->64->64->3, appearance 32)
 // and {5|7}-level 2L->16->1 proposal nets; other shapes return CN_ERR_UNSUPPORTED.
+#include <cstdlib>
+
 #include "cn_common.hpp"
 #include "wave_ops.hpp"
 
@@ -146,6 +148,7 @@ struct FieldBwdArgs {
   const float *d_density, *d_rgb, *d_sem;
   long long R;
   int S;
+  int debug_skip;  // profiling aid (env CN_DEBUG_SKIP): 1 hash atomics, 2 embedding atomics, 4 weight-gradient dots
 };
 
 // LDS rows (each LD floats)
@@ -261,20 +264,20 @@ __global__ void __launch_bounds__(TB) field_backward_kernel(FieldBwdArgs A) {
       dA[wave * LD + lane] = up * s * (1.f - s);
     }
     __syncthreads();
-    gWc2.add(dA, c2, tid);
+    if (!(A.debug_skip & 4)) gWc2.add(dA, c2, tid);
     bias_add<3>(gbc2, dA, tid);
     bwd_rows<64, 3>(A.p.wc2, dA, dB, c2, 0, 64, wave, lane);  // delta_c2 (ReLU-gated) -> dB
     __syncthreads();
-    gWc1.add(dB, c1, tid);
+    if (!(A.debug_skip & 4)) gWc1.add(dB, c1, tid);
     bias_add<64>(gbc1, dB, tid);
     bwd_rows<64, 64>(A.p.wc1, dB, dA, c1, 0, 64, wave, lane);  // delta_c1 -> dA
     __syncthreads();
-    gWc0.add(dA, cin, tid);
+    if (!(A.debug_skip & 4)) gWc0.add(dA, cin, tid);
     bias_add<64>(gbc0, dA, tid);
     // delta of the colour input: geo rows (16..30) feed the base MLP, appearance rows (31..62) the embedding
     bwd_rows<63, 64>(A.p.wc0, dA, dB, nullptr, 16, 63, wave, lane);  // dB rows 16..62
     __syncthreads();
-    if (A.app_per_camera && valid) {
+    if (A.app_per_camera && valid && !(A.debug_skip & 2)) {
       for (int k = wave; k < 32; k += 4) atomicAdd(A.g.emb + A.cam_idx[r] * 32 + k, dB[(31 + k) * LD + lane]);
     }
     // delta_o16 -> dA' : row 0 = density logit, rows 1..15 = geo (from the colour branch only: semantics sees detached geo)
@@ -283,15 +286,15 @@ __global__ void __launch_bounds__(TB) field_backward_kernel(FieldBwdArgs A) {
     if (wave == 0) dA[lane] = misc[4 * LD + lane];
     for (int k = wave; k < 15; k += 4) dA[(1 + k) * LD + lane] = dB[(16 + k) * LD + lane];
     __syncthreads();
-    gW1.add(dA, h1, tid);
+    if (!(A.debug_skip & 4)) gW1.add(dA, h1, tid);
     bias_add<16>(gb1, dA, tid);
     bwd_rows<64, 16>(A.p.w1, dA, dB, h1, 0, 64, wave, lane);  // delta_h1 -> dB
     __syncthreads();
-    gW0.add(dB, enc, tid);
+    if (!(A.debug_skip & 4)) gW0.add(dB, enc, tid);
     bias_add<64>(gb0, dB, tid);
     bwd_rows<32, 64>(A.p.w0, dB, dA, nullptr, 0, 32, wave, lane);  // delta_enc -> dA rows 0..31
     __syncthreads();
-    if (valid) {
+    if (valid && !(A.debug_skip & 1)) {
       const float px = misc[0 * LD + lane], py = misc[1 * LD + lane], pz = misc[2 * LD + lane];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -303,15 +306,15 @@ __global__ void __launch_bounds__(TB) field_backward_kernel(FieldBwdArgs A) {
     __syncthreads();
     // ---- semantic branch: sem = Wh s2 + bh; gradients stop at the (detached) geo features ------------------------------
     // delta_sem (1 row) is misc row 5
-    gWh.add(misc + 5 * LD, s2, tid);
+    if (!(A.debug_skip & 4)) gWh.add(misc + 5 * LD, s2, tid);
     bias_add<1>(gbh, misc + 5 * LD, tid);
     bwd_rows<64, 1>(A.p.wh, misc + 5 * LD, dB, nullptr, 0, 64, wave, lane);  // delta_s2 -> dB
     __syncthreads();
-    gWs1.add(dB, s1, tid);
+    if (!(A.debug_skip & 4)) gWs1.add(dB, s1, tid);
     bias_add<64>(gbs1, dB, tid);
     bwd_rows<64, 64>(A.p.ws1, dB, dA, s1, 0, 64, wave, lane);  // delta_s1 -> dA
     __syncthreads();
-    gWs0.add(dA, o16 + LD, tid);
+    if (!(A.debug_skip & 4)) gWs0.add(dA, o16 + LD, tid);
     bias_add<64>(gbs0, dA, tid);
     __syncthreads();
   }
@@ -495,6 +498,10 @@ extern "C" int cn_field_backward(const cn_field_params* params, const cn_field_p
   A.d_sem = d_semantics;
   A.R = num_rays;
   A.S = num_samples;
+  {
+    const char* dbg = getenv("CN_DEBUG_SKIP");
+    A.debug_skip = dbg ? atoi(dbg) : 0;
+  }
   size_t lds = (size_t)cn::FIELD_ROWS * cn::LD * sizeof(float);
   static bool attr = false;
   if (!attr) {

@@ -1,0 +1,26 @@
+"""Times the default fruit_nerf training iteration (4096 random rays) on cuda:0; CN_DEBUG_SKIP ablates parts of
+cn_field_backward (1 hash atomics, 2 embedding atomics, 4 weight-gradient dots).  Profiling aid, not a test."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cropnerf_amd import config as PC, ops, synthetic
+from cropnerf_amd.fruit_nerf.fruit_nerf import FruitModel, Semantics
+from cropnerf_amd.fruit_nerf.trainer import FruitTrainer
+from cropnerf_amd.rays import RayBundle, SceneBox, Cameras
+dev = "cuda"
+cfg = PC.FruitNerfModelConfig()
+fspec = cfg.field_spec(100)
+params = synthetic.p_rand(fspec, cfg.proposal_specs(), seed=0, device=dev)
+model = FruitModel(cfg, SceneBox(torch.tensor([[-1.0,-1,-1],[1,1,1]])), 100, {"semantics": Semantics()}, device=dev, params=params)
+model.training = True
+tr = FruitTrainer(model)
+c2w, intr = synthetic.orbit_cameras(100)
+cams = Cameras(c2w, intr[:,0], intr[:,1], intr[:,2], intr[:,3], 800, 800).to(dev)
+g = torch.Generator().manual_seed(0)
+R = 4096
+idx = torch.stack([torch.randint(0,100,(R,),generator=g), torch.randint(0,800,(R,),generator=g), torch.randint(0,800,(R,),generator=g)],-1)
+rb = cams.generate_rays(idx.to(dev))
+batch = {"image": torch.rand(R,3,generator=g).to(dev), "fruit_mask": (torch.rand(R,1,generator=g)>0.5).float().to(dev)}
+for i in range(2): tr.train_iteration(rb, batch)
+torch.cuda.synchronize(); t=time.perf_counter()
+for i in range(5): tr.train_iteration(rb, batch)
+torch.cuda.synchronize(); print("CN_DEBUG_SKIP", os.environ.get("CN_DEBUG_SKIP"), "ms/iter", (time.perf_counter()-t)/5*1e3)
