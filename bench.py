@@ -64,8 +64,15 @@ def setup_dist(n_gpus: int):
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # rehearsal hook for a one-GPU box: BENCH_REHEARSE_ON_ONE_GPU=1 puts every rank on cuda:0 and exchanges over
+        # gloo (host staging).  Never set by the driver; the real path below is one rank per GPU over RCCL.
+        if os.environ.get("BENCH_REHEARSE_ON_ONE_GPU") == "1":
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
     if world != n_gpus:
@@ -118,7 +125,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        gather_buf = torch.empty(world, R, 6, device=device)
+        gather_buf = torch.empty(world * R, 6, device=device)  # concatenated along dim 0 (valid for RCCL and gloo)
 
     def step(i: int):
         o, d, n, f, cam = batches[i % DISTINCT_BATCHES]
@@ -129,7 +136,12 @@ def main():
             out = ops.render_rays(fh, scene_c, opts, o, d, n, f, bins=ps["euclidean_bins"])
         if world > 1:
             packed = torch.cat([out["rgb"], out["accumulation"], out["depth"], out["semantics"]], dim=-1)
-            dist.all_gather_into_tensor(gather_buf, packed)
+            if dist.get_backend() == "gloo":  # rehearsal only
+                host = torch.empty(gather_buf.shape)
+                dist.all_gather_into_tensor(host, packed.cpu())
+                gather_buf.copy_(host)
+            else:
+                dist.all_gather_into_tensor(gather_buf, packed)
         return out
 
     def barrier():
@@ -146,7 +158,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

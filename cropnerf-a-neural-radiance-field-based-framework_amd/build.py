@@ -45,6 +45,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     BUILD.mkdir(exist_ok=True)
     headers = [CSRC / h for h in HEADERS]
     flags = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-x", "hip", "-Wno-unused-result"]
+    flags += os.environ.get("CN_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DCN_FUSED_PIPELINE=0 for A/B builds
     jobs = []
     objs = []
     for src in SOURCES:

@@ -467,3 +467,56 @@ def test_full_size_chunk_properties(ops):
     ref = m.forward(rb)
     assert_close(out["rgb"][idx.cuda()], ref["rgb"], RTOL, ATOL, "rgb spot check")
     assert_close(out["accumulation"][idx.cuda()], ref["accumulation"], RTOL, ATOL, "acc spot check")
+
+
+# ------------------------------------------------------------------------------------------------ edge cases
+@pytest.mark.parametrize("R,S", [(1, 1), (3, 2), (5, 65), (130, 1)])
+def test_render_rays_tiny_shapes(scene, ops, handles, R, S):
+    """Fewer rays than waves, a single sample, a chunk boundary + 1."""
+    ref, out = _fused_vs_oracle(scene, ops, handles, S, False, R, 2)
+    assert_close(out["weights"], ref["_weights"][..., 0], RTOL, 1e-6, "weights")
+    assert_close(out["rgb"], ref["rgb"], RTOL, ATOL, "rgb")
+    assert_close(out["semantics"], ref["semantics"], RTOL, 5e-5, "semantics")
+    _depth_match(out["depth"], ref["depth"], 0.99 if R > 50 else 1.0)
+
+
+def test_render_rays_empty_and_missing_rays(scene, ops, handles):
+    """R = 0 is a no-op; rays that miss the box (near = far = 1e10, fruit_nerf.py:286) composite to zero weight and
+    take the last-sample colour, exactly like the oracle."""
+    dp, fh, dh = handles
+    sc = ops.scene_struct(scene.aabb, False)
+    opts = ops.render_opts(32)
+    z3, z1 = torch.empty(0, 3, device="cuda"), torch.empty(0, 1, device="cuda")
+    out = ops.render_rays(fh, sc, opts, z3, z3, z1, z1)
+    assert out["rgb"].shape == (0, 3)
+    rb = ORY.image_rays(scene.c2w, scene.intr, 0, scene.height, scene.width).slice(0, 64)
+    rb = ORY.with_aabb_near_far(rb, torch.tensor([5.0, 5, 5, 6, 6, 6]))
+    assert float(rb.nears.min()) == 1e10
+    m = oracle_model(scene, "inference", disable_scene_contraction=True)
+    m.uniform_samples = 32
+    ref = m.forward(rb)
+    out = ops.render_rays(fh, sc, opts, to_dev(rb.origins), to_dev(rb.directions), to_dev(rb.nears), to_dev(rb.fars))
+    assert float(out["accumulation"].abs().max()) == 0.0 and float(ref["accumulation"].abs().max()) == 0.0
+    assert_close(out["rgb"], ref["rgb"], RTOL, ATOL, "rgb of missing rays")
+    assert_close(out["depth"], ref["depth"], 1e-6, 0, "depth of missing rays")
+
+
+def test_unsupported_shape_is_reported_not_computed(scene, ops):
+    """The fused kernel refuses field shapes it is not built for (CN_ERR_UNSUPPORTED) instead of guessing."""
+    from cropnerf_amd import config as PC
+    from cropnerf_amd._lib import CropNerfHipError
+
+    spec = PC.FieldSpec(grid=PC.GridSpec(log2_hashmap_size=10), geo_feat_dim=30, num_layers_semantic=3,
+                        hidden_dim_semantics=128, num_images=2)
+    params = PC.init_params(spec, [], device="cuda")
+    fh = ops.FieldHandle(params, spec)
+    o = torch.zeros(4, 3, device="cuda")
+    d = torch.ones(4, 3, device="cuda")
+    n, f = torch.zeros(4, 1, device="cuda"), torch.ones(4, 1, device="cuda")
+    with pytest.raises(CropNerfHipError) as ei:
+        ops.render_rays(fh, ops.scene_struct(scene.aabb, False), ops.render_opts(8), o, d, n, f)
+    assert ei.value.code == -2
+    # ... while the shape-generic kernel evaluates it (fruit_nerf_method_big field: geo 30, 3-layer 128-wide semantics)
+    sm = ops.sample_spaced(n, f, 8)
+    out = ops.field_eval(fh, ops.scene_struct(scene.aabb, False), o, d, None, sm["starts"], sm["ends"])
+    assert torch.isfinite(out["rgb"]).all() and out["rgb"].shape == (4, 8, 3)
