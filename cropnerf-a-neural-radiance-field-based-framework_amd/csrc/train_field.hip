@@ -96,9 +96,48 @@ __device__ __forceinline__ void bias_add(float& acc, const float* dy, int tid) {
   }
 }
 
+// Run-length pre-reduction of scatter-adds inside each 16-lane row.  Lanes are consecutive samples of a ray, so at the
+// coarser levels neighbouring lanes hit the same grid cell: runs of equal `key` are summed with a segmented scan on DPP
+// row shifts (no LDS, no address registers) and only the last lane of a run issues the atomic.  Must be called by all
+// 64 lanes (pass zeros for lanes with nothing to add).  Returns true where the (summed) v0 / v1 are to be added.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ bool row_run_reduce(unsigned key, float& v0, float& v1, int row_lane) {
+  const unsigned prev = dpp_u32<0x111>(key);  // row_shr:1
+  unsigned head = (row_lane == 0 || prev != key) ? 1u : 0u;
+  const unsigned next_head = dpp_u32<0x101>(head);  // row_shl:1 (0 past the row end)
+  const bool last = row_lane == 15 || next_head != 0u;
+  unsigned f = head;
+#define CN_SEG_STEP(CTRL)                         \
+  {                                               \
+    const float a0 = dpp_f32<CTRL>(v0);           \
+    const float a1 = dpp_f32<CTRL>(v1);           \
+    const unsigned fu = dpp_u32<CTRL>(f);         \
+    if (!f) {                                     \
+      v0 += a0;                                   \
+      v1 += a1;                                   \
+      f |= fu;                                    \
+    }                                             \
+  }
+  CN_SEG_STEP(0x111)
+  CN_SEG_STEP(0x112)
+  CN_SEG_STEP(0x114)
+  CN_SEG_STEP(0x118)
+#undef CN_SEG_STEP
+  return last;
+}
+
 // scatter d(loss)/d(features of one level) into the table gradient with the forward's trilinear weights
+// (all 64 lanes call it; g0 = g1 = 0 for lanes without a sample)
 __device__ __forceinline__ void hash_level_backward(float* __restrict__ gtab, unsigned level_off, unsigned mask,
-                                                    float scale, float px, float py, float pz, float g0, float g1) {
+                                                    float scale, float px, float py, float pz, float g0, float g1,
+                                                    int lane) {
   float sx = px * scale, sy = py * scale, sz = pz * scale;
   float fx = floorf(sx), fy = floorf(sy), fz = floorf(sz);
   float ox = sx - fx, oy = sy - fy, oz = sz - fz;
@@ -107,14 +146,17 @@ __device__ __forceinline__ void hash_level_backward(float* __restrict__ gtab, un
   unsigned hy[2] = {iy * CN_P1, iy * CN_P1 + CN_P1};
   unsigned hz[2] = {iz * CN_P2, iz * CN_P2 + CN_P2};
   float wx[2] = {1.f - ox, ox}, wy[2] = {1.f - oy, oy}, wz[2] = {1.f - oz, oz};  // index 1 = ceil corner
+  const int row_lane = lane & 15;
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const int a = c & 1, b = (c >> 1) & 1, d = c >> 2;
     const float w = wx[a] * wy[b] * wz[d];
     const unsigned e = ((hx[a] ^ hy[b] ^ hz[d]) & mask) + level_off;
-    if (w != 0.f) {
-      atomicAdd(gtab + 2 * (size_t)e, w * g0);
-      atomicAdd(gtab + 2 * (size_t)e + 1, w * g1);
+    float v0 = w * g0, v1 = w * g1;
+    const bool issue = row_run_reduce(e, v0, v1, row_lane);
+    if (issue && (v0 != 0.f || v1 != 0.f)) {
+      atomicAdd(gtab + 2 * (size_t)e, v0);
+      atomicAdd(gtab + 2 * (size_t)e + 1, v1);
     }
   }
 }
@@ -294,13 +336,13 @@ __global__ void __launch_bounds__(TB) field_backward_kernel(FieldBwdArgs A) {
     bias_add<64>(gb0, dB, tid);
     bwd_rows<32, 64>(A.p.w0, dB, dA, nullptr, 0, 32, wave, lane);  // delta_enc -> dA rows 0..31
     __syncthreads();
-    if (valid && !(A.debug_skip & 1)) {
+    if (!(A.debug_skip & 1)) {
       const float px = misc[0 * LD + lane], py = misc[1 * LD + lane], pz = misc[2 * LD + lane];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int l = 4 * wave + q;
         hash_level_backward(A.g.table, (unsigned)l * A.level_stride, A.mask, A.scale[l], px, py, pz,
-                            dA[(2 * l) * LD + lane], dA[(2 * l + 1) * LD + lane]);
+                            valid ? dA[(2 * l) * LD + lane] : 0.f, valid ? dA[(2 * l + 1) * LD + lane] : 0.f, lane);
       }
     }
     __syncthreads();
@@ -407,18 +449,16 @@ __global__ void __launch_bounds__(TB) proposal_backward_kernel(PropBwdArgs A) {
     gW0.add(dh, enc, tid);
     bias_add<H>(gb0, dh, tid);
     // delta_enc[k] = sum_n W0[n][k] dh[n] -> straight into the table gradient
-    if (valid) {
-      for (int l = wave; l < L; l += 4) {
-        float g0 = 0.f, g1 = 0.f;
+    for (int l = wave; l < L; l += 4) {
+      float g0 = 0.f, g1 = 0.f;
 #pragma unroll
-        for (int n = 0; n < H; ++n) {
-          const float d = dh[n * LD + lane];
-          g0 = fmaf(A.w0[n * K + 2 * l], d, g0);
-          g1 = fmaf(A.w0[n * K + 2 * l + 1], d, g1);
-        }
-        hash_level_backward(A.g_table, (unsigned)l * A.level_stride, A.mask, A.scale[l], misc[lane], misc[LD + lane],
-                            misc[2 * LD + lane], g0, g1);
+      for (int n = 0; n < H; ++n) {
+        const float d = dh[n * LD + lane];
+        g0 = fmaf(A.w0[n * K + 2 * l], d, g0);
+        g1 = fmaf(A.w0[n * K + 2 * l + 1], d, g1);
       }
+      hash_level_backward(A.g_table, (unsigned)l * A.level_stride, A.mask, A.scale[l], misc[lane], misc[LD + lane],
+                          misc[2 * LD + lane], valid ? g0 : 0.f, valid ? g1 : 0.f, lane);
     }
     __syncthreads();
   }
