@@ -51,6 +51,9 @@ def parse_args():
                     help="uniform: 192 field evals/ray (headline); proposal: + (256,96) proposal-net evals/ray")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step timing")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="headline workload only (use under rocprofv3 so per-kernel averages are not mixed with the "
+                         "proposal-mode and training launches)")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -193,7 +196,7 @@ def main():
         cpu_baseline, psnr = run_cpu_baseline(args, params, fspec, pspecs, batches, ops, fh, scene_u, opts)
 
     # ---- secondary numbers (rank 0, N=1): proposal-mode render and training iterations --------------------------------
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_secondary:
         extra.update(secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, opts))
 
     if rank == 0:

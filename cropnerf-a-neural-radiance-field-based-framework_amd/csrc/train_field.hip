@@ -28,10 +28,17 @@ constexpr int TS = 64;       // samples per tile
 constexpr int LD = TS + 1;   // padded row length
 constexpr int TB = 256;      // threads per workgroup
 
+// Weights are read-only for the whole launch (gradients go to separate buffers), so they are addressed through the
+// constant address space: with a wave-uniform index the compiler then emits s_load (SGPR operands for v_fma) instead of
+// one broadcast global_load per multiply -- it cannot prove invariance for plain global pointers next to the atomics.
+typedef const float __attribute__((address_space(4)))* cfloat_ptr;
+__device__ __forceinline__ cfloat_ptr as_const(const float* p) { return (cfloat_ptr)(unsigned long long)p; }
+
 // y[n][lane] = act(b[n] + sum_k W[n][k] x[k][lane]) for the rows n = wave, wave+4, ...
 template <int K, int N, bool RELU>
-__device__ __forceinline__ void fwd_rows(const float* __restrict__ W, const float* __restrict__ b, const float* x,
+__device__ __forceinline__ void fwd_rows(const float* __restrict__ Wg, const float* __restrict__ bg, const float* x,
                                          float* y, int wave, int lane) {
+  const cfloat_ptr W = as_const(Wg), b = as_const(bg);
   for (int n = wave; n < N; n += 4) {
     float acc = b[n];
 #pragma unroll 8
@@ -42,8 +49,9 @@ __device__ __forceinline__ void fwd_rows(const float* __restrict__ W, const floa
 
 // dx[k][lane] = (sum_n W[n][k] dy[n][lane]) * (gate ? act[k][lane] > 0 : 1) for rows k = k0 + wave, +4, ... < k1
 template <int K, int N>
-__device__ __forceinline__ void bwd_rows(const float* __restrict__ W, const float* dy, float* dx, const float* act,
+__device__ __forceinline__ void bwd_rows(const float* __restrict__ Wg, const float* dy, float* dx, const float* act,
                                          int k0, int k1, int wave, int lane) {
+  const cfloat_ptr W = as_const(Wg);
   for (int k = k0 + wave; k < k1; k += 4) {
     float acc = 0.f;
 #pragma unroll 8
@@ -209,7 +217,8 @@ constexpr int FIELD_ROWS = R_MISC + 10;
 
 __global__ void __launch_bounds__(TB) field_backward_kernel(FieldBwdArgs A) {
   extern __shared__ __align__(16) float lds[];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> weights come through s_load
   float* enc = lds + R_ENC * LD;
   float* h1 = lds + R_H1 * LD;
   float* o16 = lds + R_O16 * LD;
@@ -398,7 +407,8 @@ __global__ void __launch_bounds__(TB) proposal_backward_kernel(PropBwdArgs A) {
   float* dh = hid + H * LD;          // [H] delta hidden
   float* dout = dh + H * LD;         // [1] delta logit
   float* misc = dout + LD;           // pos(3)
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> weights come through s_load
   WGrad<K, H> gW0;
   WGrad<H, 1> gW1;
   gW0.zero();
