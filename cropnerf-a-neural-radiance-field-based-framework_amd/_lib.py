@@ -96,6 +96,7 @@ SIGNATURES = {
                                     _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
     "cn_proposal_backward": (C.c_int, [C.POINTER(DensityParams), C.POINTER(DensityParams), C.POINTER(Scene), _P, _P,
                                        _P, _P, _P, _I64, _I32, _P]),
+    "cn_distortion_metric": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "cn_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _I32, C.c_double, C.c_double, C.c_double, C.c_double, _I32, _P]),
 }
 

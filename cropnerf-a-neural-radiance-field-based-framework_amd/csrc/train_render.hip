@@ -214,6 +214,41 @@ interlevel_backward_kernel(const float* __restrict__ c_bins, const float* __rest
   }
 }
 
+// nerfstudio distortion_loss on the final level (a metric in the reference, fruit_nerf.py:643):
+// mean over rays of  sum_ij w_i w_j |u_i - u_j| + 1/3 sum_i w_i^2 (c_{i+1} - c_i),  u = bin mid-points in the spacing domain.
+// One wave per ray; LDS per wave: w[S] | u[S].
+__global__ void __launch_bounds__(256)
+distortion_kernel(const float* __restrict__ bins, const float* __restrict__ weights, long long R, int S,
+                  float* __restrict__ sum_out) {
+  extern __shared__ __align__(16) float lds[];
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  float* w = lds + wave * 2 * S;
+  float* u = w + S;
+  const long long waves = (long long)gridDim.x * 4;
+  for (long long r = blockIdx.x * 4LL + wave; r < R; r += waves) {
+    float intra = 0.f;
+    for (int i = lane; i < S; i += 64) {
+      const float c0 = bins[r * (S + 1) + i], c1 = bins[r * (S + 1) + i + 1];
+      const float wi = weights[r * (long long)S + i];
+      w[i] = wi;
+      u[i] = (c0 + c1) / 2.f;
+      intra += wi * wi * (c1 - c0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float inter = 0.f;
+    for (int i = lane; i < S; i += 64) {
+      float s = 0.f;
+      const float ui = u[i];
+      for (int j = 0; j < S; ++j) s += w[j] * fabsf(ui - u[j]);
+      inter += w[i] * s;
+    }
+    const float total = wave_sum(inter + intra / 3.f);
+    if (lane == 0) atomicAdd(sum_out, total);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 __global__ void __launch_bounds__(256)
 adam_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                  long long n, float step_size, float beta1, float beta2, float omb1, float omb2, float inv_sqrt_bc2,
@@ -280,4 +315,16 @@ extern "C" int cn_adam_step(float* param, float* grad, float* exp_avg, float* ex
                      grad, exp_avg, exp_avg_sq, (long long)n, (float)(lr / bc1), (float)beta1, (float)beta2,
                      (float)(1.0 - beta1), (float)(1.0 - beta2), (float)(1.0 / sqrt(bc2)), (float)eps, zero_grad);
   return cn::check_launch("cn_adam_step");
+}
+
+extern "C" int cn_distortion_metric(const float* spacing_bins, const float* weights, int64_t num_rays,
+                                    int32_t num_samples, float* sum_out, cn_stream_t stream) {
+  CN_REQUIRE(spacing_bins && weights && sum_out, CN_ERR_INVALID, "cn_distortion_metric: null argument");
+  CN_REQUIRE(num_samples >= 1 && num_samples <= cn::TRAIN_MAX_S, CN_ERR_UNSUPPORTED,
+             "cn_distortion_metric: %d samples per ray (max %d)", num_samples, cn::TRAIN_MAX_S);
+  if (num_rays <= 0) return CN_OK;
+  size_t lds = (size_t)4 * 2 * num_samples * sizeof(float);
+  hipLaunchKernelGGL(cn::distortion_kernel, dim3(cn::grid_for(num_rays, 4, 4096)), dim3(256), lds, cn::as_stream(stream),
+                     spacing_bins, weights, (long long)num_rays, num_samples, sum_out);
+  return cn::check_launch("cn_distortion_metric");
 }

@@ -47,7 +47,14 @@ class FruitTrainer:
         self.groups = groups or {"proposal_networks": OptimGroup(), "fields": OptimGroup()}
         dev = model.device
         self.trainable = [k for k in model.params if not k.startswith("camera_optimizer.")]
-        self.grads = {k: torch.zeros_like(v) for k, v in model.params.items()}
+        # one flat gradient buffer with per-parameter views: data-parallel training all-reduces it in ONE collective
+        # (the reference's DDP, fruit_pipeline.py:119-121, made explicit; 78 MB per step for the default field)
+        sizes = {k: v.numel() for k, v in model.params.items()}
+        self.flat_grads = torch.zeros(sum(sizes.values()), device=dev)
+        self.grads, off = {}, 0
+        for k, v in model.params.items():
+            self.grads[k] = self.flat_grads[off:off + sizes[k]].view_as(v)
+            off += sizes[k]
         self.exp_avg = {k: torch.zeros_like(model.params[k]) for k in self.trainable}
         self.exp_avg_sq = {k: torch.zeros_like(model.params[k]) for k in self.trainable}
         self.grad_field = ops.FieldHandle(self.grads, model.field_spec)
@@ -115,11 +122,18 @@ class FruitTrainer:
             dd = ops.interlevel_backward(bins, rb_out["weights"], lv["bins"], lv["starts"], lv["ends"], lv["density"],
                                          cfg.interlevel_loss_mult, self.loss_sums[2:3])
             ops.proposal_backward(m.proposal_networks[lvl], self.grad_props[lvl], scene, o, d, lv["starts"], lv["ends"], dd)
+        self._last_bins, self._last_weights = bins, rb_out["weights"]
         sums = self.loss_sums
         loss_dict = {"rgb_loss": sums[0] / (3.0 * R), "semantics_loss": cfg.semantic_loss_weight * sums[1] / R,
                      "interlevel_loss": cfg.interlevel_loss_mult * sums[2] / (R * S)}
         return {"loss_dict": loss_dict, "rgb": rb_out["rgb"], "semantics": rb_out["semantics"],
                 "accumulation": rb_out["accumulation"]}
+
+    def all_reduce_gradients(self, group=None) -> None:
+        """Data-parallel step: average the gradients of all ranks (each rank trained on its own ray batch)."""
+        from ..distributed import all_reduce_mean
+
+        self.flat_grads.copy_(all_reduce_mean(self.flat_grads, group))
 
     def optimizer_step(self) -> None:
         self.step += 1
@@ -131,7 +145,16 @@ class FruitTrainer:
     def train_iteration(self, ray_bundle: RayBundle, batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
         self.set_anneal(self.step)
         out = self.forward_backward(ray_bundle, batch)
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self.all_reduce_gradients()
         self.optimizer_step()
-        mse = out["loss_dict"]["rgb_loss"]
-        out["metrics_dict"] = {"psnr": -10.0 * torch.log10(mse)}
+        out["metrics_dict"] = self.get_metrics_dict(out)
         return out
+
+    def get_metrics_dict(self, out) -> Dict[str, Tensor]:
+        """``get_metrics_dict`` (``fruit_nerf.py:639-645``): PSNR and the distortion metric of the last batch."""
+        mse = out["loss_dict"]["rgb_loss"]
+        return {"psnr": -10.0 * torch.log10(mse),
+                "distortion": ops.distortion_metric(self._last_bins, self._last_weights)}

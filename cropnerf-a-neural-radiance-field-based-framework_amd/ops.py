@@ -489,3 +489,13 @@ def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, 
     L.check(lib.cn_adam_step(_p(_f32(param, "param")), _p(_f32(grad, "grad")), _p(_f32(exp_avg, "exp_avg")),
                              _p(_f32(exp_avg_sq, "exp_avg_sq")), param.numel(), int(step), float(lr), beta1, beta2,
                              eps, 1 if zero_grad else 0, _stream(param)))
+
+
+def distortion_metric(spacing_bins: Tensor, weights: Tensor) -> Tensor:
+    """mean over rays of nerfstudio's distortion loss (get_metrics_dict "distortion")."""
+    lib = L.load()
+    R, S = weights.shape
+    acc = torch.zeros(1, device=weights.device)
+    L.check(lib.cn_distortion_metric(_p(_f32(spacing_bins, "spacing_bins")), _p(_f32(weights, "weights")), R, S, _p(acc),
+                                     _stream(weights)))
+    return acc[0] / R

@@ -313,6 +313,11 @@ int cn_proposal_backward(const cn_density_params* params, const cn_density_param
                          const float* origins, const float* directions, const float* starts, const float* ends,
                          const float* d_density, int64_t num_rays, int32_t num_samples, cn_stream_t stream);
 
+/* nerfstudio distortion_loss of the final level (the "distortion" entry of get_metrics_dict,
+ * fruit_nerf/fruit_nerf.py:643): adds sum over rays to *sum_out (divide by R on the host). */
+int cn_distortion_metric(const float* spacing_bins /*[R,S+1]*/, const float* weights /*[R,S]*/, int64_t num_rays,
+                         int32_t num_samples, float* sum_out, cn_stream_t stream);
+
 /* torch.optim.Adam step (no weight decay / amsgrad) on one flat tensor; `step` is 1-based;
  * zero_grad != 0 clears the gradient after use. */
 int cn_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step, double lr,

@@ -76,6 +76,21 @@ def _case_points(rank, world):
     return {"shape": tuple(out.shape), "first": [float(out[:, 0].min()), float(out[:, 0].max())], "mean": float(mean)}
 
 
+def _case_grad_allreduce(rank, world):
+    """Data-parallel gradient averaging (what FruitTrainer.all_reduce_gradients does with its flat buffer)."""
+    from cropnerf_amd import distributed as D
+
+    flat = torch.arange(10, dtype=torch.float32) * (rank + 1)
+    out = D.all_reduce_mean(flat)
+    return out.tolist()
+
+
+def test_gradient_all_reduce_mean():
+    res = _run("_case_grad_allreduce", 2)
+    expect = [1.5 * i for i in range(10)]
+    assert res[0] == expect and res[1] == expect
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_render_equals_single_rank(world):
     res = _run("_case_render", world)

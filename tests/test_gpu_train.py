@@ -78,6 +78,13 @@ def test_gradients_match_autograd():
     bad = {k: v for k, v in worst.items() if v > 3e-3}
     assert not bad, f"relative gradient error too large: {bad}"
     assert float(tr.grads["camera_optimizer.pose_adjustment"].abs().sum()) == 0.0
+    # metrics (fruit_nerf.py:639-645)
+    md = tr.get_metrics_dict(out)
+    ref_dist = OL.distortion_loss([w.detach() for w in ref_out["weights_list"]], ref_out["ray_samples_list"])
+    assert abs(float(md["distortion"]) - float(ref_dist)) <= 2e-4 * abs(float(ref_dist)) + 1e-8
+    assert abs(float(md["psnr"]) + 10 * math.log10(ref_loss["rgb_loss"])) < 1e-3
+    # the flat buffer really is the storage behind every gradient view (one all-reduce covers all parameters)
+    assert abs(float(tr.flat_grads.abs().sum()) - sum(float(g.abs().sum()) for g in tr.grads.values())) < 1e-3
 
 
 def test_adam_step_matches_torch_semantics():
