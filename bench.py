@@ -50,6 +50,8 @@ def parse_args():
     ap.add_argument("--mode", choices=["uniform", "proposal"], default="uniform",
                     help="uniform: 192 field evals/ray (headline); proposal: + (256,96) proposal-net evals/ray")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-image-hint", action="store_true",
+                    help="do not tell the renderer that a batch is a pixel run of an 800-wide image (A/B of the XCD stripe mapping)")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training-step timing")
     ap.add_argument("--no-secondary", action="store_true",
                     help="headline workload only (use under rocprofv3 so per-kernel averages are not mixed with the "
@@ -106,7 +108,7 @@ def make_batches(ops, c2w, intr, rank: int, world: int):
         start = (b * R) % (H * W - R)
         rays = ops.raygen_pinhole(c2w, intr, cam=cam, height=H, width=W, pixel_start=start, num_rays=R)
         nears, fars = ops.intersect_aabb(rays["origins"], rays["directions"], aabb6)
-        batches.append((rays["origins"], rays["directions"], nears, fars, rays["camera_indices"][:, 0].contiguous()))
+        batches.append((rays["origins"], rays["directions"], nears, fars, rays["camera_indices"][:, 0].contiguous(), start))
     return batches
 
 
@@ -123,6 +125,9 @@ def main():
     batches = make_batches(ops, c2w, intr, rank, world)
     scene_u = ops.scene_struct(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), contraction=False)
     scene_c = ops.scene_struct(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), contraction=True)
+    def opts_for(start):
+        return ops.render_opts(S) if args.no_image_hint else ops.render_opts(S, image_width=W, pixel_start=start)
+
     opts = ops.render_opts(S)
     gather_buf = None
     if world > 1:
@@ -131,12 +136,12 @@ def main():
         gather_buf = torch.empty(world * R, 6, device=device)  # concatenated along dim 0 (valid for RCCL and gloo)
 
     def step(i: int):
-        o, d, n, f, cam = batches[i % DISTINCT_BATCHES]
+        o, d, n, f, cam, start = batches[i % DISTINCT_BATCHES]
         if args.mode == "uniform":
-            out = ops.render_rays(fh, scene_u, opts, o, d, n, f)
+            out = ops.render_rays(fh, scene_u, opts_for(start), o, d, n, f)
         else:
             ps = ops.proposal_sample(dh, scene_c, o, d, n, f, cfg.num_proposal_samples_per_ray, S)
-            out = ops.render_rays(fh, scene_c, opts, o, d, n, f, bins=ps["euclidean_bins"])
+            out = ops.render_rays(fh, scene_c, opts_for(start), o, d, n, f, bins=ps["euclidean_bins"])
         if world > 1:
             packed = torch.cat([out["rgb"], out["accumulation"], out["depth"], out["semantics"]], dim=-1)
             if dist.get_backend() == "gloo":  # rehearsal only
@@ -172,9 +177,9 @@ def main():
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         durs = []
         for i in range(min(args.steps, 20)):
-            o, d, n, f, cam = batches[i % DISTINCT_BATCHES]
+            o, d, n, f, cam, start = batches[i % DISTINCT_BATCHES]
             ev0.record()
-            ops.render_rays(fh, scene_u, opts, o, d, n, f)
+            ops.render_rays(fh, scene_u, opts_for(start), o, d, n, f)
             ev1.record()
             ev1.synchronize()
             durs.append(ev0.elapsed_time(ev1) * 1e-3)
@@ -266,9 +271,10 @@ def secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, o
         return ev0.elapsed_time(ev1) * 1e-3 / n
 
     def prop(i):
-        o, d, n, f, cam = batches[i % DISTINCT_BATCHES]
+        o, d, n, f, cam, start = batches[i % DISTINCT_BATCHES]
         ps = ops.proposal_sample(dh, scene_c, o, d, n, f, cfg.num_proposal_samples_per_ray, S)
-        ops.render_rays(fh, scene_c, opts, o, d, n, f, bins=ps["euclidean_bins"])
+        o_ = opts if args.no_image_hint else ops.render_opts(S, image_width=W, pixel_start=start)
+        ops.render_rays(fh, scene_c, o_, o, d, n, f, bins=ps["euclidean_bins"])
 
     t = timed(prop, 10)
     out["proposal_mode"] = {"ms_per_batch": round(t * 1e3, 3), "rays_per_sec": R / t, "field_samples_per_sec": R * S / t,
@@ -326,7 +332,7 @@ def run_cpu_baseline(args, params, fspec, pspecs, batches, ops, fh, scene_u, opt
     model = OM.OracleModel(cpu_params, OM.ModelConfig(field=ofs, proposals=ops_, disable_scene_contraction=True),
                            torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), test_mode="inference")
     model.uniform_samples = S
-    o, d, n, f, cam = (t.detach().cpu() for t in batches[0])
+    o, d, n, f, cam = (t.detach().cpu() for t in batches[0][:5])
     chunk = 1024
     idx = torch.arange(0, R, R // chunk)[:chunk]  # spread over the batch
 

@@ -57,7 +57,8 @@ class Scene(C.Structure):
 class RenderOpts(C.Structure):
     _fields_ = [("num_samples", C.c_int32), ("spacing", C.c_int32), ("bg_mode", C.c_int32),
                 ("bg_color", C.c_float * 3), ("app_mode", C.c_int32), ("sh_unit_dir", C.c_int32),
-                ("eval_clamp", C.c_int32), ("density_only", C.c_int32)]
+                ("eval_clamp", C.c_int32), ("density_only", C.c_int32), ("image_width", C.c_int32),
+                ("pixel_start", C.c_int64)]
 
 
 _P = C.c_void_p

@@ -100,6 +100,7 @@ class FruitModel:
         self._uniform_samples: Optional[int] = None
         self._anneal = 1.0
         self.render_rgb = True
+        self._image_hint: Tuple[int, int] = (0, 0)  # (image width, first pixel) of the chunk being rendered
 
     def state_dict(self) -> Dict[str, Tensor]:
         return dict(self.params)
@@ -175,7 +176,8 @@ class FruitModel:
         bg_mode, bg = self._background()
         return ops.render_opts(num_samples, spacing=L.SPACING_UNIFORM, bg_mode=bg_mode, bg_color=bg,
                                app_mode=self._app_mode(), sh_unit_dir=self.config.sh_input == "unit",
-                               eval_clamp=not self.training, density_only=density_only)
+                               eval_clamp=not self.training, density_only=density_only,
+                               image_width=self._image_hint[0], pixel_start=self._image_hint[1])
 
     def _sample_and_render(self, rb: RayBundle, density_only: bool = False) -> Dict[str, Tensor]:
         """proposal (or uniform) sampler -> field -> renderers, all on device."""
@@ -241,13 +243,19 @@ class FruitModel:
                 "density": out["density"], "semantics_colormap": out["semantics_colormap"]}
 
     # ------------------------------------------------------------------------------------------ chunked renders
-    def _chunked(self, camera_ray_bundle: RayBundle, fn) -> Dict[str, Tensor]:
+    def _chunked(self, camera_ray_bundle: RayBundle, fn, image_width: int = 0) -> Dict[str, Tensor]:
+        """``image_width`` > 0: the bundle is a whole row-major image, so every chunk is a pixel run -- passed to the
+        renderer as a scheduling hint (cn_render_opts.image_width / pixel_start)."""
         chunk = self.config.eval_num_rays_per_chunk
         flat = camera_ray_bundle.flatten()
         n = len(flat)
         lists: Dict[str, List[Tensor]] = {}
         for i in range(0, n, chunk):
-            out = fn(flat.get_row_major_sliced_ray_bundle(i, i + chunk))
+            self._image_hint = (image_width, i)
+            try:
+                out = fn(flat.get_row_major_sliced_ray_bundle(i, i + chunk))
+            finally:
+                self._image_hint = (0, 0)
             for k, v in out.items():
                 if isinstance(v, Tensor):
                     lists.setdefault(k, []).append(v)
@@ -257,7 +265,7 @@ class FruitModel:
     def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
         """``fruit_nerf.py:377-404``: [H,W,C] outputs of a full-image bundle."""
         image_height, image_width = camera_ray_bundle.origins.shape[:2]
-        out = self._chunked(camera_ray_bundle, self.forward)
+        out = self._chunked(camera_ray_bundle, self.forward, image_width=image_width)
         return {k: v.view(image_height, image_width, -1) for k, v in out.items()}
 
     @torch.no_grad()

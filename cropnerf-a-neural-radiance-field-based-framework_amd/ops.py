@@ -130,7 +130,8 @@ def scene_struct(aabb: Tensor, contraction: bool) -> L.Scene:
 
 def render_opts(num_samples: int, spacing: int = L.SPACING_UNIFORM, bg_mode: int = L.BG_LAST_SAMPLE,
                 bg_color: Sequence[float] = (0.0, 0.0, 0.0), app_mode: int = L.APP_MEAN, sh_unit_dir: bool = True,
-                eval_clamp: bool = True, density_only: bool = False) -> L.RenderOpts:
+                eval_clamp: bool = True, density_only: bool = False, image_width: int = 0,
+                pixel_start: int = 0) -> L.RenderOpts:
     o = L.RenderOpts()
     o.num_samples = int(num_samples)
     o.spacing = spacing
@@ -141,6 +142,8 @@ def render_opts(num_samples: int, spacing: int = L.SPACING_UNIFORM, bg_mode: int
     o.sh_unit_dir = 1 if sh_unit_dir else 0
     o.eval_clamp = 1 if eval_clamp else 0
     o.density_only = 1 if density_only else 0
+    o.image_width = int(image_width)
+    o.pixel_start = int(pixel_start)
     return o
 
 

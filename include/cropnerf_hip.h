@@ -109,6 +109,12 @@ typedef struct cn_render_opts {
   int32_t sh_unit_dir;  /* 1: SH of the unit direction (tcnn semantics); 0: SH of (d+1)/2   */
   int32_t eval_clamp;   /* 1: nan_to_num(rgb) before, clamp[0,1] after (RGBRenderer in eval) */
   int32_t density_only; /* 1: only accumulation is produced (get_density_for_camera_ray_bundle) */
+  /* Scheduling hint, never changes results: when image_width > 0 the rays of the call are pixels
+   * [pixel_start, pixel_start + num_rays) of a row-major image of that width (the chunks of
+   * get_outputs_for_camera_ray_bundle, fruit_nerf.py:388-391); the kernel then gives each XCD a column
+   * stripe instead of a run of rows, so that vertically adjacent pixels share an L2. 0 = unknown order. */
+  int32_t image_width;
+  int64_t pixel_start;
 } cn_render_opts;
 
 const char* cn_last_error(void);

@@ -520,3 +520,20 @@ def test_unsupported_shape_is_reported_not_computed(scene, ops):
     sm = ops.sample_spaced(n, f, 8)
     out = ops.field_eval(fh, ops.scene_struct(scene.aabb, False), o, d, None, sm["starts"], sm["ends"])
     assert torch.isfinite(out["rgb"]).all() and out["rgb"].shape == (4, 8, 3)
+
+
+@pytest.mark.parametrize("width,start,R", [(40, 0, 1600), (40, 13, 1000), (37, 5, 700), (800, 777, 3000), (3, 1, 50)])
+def test_image_width_hint_changes_schedule_not_results(scene, ops, handles, width, start, R):
+    """cn_render_opts.image_width / pixel_start only re-map rays to workgroups (XCD column stripes): every ray must
+    still be rendered exactly once, bit-identically, for any width / offset / partial rows."""
+    dp, fh, dh = handles
+    g = torch.Generator().manual_seed(width * 1000 + start)
+    rb = rays_with_box(scene, 3)
+    idx = torch.randint(0, len(rb), (R,), generator=g)
+    o, d, n, f = (to_dev(t[idx]) for t in (rb.origins, rb.directions, rb.nears, rb.fars))
+    sc = ops.scene_struct(scene.aabb, True)
+    base = ops.render_rays(fh, sc, ops.render_opts(48), o, d, n, f)
+    poison = {k: torch.full_like(v, float("nan")) for k, v in base.items()}
+    hinted = ops.render_rays(fh, sc, ops.render_opts(48, image_width=width, pixel_start=start), o, d, n, f)
+    for k in base:
+        assert torch.equal(base[k], hinted[k]), k
