@@ -49,6 +49,20 @@ constexpr int WAVE_SCRATCH = 200;  // floats of per-wave LDS scratch: colour bia
 #ifndef CN_FUSED_PIPELINE
 #define CN_FUSED_PIPELINE 0
 #endif
+// timing-only ablations (outputs are wrong): 1 = skip the hash-grid gathers / skip the MLPs
+#ifndef CN_ABLATE_GATHER
+#define CN_ABLATE_GATHER 0
+#endif
+// Build-time variant: fetch the two x-neighbour corners with one 16-byte gather where they share an aligned slot
+// (cn_common.hpp: 6 instead of 8 lane-requests per sample and level).  Correct (same tests), but measured slower than
+// eight plain 8-byte gathers: 3.69 vs 3.86 Gsamples/s on C2 -- the wider requests, the extra selects and the asm-side
+// vmcnt(0) cost more than the saved requests.  Off by default.
+#ifndef CN_XPAIR_GATHER
+#define CN_XPAIR_GATHER 0
+#endif
+#ifndef CN_ABLATE_MLP
+#define CN_ABLATE_MLP 0
+#endif
 
 #ifndef CN_FUSED_WAVES
 #define CN_FUSED_WAVES 4
@@ -193,7 +207,11 @@ struct FusedArgs {
   int64_t* s_label;
 };
 
+#if CN_ABLATE_MLP  // timing-only build: one VALU op per MFMA keeps every value alive without the matrix pipe
+#define MFMA(a, b, c) ((c) + (a) * (b))
+#else
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#endif
 
 // hash_level split in two for software pipelining: issue the 8 corner gathers now, blend them later
 struct HashCorners {
@@ -279,6 +297,7 @@ __global__ void __launch_bounds__(FUSED_THREADS, CN_FUSED_MIN_WAVES_PER_SIMD) re
   float* scratch = lds + BLOB_FLOATS + wave * WAVE_SCRATCH;  // [0,64): per-ray colour bias, [64,129): chunk bin edges
   float* tbuf = scratch + 64;  // two buffers of 66 floats in the pipelined build
   const int S = A.S;
+  const u32x4_t tab_rsrc = table_rsrc(A.grid.table, (unsigned)A.grid.num_levels * A.grid.level_stride * 8u);
 
   // XCD-aware ray ownership: blocks b, b+8, ... share an XCD (round-robin dispatch) and therefore an L2.
   //  * unknown ray order: each XCD sweeps one contiguous eighth of the batch;
@@ -633,14 +652,27 @@ __global__ void __launch_bounds__(FUSED_THREADS, CN_FUSED_MIN_WAVES_PER_SIMD) re
           for (int q = 0; q < 4; ++q) {
             const unsigned level_off = (unsigned)(4 * g + q) * A.grid.level_stride;
             const float scale = lvl_scale[q];
+#if CN_XPAIR_GATHER && !CN_ABLATE_GATHER
+            XPairLoads ld0, ld1;
+            xpair_issue(ld0, tab_rsrc, level_off, A.grid.mask, scale, px[0], py[0], pz[0]);
+            xpair_issue(ld1, tab_rsrc, level_off, A.grid.mask, scale, px[1], py[1], pz[1]);
+            xpair_wait(ld0, ld1);
+#endif
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
+#if CN_ABLATE_GATHER  // timing-only build: no table reads (positions still feed the MLP so nothing is dead code)
+              float2 f = make_float2(px[c] * scale, py[c] + pz[c]);
+#elif CN_XPAIR_GATHER
+              float2 f = xpair_blend(c == 0 ? ld0 : ld1, scale, px[c], py[c], pz[c]);
+#else
               float2 f = hash_level(A.grid.table, level_off, A.grid.mask, scale, px[c], py[c], pz[c]);
+#endif
               if (q == 0) { feat[c][0].x = f.x; feat[c][0].y = f.y; }
               if (q == 1) { feat[c][0].z = f.x; feat[c][0].w = f.y; }
               if (q == 2) { feat[c][1].x = f.x; feat[c][1].y = f.y; }
               if (q == 3) { feat[c][1].z = f.x; feat[c][1].w = f.y; }
             }
+            __builtin_amdgcn_sched_barrier(0);  // one level (2 samples) of gathers in flight at a time
           }
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -39,16 +39,21 @@ __device__ __forceinline__ float wave_read(float v, int src_lane) {
 
 __device__ __forceinline__ float wave_sum(float v) { return wave_read(wave_inclusive_scan(v), 63); }
 
-// v_permlane16_swap / v_permlane32_swap (gfx950) through inline asm: with hipcc (ROCm 7.2) the second result of
-// __builtin_amdgcn_permlaneN_swap comes back as the FIRST result's register (the .s shows `v_add v0, v0, v0` after
-// the swap), so a lo+hi sum silently becomes 2*lo.  The builtin pads the VALU-write -> swap-read hazard with
-// `s_nop 1`; inside asm that is ours to do.
+// v_permlane16_swap / v_permlane32_swap (gfx950).  hipcc pitfall (ROCm 7.2): __builtin_bit_cast(float, r[1]) applied
+// directly to an ext_vector element reads element 0 (a lo+hi sum silently becomes 2*lo) -- the elements are copied
+// into scalars first.
 //   swap16: rows 1,3 of a <-> rows 0,2 of b      swap32: lanes 32..63 of a <-> lanes 0..31 of b
 __device__ __forceinline__ void permlane16_swap(unsigned& a, unsigned& b) {
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  a = r0;
+  b = r1;
 }
 __device__ __forceinline__ void permlane32_swap(unsigned& a, unsigned& b) {
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  a = r0;
+  b = r1;
 }
 
 // sum over lanes {l, l^16, l^32, l^48}
