@@ -94,9 +94,12 @@ SIGNATURES = {
                                            _P]),
     "cn_interlevel_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P, _P, _P]),
     "cn_field_backward": (C.c_int, [C.POINTER(FieldParams), C.POINTER(FieldParams), C.POINTER(Scene), _I32, _I32, _P,
-                                    _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P]),
+                                    _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P]),
     "cn_proposal_backward": (C.c_int, [C.POINTER(DensityParams), C.POINTER(DensityParams), C.POINTER(Scene), _P, _P,
-                                       _P, _P, _P, _I64, _I32, _P]),
+                                       _P, _P, _P, _I64, _I32, _P, _P]),
+    "cn_ray_backward": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _P]),
+    "cn_pose_adjustment_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P]),
+    "cn_pose_regularizer": (C.c_int, [_P, _I32, _F, _F, _P, _P, _P]),
     "cn_distortion_metric": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "cn_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _I32, C.c_double, C.c_double, C.c_double, C.c_double, _I32, _P]),
 }

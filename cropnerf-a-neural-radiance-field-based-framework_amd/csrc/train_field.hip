@@ -142,10 +142,15 @@ __device__ __forceinline__ bool row_run_reduce(unsigned key, float& v0, float& v
 }
 
 // scatter d(loss)/d(features of one level) into the table gradient with the forward's trilinear weights
-// (all 64 lanes call it; g0 = g1 = 0 for lanes without a sample)
-__device__ __forceinline__ void hash_level_backward(float* __restrict__ gtab, unsigned level_off, unsigned mask,
-                                                    float scale, float px, float py, float pz, float g0, float g1,
-                                                    int lane) {
+// (all 64 lanes call it; g0 = g1 = 0 for lanes without a sample).  POS: also accumulate d(loss)/d(normalised position)
+// -- the trilinear weights are linear in the in-cell offset, so d enc_f / d x = scale * sum_c (+-1) wy wz table[c].f
+// (the path HashEncoding.pytorch_fwd's `offset = scaled - floor(scaled)` carries gradient through; it is what feeds
+// the camera pose refinement).
+template <bool POS>
+__device__ __forceinline__ void hash_level_backward(float* __restrict__ gtab, const float* __restrict__ table,
+                                                    unsigned level_off, unsigned mask, float scale, float px, float py,
+                                                    float pz, float g0, float g1, int lane, float& dpx, float& dpy,
+                                                    float& dpz) {
   float sx = px * scale, sy = py * scale, sz = pz * scale;
   float fx = floorf(sx), fy = floorf(sy), fz = floorf(sz);
   float ox = sx - fx, oy = sy - fy, oz = sz - fz;
@@ -155,11 +160,19 @@ __device__ __forceinline__ void hash_level_backward(float* __restrict__ gtab, un
   unsigned hz[2] = {iz * CN_P2, iz * CN_P2 + CN_P2};
   float wx[2] = {1.f - ox, ox}, wy[2] = {1.f - oy, oy}, wz[2] = {1.f - oz, oz};  // index 1 = ceil corner
   const int row_lane = lane & 15;
+  float ax = 0.f, ay = 0.f, az = 0.f;
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const int a = c & 1, b = (c >> 1) & 1, d = c >> 2;
     const float w = wx[a] * wy[b] * wz[d];
     const unsigned e = ((hx[a] ^ hy[b] ^ hz[d]) & mask) + level_off;
+    if constexpr (POS) {
+      const float2 t = hash_gather(table, e);
+      const float tg = t.x * g0 + t.y * g1;
+      ax += (a ? tg : -tg) * (wy[b] * wz[d]);
+      ay += (b ? tg : -tg) * (wx[a] * wz[d]);
+      az += (d ? tg : -tg) * (wx[a] * wy[b]);
+    }
     float v0 = w * g0, v1 = w * g1;
     const bool issue = row_run_reduce(e, v0, v1, row_lane);
     if (issue && (v0 != 0.f || v1 != 0.f)) {
@@ -167,6 +180,57 @@ __device__ __forceinline__ void hash_level_backward(float* __restrict__ gtab, un
       atomicAdd(gtab + 2 * (size_t)e + 1, v1);
     }
   }
+  if constexpr (POS) {
+    dpx = fmaf(ax, scale, dpx);
+    dpy = fmaf(ay, scale, dpy);
+    dpz = fmaf(az, scale, dpz);
+  }
+}
+
+// d(loss)/d(normalised position) -> d(loss)/d(world position): the transpose Jacobian of normalize_position
+// (L-inf scene contraction then (c+2)/4, or the AABB normalisation), zero where the selector dropped the sample.
+__device__ __forceinline__ void normalize_position_backward(const SceneDev& sc, float x, float y, float z, float sel,
+                                                            float& gx, float& gy, float& gz) {
+  if (sc.contraction) {
+    gx *= 0.25f * sel;
+    gy *= 0.25f * sel;
+    gz *= 0.25f * sel;
+    const float axv = fabsf(x), ayv = fabsf(y), azv = fabsf(z);
+    const float m = fmaxf(axv, fmaxf(ayv, azv));
+    if (m >= 1.f) {
+      const float inv = 1.f / m;
+      const float k = (2.f - inv) * inv;
+      const float s = gx * x + gy * y + gz * z;
+      const float coef = 2.f * inv * inv * (inv - 1.f) * s;  // d k / d m * <g, p>
+      gx *= k;
+      gy *= k;
+      gz *= k;
+      if (axv >= ayv && axv >= azv) gx += x < 0.f ? -coef : coef;
+      else if (ayv >= azv) gy += y < 0.f ? -coef : coef;
+      else gz += z < 0.f ? -coef : coef;
+    }
+  } else {
+    gx *= sc.inv_extent[0] * sel;
+    gy *= sc.inv_extent[1] * sel;
+    gz *= sc.inv_extent[2] * sel;
+  }
+}
+
+// d SH_deg4 / d (x, y, z) contracted with g[16] (the derivative of sh_deg4 in cn_common.hpp, term by term)
+__device__ __forceinline__ void sh_deg4_backward(float x, float y, float z, const float* g, float& dx, float& dy,
+                                                 float& dz) {
+  const float xx = x * x, yy = y * y, zz = z * z;
+  dx = 0.4886025119029199f * g[3] + 1.0925484305920792f * (y * g[4] + z * g[7]) + 1.0925484305920792f * x * g[8] +
+       0.5900435899266435f * 6.f * x * y * g[9] + 2.890611442640554f * y * z * g[10] +
+       0.4570457994644658f * (5.f * zz - 1.f) * g[13] + 1.445305721320277f * 2.f * x * z * g[14] +
+       0.5900435899266435f * 3.f * (xx - yy) * g[15];
+  dy = 0.4886025119029199f * g[1] + 1.0925484305920792f * (x * g[4] + z * g[5]) - 1.0925484305920792f * y * g[8] +
+       0.5900435899266435f * 3.f * (xx - yy) * g[9] + 2.890611442640554f * x * z * g[10] +
+       0.4570457994644658f * (5.f * zz - 1.f) * g[11] - 1.445305721320277f * 2.f * y * z * g[14] -
+       0.5900435899266435f * 6.f * x * y * g[15];
+  dz = 0.4886025119029199f * g[2] + 1.0925484305920792f * (y * g[5] + x * g[7]) + 0.9461746957575601f * 2.f * z * g[6] +
+       2.890611442640554f * x * y * g[10] + 0.4570457994644658f * 10.f * z * (y * g[11] + x * g[13]) +
+       0.3731763325901154f * (15.f * zz - 3.f) * g[12] + 1.445305721320277f * (xx - yy) * g[14];
 }
 
 struct FieldPtrs {
@@ -198,6 +262,7 @@ struct FieldBwdArgs {
   const float *d_density, *d_rgb, *d_sem;
   long long R;
   int S;
+  float *d_pos, *d_dir;  // optional [R*S,3] outputs for the camera pose refinement (null: skipped)
   int debug_skip;  // profiling aid (env CN_DEBUG_SKIP): 1 hash atomics, 2 embedding atomics, 4 weight-gradient dots
 };
 
@@ -212,8 +277,10 @@ constexpr int R_C1 = R_CIN + 64;    // 64
 constexpr int R_C2 = R_C1 + 64;     // 64
 constexpr int R_DA = R_C2 + 64;     // 64 delta buffer A
 constexpr int R_DB = R_DA + 64;     // 64 delta buffer B
-constexpr int R_MISC = R_DB + 64;   // pos xyz(3) sel(1) logit-deriv(1) dsem(1) drgbpre(3) cam(1) = 10 rows
-constexpr int FIELD_ROWS = R_MISC + 10;
+// misc rows: 0-2 normalised position, 3 selector, 4 d(logit), 5 d(sem), 6-8 world position, 9-20 per-wave partial
+// d(loss)/d(normalised position) (3 per wave)
+constexpr int R_MISC = R_DB + 64;
+constexpr int FIELD_ROWS = R_MISC + 21;
 
 __global__ void __launch_bounds__(TB) field_backward_kernel(FieldBwdArgs A) {
   extern __shared__ __align__(16) float lds[];
@@ -255,6 +322,9 @@ __global__ void __launch_bounds__(TB) field_backward_kernel(FieldBwdArgs A) {
       float px = A.origins[3 * r] + A.directions[3 * r] * mid;
       float py = A.origins[3 * r + 1] + A.directions[3 * r + 1] * mid;
       float pz = A.origins[3 * r + 2] + A.directions[3 * r + 2] * mid;
+      misc[6 * LD + lane] = px;
+      misc[7 * LD + lane] = py;
+      misc[8 * LD + lane] = pz;
       bool sel = normalize_position(A.scene, px, py, pz);
       misc[0 * LD + lane] = px;
       misc[1 * LD + lane] = py;
@@ -326,10 +396,28 @@ __global__ void __launch_bounds__(TB) field_backward_kernel(FieldBwdArgs A) {
     if (!(A.debug_skip & 4)) gWc0.add(dA, cin, tid);
     bias_add<64>(gbc0, dA, tid);
     // delta of the colour input: geo rows (16..30) feed the base MLP, appearance rows (31..62) the embedding
-    bwd_rows<63, 64>(A.p.wc0, dA, dB, nullptr, 16, 63, wave, lane);  // dB rows 16..62
+    // (rows 0..15, the SH inputs, only when the direction gradient is wanted)
+    bwd_rows<63, 64>(A.p.wc0, dA, dB, nullptr, A.d_dir ? 0 : 16, 63, wave, lane);  // dB rows 16..62
     __syncthreads();
     if (A.app_per_camera && valid && !(A.debug_skip & 2)) {
       for (int k = wave; k < 32; k += 4) atomicAdd(A.g.emb + A.cam_idx[r] * 32 + k, dB[(31 + k) * LD + lane]);
+    }
+    if (A.d_dir && wave == 3 && valid) {
+      float gsh[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) gsh[k] = dB[k * LD + lane];
+      float dx = A.directions[3 * r], dy = A.directions[3 * r + 1], dz = A.directions[3 * r + 2];
+      const float chain = A.sh_unit ? 1.f : 0.5f;
+      if (!A.sh_unit) {
+        dx = (dx + 1.f) / 2.f;
+        dy = (dy + 1.f) / 2.f;
+        dz = (dz + 1.f) / 2.f;
+      }
+      float gx, gy, gz;
+      sh_deg4_backward(dx, dy, dz, gsh, gx, gy, gz);
+      A.d_dir[3 * i] = gx * chain;
+      A.d_dir[3 * i + 1] = gy * chain;
+      A.d_dir[3 * i + 2] = gz * chain;
     }
     // delta_o16 -> dA' : row 0 = density logit, rows 1..15 = geo (from the colour branch only: semantics sees detached geo)
     // (dA is still needed by nobody: gWc0 has consumed it)
@@ -347,14 +435,43 @@ __global__ void __launch_bounds__(TB) field_backward_kernel(FieldBwdArgs A) {
     __syncthreads();
     if (!(A.debug_skip & 1)) {
       const float px = misc[0 * LD + lane], py = misc[1 * LD + lane], pz = misc[2 * LD + lane];
+      float gpx = 0.f, gpy = 0.f, gpz = 0.f;
+      if (A.d_pos) {  // kernel-uniform
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int l = 4 * wave + q;
-        hash_level_backward(A.g.table, (unsigned)l * A.level_stride, A.mask, A.scale[l], px, py, pz,
-                            valid ? dA[(2 * l) * LD + lane] : 0.f, valid ? dA[(2 * l + 1) * LD + lane] : 0.f, lane);
+        for (int q = 0; q < 4; ++q) {
+          const int l = 4 * wave + q;
+          hash_level_backward<true>(A.g.table, A.p.table, (unsigned)l * A.level_stride, A.mask, A.scale[l], px, py, pz,
+                                    valid ? dA[(2 * l) * LD + lane] : 0.f, valid ? dA[(2 * l + 1) * LD + lane] : 0.f,
+                                    lane, gpx, gpy, gpz);
+        }
+        misc[(9 + 3 * wave) * LD + lane] = gpx;
+        misc[(10 + 3 * wave) * LD + lane] = gpy;
+        misc[(11 + 3 * wave) * LD + lane] = gpz;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int l = 4 * wave + q;
+          hash_level_backward<false>(A.g.table, A.p.table, (unsigned)l * A.level_stride, A.mask, A.scale[l], px, py, pz,
+                                     valid ? dA[(2 * l) * LD + lane] : 0.f, valid ? dA[(2 * l + 1) * LD + lane] : 0.f,
+                                     lane, gpx, gpy, gpz);
+        }
       }
     }
     __syncthreads();
+    if (A.d_pos && wave == 3 && valid) {
+      float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        gx += misc[(9 + 3 * w) * LD + lane];
+        gy += misc[(10 + 3 * w) * LD + lane];
+        gz += misc[(11 + 3 * w) * LD + lane];
+      }
+      normalize_position_backward(A.scene, misc[6 * LD + lane], misc[7 * LD + lane], misc[8 * LD + lane],
+                                  misc[3 * LD + lane], gx, gy, gz);
+      A.d_pos[3 * i] = gx;
+      A.d_pos[3 * i + 1] = gy;
+      A.d_pos[3 * i + 2] = gz;
+    }
     // ---- semantic branch: sem = Wh s2 + bh; gradients stop at the (detached) geo features ------------------------------
     // delta_sem (1 row) is misc row 5
     if (!(A.debug_skip & 4)) gWh.add(misc + 5 * LD, s2, tid);
@@ -394,6 +511,7 @@ struct PropBwdArgs {
   float scale[CN_MAX_LEVELS];
   SceneDev scene;
   const float *origins, *directions, *starts, *ends, *d_density;
+  float* d_pos;  // optional [R*S,3]
   long long R;
   int S;
 };
@@ -401,12 +519,12 @@ struct PropBwdArgs {
 template <int L>
 __global__ void __launch_bounds__(TB) proposal_backward_kernel(PropBwdArgs A) {
   constexpr int K = 2 * L, H = 16;
-  __shared__ float lds[(K + H + H + 1 + 4) * LD];
+  __shared__ float lds[(K + H + H + 1 + 4 + 3 + 12) * LD];
   float* enc = lds;                  // [K]
   float* hid = enc + K * LD;         // [H] post ReLU
   float* dh = hid + H * LD;          // [H] delta hidden
   float* dout = dh + H * LD;         // [1] delta logit
-  float* misc = dout + LD;           // pos(3)
+  float* misc = dout + LD;           // normalised pos(3) sel(1) world pos(3) per-wave d(pos)(12)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> weights come through s_load
   WGrad<K, H> gW0;
@@ -427,6 +545,9 @@ __global__ void __launch_bounds__(TB) proposal_backward_kernel(PropBwdArgs A) {
       float px = A.origins[3 * r] + A.directions[3 * r] * mid;
       float py = A.origins[3 * r + 1] + A.directions[3 * r + 1] * mid;
       float pz = A.origins[3 * r + 2] + A.directions[3 * r + 2] * mid;
+      misc[4 * LD + lane] = px;
+      misc[5 * LD + lane] = py;
+      misc[6 * LD + lane] = pz;
       bool sel = normalize_position(A.scene, px, py, pz);
       sel_f = sel ? 1.f : 0.f;
       misc[0 * LD + lane] = px;
@@ -459,6 +580,7 @@ __global__ void __launch_bounds__(TB) proposal_backward_kernel(PropBwdArgs A) {
     gW0.add(dh, enc, tid);
     bias_add<H>(gb0, dh, tid);
     // delta_enc[k] = sum_n W0[n][k] dh[n] -> straight into the table gradient
+    float gpx = 0.f, gpy = 0.f, gpz = 0.f;
     for (int l = wave; l < L; l += 4) {
       float g0 = 0.f, g1 = 0.f;
 #pragma unroll
@@ -467,8 +589,34 @@ __global__ void __launch_bounds__(TB) proposal_backward_kernel(PropBwdArgs A) {
         g0 = fmaf(A.w0[n * K + 2 * l], d, g0);
         g1 = fmaf(A.w0[n * K + 2 * l + 1], d, g1);
       }
-      hash_level_backward(A.g_table, (unsigned)l * A.level_stride, A.mask, A.scale[l], misc[lane], misc[LD + lane],
-                          misc[2 * LD + lane], valid ? g0 : 0.f, valid ? g1 : 0.f, lane);
+      if (A.d_pos)
+        hash_level_backward<true>(A.g_table, A.table, (unsigned)l * A.level_stride, A.mask, A.scale[l], misc[lane],
+                                  misc[LD + lane], misc[2 * LD + lane], valid ? g0 : 0.f, valid ? g1 : 0.f, lane, gpx,
+                                  gpy, gpz);
+      else
+        hash_level_backward<false>(A.g_table, A.table, (unsigned)l * A.level_stride, A.mask, A.scale[l], misc[lane],
+                                   misc[LD + lane], misc[2 * LD + lane], valid ? g0 : 0.f, valid ? g1 : 0.f, lane, gpx,
+                                   gpy, gpz);
+    }
+    if (A.d_pos) {
+      misc[(7 + 3 * wave) * LD + lane] = gpx;
+      misc[(8 + 3 * wave) * LD + lane] = gpy;
+      misc[(9 + 3 * wave) * LD + lane] = gpz;
+      __syncthreads();
+      if (wave == 0 && valid) {
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          gx += misc[(7 + 3 * w) * LD + lane];
+          gy += misc[(8 + 3 * w) * LD + lane];
+          gz += misc[(9 + 3 * w) * LD + lane];
+        }
+        normalize_position_backward(A.scene, misc[4 * LD + lane], misc[5 * LD + lane], misc[6 * LD + lane],
+                                    misc[3 * LD + lane], gx, gy, gz);
+        A.d_pos[3 * i] = gx;
+        A.d_pos[3 * i + 1] = gy;
+        A.d_pos[3 * i + 2] = gz;
+      }
     }
     __syncthreads();
   }
@@ -495,7 +643,8 @@ extern "C" int cn_field_backward(const cn_field_params* params, const cn_field_p
                                  int32_t app_mode, int32_t sh_unit_dir, const float* app_mean, const float* origins,
                                  const float* directions, const int64_t* camera_indices, const float* starts,
                                  const float* ends, const float* d_density, const float* d_rgb, const float* d_semantics,
-                                 int64_t num_rays, int32_t num_samples, cn_stream_t stream) {
+                                 int64_t num_rays, int32_t num_samples, float* d_positions, float* d_directions,
+                                 cn_stream_t stream) {
   CN_REQUIRE(params && grads && scene && origins && directions && starts && ends && d_density && d_rgb && d_semantics,
              CN_ERR_INVALID, "cn_field_backward: null argument");
   CN_REQUIRE(app_mode != CN_APP_PER_CAMERA || camera_indices, CN_ERR_INVALID, "Camera indices are not provided.");
@@ -546,6 +695,8 @@ extern "C" int cn_field_backward(const cn_field_params* params, const cn_field_p
   A.d_density = d_density;
   A.d_rgb = d_rgb;
   A.d_sem = d_semantics;
+  A.d_pos = d_positions;
+  A.d_dir = d_directions;
   A.R = num_rays;
   A.S = num_samples;
   {
@@ -568,7 +719,7 @@ extern "C" int cn_field_backward(const cn_field_params* params, const cn_field_p
 extern "C" int cn_proposal_backward(const cn_density_params* params, const cn_density_params* grads,
                                     const cn_scene* scene, const float* origins, const float* directions,
                                     const float* starts, const float* ends, const float* d_density, int64_t num_rays,
-                                    int32_t num_samples, cn_stream_t stream) {
+                                    int32_t num_samples, float* d_positions, cn_stream_t stream) {
   CN_REQUIRE(params && grads && scene && origins && directions && starts && ends && d_density, CN_ERR_INVALID,
              "cn_proposal_backward: null argument");
   int rc = cn::validate_grid(params->grid, "proposal grid");
@@ -602,6 +753,7 @@ extern "C" int cn_proposal_backward(const cn_density_params* params, const cn_de
   A.starts = starts;
   A.ends = ends;
   A.d_density = d_density;
+  A.d_pos = d_positions;
   A.R = num_rays;
   A.S = num_samples;
   long long ntiles = (num_rays * (long long)num_samples + cn::TS - 1) / cn::TS;

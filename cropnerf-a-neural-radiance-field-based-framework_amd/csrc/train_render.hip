@@ -249,6 +249,116 @@ distortion_kernel(const float* __restrict__ bins, const float* __restrict__ weig
   }
 }
 
+// Camera pose refinement, backward.  Sample positions are o + d * mid with constant mid (the sampler's bins are
+// detached), so per ray  dL/do = sum_s dL/dp_s  and  dL/dd = sum_s mid_s dL/dp_s (+ the SH-input gradient of the colour
+// branch).  One wave per ray; the sums are ACCUMULATED into d_origins / d_directions [R,3].
+__global__ void __launch_bounds__(256)
+ray_backward_kernel(const float* __restrict__ d_pos, const float* __restrict__ d_dir_samples,
+                    const float* __restrict__ starts, const float* __restrict__ ends, long long R, int S,
+                    float* __restrict__ d_origins, float* __restrict__ d_directions) {
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const long long waves = (long long)gridDim.x * 4;
+  for (long long r = blockIdx.x * 4LL + wave; r < R; r += waves) {
+    float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+    for (int i = lane; i < S; i += 64) {
+      const long long k = r * (long long)S + i;
+      const float mid = (starts[k] + ends[k]) / 2.f;
+      const float gx = d_pos[3 * k], gy = d_pos[3 * k + 1], gz = d_pos[3 * k + 2];
+      ox += gx;
+      oy += gy;
+      oz += gz;
+      dx = fmaf(mid, gx, dx);
+      dy = fmaf(mid, gy, dy);
+      dz = fmaf(mid, gz, dz);
+      if (d_dir_samples) {
+        dx += d_dir_samples[3 * k];
+        dy += d_dir_samples[3 * k + 1];
+        dz += d_dir_samples[3 * k + 2];
+      }
+    }
+    ox = wave_sum(ox); oy = wave_sum(oy); oz = wave_sum(oz);
+    dx = wave_sum(dx); dy = wave_sum(dy); dz = wave_sum(dz);
+    if (lane == 0) {
+      d_origins[3 * r] += ox;
+      d_origins[3 * r + 1] += oy;
+      d_origins[3 * r + 2] += oz;
+      d_directions[3 * r] += dx;
+      d_directions[3 * r + 1] += dy;
+      d_directions[3 * r + 2] += dz;
+    }
+  }
+}
+
+__device__ __forceinline__ void cross3(const float* a, const float* b, float* c) {
+  c[0] = a[1] * b[2] - a[2] * b[1];
+  c[1] = a[2] * b[0] - a[0] * b[2];
+  c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// Backward of exp_map_SO3xR3 applied to a ray (o' = o + t, d' = R(w) d with R = I + f1 K + f2 K^2, K = skew(w),
+// theta = sqrt(max(|w|^2, 1e-4)), f1 = sin(theta)/theta, f2 = (1 - cos(theta))/theta^2):
+//   dL/dt = dL/do'
+//   dL/dw = f1 (d x g) + f2 ((w x d) x g + d x (g x w)) + [|w|^2 >= 1e-4] (w / theta) (f1' g.(w x d) + f2' g.(w x (w x d)))
+// with g = dL/dd'.  One thread per ray, atomics into grad_pose[camera].
+__global__ void __launch_bounds__(256)
+pose_backward_kernel(const float* __restrict__ adj, const int64_t* __restrict__ cam, const float* __restrict__ dirs_raw,
+                     const float* __restrict__ d_origins, const float* __restrict__ d_directions, long long R,
+                     float* __restrict__ grad_pose) {
+  for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < R; r += (long long)gridDim.x * blockDim.x) {
+    const long long c = cam[r];
+    const float w[3] = {adj[6 * c + 3], adj[6 * c + 4], adj[6 * c + 5]};
+    const float d[3] = {dirs_raw[3 * r], dirs_raw[3 * r + 1], dirs_raw[3 * r + 2]};
+    const float g[3] = {d_directions[3 * r], d_directions[3 * r + 1], d_directions[3 * r + 2]};
+    const float nrm = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const float th = sqrtf(fmaxf(nrm, 1e-4f));
+    const float inv = 1.f / th;
+    const float sn = sinf(th), cs = cosf(th);
+    const float f1 = inv * sn, f2 = inv * inv * (1.f - cs);
+    float dxg[3], wxd[3], t1[3], gxw[3], t2[3], wwd[3];
+    cross3(d, g, dxg);
+    cross3(w, d, wxd);
+    cross3(wxd, g, t1);
+    cross3(g, w, gxw);
+    cross3(d, gxw, t2);
+    cross3(w, wxd, wwd);
+    float radial = 0.f;
+    if (nrm >= 1e-4f) {
+      const float df1 = (th * cs - sn) * inv * inv;
+      const float df2 = (th * sn - 2.f * (1.f - cs)) * inv * inv * inv;
+      const float a = g[0] * wxd[0] + g[1] * wxd[1] + g[2] * wxd[2];
+      const float b = g[0] * wwd[0] + g[1] * wwd[1] + g[2] * wwd[2];
+      radial = (df1 * a + df2 * b) * inv;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      atomicAdd(grad_pose + 6 * c + k, d_origins[3 * r + k]);
+      atomicAdd(grad_pose + 6 * c + 3 + k, f1 * dxg[k] + f2 * (t1[k] + t2[k]) + radial * w[k]);
+    }
+  }
+}
+
+// camera_opt_regularizer (nerfstudio CameraOptimizer.get_loss_dict): mean_c |t_c| * trans + mean_c |w_c| * rot.
+// Adds the loss to *loss_out and its gradient to grad_pose (subgradient 0 at a zero vector, like torch's norm).
+__global__ void __launch_bounds__(256)
+pose_regularizer_kernel(const float* __restrict__ adj, int C, float trans, float rot, float* __restrict__ grad_pose,
+                        float* __restrict__ loss_out) {
+  float local = 0.f;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float* v = adj + 6 * c + 3 * h;
+      const float n = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      const float pen = (h ? rot : trans) / (float)C;
+      local += n * pen;
+      if (grad_pose && n > 0.f) {
+        for (int k = 0; k < 3; ++k) grad_pose[6 * c + 3 * h + k] += pen * v[k] / n;
+      }
+    }
+  }
+  local = wave_sum(local);
+  if (lane_id() == 0 && local != 0.f) atomicAdd(loss_out, local);
+}
+
 __global__ void __launch_bounds__(256)
 adam_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                  long long n, float step_size, float beta1, float beta2, float omb1, float omb2, float inv_sqrt_bc2,
@@ -327,4 +437,40 @@ extern "C" int cn_distortion_metric(const float* spacing_bins, const float* weig
   hipLaunchKernelGGL(cn::distortion_kernel, dim3(cn::grid_for(num_rays, 4, 4096)), dim3(256), lds, cn::as_stream(stream),
                      spacing_bins, weights, (long long)num_rays, num_samples, sum_out);
   return cn::check_launch("cn_distortion_metric");
+}
+
+extern "C" int cn_ray_backward(const float* d_positions, const float* d_dir_samples, const float* starts,
+                               const float* ends, int64_t num_rays, int32_t num_samples, float* d_origins,
+                               float* d_directions, cn_stream_t stream) {
+  CN_REQUIRE(d_positions && starts && ends && d_origins && d_directions, CN_ERR_INVALID,
+             "cn_ray_backward: null argument");
+  CN_REQUIRE(num_samples >= 1, CN_ERR_INVALID, "cn_ray_backward: num_samples must be >= 1");
+  if (num_rays <= 0) return CN_OK;
+  hipLaunchKernelGGL(cn::ray_backward_kernel, dim3(cn::grid_for(num_rays, 4, 8192)), dim3(256), 0,
+                     cn::as_stream(stream), d_positions, d_dir_samples, starts, ends, (long long)num_rays, num_samples,
+                     d_origins, d_directions);
+  return cn::check_launch("cn_ray_backward");
+}
+
+extern "C" int cn_pose_adjustment_backward(const float* pose_adjustment, const int64_t* camera_indices,
+                                           const float* directions_raw, const float* d_origins,
+                                           const float* d_directions, int64_t num_rays, float* grad_pose,
+                                           cn_stream_t stream) {
+  CN_REQUIRE(pose_adjustment && camera_indices && directions_raw && d_origins && d_directions && grad_pose,
+             CN_ERR_INVALID, "cn_pose_adjustment_backward: null argument");
+  if (num_rays <= 0) return CN_OK;
+  hipLaunchKernelGGL(cn::pose_backward_kernel, dim3(cn::grid_for(num_rays, 256, 4096)), dim3(256), 0,
+                     cn::as_stream(stream), pose_adjustment, camera_indices, directions_raw, d_origins, d_directions,
+                     (long long)num_rays, grad_pose);
+  return cn::check_launch("cn_pose_adjustment_backward");
+}
+
+extern "C" int cn_pose_regularizer(const float* pose_adjustment, int32_t num_cameras, float trans_l2_penalty,
+                                   float rot_l2_penalty, float* grad_pose, float* loss_out, cn_stream_t stream) {
+  CN_REQUIRE(pose_adjustment && loss_out, CN_ERR_INVALID, "cn_pose_regularizer: null argument");
+  if (num_cameras <= 0) return CN_OK;
+  hipLaunchKernelGGL(cn::pose_regularizer_kernel, dim3(cn::grid_for(num_cameras, 256, 1024)), dim3(256), 0,
+                     cn::as_stream(stream), pose_adjustment, num_cameras, trans_l2_penalty, rot_l2_penalty, grad_pose,
+                     loss_out);
+  return cn::check_launch("cn_pose_regularizer");
 }

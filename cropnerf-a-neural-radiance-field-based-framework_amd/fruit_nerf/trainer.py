@@ -6,8 +6,12 @@ per-camera appearance) -> ``get_loss_dict`` (``fruit_nerf/fruit_nerf.py:601-615`
 -> backward -> Adam with exponential LR decay (``fruit_nerf/fruit_nerf_config.py:45-60``) -> anneal callback
 (``fruit_nerf.py:198-232``).
 
-Not trained in this round (stated in DESIGN.md): the camera pose refinement (``camera_opt`` group; the pose tweak is
-applied but frozen) and the camera-optimizer regulariser; no GradScaler / autocast (everything is fp32).
+The camera pose refinement (``camera_opt`` group, ``fruit_nerf.py:195``) is trained too: the field / proposal backward
+kernels return d loss / d sample position (and the SH-input gradient of the colour branch), ``cn_ray_backward`` reduces
+them per ray and ``cn_pose_adjustment_backward`` chains through exp_map_SO3xR3; ``camera_opt_regularizer``
+(``fruit_nerf.py:614``) is added by ``cn_pose_regularizer``.  The proposal networks follow the reference's update
+schedule (``fruit_nerf.py:144-149``): evaluated without gradient unless ``steps_since_update > update_sched(step) or
+step < 10``.  No GradScaler / autocast (everything is fp32).
 """
 
 from __future__ import annotations
@@ -44,9 +48,13 @@ class OptimGroup:
 class FruitTrainer:
     def __init__(self, model: FruitModel, groups: Optional[Dict[str, OptimGroup]] = None, seed: int = 0):
         self.model = model
-        self.groups = groups or {"proposal_networks": OptimGroup(), "fields": OptimGroup()}
+        self.groups = groups or {"proposal_networks": OptimGroup(), "fields": OptimGroup(),
+                                 "camera_opt": OptimGroup(1e-3, 1e-15, 1e-4, 5000)}
         dev = model.device
-        self.trainable = [k for k in model.params if not k.startswith("camera_optimizer.")]
+        # a group that is not listed is frozen (its gradients are still computed for "fields"/"proposal_networks")
+        self.train_pose = "camera_opt" in self.groups
+        self.trans_l2_penalty, self.rot_l2_penalty = 1e-2, 1e-3  # CameraOptimizerConfig defaults
+        self.trainable = [k for k in model.params if self.train_pose or not k.startswith("camera_optimizer.")]
         # one flat gradient buffer with per-parameter views: data-parallel training all-reduces it in ONE collective
         # (the reference's DDP, fruit_pipeline.py:119-121, made explicit; 78 MB per step for the default field)
         sizes = {k: v.numel() for k, v in model.params.items()}
@@ -60,6 +68,8 @@ class FruitTrainer:
         self.grad_field = ops.FieldHandle(self.grads, model.field_spec)
         self.grad_props = [ops.DensityHandle(self.grads, i, ps) for i, ps in enumerate(model.proposal_specs)]
         self.step = 0
+        self._steps_since_update = 0  # ProposalNetworkSampler state (_steps_since_update, _step)
+        self._sampler_step = 0
         self._gen = torch.Generator(device="cpu").manual_seed(seed)
         self.loss_sums = torch.zeros(4, device=dev)
 
@@ -73,10 +83,18 @@ class FruitTrainer:
         b = cfg.proposal_weights_anneal_slope
         self.model.set_anneal(b * frac / ((b - 1) * frac + 1))
 
+    def proposal_update_due(self, step: int) -> bool:
+        """``ProposalNetworkSampler``: proposal densities carry gradient only when this is true."""
+        cfg = self.model.config
+        sched = float(np.clip(np.interp(step, [0, cfg.proposal_warmup], [0, cfg.proposal_update_every]), 1,
+                              cfg.proposal_update_every))
+        return self._steps_since_update > sched or step < 10
+
     def forward_backward(self, ray_bundle: RayBundle, batch: Dict[str, Tensor],
-                         jitter: Optional[List[Tensor]] = None) -> Dict[str, Tensor]:
+                         jitter: Optional[List[Tensor]] = None, update_proposals: bool = True) -> Dict[str, Tensor]:
         """One training forward + backward; gradients are ACCUMULATED into ``self.grads``.  ``jitter`` = the three
-        [R,1] uniform randoms of the proposal sampler (drawn here when None)."""
+        [R,1] uniform randoms of the proposal sampler (drawn here when None).  ``update_proposals`` False = the
+        reference's ``no_grad`` proposal evaluation (interlevel loss reported, no proposal gradients)."""
         m, cfg = self.model, self.model.config
         dev = m.device
         rb = ray_bundle.flatten().to(dev)._map(lambda t: t.contiguous())
@@ -84,8 +102,12 @@ class FruitTrainer:
         if rb.camera_indices is None:
             raise AttributeError("Camera indices are not provided.")
         cam = rb.camera_indices.reshape(-1).to(torch.int64).contiguous()
+        d_raw = rb.directions
         o, d = rb.origins.clone(), rb.directions.clone()
-        ops.apply_pose_adjustment(m.params["camera_optimizer.pose_adjustment"], cam, o, d)
+        pose = m.params["camera_optimizer.pose_adjustment"]
+        ops.apply_pose_adjustment(pose, cam, o, d)
+        if self.train_pose:
+            d_o, d_d = torch.zeros(R, 3, device=dev), torch.zeros(R, 3, device=dev)
         nears = rb.nears if rb.nears is not None else torch.full((R, 1), float(cfg.near_plane), device=dev)
         fars = rb.fars if rb.fars is not None else torch.full((R, 1), float(cfg.far_plane), device=dev)
         n_lvl = len(m.proposal_networks)
@@ -115,17 +137,33 @@ class FruitTrainer:
         mask = batch["fruit_mask"].to(dev).to(torch.float32).reshape(R, 1).contiguous()
         rb_out = ops.train_render_backward(starts, ends, fo["density"], fo["rgb"], fo["semantics"], image, mask,
                                            cfg.semantic_loss_weight, self.loss_sums)
+        dpos = torch.empty(R, S, 3, device=dev) if self.train_pose else None
+        ddir = torch.empty(R, S, 3, device=dev) if self.train_pose else None
         ops.field_backward(m.field, self.grad_field, scene, o, d, cam, starts, ends, rb_out["d_density"],
                            rb_out["d_rgb"], rb_out["d_semantics"], app_mode=L.APP_PER_CAMERA,
-                           sh_unit_dir=cfg.sh_input == "unit")
+                           sh_unit_dir=cfg.sh_input == "unit", d_positions=dpos, d_directions=ddir)
+        if self.train_pose:
+            ops.ray_backward(dpos, ddir, starts, ends, d_o, d_d)
         for lvl, lv in enumerate(levels):
             dd = ops.interlevel_backward(bins, rb_out["weights"], lv["bins"], lv["starts"], lv["ends"], lv["density"],
                                          cfg.interlevel_loss_mult, self.loss_sums[2:3])
-            ops.proposal_backward(m.proposal_networks[lvl], self.grad_props[lvl], scene, o, d, lv["starts"], lv["ends"], dd)
+            if not update_proposals:
+                continue
+            dpos = torch.empty(R, lv["starts"].shape[1], 3, device=dev) if self.train_pose else None
+            ops.proposal_backward(m.proposal_networks[lvl], self.grad_props[lvl], scene, o, d, lv["starts"], lv["ends"],
+                                  dd, d_positions=dpos)
+            if self.train_pose:
+                ops.ray_backward(dpos, None, lv["starts"], lv["ends"], d_o, d_d)
+        if self.train_pose:
+            gp = self.grads["camera_optimizer.pose_adjustment"]
+            ops.pose_adjustment_backward(pose, cam, d_raw, d_o, d_d, gp)
+            ops.pose_regularizer(pose, gp, self.loss_sums[3:4], self.trans_l2_penalty, self.rot_l2_penalty)
         self._last_bins, self._last_weights = bins, rb_out["weights"]
         sums = self.loss_sums
         loss_dict = {"rgb_loss": sums[0] / (3.0 * R), "semantics_loss": cfg.semantic_loss_weight * sums[1] / R,
                      "interlevel_loss": cfg.interlevel_loss_mult * sums[2] / (R * S)}
+        if self.train_pose:
+            loss_dict["camera_opt_regularizer"] = sums[3]
         return {"loss_dict": loss_dict, "rgb": rb_out["rgb"], "semantics": rb_out["semantics"],
                 "accumulation": rb_out["accumulation"]}
 
@@ -138,23 +176,35 @@ class FruitTrainer:
     def optimizer_step(self) -> None:
         self.step += 1
         for k in self.trainable:
-            grp = self.groups["proposal_networks" if k.startswith("proposal_networks.") else "fields"]
+            grp = self.groups["proposal_networks" if k.startswith("proposal_networks.") else
+                              "camera_opt" if k.startswith("camera_optimizer.") else "fields"]
             ops.adam_step(self.model.params[k], self.grads[k], self.exp_avg[k], self.exp_avg_sq[k], self.step,
                           grp.lr_at(self.step - 1), eps=grp.eps, zero_grad=True)
 
     def train_iteration(self, ray_bundle: RayBundle, batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
         self.set_anneal(self.step)
-        out = self.forward_backward(ray_bundle, batch)
+        it = self.step
+        updated = self.proposal_update_due(self._sampler_step)
+        out = self.forward_backward(ray_bundle, batch, update_proposals=updated)
+        if updated:
+            self._steps_since_update = 0
         import torch.distributed as dist
 
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             self.all_reduce_gradients()
         self.optimizer_step()
+        self._sampler_step = it  # step_cb, an AFTER_TRAIN_ITERATION callback
+        self._steps_since_update += 1
         out["metrics_dict"] = self.get_metrics_dict(out)
         return out
 
     def get_metrics_dict(self, out) -> Dict[str, Tensor]:
         """``get_metrics_dict`` (``fruit_nerf.py:639-645``): PSNR and the distortion metric of the last batch."""
         mse = out["loss_dict"]["rgb_loss"]
-        return {"psnr": -10.0 * torch.log10(mse),
-                "distortion": ops.distortion_metric(self._last_bins, self._last_weights)}
+        md = {"psnr": -10.0 * torch.log10(mse),
+              "distortion": ops.distortion_metric(self._last_bins, self._last_weights)}
+        if self.train_pose:  # CameraOptimizer.get_metrics_dict (fruit_nerf.py:644)
+            pose = self.model.params["camera_optimizer.pose_adjustment"]
+            md["camera_opt_translation"] = pose[:, :3].norm()
+            md["camera_opt_rotation"] = pose[:, 3:].norm()
+        return md

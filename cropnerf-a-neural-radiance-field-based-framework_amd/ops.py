@@ -464,26 +464,69 @@ def interlevel_backward(final_spacing_bins: Tensor, final_weights: Tensor, prop_
 def field_backward(fh: FieldHandle, gh: FieldHandle, scene: L.Scene, origins: Tensor, directions: Tensor,
                    camera_indices: Optional[Tensor], starts: Tensor, ends: Tensor, d_density: Tensor, d_rgb: Tensor,
                    d_semantics: Tensor, app_mode: int = L.APP_PER_CAMERA, sh_unit_dir: bool = True,
-                   app_mean: Optional[Tensor] = None) -> None:
-    """Accumulates parameter gradients into the tensors behind ``gh`` (a FieldHandle over the gradient dict)."""
+                   app_mean: Optional[Tensor] = None, d_positions: Optional[Tensor] = None,
+                   d_directions: Optional[Tensor] = None) -> None:
+    """Accumulates parameter gradients into the tensors behind ``gh`` (a FieldHandle over the gradient dict).
+    ``d_positions`` / ``d_directions`` [R,S,3] (optional) are overwritten with the per-sample position / SH-direction
+    gradients that feed the camera pose refinement."""
     lib = L.load()
     R, S = starts.shape
+    for t, nm in ((d_positions, "d_positions"), (d_directions, "d_directions")):
+        if t is not None and tuple(t.shape) != (R, S, 3):
+            raise ValueError(f"{nm} must be [{R},{S},3]")
     L.check(lib.cn_field_backward(
         C.byref(fh.struct), C.byref(gh.struct), C.byref(scene), app_mode, 1 if sh_unit_dir else 0,
         _p(_f32(app_mean, "app_mean")), _p(_f32(origins, "origins")), _p(_f32(directions, "directions")),
         _p(_i64(camera_indices, "camera_indices")), _p(_f32(starts, "starts")), _p(_f32(ends, "ends")),
         _p(_f32(d_density, "d_density")), _p(_f32(d_rgb, "d_rgb")), _p(_f32(d_semantics, "d_semantics")), R, S,
-        _stream(starts)))
+        _p(_f32(d_positions, "d_positions")), _p(_f32(d_directions, "d_directions")), _stream(starts)))
 
 
 def proposal_backward(dh: DensityHandle, gh: DensityHandle, scene: L.Scene, origins: Tensor, directions: Tensor,
-                      starts: Tensor, ends: Tensor, d_density: Tensor) -> None:
+                      starts: Tensor, ends: Tensor, d_density: Tensor, d_positions: Optional[Tensor] = None) -> None:
     lib = L.load()
     R, S = starts.shape
+    if d_positions is not None and tuple(d_positions.shape) != (R, S, 3):
+        raise ValueError(f"d_positions must be [{R},{S},3]")
     L.check(lib.cn_proposal_backward(
         C.byref(dh.struct), C.byref(gh.struct), C.byref(scene), _p(_f32(origins, "origins")),
         _p(_f32(directions, "directions")), _p(_f32(starts, "starts")), _p(_f32(ends, "ends")),
-        _p(_f32(d_density, "d_density")), R, S, _stream(starts)))
+        _p(_f32(d_density, "d_density")), R, S, _p(_f32(d_positions, "d_positions")), _stream(starts)))
+
+
+def ray_backward(d_positions: Tensor, d_dir_samples: Optional[Tensor], starts: Tensor, ends: Tensor,
+                 d_origins: Tensor, d_directions: Tensor) -> None:
+    """Accumulate per-ray origin / direction gradients from per-sample position gradients (``cn_ray_backward``)."""
+    lib = L.load()
+    R, S = starts.shape
+    if tuple(d_positions.shape) != (R, S, 3) or tuple(d_origins.shape) != (R, 3) or tuple(d_directions.shape) != (R, 3):
+        raise ValueError("ray_backward: shape mismatch")
+    L.check(lib.cn_ray_backward(_p(_f32(d_positions, "d_positions")), _p(_f32(d_dir_samples, "d_dir_samples")),
+                                _p(_f32(starts, "starts")), _p(_f32(ends, "ends")), R, S,
+                                _p(_f32(d_origins, "d_origins")), _p(_f32(d_directions, "d_directions")),
+                                _stream(starts)))
+
+
+def pose_adjustment_backward(pose_adjustment: Tensor, camera_indices: Tensor, directions_raw: Tensor,
+                             d_origins: Tensor, d_directions: Tensor, grad_pose: Tensor) -> None:
+    """Chain per-ray gradients through exp_map_SO3xR3 into ``grad_pose`` [C,6] (accumulated)."""
+    lib = L.load()
+    R = directions_raw.shape[0]
+    if grad_pose.shape != pose_adjustment.shape:
+        raise ValueError("grad_pose must have the shape of pose_adjustment")
+    L.check(lib.cn_pose_adjustment_backward(
+        _p(_f32(pose_adjustment, "pose_adjustment")), _p(_i64(camera_indices, "camera_indices")),
+        _p(_f32(directions_raw, "directions_raw")), _p(_f32(d_origins, "d_origins")),
+        _p(_f32(d_directions, "d_directions")), R, _p(_f32(grad_pose, "grad_pose")), _stream(directions_raw)))
+
+
+def pose_regularizer(pose_adjustment: Tensor, grad_pose: Optional[Tensor], loss_out: Tensor,
+                     trans_l2_penalty: float = 1e-2, rot_l2_penalty: float = 1e-3) -> None:
+    """``camera_opt_regularizer``: adds the loss to ``loss_out`` [1] and its gradient to ``grad_pose``."""
+    lib = L.load()
+    L.check(lib.cn_pose_regularizer(_p(_f32(pose_adjustment, "pose_adjustment")), pose_adjustment.shape[0],
+                                    float(trans_l2_penalty), float(rot_l2_penalty), _p(_f32(grad_pose, "grad_pose")),
+                                    _p(_f32(loss_out, "loss_out")), _stream(pose_adjustment)))
 
 
 def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step: int, lr: float,

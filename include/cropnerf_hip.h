@@ -307,17 +307,40 @@ int cn_interlevel_backward(const float* final_spacing_bins, const float* final_w
 
 /* Parameter gradients of FruitField (training branch: per-camera appearance, semantic MLP on detached geo
  * features, fruit_nerf/fruit_field.py:235-282) from per-sample upstream gradients; the forward is recomputed
- * tile by tile.  app_mean [app_dim] is read with CN_APP_MEAN only. */
+ * tile by tile.  app_mean [app_dim] is read with CN_APP_MEAN only.  d_positions / d_directions (optional) receive
+ * d loss / d (world sample position) and d loss / d (ray direction, through the SH colour input) per sample -- the
+ * inputs of the camera pose refinement's backward (the positions get `requires_grad`, fruit_field.py:181-184). */
 int cn_field_backward(const cn_field_params* params, const cn_field_params* grads, const cn_scene* scene,
                       int32_t app_mode, int32_t sh_unit_dir, const float* app_mean, const float* origins,
                       const float* directions, const int64_t* camera_indices, const float* starts,
                       const float* ends, const float* d_density, const float* d_rgb, const float* d_semantics,
-                      int64_t num_rays, int32_t num_samples, cn_stream_t stream);
+                      int64_t num_rays, int32_t num_samples, float* d_positions /*[R,S,3] or NULL*/,
+                      float* d_directions /*[R,S,3] or NULL*/, cn_stream_t stream);
 
-/* Parameter gradients of one proposal network from d loss / d density [R,S]. */
+/* Parameter gradients of one proposal network from d loss / d density [R,S]; d_positions as above. */
 int cn_proposal_backward(const cn_density_params* params, const cn_density_params* grads, const cn_scene* scene,
                          const float* origins, const float* directions, const float* starts, const float* ends,
-                         const float* d_density, int64_t num_rays, int32_t num_samples, cn_stream_t stream);
+                         const float* d_density, int64_t num_rays, int32_t num_samples,
+                         float* d_positions /*[R,S,3] or NULL*/, cn_stream_t stream);
+
+/* Camera pose refinement backward (camera_optimizer.apply_to_raybundle, fruit_nerf/fruit_nerf.py:547, trained through
+ * the "camera_opt" group, fruit_nerf.py:195).  Step 1, per sample set: ACCUMULATE per-ray
+ * d_origins += sum_s d_positions, d_directions += sum_s mid_s d_positions (+ sum_s d_dir_samples when not NULL). */
+int cn_ray_backward(const float* d_positions /*[R,S,3]*/, const float* d_dir_samples /*[R,S,3] or NULL*/,
+                    const float* starts, const float* ends, int64_t num_rays, int32_t num_samples,
+                    float* d_origins /*[R,3]*/, float* d_directions /*[R,3]*/, cn_stream_t stream);
+
+/* Step 2: chain through exp_map_SO3xR3 (o' = o + t, d' = R(w) d): ACCUMULATE into grad_pose [C,6].
+ * directions_raw = the ray directions BEFORE cn_apply_pose_adjustment. */
+int cn_pose_adjustment_backward(const float* pose_adjustment /*[C,6]*/, const int64_t* camera_indices,
+                                const float* directions_raw /*[R,3]*/, const float* d_origins,
+                                const float* d_directions, int64_t num_rays, float* grad_pose, cn_stream_t stream);
+
+/* camera_opt_regularizer of CameraOptimizer.get_loss_dict (fruit_nerf/fruit_nerf.py:614):
+ * mean_c |t_c| * trans_l2_penalty + mean_c |w_c| * rot_l2_penalty; adds the loss to *loss_out and, when grad_pose
+ * is not NULL, its gradient to grad_pose. */
+int cn_pose_regularizer(const float* pose_adjustment, int32_t num_cameras, float trans_l2_penalty,
+                        float rot_l2_penalty, float* grad_pose, float* loss_out, cn_stream_t stream);
 
 /* nerfstudio distortion_loss of the final level (the "distortion" entry of get_metrics_dict,
  * fruit_nerf/fruit_nerf.py:643): adds sum over rays to *sum_out (divide by R on the host). */

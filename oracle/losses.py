@@ -68,13 +68,21 @@ def train_forward(
     rb: RY.RayBundle, params: Dict[str, Tensor], fspec: F.FieldSpec, pspecs: List[F.ProposalSpec], aabb: Tensor,
     num_proposal_samples: Sequence[int], num_nerf_samples: int, jitter: Sequence[Optional[Tensor]],
     anneal: float = 1.0, near_plane: float = 0.05, far_plane: float = 1000.0, apply_pose: bool = True,
+    update_proposals: bool = True,
 ) -> Dict[str, Tensor]:
     """``FruitModel.get_outputs`` with ``self.training`` (``fruit_nerf.py:543-599``): collider near 0.05, pose tweak,
     proposal sampler with single-jitter randoms ``jitter[level]`` ([R,1] each), per-camera appearance, no clamp."""
     rb = RY.near_far_collider(rb, training=True, near_plane=near_plane, far_plane=far_plane)
     if apply_pose:
-        rb = RY.apply_pose_adjustment(rb, params["camera_optimizer.pose_adjustment"].detach())
-    fns = [(lambda pos, i=i, ps=ps: F.proposal_density(pos, params, i, ps, aabb, True)) for i, ps in enumerate(pspecs)]
+        rb = RY.apply_pose_adjustment(rb, params["camera_optimizer.pose_adjustment"])
+    # update_proposals False = the sampler's ``with torch.no_grad()`` branch between scheduled proposal updates
+    def _fn(i, ps):
+        def fn(pos):
+            den = F.proposal_density(pos, params, i, ps, aabb, True)
+            return den if update_proposals else den.detach()
+        return fn
+
+    fns = [_fn(i, ps) for i, ps in enumerate(pspecs)]
     rs, weights_list, samples_list = SM.proposal_sampler(rb, fns, num_proposal_samples, num_nerf_samples,
                                                          anneal=anneal, jitter=jitter)
     fo = F.field_forward(rs.positions(), rs.directions, rs.camera_indices, params, fspec, aabb, True, "val",
@@ -103,6 +111,22 @@ def loss_dict(outputs: Dict[str, Tensor], image: Tensor, fruit_mask: Tensor, sem
             outputs["semantics"], fruit_mask),
         "interlevel_loss": interlevel_loss_mult * interlevel_loss(outputs["weights_list"], outputs["ray_samples_list"]),
     }
+
+
+def camera_opt_regularizer(pose_adjustment: Tensor, trans_l2_penalty: float = 1e-2,
+                           rot_l2_penalty: float = 1e-3) -> Tensor:
+    """nerfstudio ``CameraOptimizer.get_loss_dict`` (called at ``fruit_nerf.py:614``), mode SO3xR3."""
+    return (pose_adjustment[:, :3].norm(dim=-1).mean() * trans_l2_penalty
+            + pose_adjustment[:, 3:].norm(dim=-1).mean() * rot_l2_penalty)
+
+
+def proposal_update_due(step: int, steps_since_update: int, proposal_warmup: int = 5000,
+                        proposal_update_every: int = 5) -> bool:
+    """``ProposalNetworkSampler.generate_ray_samples``: ``updated`` (schedule at ``fruit_nerf.py:144-149``)."""
+    import numpy as np
+
+    sched = np.clip(np.interp(step, [0, proposal_warmup], [0, proposal_update_every]), 1, proposal_update_every)
+    return bool(steps_since_update > sched or step < 10)
 
 
 def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, beta1=0.9, beta2=0.999, eps=1e-15):
