@@ -58,7 +58,7 @@ class RenderOpts(C.Structure):
     _fields_ = [("num_samples", C.c_int32), ("spacing", C.c_int32), ("bg_mode", C.c_int32),
                 ("bg_color", C.c_float * 3), ("app_mode", C.c_int32), ("sh_unit_dir", C.c_int32),
                 ("eval_clamp", C.c_int32), ("density_only", C.c_int32), ("image_width", C.c_int32),
-                ("pixel_start", C.c_int64)]
+                ("pixel_start", C.c_int64), ("early_stop_transmittance", C.c_float)]
 
 
 _P = C.c_void_p

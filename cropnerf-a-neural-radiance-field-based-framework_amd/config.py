@@ -106,6 +106,9 @@ class FruitNerfModelConfig:
     distortion_loss_mult: float = 0.002
     eval_num_rays_per_chunk: int = 1 << 15
     sh_input: str = "unit"
+    # extension (not in the reference, which composites every sample): > 0 stops a ray in eval renders once its
+    # transmittance falls below this value; 0 keeps the reference's behaviour
+    early_stop_transmittance: float = 0.0
 
     def field_spec(self, num_images: int) -> FieldSpec:
         # FruitModel.populate_modules forwards only these (fruit_nerf.py:97-112); the rest stay FruitField defaults.

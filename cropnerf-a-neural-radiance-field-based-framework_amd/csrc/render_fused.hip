@@ -197,6 +197,7 @@ struct FusedArgs {
   int app_per_camera;
   int sh_unit;
   int eval_clamp;
+  float early_stop;  // 0 = off
   int image_width;        // > 0: rays are pixels [pixel_start, pixel_start + num_rays) of a row-major image
   int stripes_per_xcd;    // column stripes each XCD sweeps one after the other (stripe ~24 pixels wide)
   long long pixel_start;
@@ -822,6 +823,19 @@ __global__ void __launch_bounds__(FUSED_THREADS, CN_FUSED_MIN_WAVES_PER_SIMD) re
       } else {
         float w = composite_chunk(st, valid, i == S - 1, e1 - e0, density, mid, cr, cg, cb, sem, A.eval_clamp != 0);
         if (A.out_w && valid) A.out_w[r * (long long)S + i] = w;
+        // Optional early ray termination (cn_render_opts.early_stop_transmittance; the reference has none, so it is off
+        // by default): once the transmittance behind this chunk is below the threshold the remaining samples carry
+        // less than that much weight in total -- the wave drops them and moves on to its next ray.  The "last sample"
+        // background takes the last evaluated sample's colour (it is scaled by 1 - accumulation < threshold).
+        if (A.early_stop > 0.f && c0 + 64 < S && __expf(-st.carry_dd) < A.early_stop) {  // wave-uniform
+          st.last_r = wave_read(A.eval_clamp ? nan_to_num(cr) : cr, 63);
+          st.last_g = wave_read(A.eval_clamp ? nan_to_num(cg) : cg, 63);
+          st.last_b = wave_read(A.eval_clamp ? nan_to_num(cb) : cb, 63);
+          st.last_mid = wave_read(mid, 63);
+          if (A.out_w)
+            for (int k = c0 + 64 + lane; k < S; k += 64) A.out_w[r * (long long)S + k] = 0.f;
+          break;
+        }
       }
     }
 #endif
@@ -960,6 +974,7 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   A.app_per_camera = opts->app_mode == CN_APP_PER_CAMERA;
   A.sh_unit = opts->sh_unit_dir;
   A.eval_clamp = opts->eval_clamp;
+  A.early_stop = opts->early_stop_transmittance > 0.f ? opts->early_stop_transmittance : 0.f;
   A.image_width = opts->image_width > 0 ? opts->image_width : 0;
   // ~400 rays are in flight per XCD; a stripe about 24 pixels wide makes that patch roughly square (measured at
   // 800 px: 1/2/4/8 stripes per XCD -> 3.57 / 3.78 / 3.83 / 3.66 Gsamples/s)

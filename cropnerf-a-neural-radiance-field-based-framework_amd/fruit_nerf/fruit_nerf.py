@@ -177,7 +177,9 @@ class FruitModel:
         return ops.render_opts(num_samples, spacing=L.SPACING_UNIFORM, bg_mode=bg_mode, bg_color=bg,
                                app_mode=self._app_mode(), sh_unit_dir=self.config.sh_input == "unit",
                                eval_clamp=not self.training, density_only=density_only,
-                               image_width=self._image_hint[0], pixel_start=self._image_hint[1])
+                               image_width=self._image_hint[0], pixel_start=self._image_hint[1],
+                               early_stop_transmittance=0.0 if self.training else
+                               getattr(self.config, "early_stop_transmittance", 0.0))
 
     def _sample_and_render(self, rb: RayBundle, density_only: bool = False) -> Dict[str, Tensor]:
         """proposal (or uniform) sampler -> field -> renderers, all on device."""

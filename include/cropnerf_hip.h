@@ -115,6 +115,10 @@ typedef struct cn_render_opts {
    * stripe instead of a run of rows, so that vertically adjacent pixels share an L2. 0 = unknown order. */
   int32_t image_width;
   int64_t pixel_start;
+  /* Early ray termination, an extension (the reference composites every sample): > 0 lets cn_render_rays
+   * stop a ray after a 64-sample chunk once the transmittance behind it is below this value; every output
+   * then differs from the full result by less than the threshold (times the value range).  0 = off. */
+  float early_stop_transmittance;
 } cn_render_opts;
 
 const char* cn_last_error(void);

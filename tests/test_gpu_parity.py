@@ -537,3 +537,34 @@ def test_image_width_hint_changes_schedule_not_results(scene, ops, handles, widt
     hinted = ops.render_rays(fh, sc, ops.render_opts(48, image_width=width, pixel_start=start), o, d, n, f)
     for k in base:
         assert torch.equal(base[k], hinted[k]), k
+
+
+@pytest.mark.parametrize("eps", [1e-2, 1e-4])
+def test_early_stop_is_off_by_default_and_bounded_when_on(scene, ops, eps):
+    """cn_render_opts.early_stop_transmittance (an extension; the reference composites every sample): 0 is bit-identical
+    to the plain render, > 0 on an opaque medium changes every output by less than the threshold and really stops
+    (the weights behind the cut are exactly 0)."""
+    fspec, _ = product_specs(scene)
+    dp = dev_params(scene)
+    dp = {k: v.clone() for k, v in dp.items()}
+    dp["field.mlp_base_mlp.layers.1.bias"][0] += 4.0  # density x e^4: rays go opaque within the first chunks
+    fh = ops.FieldHandle(dp, fspec)
+    rb = rays_with_box(scene, 2)
+    o, d, n, f = (to_dev(t[:1500]) for t in (rb.origins, rb.directions, rb.nears, rb.fars))
+    sc = ops.scene_struct(scene.aabb, True)
+    S = 256
+    full = ops.render_rays(fh, sc, ops.render_opts(S), o, d, n, f, want_weights=True)
+    off = ops.render_rays(fh, sc, ops.render_opts(S, early_stop_transmittance=0.0), o, d, n, f, want_weights=True)
+    for k in full:
+        assert torch.equal(full[k], off[k]), k
+    cut = ops.render_rays(fh, sc, ops.render_opts(S, early_stop_transmittance=eps), o, d, n, f, want_weights=True)
+    stopped = (cut["weights"][:, 192:] == 0).all(dim=1) & (full["weights"][:, 192:] != 0).any(dim=1)
+    assert stopped.float().mean() > 0.5, "the medium was meant to be opaque enough to stop most rays"
+    assert_close(cut["rgb"], full["rgb"], 0, 1.01 * eps, "early-stop rgb")
+    assert_close(cut["accumulation"], full["accumulation"], 0, 1.01 * eps, "early-stop accumulation")
+    sem_scale = float(full["semantics"].abs().max()) + 1.0
+    assert_close(cut["semantics"], full["semantics"], 0, 4 * eps * sem_scale, "early-stop semantics")
+    assert torch.equal(cut["depth"], full["depth"])  # the median is always inside the evaluated part (T < 0.5)
+    # where a ray was not stopped nothing changes at all
+    kept = ~(cut["weights"] == 0).all(dim=1) & (cut["weights"][:, -1] != 0)
+    assert torch.equal(cut["rgb"][kept], full["rgb"][kept])
