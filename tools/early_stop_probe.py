@@ -13,7 +13,7 @@ c2w, intr = synthetic.orbit_cameras(100, height=H, width=W)
 c2w, intr = c2w.to(dev), intr.to(dev)
 sc = ops.scene_struct(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), True)
 res = {}
-for boost in (0.0, 3.0, 5.0):
+for boost in [float(b) for b in os.environ.get("BOOSTS", "0,3,5").split(",")]:
     params = synthetic.p_rand(fspec, cfg.proposal_specs(), seed=0, device=dev)
     params["field.mlp_base_mlp.layers.1.bias"][0] += boost
     fh = ops.FieldHandle(params, fspec)
@@ -25,10 +25,10 @@ for boost in (0.0, 3.0, 5.0):
         out = ops.render_rays(fh, sc, opts, rg["origins"], rg["directions"], n, f)
         torch.cuda.synchronize()
         t = time.perf_counter()
-        for _ in range(10):
+        for _ in range(30):
             out = ops.render_rays(fh, sc, opts, rg["origins"], rg["directions"], n, f)
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t) / 10 * 1e3
+        ms = (time.perf_counter() - t) / 30 * 1e3
         if eps == 0.0:
             ref = out
         row[f"eps={eps:g}"] = {"ms": round(ms, 3), "max_rgb_err": float((out["rgb"] - ref["rgb"]).abs().max()),
