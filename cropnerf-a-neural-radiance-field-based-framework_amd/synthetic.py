@@ -46,3 +46,74 @@ def p_rand(spec: FieldSpec, prop_specs: List[ProposalSpec], seed: int = 0, devic
 
 
 SCENE_AABB = ((-1.0, -1.0, -1.0), (1.0, 1.0, 1.0))  # SceneBox(+-1), data/cotton_nerf_dataparser.py
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Analytic "cotton plant" (parameter set P-fit): three coloured spheres ("bolls", semantic class 1)
+# on a vertical cylinder ("stem", class 0) in front of a constant background, rendered in closed form.  It is the
+# stand-in for the 3DCotton images: ground-truth pixels and fruit masks for any camera, so that the training rows can
+# be exercised end to end and PSNR has a meaning.
+# ------------------------------------------------------------------------------------------------------------------
+BOLLS = (  # centre xyz, radius, rgb
+    ((0.10, 0.00, 0.12), 0.085, (0.92, 0.90, 0.84)),
+    ((-0.06, 0.09, -0.05), 0.075, (0.90, 0.62, 0.58)),
+    ((-0.04, -0.10, 0.22), 0.065, (0.62, 0.80, 0.92)),
+)
+STEM = (0.035, -0.35, 0.35, (0.36, 0.25, 0.12))  # radius, z0, z1, rgb
+BACKGROUND = (0.08, 0.09, 0.12)
+LIGHT = (0.3, 0.5, 0.81)
+
+
+def analytic_render(origins: torch.Tensor, directions: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Closed-form image of the analytic plant for rays [..., 3] (unit directions): rgb [...,3], fruit mask [...,1]
+    (1 where a boll is the first hit), depth [...,1] (1e10 on a miss).  Lambert-like view-independent shading."""
+    o, d = origins.to(torch.float32), directions.to(torch.float32)
+    dev = o.device
+    light = torch.tensor(LIGHT, device=dev)
+    light = light / light.norm()
+    best_t = torch.full(o.shape[:-1], 1e10, device=dev)
+    rgb = torch.tensor(BACKGROUND, device=dev).expand(*o.shape[:-1], 3).clone()
+    mask = torch.zeros(*o.shape[:-1], device=dev)
+
+    def shade(base, normal):
+        k = 0.55 + 0.45 * (normal * light).sum(-1).clamp(min=0.0)
+        return torch.tensor(base, device=dev) * k[..., None]
+
+    for centre, radius, colour in BOLLS:
+        c = torch.tensor(centre, device=dev)
+        oc = o - c
+        b = (oc * d).sum(-1)
+        disc = b * b - ((oc * oc).sum(-1) - radius * radius)
+        t = -b - torch.sqrt(disc.clamp(min=0.0))
+        hit = (disc > 0) & (t > 0) & (t < best_t)
+        n = (oc + d * t[..., None]) / radius
+        rgb = torch.where(hit[..., None], shade(colour, n), rgb)
+        mask = torch.where(hit, torch.ones_like(mask), mask)
+        best_t = torch.where(hit, t, best_t)
+    radius, z0, z1, colour = STEM
+    a = (d[..., :2] ** 2).sum(-1).clamp(min=1e-12)
+    b = (o[..., :2] * d[..., :2]).sum(-1)
+    cc = (o[..., :2] ** 2).sum(-1) - radius * radius
+    disc = b * b - a * cc
+    t = (-b - torch.sqrt(disc.clamp(min=0.0))) / a
+    z = o[..., 2] + d[..., 2] * t
+    hit = (disc > 0) & (t > 0) & (t < best_t) & (z > z0) & (z < z1)
+    p = o + d * t[..., None]
+    n = torch.cat([p[..., :2] / radius, torch.zeros_like(p[..., :1])], -1)
+    rgb = torch.where(hit[..., None], shade(colour, n), rgb)
+    mask = torch.where(hit, torch.zeros_like(mask), mask)
+    best_t = torch.where(hit, t, best_t)
+    return rgb, mask[..., None], best_t[..., None]
+
+
+def analytic_dataset(cameras, device="cuda") -> Tuple[torch.Tensor, torch.Tensor]:
+    """Ground-truth images [N,H,W,3] and fruit masks [N,H,W,1] of the analytic plant for ``cameras`` (rays from the
+    product ray generator, so pixel centres follow the reference's convention)."""
+    cams = cameras.to(device)
+    images, masks = [], []
+    for i in range(len(cams)):
+        rb = cams.generate_rays(i, keep_shape=True)
+        rgb, m, _ = analytic_render(rb.origins, rb.directions)
+        images.append(rgb)
+        masks.append(m)
+    return torch.stack(images), torch.stack(masks)

@@ -199,3 +199,26 @@ def test_training_reduces_loss_like_the_oracle():
     assert hip_losses[-1] < hip_losses[0] and ref_losses[-1] < ref_losses[0]
     for a, b in zip(hip_losses, ref_losses):
         assert abs(a - b) <= 0.03 * abs(b) + 1e-4, (hip_losses, ref_losses)
+
+
+def test_fit_analytic_plant_end_to_end():
+    """P-fit: the full training loop (datamanager -> FruitTrainer.train_iteration with anneal, proposal
+    update schedule, three optimiser groups) on the closed-form plant.  The loss must fall and the rendered training
+    pixels approach the ground truth; then the trained model is rendered in eval mode by the HIP path and by the CPU
+    oracle -- on a fitted, opaque scene -- and their PSNRs against the ground truth must agree within 0.1 dB
+    (BASELINE.json's parity criterion)."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fit_scene
+
+    res, pipe, data = fit_scene.fit(iters=500, res=64, n_train=24, rays=2048, log2_T=15, log_every=100)
+    first, last = res["log"][0], res["log"][-1]
+    assert last["rgb_loss"] < 0.1 * first["rgb_loss"], res["log"]
+    assert last["semantics_loss"] < 0.2 * first["semantics_loss"], res["log"]
+    assert max(e["psnr"] for e in res["log"][-2:]) > 22.0, res["log"]
+    assert all(v["psnr"] > 8.0 for v in res["held_out"]), res["held_out"]  # short fit: held-out quality is not the point
+    chk = fit_scene.oracle_check(pipe, data, res_small=32)
+    assert chk["psnr_hip_vs_oracle"] > 60.0, chk
+    assert abs(chk["psnr_hip_vs_gt"] - chk["psnr_oracle_vs_gt"]) < 0.1, chk
