@@ -17,6 +17,7 @@
 //
 // Shapes: the default fruit_nerf_method field (16 levels, 32->64->16, 15->64->64->1, 63->64->64->3, appearance 32)
 // and {5|7}-level 2L->16->1 proposal nets; other shapes return CN_ERR_UNSUPPORTED.
+#include <cstring>
 #include <cstdlib>
 
 #include "cn_common.hpp"
@@ -500,6 +501,10 @@ __global__ void __launch_bounds__(TB) field_backward_kernel(FieldBwdArgs A) {
   if (tid < 1) atomicAdd(A.g.bh + tid, gbh);
 }
 
+}  // namespace cn
+#include "train_field_mfma.hpp"
+namespace cn {
+
 // ------------------------------------------------------------------------------------------------------------------------
 // proposal network backward
 // ------------------------------------------------------------------------------------------------------------------------
@@ -703,16 +708,32 @@ extern "C" int cn_field_backward(const cn_field_params* params, const cn_field_p
     const char* dbg = getenv("CN_DEBUG_SKIP");
     A.debug_skip = dbg ? atoi(dbg) : 0;
   }
-  size_t lds = (size_t)cn::FIELD_ROWS * cn::LD * sizeof(float);
+  // default: the matrix-core kernel; CN_FIELD_BACKWARD_IMPL=scalar selects the first (scalar-FMA) implementation,
+  // kept as an independent device implementation for cross-checks
+  static const bool use_scalar = [] {
+    const char* e = getenv("CN_FIELD_BACKWARD_IMPL");
+    return e && std::strcmp(e, "scalar") == 0;
+  }();
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::field_backward_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)((size_t)cn::FIELD_ROWS * cn::LD * sizeof(float)));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::mf::field_backward_mfma_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)cn::mf::LDS_BYTES);
     attr = true;
   }
-  long long ntiles = (num_rays * (long long)num_samples + cn::TS - 1) / cn::TS;
-  hipLaunchKernelGGL(cn::field_backward_kernel, dim3(cn::grid_for(ntiles, 1, 256)), dim3(cn::TB), lds,
-                     cn::as_stream(stream), A);
+  const long long nsamp = num_rays * (long long)num_samples;
+  if (use_scalar) {
+    size_t lds = (size_t)cn::FIELD_ROWS * cn::LD * sizeof(float);
+    long long ntiles = (nsamp + cn::TS - 1) / cn::TS;
+    hipLaunchKernelGGL(cn::field_backward_kernel, dim3(cn::grid_for(ntiles, 1, 256)), dim3(cn::TB), lds,
+                       cn::as_stream(stream), A);
+  } else {
+    long long ntiles = (nsamp + cn::mf::TSM - 1) / cn::mf::TSM;
+    hipLaunchKernelGGL(cn::mf::field_backward_mfma_kernel, dim3(cn::grid_for(ntiles, 1, 256)), dim3(cn::mf::NT),
+                       cn::mf::LDS_BYTES, cn::as_stream(stream), A);
+  }
   return cn::check_launch("cn_field_backward");
 }
 

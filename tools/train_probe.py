@@ -22,5 +22,5 @@ rb = cams.generate_rays(idx.to(dev))
 batch = {"image": torch.rand(R,3,generator=g).to(dev), "fruit_mask": (torch.rand(R,1,generator=g)>0.5).float().to(dev)}
 for i in range(2): tr.train_iteration(rb, batch)
 torch.cuda.synchronize(); t=time.perf_counter()
-for i in range(5): tr.train_iteration(rb, batch)
-torch.cuda.synchronize(); print("CN_DEBUG_SKIP", os.environ.get("CN_DEBUG_SKIP"), "ms/iter", (time.perf_counter()-t)/5*1e3)
+for i in range(20): tr.train_iteration(rb, batch)
+torch.cuda.synchronize(); print("CN_DEBUG_SKIP", os.environ.get("CN_DEBUG_SKIP"), "ms/iter", (time.perf_counter()-t)/20*1e3)
