@@ -142,6 +142,9 @@ __device__ __forceinline__ bool row_run_reduce(unsigned key, float& v0, float& v
   return last;
 }
 
+#ifndef CN_PAIRED_ATOMICS
+#define CN_PAIRED_ATOMICS 1
+#endif
 // scatter d(loss)/d(features of one level) into the table gradient with the forward's trilinear weights
 // (all 64 lanes call it; g0 = g1 = 0 for lanes without a sample).  POS: also accumulate d(loss)/d(normalised position)
 // -- the trilinear weights are linear in the in-cell offset, so d enc_f / d x = scale * sum_c (+-1) wy wz table[c].f
@@ -176,10 +179,24 @@ __device__ __forceinline__ void hash_level_backward(float* __restrict__ gtab, co
     }
     float v0 = w * g0, v1 = w * g1;
     const bool issue = row_run_reduce(e, v0, v1, row_lane);
+#if CN_PAIRED_ATOMICS
+    // The two features of an entry are adjacent dwords.  Issue them from ADJACENT LANES of one instruction (first the
+    // entries of the even lanes, then those of the odd lanes) instead of from the same lane in two instructions, so
+    // that the pair travels as one request.
+    const unsigned eu = issue && (v0 != 0.f || v1 != 0.f) ? e : 0xffffffffu;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const unsigned es = h ? dpp_u32<0xF5>(eu) : dpp_u32<0xA0>(eu);   // quad_perm [1,1,3,3] / [0,0,2,2]
+      const float a0 = h ? dpp_f32<0xF5>(v0) : dpp_f32<0xA0>(v0);
+      const float a1 = h ? dpp_f32<0xF5>(v1) : dpp_f32<0xA0>(v1);
+      if (es != 0xffffffffu) atomicAdd(gtab + 2 * (size_t)es + (lane & 1), (lane & 1) ? a1 : a0);
+    }
+#else
     if (issue && (v0 != 0.f || v1 != 0.f)) {
       atomicAdd(gtab + 2 * (size_t)e, v0);
       atomicAdd(gtab + 2 * (size_t)e + 1, v1);
     }
+#endif
   }
   if constexpr (POS) {
     dpx = fmaf(ax, scale, dpx);
