@@ -536,6 +536,7 @@ struct PropBwdArgs {
   float* d_pos;  // optional [R*S,3]
   long long R;
   int S;
+  int debug_skip;  // CN_DEBUG_SKIP: 8 hash atomics, 16 weight-gradient dots
 };
 
 template <int L>
@@ -595,11 +596,11 @@ __global__ void __launch_bounds__(TB) proposal_backward_kernel(PropBwdArgs A) {
       dout[lane] = up * misc[3 * LD + lane] * expf(fminf(fmaxf(logit, -15.f), 15.f));
     }
     __syncthreads();
-    gW1.add(dout, hid, tid);
+    if (!(A.debug_skip & 16)) gW1.add(dout, hid, tid);
     bias_add<1>(gb1, dout, tid);
     bwd_rows<H, 1>(A.w1, dout, dh, hid, 0, H, wave, lane);
     __syncthreads();
-    gW0.add(dh, enc, tid);
+    if (!(A.debug_skip & 16)) gW0.add(dh, enc, tid);
     bias_add<H>(gb0, dh, tid);
     // delta_enc[k] = sum_n W0[n][k] dh[n] -> straight into the table gradient
     float gpx = 0.f, gpy = 0.f, gpz = 0.f;
@@ -611,6 +612,7 @@ __global__ void __launch_bounds__(TB) proposal_backward_kernel(PropBwdArgs A) {
         g0 = fmaf(A.w0[n * K + 2 * l], d, g0);
         g1 = fmaf(A.w0[n * K + 2 * l + 1], d, g1);
       }
+      if (A.debug_skip & 8) continue;
       if (A.d_pos)
         hash_level_backward<true>(A.g_table, A.table, (unsigned)l * A.level_stride, A.mask, A.scale[l], misc[lane],
                                   misc[LD + lane], misc[2 * LD + lane], valid ? g0 : 0.f, valid ? g1 : 0.f, lane, gpx,
@@ -794,6 +796,10 @@ extern "C" int cn_proposal_backward(const cn_density_params* params, const cn_de
   A.d_pos = d_positions;
   A.R = num_rays;
   A.S = num_samples;
+  {
+    const char* dbg = getenv("CN_DEBUG_SKIP");
+    A.debug_skip = dbg ? atoi(dbg) : 0;
+  }
   long long ntiles = (num_rays * (long long)num_samples + cn::TS - 1) / cn::TS;
   dim3 grid(cn::grid_for(ntiles, 1, 1024));
   if (L == 5)
