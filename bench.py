@@ -187,7 +187,9 @@ def main():
         alg_bytes = R * (S * BYTES_PER_SAMPLE + BYTES_PER_RAY_IO)
         achieved = alg_bytes / avg / 1e9
         traffic, traffic_note = pmc_traffic()
-        roofline = {"bound": "hbm", "kernel": "render_fused_kernel<false,false>", "achieved": round(achieved, 1),
+        kernel_name = ("render_fused_kernel<false,false>" if os.environ.get("CN_FUSED_SPLIT", "1") == "0"
+                       else "render_split_kernel")
+        roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                     "traffic": traffic, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": alg_bytes,
                     "avg_launch_ms": round(avg * 1e3, 4),

@@ -71,6 +71,11 @@ constexpr int WAVE_SCRATCH = 200;  // floats of per-wave LDS scratch: colour bia
 #define CN_FUSED_MIN_WAVES_PER_SIMD 3
 #endif
 // 4 waves x 3 blocks/CU measured faster than 8 waves x 2 blocks/CU (3.38 vs 3.06 Gsamples/s at C2)
+// 1: the composited full render runs as render_split_kernel (gather waves feeding matrix waves, render_split.hpp);
+// CN_FUSED_SPLIT=0 in the environment selects render_fused_kernel<false,false> instead (A/B runs, cross-check tests)
+#ifndef CN_FUSED_SPLIT_DEFAULT
+#define CN_FUSED_SPLIT_DEFAULT 1
+#endif
 constexpr int FUSED_WAVES = CN_FUSED_WAVES;  // waves per workgroup (they share one LDS weight image)
 constexpr int FUSED_THREADS = FUSED_WAVES * 64;
 
@@ -863,6 +868,10 @@ __global__ void __launch_bounds__(FUSED_THREADS, CN_FUSED_MIN_WAVES_PER_SIMD) re
   }
 }
 
+}  // namespace cn
+#include "render_split.hpp"
+namespace cn {
+
 int validate_field(const cn_field_params& p);  // field_simple.hip
 
 static int check_fused_shape(const cn_field_params& p) {
@@ -979,6 +988,7 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   // ~400 rays are in flight per XCD; a stripe about 24 pixels wide makes that patch roughly square (measured at
   // 800 px: 1/2/4/8 stripes per XCD -> 3.57 / 3.78 / 3.83 / 3.66 Gsamples/s)
   A.stripes_per_xcd = A.image_width > 0 ? (A.image_width + 96) / 192 : 1;
+  if (const char* e = getenv("CN_STRIPES_PER_XCD")) A.stripes_per_xcd = atoi(e);  // tuning aid
   if (A.stripes_per_xcd < 1) A.stripes_per_xcd = 1;
   A.pixel_start = opts->pixel_start;
   // persistent grid: exactly the resident block count (a multiple of 8 = XCD groups), never more waves than rays
@@ -988,6 +998,28 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   const long long cap = PER_SAMPLE ? res_sample : (opts->density_only ? res_density : res_full);
   const long long want = (((num_rays + FUSED_WAVES - 1) / FUSED_WAVES) + 7) / 8 * 8;
   const unsigned blocks = (unsigned)(want < cap ? want : cap);
+  // producer/consumer variant of the composited full render (render_split.hpp)
+  // (the environment is read per call so that one process can compare both forms)
+  const char* split_env = getenv("CN_FUSED_SPLIT");
+  const int split_mode = split_env ? atoi(split_env) : CN_FUSED_SPLIT_DEFAULT;
+  if (!PER_SAMPLE && !opts->density_only && split_mode && A.early_stop == 0.f) {
+    static int resident = 0;  // workgroups the device holds at once (a multiple of 8 = XCD teams)
+    if (!resident) {
+      int dev = 0, cus = 256, per_cu = 1;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS_BYTES);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_split_kernel, SPLIT_THREADS, SPLIT_LDS_BYTES) !=
+              hipSuccess || per_cu < 1)
+        per_cu = 1;
+      resident = cus * per_cu;
+      resident = resident >= 8 ? (resident / 8) * 8 : 8;
+    }
+    const long long want_s = (((num_rays + SPLIT_PAIRS - 1) / SPLIT_PAIRS) + 7) / 8 * 8;
+    const unsigned nb = (unsigned)(want_s < resident ? want_s : resident);
+    hipLaunchKernelGGL(render_split_kernel, dim3(nb), dim3(SPLIT_THREADS), SPLIT_LDS_BYTES, s, A);
+    return check_launch(who);
+  }
   if (PER_SAMPLE) {
     hipLaunchKernelGGL((render_fused_kernel<true, false>), dim3(blocks), dim3(FUSED_THREADS), 0, s, A);
   } else if (opts->density_only) {

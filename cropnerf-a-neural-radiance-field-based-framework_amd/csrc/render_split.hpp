@@ -1,0 +1,462 @@
+// Producer / consumer form of render_fused_kernel<false,false> (included by render_fused.hip).
+//
+// The fused kernel is bound by the rate at which a CU's texture-address unit takes divergent 8-byte gathers (~1.25
+// lanes per clock), with the matrix work (~80 % of that time) hidden under it only partly: a wave that is inside its
+// MFMA chain issues no gathers, so the TA idles whenever too many of the 12 resident waves are in that phase.  Here the
+// two halves of the per-sample work run in DIFFERENT waves of one 1024-thread workgroup (one per CU):
+//   * 8 gather waves: positions -> hash -> 128 corner gathers per sample -> trilinear blend -> 32 features, written to LDS
+//     in the lane layout the first MFMA wants (a register hand-off: 4 x 16-byte stores per lane);
+//   * 8 matrix waves: features from LDS -> the MFMA chain of the field -> heads -> wave-scan compositing.
+// Gather wave p feeds matrix wave p one 32-sample half-step ahead through a two-slot ring; one workgroup barrier per
+// half-step is the only synchronisation.  Gather waves never wait for matrix work, so the TA always has requests queued,
+// and the matrix waves (2 per SIMD) never wait for memory.  Ray -> pair scheduling, arithmetic and outputs are exactly
+// those of render_fused_kernel (tests compare the two; the binaries differ by an ulp where hipcc contracts
+// multiply-adds differently).  Measured at C2: 3.24 -> 2.56 ms per 65 536-ray batch.
+#pragma once
+
+namespace cn {
+
+// levels whose gathers a gather wave keeps in flight per lane (16 loads each; measured at C2: 1 -> 4.83, 2 -> 4.85,
+// 4 -> 4.92 Gsamples/s -- a gather wave has the registers to spare)
+#ifndef CN_SPLIT_LEVELS_IN_FLIGHT
+#define CN_SPLIT_LEVELS_IN_FLIGHT 4
+#endif
+// CN_SPLIT_G gather waves, each feeding CN_SPLIT_MPG matrix waves ("pairs" below = matrix waves = rays in flight)
+#ifndef CN_SPLIT_SEPARATE_LOOPS
+#define CN_SPLIT_SEPARATE_LOOPS 0
+#endif
+// Build variants that were measured and lost (kept for A/B runs), C2 workload, Gsamples/s:
+//   CN_SPLIT_SYNC_FLAGS=1     per-pair full/empty flags in LDS instead of the workgroup barrier     4.31 vs 4.89
+//   CN_SPLIT_SEPARATE_LOOPS=1 one loop per role instead of one loop with a role branch             4.65 vs 4.93
+//   CN_SPLIT_G x CN_SPLIT_MPG 4x3 / 5x2 / 4x2 / 6x1 (fewer gather waves, more matrix waves each)    3.49 / 3.82 / 4.43 / 4.17
+//   (8x1 = 4.93: with fewer gather waves the gather side becomes the bound, with 8x1 the matrix pipe is ~66 % busy)
+#ifndef CN_SPLIT_SYNC_FLAGS
+#define CN_SPLIT_SYNC_FLAGS 0
+#endif
+#ifndef CN_SPLIT_G
+#define CN_SPLIT_G 8
+#endif
+#ifndef CN_SPLIT_MPG
+#define CN_SPLIT_MPG 1
+#endif
+constexpr int SPLIT_G = CN_SPLIT_G, SPLIT_MPG = CN_SPLIT_MPG;
+constexpr int SPLIT_PAIRS = SPLIT_G * SPLIT_MPG;
+constexpr int SPLIT_THREADS = (SPLIT_G + SPLIT_PAIRS) * 64;
+static_assert(SPLIT_THREADS <= 1024, "at most 16 waves per workgroup");
+constexpr int XCH_FLOATS = 16 * 64 + 64;                        // one half-step: 16 feature floats + selector bits per lane
+constexpr int PAIR_SCRATCH = 2 * XCH_FLOATS + 64 + 68 + 68 + 4;  // ring | per-ray colour bias | matrix edges | gather edges | slot flags
+constexpr int PAIR_FLAGS = 2 * XCH_FLOATS + 64 + 68 + 68;
+constexpr size_t SPLIT_LDS_BYTES = (size_t)(BLOB_FLOATS + SPLIT_PAIRS * PAIR_SCRATCH) * sizeof(float);
+
+struct SplitRay {
+  float ox, oy, oz, dx, dy, dz, sn, sf;
+  const float* bins;
+  long long r;
+  bool valid;
+};
+
+// ray of schedule slot q for this pair (same mapping as render_fused_kernel)
+__device__ __forceinline__ void split_ray_setup(const FusedArgs& A, long long q, long long items, int xcd, bool striped,
+                                                long long rows, int cw, long long first_row, long long per_xcd,
+                                                SplitRay& ray) {
+  ray.valid = false;
+  if (q >= items) return;
+  long long rr;
+  if (striped) {
+    const long long sq = q / (rows * cw);
+    const long long qq = q - sq * rows * cw;
+    const long long vrow = qq / cw;
+    const int col = (int)(sq * 8 + xcd) * cw + (int)(qq - vrow * cw);
+    rr = (first_row + vrow) * A.image_width + col - A.pixel_start;
+    if (col >= A.image_width || rr < 0 || rr >= A.num_rays) return;
+  } else {
+    rr = xcd * per_xcd + q;
+  }
+  const long long r = __builtin_amdgcn_readfirstlane((int)rr);
+  ray.r = r;
+  ray.ox = A.origins[3 * r];
+  ray.oy = A.origins[3 * r + 1];
+  ray.oz = A.origins[3 * r + 2];
+  ray.dx = A.directions[3 * r];
+  ray.dy = A.directions[3 * r + 1];
+  ray.dz = A.directions[3 * r + 2];
+  ray.sn = spacing_fn(A.spacing, A.nears[r]);
+  ray.sf = spacing_fn(A.spacing, A.fars[r]);
+  ray.bins = A.bins ? A.bins + r * (long long)(A.S + 1) : nullptr;
+  ray.valid = true;
+}
+
+__device__ __forceinline__ float split_edge(const FusedArgs& A, const SplitRay& ray, int i) {
+  i = min(i, A.S);
+  return ray.bins ? ray.bins[i] : spacing_to_euclid(A.spacing, linspace01(i, A.S + 1), ray.sn, ray.sf);
+}
+
+__device__ __forceinline__ void split_fill_edges(const FusedArgs& A, const SplitRay& ray, int c0, float* tb, int lane) {
+  const float e_lo = split_edge(A, ray, c0 + lane);
+  const float e_top = split_edge(A, ray, c0 + 64);
+  __builtin_amdgcn_wave_barrier();
+  tb[lane] = e_lo;
+  if (lane == 0) tb[64] = e_top;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void split_wait_flag(int* flag, int want) {
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != want) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  asm volatile("" ::: "memory");  // also keeps the (loop-invariant) weight reads of the MFMA chain from being hoisted
+}
+__device__ __forceinline__ void split_set_flag(int* flag, int v) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+}
+
+__global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A) {
+  extern __shared__ __align__(16) float lds[];
+  {
+    const float4* src = reinterpret_cast<const float4*>(A.blob);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    for (int i = threadIdx.x; i < BLOB_FLOATS / 4; i += SPLIT_THREADS) dst[i] = src[i];
+    if (threadIdx.x < SPLIT_PAIRS * 4)
+      reinterpret_cast<int*>(lds + BLOB_FLOATS + (threadIdx.x >> 2) * PAIR_SCRATCH + PAIR_FLAGS)[threadIdx.x & 3] = 0;
+  }
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane0 = lane_id();
+  const bool matrix_role = wave >= SPLIT_G;
+  const int pair = matrix_role ? wave - SPLIT_G : wave * SPLIT_MPG;  // matrix wave: its own; gather wave: its first
+  float* ps = lds + BLOB_FLOATS + pair * PAIR_SCRATCH;
+  float* ring = ps;
+  float* scratch = ps + 2 * XCH_FLOATS;  // per-ray colour bias (written and read by the matrix wave only)
+  float* tb_m = scratch + 64;
+  const int S = A.S;
+
+  const int xcd = blockIdx.x & 7;
+  const int slot = blockIdx.x >> 3;
+  const long long stride = (long long)(gridDim.x >> 3) * SPLIT_PAIRS;
+  const bool striped = A.image_width > 0;
+  const long long per_xcd = (A.num_rays + 7) >> 3;
+  const int nstripe = 8 * A.stripes_per_xcd;
+  const int cw = striped ? (A.image_width + nstripe - 1) / nstripe : 0;
+  const long long first_row = striped ? A.pixel_start / A.image_width : 0;
+  const long long last_row = striped ? (A.pixel_start + A.num_rays - 1) / A.image_width : 0;
+  const long long rows = last_row - first_row + 1;
+  const long long items =
+      striped ? rows * cw * A.stripes_per_xcd : min(per_xcd, max(A.num_rays - xcd * per_xcd, 0LL));
+
+  // every wave of the workgroup runs the same number of half-steps (the barrier count must match): the schedule slots
+  // of pair 0, the longest list; a slot without a ray (past the end, outside the image) is an idle step
+  const long long q_first = (long long)slot * SPLIT_PAIRS;
+  const long long n_q = q_first < items ? (items - q_first + stride - 1) / stride : 0;
+  const int nhalf = 2 * ((S + 63) >> 6);
+  const long long total = n_q * nhalf;
+
+  SplitRay ray;
+  ray.valid = false;
+  SplitRay gray[SPLIT_MPG];  // gather wave: the rays of the matrix waves it feeds
+#pragma unroll
+  for (int m = 0; m < SPLIT_MPG; ++m) gray[m].valid = false;
+  CompositeState st;
+  float my_dlogit = 0.f, my_sel = 0.f, my_sem = 0.f, my_r = 0.f, my_g = 0.f, my_b = 0.f;
+
+  // The two roles run separate loops (same trip count, one barrier per iteration) so that neither role's registers are
+  // live in the other's code.
+#if CN_SPLIT_SEPARATE_LOOPS
+  if (!matrix_role) {
+    for (long long step = 0; step <= total; ++step) {
+#else
+  for (long long step = 0; step <= total; ++step) {
+    if (!matrix_role) {
+#endif
+      // ================= gather wave: produce half-step `step` =======================================================
+      // (lane coordinates through an empty volatile asm per iteration: keeps LICM from hoisting every lane-dependent
+      //  LDS address out of the loop and spilling them)
+      int lane = lane0;
+      asm volatile("" : "+v"(lane));
+      const int g = lane >> 4, j = lane & 15;
+      if (step < total) {
+        const long long qi = step / nhalf;
+        const int k = (int)(step - qi * nhalf);
+#pragma unroll
+        for (int m = 0; m < SPLIT_MPG; ++m) {
+          SplitRay& gr = gray[m];
+          float* gring = ring + m * PAIR_SCRATCH;
+          float* tb_g = gring + 2 * XCH_FLOATS + 64 + 68;
+          if (k == 0)
+            split_ray_setup(A, q_first + pair + m + qi * stride, items, xcd, striped, rows, cw, first_row, per_xcd, gr);
+          if (gr.valid) {
+            const int chunk = k >> 1, half = k & 1;
+#if CN_SPLIT_SYNC_FLAGS
+            // wait for the slot BEFORE the gathers are issued: nothing but the ray state is live across the spin
+            int* flag = reinterpret_cast<int*>(gring + PAIR_FLAGS) + (int)(step & 1);
+            split_wait_flag(flag, 0);
+#endif
+            if (half == 0) split_fill_edges(A, gr, chunk * 64, tb_g, lane);
+            float px[2], py[2], pz[2];
+            bool sel[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              const int kk = 32 * half + 16 * c + j;
+              const float mid = (tb_g[kk] + tb_g[kk + 1]) / 2.f;
+              px[c] = gr.ox + gr.dx * mid;
+              py[c] = gr.oy + gr.dy * mid;
+              pz[c] = gr.oz + gr.dz * mid;
+              sel[c] = normalize_position(A.scene, px[c], py[c], pz[c]);
+            }
+            f32x4 feat[2][2];
+            const f32x4 lvl_scale = *reinterpret_cast<const f32x4*>(lds + OFF_SCALE + 4 * g);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const unsigned level_off = (unsigned)(4 * g + q) * A.grid.level_stride;
+              const float scale = lvl_scale[q];
+#pragma unroll
+              for (int c = 0; c < 2; ++c) {
+                const float2 f = hash_level(A.grid.table, level_off, A.grid.mask, scale, px[c], py[c], pz[c]);
+                if (q == 0) { feat[c][0].x = f.x; feat[c][0].y = f.y; }
+                if (q == 1) { feat[c][0].z = f.x; feat[c][0].w = f.y; }
+                if (q == 2) { feat[c][1].x = f.x; feat[c][1].y = f.y; }
+                if (q == 3) { feat[c][1].z = f.x; feat[c][1].w = f.y; }
+              }
+              if ((q + 1) % CN_SPLIT_LEVELS_IN_FLIGHT == 0)
+                __builtin_amdgcn_sched_barrier(0);  // bound the gathers in flight (16 per lane and level)
+            }
+            float* xs = gring + (int)(step & 1) * XCH_FLOATS;
+            f32x4* xv = reinterpret_cast<f32x4*>(xs);
+            xv[0 * 64 + lane] = feat[0][0];
+            xv[1 * 64 + lane] = feat[0][1];
+            xv[2 * 64 + lane] = feat[1][0];
+            xv[3 * 64 + lane] = feat[1][1];
+            xs[1024 + lane] = (sel[0] ? 1.f : 0.f) + (sel[1] ? 2.f : 0.f);
+#if CN_SPLIT_SYNC_FLAGS
+            split_set_flag(flag, 1);
+#endif
+          }
+          __builtin_amdgcn_sched_barrier(0);  // one consumer's half-step at a time
+        }
+      }
+#if CN_SPLIT_SEPARATE_LOOPS
+#if !CN_SPLIT_SYNC_FLAGS
+      __syncthreads();
+#endif
+    }
+    return;
+  }
+  for (long long step = 0; step <= total; ++step) {
+    if (step >= 1) {
+#else
+    } else if (step >= 1) {
+#endif
+      // ================= matrix wave: consume half-step `step - 1` ===================================================
+      int lane = lane0;
+      asm volatile("" : "+v"(lane));
+      const int g = lane >> 4, j = lane & 15;
+      (void)j;
+      const long long hs = step - 1;
+      const long long qi = hs / nhalf;
+      const int k = (int)(hs - qi * nhalf);
+      if (k == 0) {
+        split_ray_setup(A, q_first + pair + qi * stride, items, xcd, striped, rows, cw, first_row, per_xcd, ray);
+        st = CompositeState();
+        if (ray.valid) {
+          // per-ray colour bias: bc0 + Wc0[:, sh].SH(d) + Wc0[:, app].app  (lane n = neuron n)
+          float sx = ray.dx, sy = ray.dy, sz = ray.dz;
+          if (!A.sh_unit) {
+            sx = (sx + 1.f) / 2.f;
+            sy = (sy + 1.f) / 2.f;
+            sz = (sz + 1.f) / 2.f;
+          }
+          float sh[16];
+          sh_deg4(sx, sy, sz, sh);
+          const long long row = A.app_per_camera ? A.cam_idx[ray.r] : 0;
+          float bias = A.app_bias[row * 64 + lane];
+          const f32x4* wsh = reinterpret_cast<const f32x4*>(lds + OFF_WSH + lane * 16);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 w = wsh[q];
+            bias = fmaf(w.x, sh[4 * q + 0], bias);
+            bias = fmaf(w.y, sh[4 * q + 1], bias);
+            bias = fmaf(w.z, sh[4 * q + 2], bias);
+            bias = fmaf(w.w, sh[4 * q + 3], bias);
+          }
+          __builtin_amdgcn_wave_barrier();
+          scratch[lane] = bias;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      if (ray.valid) {
+        const int chunk = k >> 1, half = k & 1;
+        const int c0 = chunk * 64;
+        if (half == 0) {
+          split_fill_edges(A, ray, c0, tb_m, lane);
+          my_dlogit = my_sel = my_sem = my_r = my_g = my_b = 0.f;
+        }
+        const float* xs = ring + (int)(hs & 1) * XCH_FLOATS;
+        const f32x4* xv = reinterpret_cast<const f32x4*>(xs);
+#if CN_SPLIT_SYNC_FLAGS
+        split_wait_flag(reinterpret_cast<int*>(ring + PAIR_FLAGS) + (int)(hs & 1), 1);
+#endif
+        f32x4 feat[2][2];
+        feat[0][0] = xv[0 * 64 + lane];
+        feat[0][1] = xv[1 * 64 + lane];
+        feat[1][0] = xv[2 * 64 + lane];
+        feat[1][1] = xv[3 * 64 + lane];
+        const int selbits = (int)xs[1024 + lane];
+#if CN_SPLIT_SYNC_FLAGS
+        split_set_flag(reinterpret_cast<int*>(ring + PAIR_FLAGS) + (int)(hs & 1), 0);  // slot read: the gather wave may refill it
+#endif
+        // ---- base MLP layer 0: 32 -> 64, ReLU ------------------------------------------------------------------------
+        f32x4 h[4][2];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B0 + 16 * mt + 4 * g);
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(lds + OFF_A0 + ((mt * 2 + 0) * 64 + lane) * 4);
+          const f32x4 a1 = *reinterpret_cast<const f32x4*>(lds + OFF_A0 + ((mt * 2 + 1) * 64 + lane) * 4);
+          f32x4 acc[2] = {b, b};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[c] = MFMA(a0[e], feat[c][0][e], acc[c]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[c] = MFMA(a1[e], feat[c][1][e], acc[c]);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) h[mt][c] = relu4(acc[c]);
+        }
+        // ---- base MLP layer 1: 64 -> 16 ---------------------------------------------------------------------------------
+        f32x4 o16[2];
+        {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B1 + 4 * g);
+          f32x4 acc[2] = {b, b};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_A1 + (t * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int c = 0; c < 2; ++c) acc[c] = MFMA(a[e], h[t][c][e], acc[c]);
+          }
+          o16[0] = acc[0];
+          o16[1] = acc[1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bool mine = (g >> 1) == half;
+        const bool odd = (g & 1) != 0;
+        {
+          const float d0 = row0_broadcast(o16[0].x), d1 = row0_broadcast(o16[1].x);
+          const float dsel = odd ? d1 : d0;
+          const float ssel = (selbits & (odd ? 2 : 1)) ? 1.f : 0.f;
+          my_dlogit = mine ? dsel : my_dlogit;
+          my_sel = mine ? ssel : my_sel;
+        }
+        // ---- semantics ------------------------------------------------------------------------------------------------------
+        float sem_part[2] = {0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_BS0 + 16 * mt + 4 * g);
+          const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_AS0 + (mt * 64 + lane) * 4);
+          const f32x4 wf = *reinterpret_cast<const f32x4*>(lds + OFF_WF + 16 * mt + 4 * g);
+          f32x4 acc[2] = {b, b};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[c] = MFMA(a[e], o16[c][e], acc[c]);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) sem_part[c] = dot4(wf, relu4(acc[c]), sem_part[c]);
+        }
+        // ---- colour layer 0 ----------------------------------------------------------------------------------------------------
+        f32x4 c1[4][2];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_AC0 + (mt * 64 + lane) * 4);
+          const f32x4 cb = *reinterpret_cast<const f32x4*>(scratch + 16 * mt + 4 * g);
+          f32x4 acc[2] = {cb, cb};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[c] = MFMA(a[e], o16[c][e], acc[c]);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) c1[mt][c] = relu4(acc[c]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- colour layer 1 + rgb head -------------------------------------------------------------------------------------------
+        float rgb_part[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_BC1 + 16 * mt + 4 * g);
+          f32x4 acc[2] = {b, b};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_AC1 + ((mt * 4 + t) * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int c = 0; c < 2; ++c) acc[c] = MFMA(a[e], c1[t][c][e], acc[c]);
+          }
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(lds + OFF_WRGB + 0 * 64 + 16 * mt + 4 * g);
+          const f32x4 w1 = *reinterpret_cast<const f32x4*>(lds + OFF_WRGB + 1 * 64 + 16 * mt + 4 * g);
+          const f32x4 w2 = *reinterpret_cast<const f32x4*>(lds + OFF_WRGB + 2 * 64 + 16 * mt + 4 * g);
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const f32x4 v = relu4(acc[c]);
+            rgb_part[c][0] = dot4(w0, v, rgb_part[c][0]);
+            rgb_part[c][1] = dot4(w1, v, rgb_part[c][1]);
+            rgb_part[c][2] = dot4(w2, v, rgb_part[c][2]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          const float s0 = group_sum(sem_part[0]), s1 = group_sum(sem_part[1]);
+          my_sem = mine ? (odd ? s1 : s0) : my_sem;
+          const float r0 = group_sum(rgb_part[0][0]), r1 = group_sum(rgb_part[1][0]);
+          my_r = mine ? (odd ? r1 : r0) : my_r;
+          const float g0 = group_sum(rgb_part[0][1]), g1 = group_sum(rgb_part[1][1]);
+          my_g = mine ? (odd ? g1 : g0) : my_g;
+          const float b0 = group_sum(rgb_part[0][2]), b1 = group_sum(rgb_part[1][2]);
+          my_b = mine ? (odd ? b1 : b0) : my_b;
+        }
+        if (half == 1) {
+          // ---- lane l holds sample c0 + l: composite the chunk -----------------------------------------------------------
+          const float density = expf(my_dlogit) * my_sel;
+          const float sem = my_sem + lds[OFF_MISC + 0];
+          const float cr = sigmoidf(my_r + lds[OFF_MISC + 1]);
+          const float cg = sigmoidf(my_g + lds[OFF_MISC + 2]);
+          const float cb = sigmoidf(my_b + lds[OFF_MISC + 3]);
+          const int i = c0 + lane;
+          const bool valid = i < S;
+          const float e0 = tb_m[lane], e1 = tb_m[lane + 1];
+          const float mid = (e0 + e1) / 2.f;
+          const float w = composite_chunk(st, valid, i == S - 1, e1 - e0, density, mid, cr, cg, cb, sem, A.eval_clamp != 0);
+          if (A.out_w && valid) A.out_w[ray.r * (long long)S + i] = w;
+          if (k == nhalf - 1) {
+            const CompositeOut o = composite_finish(st, A.bg_mode, A.bg[0], A.bg[1], A.bg[2], A.eval_clamp != 0);
+            if (lane == 0) {
+              const long long r = ray.r;
+              if (A.out_acc) A.out_acc[r] = o.acc;
+              if (A.out_depth) A.out_depth[r] = o.depth;
+              if (A.out_rgb) {
+                A.out_rgb[3 * r + 0] = o.r;
+                A.out_rgb[3 * r + 1] = o.g;
+                A.out_rgb[3 * r + 2] = o.b;
+              }
+              if (A.out_sem) A.out_sem[r] = o.sem;
+              if (A.out_cmap) {
+                const float l = semantics_label(o.sem);
+                A.out_cmap[3 * r + 0] = l;
+                A.out_cmap[3 * r + 1] = l;
+                A.out_cmap[3 * r + 2] = l;
+              }
+            }
+          }
+        }
+      }
+    }
+#if !CN_SPLIT_SYNC_FLAGS
+    __syncthreads();
+#endif
+  }
+}
+
+}  // namespace cn

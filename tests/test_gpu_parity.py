@@ -568,3 +568,33 @@ def test_early_stop_is_off_by_default_and_bounded_when_on(scene, ops, eps):
     # where a ray was not stopped nothing changes at all
     kept = ~(cut["weights"] == 0).all(dim=1) & (cut["weights"][:, -1] != 0)
     assert torch.equal(cut["rgb"][kept], full["rgb"][kept])
+
+
+@pytest.mark.parametrize("S,width", [(48, 0), (192, 40), (100, 37), (7, 0)])
+def test_split_kernel_matches_fused(scene, ops, handles, S, width, monkeypatch):
+    """render_split_kernel (gather waves feeding matrix waves through LDS) is a re-scheduling of render_fused_kernel:
+    same arithmetic in the same order; the two binaries differ only in where hipcc contracts multiply-adds, i.e. by an
+    ulp here and there (measured <= 3e-7 on O(1) outputs) -- with and without the image hint, with per-camera
+    appearance, proposal bins, ragged S and weights requested.  Median depth and the label image are exact."""
+    dp, fh, dh = handles
+    rb = rays_with_box(scene, 1)
+    g = torch.Generator().manual_seed(S)
+    idx = torch.randint(0, len(rb), (1237,), generator=g)
+    o, d, n, f = (to_dev(t[idx]) for t in (rb.origins, rb.directions, rb.nears, rb.fars))
+    cam = torch.randint(0, scene.c2w.shape[0], (1237,), generator=g).cuda()
+    sc = ops.scene_struct(scene.aabb, True)
+    bins = None
+    if S == 48:
+        ps = ops.proposal_sample(dh, sc, o, d, n, f, (64, 32), S)
+        bins = ps["euclidean_bins"]
+    opts = ops.render_opts(S, app_mode=2, image_width=width, pixel_start=3 if width else 0, eval_clamp=S != 100)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CN_FUSED_SPLIT", mode)
+        outs[mode] = ops.render_rays(fh, sc, opts, o, d, n, f, camera_indices=cam, bins=bins, want_weights=True)
+    for k in outs["0"]:
+        if k in ("depth", "semantics_colormap"):
+            assert torch.equal(outs["0"][k], outs["1"][k]), k
+        else:
+            assert_close(outs["1"][k], outs["0"][k], 2e-6, 1e-6, f"split vs fused {k}")
+    assert torch.isfinite(outs["1"]["rgb"]).all()
