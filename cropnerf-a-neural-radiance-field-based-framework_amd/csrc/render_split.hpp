@@ -30,6 +30,11 @@ namespace cn {
 //   CN_SPLIT_SEPARATE_LOOPS=1 one loop per role instead of one loop with a role branch             4.65 vs 4.93
 //   CN_SPLIT_G x CN_SPLIT_MPG 4x3 / 5x2 / 4x2 / 6x1 (fewer gather waves, more matrix waves each)    3.49 / 3.82 / 4.43 / 4.17
 //   (8x1 = 4.93: with fewer gather waves the gather side becomes the bound, with 8x1 the matrix pipe is ~66 % busy)
+//   deferring the compositing of one of the two matrix waves of a SIMD to its next half-step (so that the two do not
+//   reach that VALU-only tail together): 4.88 vs 4.89 -- no gain, removed again
+// Ablation builds of this kernel (timing only): -DCN_ABLATE_GATHER=1 2.12 ms, -DCN_ABLATE_MLP=1 1.81 ms, both 1.36 ms
+// per C2 batch against 2.56 ms for the real thing: the matrix side (2.12) is the longer one, and ~1 ms of every variant
+// is the non-gather, non-MFMA work (addresses, blends, activations, compositing, LDS traffic, barriers).
 #ifndef CN_SPLIT_SYNC_FLAGS
 #define CN_SPLIT_SYNC_FLAGS 0
 #endif
@@ -212,7 +217,11 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
               const float scale = lvl_scale[q];
 #pragma unroll
               for (int c = 0; c < 2; ++c) {
+#if CN_ABLATE_GATHER  // timing-only build: no table reads
+                const float2 f = make_float2(px[c] * scale, py[c] + pz[c]);
+#else
                 const float2 f = hash_level(A.grid.table, level_off, A.grid.mask, scale, px[c], py[c], pz[c]);
+#endif
                 if (q == 0) { feat[c][0].x = f.x; feat[c][0].y = f.y; }
                 if (q == 1) { feat[c][0].z = f.x; feat[c][0].w = f.y; }
                 if (q == 2) { feat[c][1].x = f.x; feat[c][1].y = f.y; }
