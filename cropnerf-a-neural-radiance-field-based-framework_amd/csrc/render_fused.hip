@@ -1002,23 +1002,30 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   // (the environment is read per call so that one process can compare both forms)
   const char* split_env = getenv("CN_FUSED_SPLIT");
   const int split_mode = split_env ? atoi(split_env) : CN_FUSED_SPLIT_DEFAULT;
-  if (!PER_SAMPLE && !opts->density_only && split_mode && A.early_stop == 0.f) {
+  if (!opts->density_only && split_mode && (PER_SAMPLE || A.early_stop == 0.f)) {
     static int resident = 0;  // workgroups the device holds at once (a multiple of 8 = XCD teams)
     if (!resident) {
       int dev = 0, cus = 256, per_cu = 1;
       if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS_BYTES);
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_split_kernel, SPLIT_THREADS, SPLIT_LDS_BYTES) !=
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS_BYTES);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_split_kernel<false>, SPLIT_THREADS, SPLIT_LDS_BYTES) !=
               hipSuccess || per_cu < 1)
         per_cu = 1;
       resident = cus * per_cu;
       resident = resident >= 8 ? (resident / 8) * 8 : 8;
     }
-    const long long want_s = (((num_rays + SPLIT_PAIRS - 1) / SPLIT_PAIRS) + 7) / 8 * 8;
-    const unsigned nb = (unsigned)(want_s < resident ? want_s : resident);
-    hipLaunchKernelGGL(render_split_kernel, dim3(nb), dim3(SPLIT_THREADS), SPLIT_LDS_BYTES, s, A);
-    return check_launch(who);
+    const long long work = PER_SAMPLE ? num_rays * ((opts->num_samples + 63) / 64) : num_rays;  // (ray, chunk) items
+    const long long want_s = (((work + SPLIT_PAIRS - 1) / SPLIT_PAIRS) + 7) / 8 * 8;
+    // one workgroup per CU carries 8 rays at a time: with fewer rays than that fills the device (the exporters' 512-ray
+    // x 3000-sample calls) the 4-wave workgroups of render_fused_kernel spread over more CUs
+    if (want_s >= resident || split_mode > 1) {
+      const unsigned nb = (unsigned)(want_s < resident ? want_s : resident);
+      hipLaunchKernelGGL(render_split_kernel<PER_SAMPLE>, dim3(nb), dim3(SPLIT_THREADS), SPLIT_LDS_BYTES, s, A);
+      return check_launch(who);
+    }
   }
   if (PER_SAMPLE) {
     hipLaunchKernelGGL((render_fused_kernel<true, false>), dim3(blocks), dim3(FUSED_THREADS), 0, s, A);

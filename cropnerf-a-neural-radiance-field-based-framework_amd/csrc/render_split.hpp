@@ -57,14 +57,16 @@ struct SplitRay {
   float ox, oy, oz, dx, dy, dz, sn, sf;
   const float* bins;
   long long r;
+  int chunk;  // per-sample outputs: the 64-sample chunk this work item covers
   bool valid;
 };
 
 // ray of schedule slot q for this pair (same mapping as render_fused_kernel)
 __device__ __forceinline__ void split_ray_setup(const FusedArgs& A, long long q, long long items, int xcd, bool striped,
                                                 long long rows, int cw, long long first_row, long long per_xcd,
-                                                SplitRay& ray) {
+                                                int chunks_per_ray, SplitRay& ray) {
   ray.valid = false;
+  ray.chunk = 0;
   if (q >= items) return;
   long long rr;
   if (striped) {
@@ -76,6 +78,10 @@ __device__ __forceinline__ void split_ray_setup(const FusedArgs& A, long long q,
     if (col >= A.image_width || rr < 0 || rr >= A.num_rays) return;
   } else {
     rr = xcd * per_xcd + q;
+  }
+  if (chunks_per_ray > 0) {  // work items are (ray, chunk) pairs
+    ray.chunk = (int)(rr % chunks_per_ray);
+    rr /= chunks_per_ray;
   }
   const long long r = __builtin_amdgcn_readfirstlane((int)rr);
   ray.r = r;
@@ -117,6 +123,7 @@ __device__ __forceinline__ void split_set_flag(int* flag, int v) {
   asm volatile("" ::: "memory");
 }
 
+template <bool PER_SAMPLE>
 __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A) {
   extern __shared__ __align__(16) float lds[];
   {
@@ -140,21 +147,26 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
   const int xcd = blockIdx.x & 7;
   const int slot = blockIdx.x >> 3;
   const long long stride = (long long)(gridDim.x >> 3) * SPLIT_PAIRS;
-  const bool striped = A.image_width > 0;
-  const long long per_xcd = (A.num_rays + 7) >> 3;
+  // Per-sample outputs have no dependency between the chunks of a ray, so the work items are (ray, 64-sample chunk)
+  // pairs: the exporters' 512-ray x 3000-sample calls then fill the device (24 064 items instead of 512).
+  const int nchunks = (S + 63) >> 6;
+  const int chunks_per_item_ray = PER_SAMPLE ? nchunks : 0;
+  const long long nwork = PER_SAMPLE ? A.num_rays * nchunks : A.num_rays;
+  const bool striped = !PER_SAMPLE && A.image_width > 0;
+  const long long per_xcd = (nwork + 7) >> 3;
   const int nstripe = 8 * A.stripes_per_xcd;
   const int cw = striped ? (A.image_width + nstripe - 1) / nstripe : 0;
   const long long first_row = striped ? A.pixel_start / A.image_width : 0;
   const long long last_row = striped ? (A.pixel_start + A.num_rays - 1) / A.image_width : 0;
   const long long rows = last_row - first_row + 1;
   const long long items =
-      striped ? rows * cw * A.stripes_per_xcd : min(per_xcd, max(A.num_rays - xcd * per_xcd, 0LL));
+      striped ? rows * cw * A.stripes_per_xcd : min(per_xcd, max(nwork - xcd * per_xcd, 0LL));
 
   // every wave of the workgroup runs the same number of half-steps (the barrier count must match): the schedule slots
   // of pair 0, the longest list; a slot without a ray (past the end, outside the image) is an idle step
   const long long q_first = (long long)slot * SPLIT_PAIRS;
   const long long n_q = q_first < items ? (items - q_first + stride - 1) / stride : 0;
-  const int nhalf = 2 * ((S + 63) >> 6);
+  const int nhalf = PER_SAMPLE ? 2 : 2 * nchunks;
   const long long total = n_q * nhalf;
 
   SplitRay ray;
@@ -189,9 +201,9 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
           float* gring = ring + m * PAIR_SCRATCH;
           float* tb_g = gring + 2 * XCH_FLOATS + 64 + 68;
           if (k == 0)
-            split_ray_setup(A, q_first + pair + m + qi * stride, items, xcd, striped, rows, cw, first_row, per_xcd, gr);
+            split_ray_setup(A, q_first + pair + m + qi * stride, items, xcd, striped, rows, cw, first_row, per_xcd, chunks_per_item_ray, gr);
           if (gr.valid) {
-            const int chunk = k >> 1, half = k & 1;
+            const int chunk = PER_SAMPLE ? gr.chunk : (k >> 1), half = k & 1;
 #if CN_SPLIT_SYNC_FLAGS
             // wait for the slot BEFORE the gathers are issued: nothing but the ray state is live across the spin
             int* flag = reinterpret_cast<int*>(gring + PAIR_FLAGS) + (int)(step & 1);
@@ -265,7 +277,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
       const long long qi = hs / nhalf;
       const int k = (int)(hs - qi * nhalf);
       if (k == 0) {
-        split_ray_setup(A, q_first + pair + qi * stride, items, xcd, striped, rows, cw, first_row, per_xcd, ray);
+        split_ray_setup(A, q_first + pair + qi * stride, items, xcd, striped, rows, cw, first_row, per_xcd, chunks_per_item_ray, ray);
         st = CompositeState();
         if (ray.valid) {
           // per-ray colour bias: bc0 + Wc0[:, sh].SH(d) + Wc0[:, app].app  (lane n = neuron n)
@@ -295,7 +307,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
         }
       }
       if (ray.valid) {
-        const int chunk = k >> 1, half = k & 1;
+        const int chunk = PER_SAMPLE ? ray.chunk : (k >> 1), half = k & 1;
         const int c0 = chunk * 64;
         if (half == 0) {
           split_fill_edges(A, ray, c0, tb_m, lane);
@@ -437,6 +449,24 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
           const bool valid = i < S;
           const float e0 = tb_m[lane], e1 = tb_m[lane + 1];
           const float mid = (e0 + e1) / 2.f;
+          if (PER_SAMPLE) {
+            if (valid) {
+              const long long o = ray.r * (long long)S + i;
+              if (A.s_density) A.s_density[o] = density;
+              if (A.s_sem) A.s_sem[o] = sem;
+              if (A.s_label) A.s_label[o] = (int64_t)semantics_label(sem);
+              if (A.s_rgb) {
+                A.s_rgb[3 * o + 0] = cr;
+                A.s_rgb[3 * o + 1] = cg;
+                A.s_rgb[3 * o + 2] = cb;
+              }
+              if (A.s_pos) {
+                A.s_pos[3 * o + 0] = ray.ox + ray.dx * mid;
+                A.s_pos[3 * o + 1] = ray.oy + ray.dy * mid;
+                A.s_pos[3 * o + 2] = ray.oz + ray.dz * mid;
+              }
+            }
+          } else {
           const float w = composite_chunk(st, valid, i == S - 1, e1 - e0, density, mid, cr, cg, cb, sem, A.eval_clamp != 0);
           if (A.out_w && valid) A.out_w[ray.r * (long long)S + i] = w;
           if (k == nhalf - 1) {
@@ -459,6 +489,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
               }
             }
           }
+          }  // !PER_SAMPLE
         }
       }
     }

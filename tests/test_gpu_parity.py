@@ -590,7 +590,7 @@ def test_split_kernel_matches_fused(scene, ops, handles, S, width, monkeypatch):
     opts = ops.render_opts(S, app_mode=2, image_width=width, pixel_start=3 if width else 0, eval_clamp=S != 100)
     outs = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("CN_FUSED_SPLIT", mode)
+        monkeypatch.setenv("CN_FUSED_SPLIT", "2" if mode == "1" else "0")  # 2 = split even for small batches
         outs[mode] = ops.render_rays(fh, sc, opts, o, d, n, f, camera_indices=cam, bins=bins, want_weights=True)
     for k in outs["0"]:
         if k in ("depth", "semantics_colormap"):
@@ -598,3 +598,19 @@ def test_split_kernel_matches_fused(scene, ops, handles, S, width, monkeypatch):
         else:
             assert_close(outs["1"][k], outs["0"][k], 2e-6, 1e-6, f"split vs fused {k}")
     assert torch.isfinite(outs["1"]["rgb"]).all()
+
+
+@pytest.mark.parametrize("S,contraction", [(70, False), (128, True)])
+def test_split_kernel_per_sample_outputs_match_fused(scene, ops, handles, S, contraction, monkeypatch):
+    """The export-mode forward (cn_render_samples) in its producer/consumer form against the single-wave form."""
+    dp, fh, dh = handles
+    rb = rays_with_box(scene, 2)
+    o, d, n, f = (to_dev(t[100:611]) for t in (rb.origins, rb.directions, rb.nears, rb.fars))
+    sc = ops.scene_struct(scene.aabb, contraction)
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CN_FUSED_SPLIT", "2" if mode == "1" else "0")  # 2 = split even for small batches
+        outs[mode] = ops.render_samples(fh, sc, ops.render_opts(S), o, d, n, f)
+    assert torch.equal(outs["0"]["semantics_colormap"], outs["1"]["semantics_colormap"])
+    for k in ("density", "rgb", "semantics", "positions"):
+        assert_close(outs["1"][k], outs["0"][k], 2e-6, 1e-6, f"split vs fused per-sample {k}")
