@@ -48,7 +48,13 @@ constexpr int SPLIT_G = CN_SPLIT_G, SPLIT_MPG = CN_SPLIT_MPG;
 constexpr int SPLIT_PAIRS = SPLIT_G * SPLIT_MPG;
 constexpr int SPLIT_THREADS = (SPLIT_G + SPLIT_PAIRS) * 64;
 static_assert(SPLIT_THREADS <= 1024, "at most 16 waves per workgroup");
-constexpr int XCH_FLOATS = 16 * 64 + 64;                        // one half-step: 16 feature floats + selector bits per lane
+// 1: the gather waves also run the base MLP (96 of the 288 MFMAs of a half-step) and hand over its 16 outputs.  Measured
+// slower (4.29 vs 4.87 Gsamples/s): the MFMAs extend the gather wave's serial chain behind the gather latency.
+#ifndef CN_SPLIT_BASE_IN_GATHER
+#define CN_SPLIT_BASE_IN_GATHER 0
+#endif
+// one half-step in the ring: per lane 16 feature floats (or the 8 base-MLP outputs) + selector bits
+constexpr int XCH_FLOATS = (CN_SPLIT_BASE_IN_GATHER ? 8 : 16) * 64 + 64;
 constexpr int PAIR_SCRATCH = 2 * XCH_FLOATS + 64 + 68 + 68 + 4;  // ring | per-ray colour bias | matrix edges | gather edges | slot flags
 constexpr int PAIR_FLAGS = 2 * XCH_FLOATS + 64 + 68 + 68;
 constexpr size_t SPLIT_LDS_BYTES = (size_t)(BLOB_FLOATS + SPLIT_PAIRS * PAIR_SCRATCH) * sizeof(float);
@@ -244,11 +250,54 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
             }
             float* xs = gring + (int)(step & 1) * XCH_FLOATS;
             f32x4* xv = reinterpret_cast<f32x4*>(xs);
+#if CN_SPLIT_BASE_IN_GATHER
+            // the base MLP (96 of the 288 MFMAs of a half-step) runs here: the matrix pipe gets work from four waves per
+            // SIMD instead of two, the two sides of the hand-off are closer in length, and the slot shrinks to 16 floats
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- base MLP layer 0: 32 -> 64, ReLU ------------------------------------------------------------------------
+            f32x4 h[4][2];
+    #pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+              const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B0 + 16 * mt + 4 * g);
+              const f32x4 a0 = *reinterpret_cast<const f32x4*>(lds + OFF_A0 + ((mt * 2 + 0) * 64 + lane) * 4);
+              const f32x4 a1 = *reinterpret_cast<const f32x4*>(lds + OFF_A0 + ((mt * 2 + 1) * 64 + lane) * 4);
+              f32x4 acc[2] = {b, b};
+    #pragma unroll
+              for (int e = 0; e < 4; ++e)
+    #pragma unroll
+                for (int c = 0; c < 2; ++c) acc[c] = MFMA(a0[e], feat[c][0][e], acc[c]);
+    #pragma unroll
+              for (int e = 0; e < 4; ++e)
+    #pragma unroll
+                for (int c = 0; c < 2; ++c) acc[c] = MFMA(a1[e], feat[c][1][e], acc[c]);
+    #pragma unroll
+              for (int c = 0; c < 2; ++c) h[mt][c] = relu4(acc[c]);
+            }
+            // ---- base MLP layer 1: 64 -> 16 ---------------------------------------------------------------------------------
+            f32x4 o16[2];
+            {
+              const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B1 + 4 * g);
+              f32x4 acc[2] = {b, b};
+    #pragma unroll
+              for (int t = 0; t < 4; ++t) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_A1 + (t * 64 + lane) * 4);
+    #pragma unroll
+                for (int e = 0; e < 4; ++e)
+    #pragma unroll
+                  for (int c = 0; c < 2; ++c) acc[c] = MFMA(a[e], h[t][c][e], acc[c]);
+              }
+              o16[0] = acc[0];
+              o16[1] = acc[1];
+            }
+            xv[0 * 64 + lane] = o16[0];
+            xv[1 * 64 + lane] = o16[1];
+#else
             xv[0 * 64 + lane] = feat[0][0];
             xv[1 * 64 + lane] = feat[0][1];
             xv[2 * 64 + lane] = feat[1][0];
             xv[3 * 64 + lane] = feat[1][1];
-            xs[1024 + lane] = (sel[0] ? 1.f : 0.f) + (sel[1] ? 2.f : 0.f);
+#endif
+            xs[XCH_FLOATS - 64 + lane] = (sel[0] ? 1.f : 0.f) + (sel[1] ? 2.f : 0.f);
 #if CN_SPLIT_SYNC_FLAGS
             split_set_flag(flag, 1);
 #endif
@@ -318,15 +367,22 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
 #if CN_SPLIT_SYNC_FLAGS
         split_wait_flag(reinterpret_cast<int*>(ring + PAIR_FLAGS) + (int)(hs & 1), 1);
 #endif
+#if !CN_SPLIT_BASE_IN_GATHER
         f32x4 feat[2][2];
         feat[0][0] = xv[0 * 64 + lane];
         feat[0][1] = xv[1 * 64 + lane];
         feat[1][0] = xv[2 * 64 + lane];
         feat[1][1] = xv[3 * 64 + lane];
-        const int selbits = (int)xs[1024 + lane];
+#endif
+        const int selbits = (int)xs[XCH_FLOATS - 64 + lane];
 #if CN_SPLIT_SYNC_FLAGS
         split_set_flag(reinterpret_cast<int*>(ring + PAIR_FLAGS) + (int)(hs & 1), 0);  // slot read: the gather wave may refill it
 #endif
+#if CN_SPLIT_BASE_IN_GATHER
+        f32x4 o16[2];  // the gather wave has run the base MLP: the slot holds its 16 outputs per sample
+        o16[0] = xv[0 * 64 + lane];
+        o16[1] = xv[1 * 64 + lane];
+#else
         // ---- base MLP layer 0: 32 -> 64, ReLU ------------------------------------------------------------------------
         f32x4 h[4][2];
 #pragma unroll
@@ -362,6 +418,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
           o16[0] = acc[0];
           o16[1] = acc[1];
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         const bool mine = (g >> 1) == half;
         const bool odd = (g & 1) != 0;
