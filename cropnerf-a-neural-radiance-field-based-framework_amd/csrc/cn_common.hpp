@@ -134,6 +134,49 @@ __device__ __forceinline__ float2 hash_level(const float* __restrict__ table, un
   float2 fff = hash_gather(table, ((hx0 ^ hy0 ^ hz0) & mask) + level_off);  // f_6
   float2 fcf = hash_gather(table, ((hx0 ^ hy1 ^ hz0) & mask) + level_off);  // f_7
   float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
+  // The two features of a corner sit in one register pair: blending them as 2-vectors with scalar weights maps onto
+  // v_pk_mul_f32 / v_pk_fma_f32 with the weight broadcast by op_sel, with no register shuffling (written per component,
+  // hipcc's SLP vectoriser packs ACROSS corners instead and pays ~18 v_mov per level and sample for it).
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  auto V = [](float2 t) {
+    v2f v;
+    v.x = t.x;
+    v.y = t.y;
+    return v;
+  };
+  const v2f f03 = V(ccc) * ox + V(fcc) * mx, f12 = V(cfc) * ox + V(ffc) * mx;
+  const v2f f56 = V(cff) * ox + V(fff) * mx, f47 = V(ccf) * ox + V(fcf) * mx;
+  const v2f a = f03 * oy + f12 * my, b = f47 * oy + f56 * my;
+  const v2f rv = a * oz + b * mz;
+  float2 r;
+  r.x = rv.x;
+  r.y = rv.y;
+  return r;
+}
+
+// The same with the blend written per component.  hipcc then SLP-packs across corners (~18 extra v_mov per level and
+// sample) but also interleaves each level's 8 gathers with the previous level's blend, waiting for them a few at a
+// time -- in the render kernels' gather waves that schedule measures FASTER than the leaner code above (4.9 vs 4.4
+// Gsamples/s at C2; hand-pipelining 16-32 gathers in flight per wave is slower still: 4.2), so they keep this form.
+__device__ __forceinline__ float2 hash_level_sc(const float* __restrict__ table, unsigned level_off, unsigned mask,
+                                             float scale, float px, float py, float pz) {
+  float sx = px * scale, sy = py * scale, sz = pz * scale;
+  float fx = floorf(sx), fy = floorf(sy), fz = floorf(sz);
+  float ox = sx - fx, oy = sy - fy, oz = sz - fz;
+  unsigned ix = (unsigned)(int)fx, iy = (unsigned)(int)fy, iz = (unsigned)(int)fz;
+  // ceil corner: ceil(s) == floor(s)+1 unless s is integral, where its weight (offset) is 0.
+  unsigned hx0 = ix, hx1 = ix + 1u;
+  unsigned hy0 = iy * CN_P1, hy1 = hy0 + CN_P1;
+  unsigned hz0 = iz * CN_P2, hz1 = hz0 + CN_P2;
+  float2 ccc = hash_gather(table, ((hx1 ^ hy1 ^ hz1) & mask) + level_off);  // f_0
+  float2 cfc = hash_gather(table, ((hx1 ^ hy0 ^ hz1) & mask) + level_off);  // f_1
+  float2 ffc = hash_gather(table, ((hx0 ^ hy0 ^ hz1) & mask) + level_off);  // f_2
+  float2 fcc = hash_gather(table, ((hx0 ^ hy1 ^ hz1) & mask) + level_off);  // f_3
+  float2 ccf = hash_gather(table, ((hx1 ^ hy1 ^ hz0) & mask) + level_off);  // f_4
+  float2 cff = hash_gather(table, ((hx1 ^ hy0 ^ hz0) & mask) + level_off);  // f_5
+  float2 fff = hash_gather(table, ((hx0 ^ hy0 ^ hz0) & mask) + level_off);  // f_6
+  float2 fcf = hash_gather(table, ((hx0 ^ hy1 ^ hz0) & mask) + level_off);  // f_7
+  float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
   float2 r;
   {
     float f03 = ccc.x * ox + fcc.x * mx, f12 = cfc.x * ox + ffc.x * mx;

@@ -412,7 +412,7 @@ __global__ void __launch_bounds__(FUSED_THREADS, CN_FUSED_MIN_WAVES_PER_SIMD) re
       for (int q = 0; q < 4; ++q) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-          float2 f = hash_level(A.grid.table, lvl_base + q * A.grid.level_stride, A.grid.mask, lvl_scale[q], px[c],
+          float2 f = hash_level_sc(A.grid.table, lvl_base + q * A.grid.level_stride, A.grid.mask, lvl_scale[q], px[c],
                                 py[c], pz[c]);
           feat[c][q >> 1][2 * (q & 1)] = f.x;
           feat[c][q >> 1][2 * (q & 1) + 1] = f.y;
@@ -671,7 +671,7 @@ __global__ void __launch_bounds__(FUSED_THREADS, CN_FUSED_MIN_WAVES_PER_SIMD) re
 #elif CN_XPAIR_GATHER
               float2 f = xpair_blend(c == 0 ? ld0 : ld1, scale, px[c], py[c], pz[c]);
 #else
-              float2 f = hash_level(A.grid.table, level_off, A.grid.mask, scale, px[c], py[c], pz[c]);
+              float2 f = hash_level_sc(A.grid.table, level_off, A.grid.mask, scale, px[c], py[c], pz[c]);
 #endif
               if (q == 0) { feat[c][0].x = f.x; feat[c][0].y = f.y; }
               if (q == 1) { feat[c][0].z = f.x; feat[c][0].w = f.y; }

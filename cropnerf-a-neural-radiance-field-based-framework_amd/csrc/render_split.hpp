@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
 #if CN_ABLATE_GATHER  // timing-only build: no table reads
                 const float2 f = make_float2(px[c] * scale, py[c] + pz[c]);
 #else
-                const float2 f = hash_level(A.grid.table, level_off, A.grid.mask, scale, px[c], py[c], pz[c]);
+                const float2 f = hash_level_sc(A.grid.table, level_off, A.grid.mask, scale, px[c], py[c], pz[c]);
 #endif
                 if (q == 0) { feat[c][0].x = f.x; feat[c][0].y = f.y; }
                 if (q == 1) { feat[c][0].z = f.x; feat[c][0].w = f.y; }
