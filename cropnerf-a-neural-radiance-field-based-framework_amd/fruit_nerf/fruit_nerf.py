@@ -101,6 +101,16 @@ class FruitModel:
         self._anneal = 1.0
         self.render_rgb = True
         self._image_hint: Tuple[int, int] = (0, 0)  # (image width, first pixel) of the chunk being rendered
+        # The fused kernels are specialised for the default fruit_nerf_method field; fruit_nerf_method_big / _huge
+        # (geo_feat_dim 30, 3 x 128 semantic layers: fruit_nerf_config.py:66-172) run the same path through the
+        # shape-generic kernels (sampler -> cn_field_eval -> cn_composite, [R,S,.] tensors materialised per sub-chunk).
+        fs = self.field_spec
+        self._fused_shape = (fs.grid.num_levels == 16 and fs.grid.features_per_level == 2 and fs.hidden_dim == 64
+                             and fs.geo_feat_dim == 15 and fs.num_layers_semantic == 2
+                             and fs.hidden_dim_semantics == 64 and fs.hidden_dim_transient == 64
+                             and fs.hidden_dim_color == 64 and fs.num_layers_color == 3
+                             and fs.appearance_embedding_dim == 32)
+        self.general_rays_per_call = 8192
 
     def state_dict(self) -> Dict[str, Tensor]:
         return dict(self.params)
@@ -189,17 +199,51 @@ class FruitModel:
             raise AttributeError("Camera indices are not provided.")  # fruit_field.py:241-242
         if self._uniform_samples is not None:
             S = self._uniform_samples
+            if not self._fused_shape:
+                return self._render_general(o, d, n, f, cam, S, None, density_only)
             return ops.render_rays(self.field, self._scene(self._field_contraction), self._opts(S, density_only),
                                    o, d, n, f, camera_indices=cam)
         cfg = self.config
         S = cfg.num_nerf_samples_per_ray
         ps = ops.proposal_sample(self.proposal_networks, self._scene(self._prop_contraction), o, d, n, f,
                                  cfg.num_proposal_samples_per_ray, S, anneal=self._anneal)
-        out = ops.render_rays(self.field, self._scene(self._field_contraction), self._opts(S, density_only), o, d, n, f,
-                              camera_indices=cam, bins=ps["euclidean_bins"])
+        if not self._fused_shape:
+            out = self._render_general(o, d, n, f, cam, S, ps["euclidean_bins"], density_only)
+        else:
+            out = ops.render_rays(self.field, self._scene(self._field_contraction), self._opts(S, density_only), o, d,
+                                  n, f, camera_indices=cam, bins=ps["euclidean_bins"])
         for i in range(len(self.proposal_networks)):
             out[f"prop_depth_{i}"] = ps["prop_depth"][i][:, None]
         return out
+
+    def _general_samples(self, n: Tensor, f: Tensor, S: int, bins: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
+        if bins is not None:
+            return bins[:, :-1].contiguous(), bins[:, 1:].contiguous()
+        sm = ops.sample_spaced(n, f, S, L.SPACING_UNIFORM)
+        return sm["starts"], sm["ends"]
+
+    def _render_general(self, o: Tensor, d: Tensor, n: Tensor, f: Tensor, cam: Optional[Tensor], S: int,
+                        bins: Optional[Tensor], density_only: bool) -> Dict[str, Tensor]:
+        """Any field shape: cn_field_eval + cn_composite on sub-chunks (the [R,S,.] tensors exist only per sub-chunk)."""
+        scene = self._scene(self._field_contraction)
+        bg_mode, bg = self._background()
+        outs: Dict[str, List[Tensor]] = {}
+        step = self.general_rays_per_call
+        for i in range(0, o.shape[0], step):
+            sl = slice(i, i + step)
+            starts, ends = self._general_samples(n[sl], f[sl], S, None if bins is None else bins[sl])
+            fo = ops.field_eval(self.field, scene, o[sl].contiguous(), d[sl].contiguous(),
+                                None if cam is None else cam[sl].contiguous(), starts, ends,
+                                app_mode=self._app_mode(), sh_unit_dir=self.config.sh_input == "unit")
+            if density_only:
+                comp = ops.composite(starts, ends, fo["density"], None, None, bg_mode, bg, eval_clamp=not self.training)
+                comp = {"accumulation": comp["accumulation"]}
+            else:
+                comp = ops.composite(starts, ends, fo["density"], fo["rgb"], fo["semantics"], bg_mode, bg,
+                                     eval_clamp=not self.training)
+            for k, v in comp.items():
+                outs.setdefault(k, []).append(v)
+        return {k: torch.cat(v) for k, v in outs.items()}
 
     # ------------------------------------------------------------------------------------------ forward variants
     def forward(self, ray_bundle: RayBundle) -> Dict[str, Union[Tensor, List]]:
@@ -239,6 +283,14 @@ class FruitModel:
         if self._uniform_samples is None:
             raise RuntimeError("export mode needs setup_inference(render_rgb, num_inference_samples) first")
         rb = ray_bundle
+        if not self._fused_shape:
+            starts, ends = self._general_samples(rb.nears, rb.fars, self._uniform_samples, None)
+            fo = ops.field_eval(self.field, self._scene(self._field_contraction), rb.origins, rb.directions,
+                                self._cam_idx(rb), starts, ends, app_mode=self._app_mode(),
+                                sh_unit_dir=self.config.sh_input == "unit", want_positions=True)
+            label = (torch.sigmoid(fo["semantics"]) - 0.9 > 0).to(torch.int64)  # fruit_nerf.py:488-492
+            return {"rgb": fo["rgb"], "point_location": fo["positions"], "semantics": fo["semantics"],
+                    "density": fo["density"], "semantics_colormap": label}
         out = ops.render_samples(self.field, self._scene(self._field_contraction), self._opts(self._uniform_samples),
                                  rb.origins, rb.directions, rb.nears, rb.fars, camera_indices=self._cam_idx(rb))
         return {"rgb": out["rgb"], "point_location": out["positions"], "semantics": out["semantics"],

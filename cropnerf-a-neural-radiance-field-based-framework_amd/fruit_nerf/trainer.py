@@ -47,6 +47,11 @@ class OptimGroup:
 
 class FruitTrainer:
     def __init__(self, model: FruitModel, groups: Optional[Dict[str, OptimGroup]] = None, seed: int = 0):
+        if not model._fused_shape:
+            raise NotImplementedError(
+                "training is built for the default fruit_nerf_method field shape; the _big / _huge shapes "
+                "(geo_feat_dim 30, 3 x 128 semantic layers) render through the shape-generic kernels but have no "
+                "backward kernels yet")
         self.model = model
         self.groups = groups or {"proposal_networks": OptimGroup(), "fields": OptimGroup(),
                                  "camera_opt": OptimGroup(1e-3, 1e-15, 1e-4, 5000)}

@@ -255,3 +255,54 @@ def test_cli_end_to_end(scene, tmp_path):
     assert hit.shape == (20, 20, 3) and hit.max() > 0 and miss.max() == 0
     semantic_projection.entrypoint(["cameras", "--load-config", str(cfg_path), "--output-dir", str(out)])
     assert len(json.loads((out / "transforms_train.json").read_text())) == 3
+
+
+def test_big_method_shape_runs_through_the_generic_kernels():
+    """fruit_nerf_method_big / _huge change the field shape (geo_feat_dim 30, 3 x 128 semantic layers, max_res 4096:
+    fruit_nerf_config.py:66-172); the fused kernels are built for the default shape, so FruitModel routes these through
+    sampler -> cn_field_eval -> cn_composite.  Same outputs, same keys, checked against the oracle in the test, inference
+    and export wirings."""
+    from cropnerf_amd import synthetic
+    from cropnerf_amd.config import FruitNerfModelConfig
+    from cropnerf_amd.fruit_nerf.fruit_nerf import FruitModel, Semantics
+    from cropnerf_amd.rays import SceneBox
+
+    n_img, H = 4, 20
+    fspec = OF.FieldSpec(grid=OF.GridSpec(16, 16, 4096, 13, 2), geo_feat_dim=30, num_layers_semantic=3,
+                         hidden_dim_semantics=128, num_images=n_img)
+    pspecs = [OF.ProposalSpec(OF.GridSpec(5, 16, 512, 11)), OF.ProposalSpec(OF.GridSpec(7, 16, 2048, 11))]
+    params = OF.random_params(fspec, pspecs, seed=11, grid_scale=0.1)
+    c2w, intr = synthetic.orbit_cameras(n_img, height=H, width=H, focal=27.0)
+    aabb = torch.tensor(synthetic.SCENE_AABB, dtype=torch.float32)
+    pl = [{"hidden_dim": 16, "log2_hashmap_size": 11, "num_levels": 5, "max_res": 512},
+          {"hidden_dim": 16, "log2_hashmap_size": 11, "num_levels": 7, "max_res": 2048}]
+    cfg = FruitNerfModelConfig(geo_feat_dim=30, num_layers_semantic=3, hidden_dim_semantics=128, max_res=4096,
+                               log2_hashmap_size=13, proposal_net_args_list=pl, num_proposal_samples_per_ray=(64, 32),
+                               num_nerf_samples_per_ray=24)
+    ocfg = OM.ModelConfig(field=fspec, proposals=pspecs, num_proposal_samples_per_ray=(64, 32), num_nerf_samples_per_ray=24)
+    orb = ORY.image_rays(c2w, intr, 1, H, H)
+    from cropnerf_amd.rays import Cameras
+
+    cams = Cameras(c2w, intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], H, H).to("cuda")
+    for mode in ("test", "inference"):
+        m = FruitModel(cfg, SceneBox(aabb), n_img, {"semantics": Semantics()}, device="cuda", test_mode=mode, params=params)
+        assert not m._fused_shape
+        m.general_rays_per_call = 150  # several sub-chunks
+        out = m(cams.generate_rays(camera_indices=1, keep_shape=False))
+        ref = OM.OracleModel(params, ocfg, aabb, test_mode=mode).forward(orb)
+        assert list(out) == ["rgb", "accumulation", "depth", "prop_depth_0", "prop_depth_1", "semantics", "semantics_colormap"]
+        assert_close(out["rgb"], ref["rgb"], 2e-3, 2e-3, f"{mode} rgb", frac_ok=0.99)
+        assert_close(out["accumulation"], ref["accumulation"], 2e-3, 2e-3, f"{mode} accumulation", frac_ok=0.99)
+        assert_close(out["semantics"], ref["semantics"], 2e-3, 2e-3, f"{mode} semantics", frac_ok=0.99)
+    # export wiring: uniform samples, AABB normalisation, per-sample outputs
+    m = FruitModel(cfg, SceneBox(aabb), n_img, {"semantics": Semantics()}, device="cuda", test_mode="export", params=params)
+    m.setup_inference(True, 40)
+    om = OM.OracleModel(params, ocfg, aabb, test_mode="export")
+    om.setup_inference(True, 40)
+    rb = cams.generate_rays(camera_indices=2, keep_shape=False, aabb_box=SceneBox(aabb))
+    out = m(rb)
+    ref = om.forward(ORY.with_aabb_near_far(ORY.image_rays(c2w, intr, 2, H, H), aabb.reshape(-1)))
+    assert_close(out["density"], ref["density"], RTOL, ATOL, "export density")
+    assert_close(out["rgb"], ref["rgb"], RTOL, ATOL, "export rgb")
+    assert_close(out["semantics"], ref["semantics"], RTOL, 5e-5, "export semantics")
+    assert torch.equal(out["semantics_colormap"].cpu(), ref["semantics_colormap"].reshape(out["semantics_colormap"].shape))
