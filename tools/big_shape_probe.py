@@ -1,0 +1,30 @@
+"""Throughput of the shape-generic path on the fruit_nerf_method_big field (geo 30, 3 x 128 semantic layers, 2^21-entry
+levels, 128 samples per ray behind a (512, 256) proposal sampler).  Profiling aid:  python tools/big_shape_probe.py"""
+import json, os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cropnerf_amd import synthetic
+from cropnerf_amd.fruit_nerf.fruit_nerf import FruitModel, Semantics
+from cropnerf_amd.fruit_nerf.fruit_nerf_config import fruit_nerf_method_big
+from cropnerf_amd.rays import Cameras, SceneBox
+
+cfg = fruit_nerf_method_big.config.pipeline.model
+c2w, intr = synthetic.orbit_cameras(8, height=800, width=800)
+cams = Cameras(c2w, intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], 800, 800).to("cuda")
+m = FruitModel(cfg, SceneBox(torch.tensor(synthetic.SCENE_AABB)), 8, {"semantics": Semantics()}, device="cuda", test_mode="inference")
+for k, v in m.params.items():
+    if k.endswith("hash_table"):
+        v.mul_(100.0)  # the 1e-3 init is an empty volume
+rb = cams.generate_rays(0, keep_shape=False, aabb_box=SceneBox(torch.tensor(synthetic.SCENE_AABB)))
+rb = rb[:65536] if hasattr(rb, "__getitem__") else rb
+out = m(rb)
+torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(3):
+    out = m(rb)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t) / 3
+R = out["rgb"].shape[0]
+S = cfg.num_nerf_samples_per_ray
+print(json.dumps({"rays": R, "field_samples_per_ray": S, "proposal_samples_per_ray": list(cfg.num_proposal_samples_per_ray),
+                  "ms_per_call": round(dt * 1e3, 2), "rays_per_sec": R / dt, "field_samples_per_sec": R * S / dt,
+                  "finite": bool(torch.isfinite(out["rgb"]).all())}))
