@@ -5,6 +5,9 @@
 // render_fused.hip, which is checked against both the CPU oracle and this kernel.
 //
 // Reference: fruit_nerf/fruit_field.py:169-302 (FruitField), fruit_nerf/fruit_nerf.py:118-142 (proposal nets).
+#include <cstdlib>
+#include <cstring>
+
 #include "cn_common.hpp"
 #include "wave_ops.hpp"
 
@@ -241,6 +244,185 @@ int validate_grid(const cn_grid& g, const char* name) {
   return CN_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Shape-generic FruitField on the fp32 matrix cores (the path fruit_nerf_method_big / _huge take).
+// One 256-thread workgroup walks 64-sample tiles.  Activations live in LDS as [feature][68] (64 samples + 4 pad), three
+// 128-row buffers + one for the base output; every dense layer is staged 64 output rows at a time into LDS as
+// [row][Kpad + 4] (zero-padded to multiples of 16) and evaluated with v_mfma_f32_16x16x4_f32: wave w owns the 16-sample
+// column tile w and walks the row tiles.  Pad rows come out as exact zeros, so they are valid pad inputs of the next
+// layer.  Works for any layer widths <= 128 (the reference's configs: 64 / 128); wider shapes fall back to
+// field_eval_kernel.
+// ------------------------------------------------------------------------------------------------------------------------
+namespace gm {
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int TS = 64, LDA = 68, NT = 256, WMAX = 128, WS_MAX = WMAX + 4;
+constexpr int ROWS_G = 48;
+constexpr size_t LDS_FLOATS = (size_t)3 * WMAX * LDA + ROWS_G * LDA + 64 * WS_MAX + WMAX;
+
+__device__ __forceinline__ void dense_mfma(const float* __restrict__ Wg, const float* __restrict__ bg, int K, int N,
+                                           const float* in, float* out, bool relu, float* wbuf, int tid) {
+  const int Kp = (K + 15) & ~15, ws = Kp + 4;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4, s0 = 16 * wave;
+  for (int p0 = 0; p0 < N; p0 += 64) {
+    const int rows = min(64, N - p0), rows_p = (rows + 15) & ~15;
+    __syncthreads();  // the previous pass / layer has finished with wbuf, and `in` is complete
+    for (int e = tid; e < rows_p * Kp; e += NT) {
+      const int row = e / Kp, k = e - row * Kp;
+      wbuf[row * ws + k] = (row < rows && k < K) ? Wg[(size_t)(p0 + row) * K + k] : 0.f;
+    }
+    __syncthreads();
+    for (int nt = 0; nt < rows_p / 16; ++nt) {
+      f32x4 acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = p0 + 16 * nt + 4 * q + r;
+        acc[r] = n < N ? bg[n] : 0.f;
+      }
+      for (int kb = 0; kb < Kp / 16; ++kb) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(wbuf + (16 * nt + i) * ws + 16 * kb + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float av = a[e];
+          const float b = in[(16 * kb + 4 * q + e) * LDA + s0 + i];
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[r];
+        if (relu) v = fmaxf(v, 0.f);
+        out[(p0 + 16 * nt + 4 * q + r) * LDA + s0 + i] = v;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(NT)
+field_eval_mfma_kernel(FieldDev fp, SceneDev sc, int app_mode, int sh_unit, const float* __restrict__ origins,
+                       const float* __restrict__ directions, const int64_t* __restrict__ cam_idx,
+                       const float* __restrict__ starts, const float* __restrict__ ends, long long num_rays, int S,
+                       float* __restrict__ density, float* __restrict__ rgb, float* __restrict__ semantics,
+                       float* __restrict__ positions) {
+  extern __shared__ __align__(16) float lds[];
+  float* bufA = lds;
+  float* bufB = bufA + WMAX * LDA;
+  float* bufC = bufB + WMAX * LDA;
+  float* bufG = bufC + WMAX * LDA;        // base output: row 0 = density logit, rows 1..geo = geo features, rest zero
+  float* wbuf = bufG + ROWS_G * LDA;
+  float* app_mean = wbuf + 64 * WS_MAX;
+  const int tid = threadIdx.x, s = tid & 63, grp = tid >> 6;
+  for (int e = tid; e < (int)(3 * WMAX * LDA + ROWS_G * LDA); e += NT) lds[e] = 0.f;
+  if (app_mode == CN_APP_MEAN) {
+    for (int j = tid; j < fp.app_dim; j += NT) {
+      float m = 0.f;
+      for (int n = 0; n < fp.num_images; ++n) m += fp.appearance[(long long)n * fp.app_dim + j];
+      app_mean[j] = m / (float)fp.num_images;
+    }
+  }
+  __syncthreads();
+  const int enc_dim = 2 * fp.grid.num_levels;
+  const int cin_dim = 16 + fp.geo + fp.app_dim;
+  const long long total = num_rays * (long long)S;
+  const long long ntiles = (total + TS - 1) / TS;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long ismp = tile * TS + s;
+    const bool valid = ismp < total;
+    const long long ic = valid ? ismp : total - 1;
+    const long long r = ic / S;
+    const float dx = directions[3 * r], dy = directions[3 * r + 1], dz = directions[3 * r + 2];
+    const float mid = (starts[ic] + ends[ic]) / 2.f;
+    float px = origins[3 * r] + dx * mid, py = origins[3 * r + 1] + dy * mid, pz = origins[3 * r + 2] + dz * mid;
+    if (positions && valid && grp == 0) {
+      positions[3 * ismp + 0] = px;
+      positions[3 * ismp + 1] = py;
+      positions[3 * ismp + 2] = pz;
+    }
+    const bool sel = normalize_position(sc, px, py, pz);
+    __syncthreads();  // the previous tile's readers of bufA / bufC are done
+    for (int l = grp; l < fp.grid.num_levels; l += 4) {
+      const float2 f = hash_level(fp.grid.table, (unsigned)l * fp.grid.level_stride, fp.grid.mask, fp.grid.scale[l], px, py, pz);
+      bufA[(2 * l) * LDA + s] = f.x;
+      bufA[(2 * l + 1) * LDA + s] = f.y;
+    }
+    for (int k = enc_dim + grp; k < ((enc_dim + 15) & ~15); k += 4) bufA[k * LDA + s] = 0.f;
+    // colour input rows that do not depend on the base MLP: SH (rows 0..15) and appearance
+    if (rgb) {
+      if (grp == 1) {
+        float sx = dx, sy = dy, sz = dz;
+        if (!sh_unit) {
+          sx = (dx + 1.f) / 2.f;
+          sy = (dy + 1.f) / 2.f;
+          sz = (dz + 1.f) / 2.f;
+        }
+        float sh[16];
+        sh_deg4(sx, sy, sz, sh);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) bufC[k * LDA + s] = sh[k];
+      }
+      const float* emb = app_mode == CN_APP_PER_CAMERA ? fp.appearance + cam_idx[r] * (long long)fp.app_dim : nullptr;
+      for (int k = grp; k < fp.app_dim; k += 4)
+        bufC[(16 + fp.geo + k) * LDA + s] = app_mode == CN_APP_MEAN ? app_mean[k] : (emb ? emb[k] : 0.f);
+      for (int k = cin_dim + grp; k < ((cin_dim + 15) & ~15); k += 4) bufC[k * LDA + s] = 0.f;
+    }
+    // ---- base MLP: bufA -> (bufB -> bufA ...) -> bufG ------------------------------------------------------------------
+    {
+      const float* x = bufA;
+      for (int l = 0; l < fp.base.num_layers; ++l) {
+        const bool last = l == fp.base.num_layers - 1;
+        float* y = last ? bufG : (x == bufA ? bufB : bufA);
+        dense_mfma(fp.base.w[l], fp.base.b[l], fp.base.dims[l], fp.base.dims[l + 1], x, y, !last, wbuf, tid);
+        x = y;
+      }
+    }
+    __syncthreads();
+    if (grp == 0 && density && valid) density[ismp] = expf(bufG[s]) * (sel ? 1.f : 0.f);
+    if (rgb)
+      for (int k = grp; k < fp.geo; k += 4) bufC[(16 + k) * LDA + s] = bufG[(1 + k) * LDA + s];
+    // ---- semantics: mlp_semantics(geo) -> Linear(Ht, 1) --------------------------------------------------------------------
+    {
+      const float* x = bufG + LDA;
+      for (int l = 0; l < fp.sem.num_layers; ++l) {
+        float* y = (x == bufA) ? bufB : bufA;
+        dense_mfma(fp.sem.w[l], fp.sem.b[l], fp.sem.dims[l], fp.sem.dims[l + 1], x, y, l < fp.sem.num_layers - 1, wbuf, tid);
+        x = y;
+      }
+      __syncthreads();
+      if (grp == 0 && semantics && valid) {
+        const int ht = fp.sem.dims[fp.sem.num_layers];
+        float v = fp.sem_head_b[0];
+        for (int k = 0; k < ht; ++k) v = fmaf(fp.sem_head_w[k], x[k * LDA + s], v);
+        semantics[ismp] = v;
+      }
+    }
+    // ---- colour: [SH16 | geo | appearance] -> mlp_head -> sigmoid -----------------------------------------------------------
+    if (rgb) {
+      const float* x = bufC;
+      for (int l = 0; l < fp.color.num_layers; ++l) {
+        float* y = (x == bufA) ? bufB : bufA;
+        dense_mfma(fp.color.w[l], fp.color.b[l], fp.color.dims[l], fp.color.dims[l + 1], x, y,
+                   l < fp.color.num_layers - 1, wbuf, tid);
+        x = y;
+      }
+      __syncthreads();
+      if (grp < 3 && valid) rgb[3 * ismp + grp] = sigmoidf(x[grp * LDA + s]);
+    }
+  }
+}
+
+// every layer's input and output width fits the 128-row LDS buffers
+static bool mfma_generic_ok(const cn_field_params& p) {
+  auto ok = [](const cn_mlp& m) {
+    for (int l = 0; l <= m.num_layers; ++l)
+      if (m.dims[l] > WMAX) return false;
+    return true;
+  };
+  return ok(p.base) && ok(p.semantics) && ok(p.color) && 1 + p.geo_feat_dim <= 32 && 2 * p.grid.num_levels <= WMAX &&
+         16 + p.geo_feat_dim + p.app_dim <= WMAX && p.app_dim <= WMAX;
+}
+}  // namespace gm
+
 int validate_field(const cn_field_params& p) {
   int rc = validate_grid(p.grid, "field grid");
   if (rc) return rc;
@@ -286,11 +468,25 @@ extern "C" int cn_field_eval(const cn_field_params* params, const cn_scene* scen
   if (rc) return rc;
   if (num_rays <= 0) return CN_OK;
   size_t lds = (size_t)(cn::GMAX + 2 * cn::KMAX) * 64 * sizeof(float) + 256 * sizeof(float);
+  const size_t lds_mfma = cn::gm::LDS_FLOATS * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::field_eval_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::gm::field_eval_mfma_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma);
     attr_set = true;
+  }
+  // default: the matrix-core kernel whenever the layer widths fit it; CN_FIELD_EVAL_IMPL=scalar forces the scalar one
+  // (kept as an independent implementation: the tests compare the two)
+  const char* impl = getenv("CN_FIELD_EVAL_IMPL");
+  if (cn::gm::mfma_generic_ok(*params) && !(impl && std::strcmp(impl, "scalar") == 0)) {
+    long long ntiles = (num_rays * (long long)num_samples + cn::gm::TS - 1) / cn::gm::TS;
+    hipLaunchKernelGGL(cn::gm::field_eval_mfma_kernel, dim3(cn::grid_for(ntiles, 1, 256)), dim3(cn::gm::NT), lds_mfma,
+                       cn::as_stream(stream), cn::make_field_dev(*params), cn::make_scene_dev(*scene), app_mode,
+                       sh_unit_dir, origins, directions, camera_indices, starts, ends, (long long)num_rays, num_samples,
+                       density, rgb, semantics, positions);
+    return cn::check_launch("cn_field_eval");
   }
   long long nblk = (num_rays * (long long)num_samples + 63) / 64;
   hipLaunchKernelGGL(cn::field_eval_kernel, dim3(cn::grid_for(nblk, 1, 256 * 8)), dim3(64), lds, cn::as_stream(stream),

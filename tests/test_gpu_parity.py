@@ -614,3 +614,27 @@ def test_split_kernel_per_sample_outputs_match_fused(scene, ops, handles, S, con
     assert torch.equal(outs["0"]["semantics_colormap"], outs["1"]["semantics_colormap"])
     for k in ("density", "rgb", "semantics", "positions"):
         assert_close(outs["1"][k], outs["0"][k], 2e-6, 1e-6, f"split vs fused per-sample {k}")
+
+
+def test_generic_field_kernels_agree(scene, ops, monkeypatch):
+    """cn_field_eval has two device implementations (matrix-core, default; scalar, CN_FIELD_EVAL_IMPL=scalar): same
+    results on the default shape and on the fruit_nerf_method_big shape, per-camera appearance, ragged sample counts."""
+    from cropnerf_amd import config as PC
+
+    rb = rays_with_box(scene, 0, 333)
+    o, d, n, f = (to_dev(t) for t in (rb.origins, rb.directions, rb.nears, rb.fars))
+    cam = (torch.arange(333) % scene.c2w.shape[0]).cuda()
+    sm = ops.sample_spaced(n, f, 37)
+    for big in (False, True):
+        spec = PC.FieldSpec(grid=PC.GridSpec(16, 16, 4096 if big else 2048, 12, 2), geo_feat_dim=30 if big else 15,
+                            num_layers_semantic=3 if big else 2, hidden_dim_semantics=128 if big else 64,
+                            num_images=scene.c2w.shape[0])
+        params = PC.init_params(spec, [], seed=3, grid_scale=0.1, device="cuda")
+        fh = ops.FieldHandle(params, spec)
+        outs = {}
+        for impl in ("mfma", "scalar"):
+            monkeypatch.setenv("CN_FIELD_EVAL_IMPL", impl)
+            outs[impl] = ops.field_eval(fh, ops.scene_struct(scene.aabb, True), o, d, cam, sm["starts"], sm["ends"],
+                                        app_mode=2, want_positions=True)
+        for k in outs["mfma"]:
+            assert_close(outs["mfma"][k], outs["scalar"][k], 2e-5, 2e-6, f"{'big' if big else 'default'} {k}")
