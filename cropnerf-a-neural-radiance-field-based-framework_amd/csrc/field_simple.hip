@@ -247,7 +247,7 @@ int validate_grid(const cn_grid& g, const char* name) {
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Shape-generic FruitField on the fp32 matrix cores (the path fruit_nerf_method_big / _huge take).
-// One 256-thread workgroup walks 64-sample tiles.  Activations live in LDS as [feature][68] (64 samples + 4 pad), three
+// One 512-thread workgroup walks 64-sample tiles.  Activations live in LDS as [feature][68] (64 samples + 4 pad), three
 // 128-row buffers + one for the base output; every dense layer is staged 64 output rows at a time into LDS as
 // [row][Kpad + 4] (zero-padded to multiples of 16) and evaluated with v_mfma_f32_16x16x4_f32: wave w owns the 16-sample
 // column tile w and walks the row tiles.  Pad rows come out as exact zeros, so they are valid pad inputs of the next
@@ -256,38 +256,54 @@ int validate_grid(const cn_grid& g, const char* name) {
 // ------------------------------------------------------------------------------------------------------------------------
 namespace gm {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int TS = 64, LDA = 68, NT = 256, WMAX = 128, WS_MAX = WMAX + 4;
+constexpr int TS = 64, LDA = 68, NT = 512, NW = NT / 64, WMAX = 128, WS_MAX = WMAX + 4;
 constexpr int ROWS_G = 48;
 constexpr size_t LDS_FLOATS = (size_t)3 * WMAX * LDA + ROWS_G * LDA + 64 * WS_MAX + WMAX;
 
-__device__ __forceinline__ void dense_mfma(const float* __restrict__ Wg, const float* __restrict__ bg, int K, int N,
-                                           const float* in, float* out, bool relu, float* wbuf, int tid) {
+// (Prefetching the next pass's weights into registers during the MFMAs was tried: no gain -- the cost of a pass is the
+// L2 -> LDS volume of re-staging 185 KB of weights per 64-sample tile, not its latency.)
+__device__ __forceinline__ void dense_mfma(const float* __restrict__ Wg, const float* __restrict__ bg_, int K_, int N_,
+                                           const float* in, float* out, bool relu, float* wbuf, int tid,
+                                           int debug_skip = 0) {
+  const float* __restrict__ bg = bg_;
+  const int K = K_, N = N_;
   const int Kp = (K + 15) & ~15, ws = Kp + 4;
   const int lane = tid & 63, wave = tid >> 6;
-  const int i = lane & 15, q = lane >> 4, s0 = 16 * wave;
+  // 8 waves (2 per SIMD): column tile = wave & 3, the two waves of a column tile split the row tiles
+  const int i = lane & 15, q = lane >> 4, s0 = 16 * (wave & 3), nt0 = wave >> 2;
   for (int p0 = 0; p0 < N; p0 += 64) {
     const int rows = min(64, N - p0), rows_p = (rows + 15) & ~15;
     __syncthreads();  // the previous pass / layer has finished with wbuf, and `in` is complete
-    for (int e = tid; e < rows_p * Kp; e += NT) {
-      const int row = e / Kp, k = e - row * Kp;
-      wbuf[row * ws + k] = (row < rows && k < K) ? Wg[(size_t)(p0 + row) * K + k] : 0.f;
-    }
+    for (int row = wave; row < rows_p; row += NW)      // wave per row, lanes along k: coalesced, no division
+      for (int k = lane; k < Kp; k += 64)
+        wbuf[row * ws + k] = (row < rows && k < K) ? Wg[(size_t)(p0 + row) * K + k] : 0.f;
     __syncthreads();
-    for (int nt = 0; nt < rows_p / 16; ++nt) {
+    for (int nt = nt0; nt < rows_p / 16 && !(debug_skip & 32); nt += 2) {
       f32x4 acc;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = p0 + 16 * nt + 4 * q + r;
         acc[r] = n < N ? bg[n] : 0.f;
       }
+      // operands of round kb + 1 are fetched from LDS while the four MFMAs of round kb run
+      f32x4 a = *reinterpret_cast<const f32x4*>(wbuf + (16 * nt + i) * ws + 4 * q);
+      float b[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b[e] = in[(4 * q + e) * LDA + s0 + i];
       for (int kb = 0; kb < Kp / 16; ++kb) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(wbuf + (16 * nt + i) * ws + 16 * kb + 4 * q);
+        const int kn = kb + 1 < Kp / 16 ? kb + 1 : kb;
+        const f32x4 an = *reinterpret_cast<const f32x4*>(wbuf + (16 * nt + i) * ws + 16 * kn + 4 * q);
+        float bn[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bn[e] = in[(16 * kn + 4 * q + e) * LDA + s0 + i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float av = a[e];
-          const float b = in[(16 * kb + 4 * q + e) * LDA + s0 + i];
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[e], acc, 0, 0, 0);
         }
+        a = an;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = bn[e];
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -304,7 +320,7 @@ field_eval_mfma_kernel(FieldDev fp, SceneDev sc, int app_mode, int sh_unit, cons
                        const float* __restrict__ directions, const int64_t* __restrict__ cam_idx,
                        const float* __restrict__ starts, const float* __restrict__ ends, long long num_rays, int S,
                        float* __restrict__ density, float* __restrict__ rgb, float* __restrict__ semantics,
-                       float* __restrict__ positions) {
+                       float* __restrict__ positions, int debug_skip) {
   extern __shared__ __align__(16) float lds[];
   float* bufA = lds;
   float* bufB = bufA + WMAX * LDA;
@@ -341,12 +357,12 @@ field_eval_mfma_kernel(FieldDev fp, SceneDev sc, int app_mode, int sh_unit, cons
     }
     const bool sel = normalize_position(sc, px, py, pz);
     __syncthreads();  // the previous tile's readers of bufA / bufC are done
-    for (int l = grp; l < fp.grid.num_levels; l += 4) {
+    for (int l = grp; l < fp.grid.num_levels && !(debug_skip & 64); l += NW) {
       const float2 f = hash_level(fp.grid.table, (unsigned)l * fp.grid.level_stride, fp.grid.mask, fp.grid.scale[l], px, py, pz);
       bufA[(2 * l) * LDA + s] = f.x;
       bufA[(2 * l + 1) * LDA + s] = f.y;
     }
-    for (int k = enc_dim + grp; k < ((enc_dim + 15) & ~15); k += 4) bufA[k * LDA + s] = 0.f;
+    for (int k = enc_dim + grp; k < ((enc_dim + 15) & ~15); k += NW) bufA[k * LDA + s] = 0.f;
     // colour input rows that do not depend on the base MLP: SH (rows 0..15) and appearance
     if (rgb) {
       if (grp == 1) {
@@ -362,9 +378,9 @@ field_eval_mfma_kernel(FieldDev fp, SceneDev sc, int app_mode, int sh_unit, cons
         for (int k = 0; k < 16; ++k) bufC[k * LDA + s] = sh[k];
       }
       const float* emb = app_mode == CN_APP_PER_CAMERA ? fp.appearance + cam_idx[r] * (long long)fp.app_dim : nullptr;
-      for (int k = grp; k < fp.app_dim; k += 4)
+      for (int k = grp; k < fp.app_dim; k += NW)
         bufC[(16 + fp.geo + k) * LDA + s] = app_mode == CN_APP_MEAN ? app_mean[k] : (emb ? emb[k] : 0.f);
-      for (int k = cin_dim + grp; k < ((cin_dim + 15) & ~15); k += 4) bufC[k * LDA + s] = 0.f;
+      for (int k = cin_dim + grp; k < ((cin_dim + 15) & ~15); k += NW) bufC[k * LDA + s] = 0.f;
     }
     // ---- base MLP: bufA -> (bufB -> bufA ...) -> bufG ------------------------------------------------------------------
     {
@@ -372,20 +388,21 @@ field_eval_mfma_kernel(FieldDev fp, SceneDev sc, int app_mode, int sh_unit, cons
       for (int l = 0; l < fp.base.num_layers; ++l) {
         const bool last = l == fp.base.num_layers - 1;
         float* y = last ? bufG : (x == bufA ? bufB : bufA);
-        dense_mfma(fp.base.w[l], fp.base.b[l], fp.base.dims[l], fp.base.dims[l + 1], x, y, !last, wbuf, tid);
+        dense_mfma(fp.base.w[l], fp.base.b[l], fp.base.dims[l], fp.base.dims[l + 1], x, y, !last, wbuf, tid, debug_skip);
         x = y;
       }
     }
     __syncthreads();
     if (grp == 0 && density && valid) density[ismp] = expf(bufG[s]) * (sel ? 1.f : 0.f);
     if (rgb)
-      for (int k = grp; k < fp.geo; k += 4) bufC[(16 + k) * LDA + s] = bufG[(1 + k) * LDA + s];
+      for (int k = grp; k < fp.geo; k += NW) bufC[(16 + k) * LDA + s] = bufG[(1 + k) * LDA + s];
     // ---- semantics: mlp_semantics(geo) -> Linear(Ht, 1) --------------------------------------------------------------------
     {
       const float* x = bufG + LDA;
       for (int l = 0; l < fp.sem.num_layers; ++l) {
         float* y = (x == bufA) ? bufB : bufA;
-        dense_mfma(fp.sem.w[l], fp.sem.b[l], fp.sem.dims[l], fp.sem.dims[l + 1], x, y, l < fp.sem.num_layers - 1, wbuf, tid);
+        dense_mfma(fp.sem.w[l], fp.sem.b[l], fp.sem.dims[l], fp.sem.dims[l + 1], x, y, l < fp.sem.num_layers - 1, wbuf, tid,
+                   debug_skip);
         x = y;
       }
       __syncthreads();
@@ -402,7 +419,7 @@ field_eval_mfma_kernel(FieldDev fp, SceneDev sc, int app_mode, int sh_unit, cons
       for (int l = 0; l < fp.color.num_layers; ++l) {
         float* y = (x == bufA) ? bufB : bufA;
         dense_mfma(fp.color.w[l], fp.color.b[l], fp.color.dims[l], fp.color.dims[l + 1], x, y,
-                   l < fp.color.num_layers - 1, wbuf, tid);
+                   l < fp.color.num_layers - 1, wbuf, tid, debug_skip);
         x = y;
       }
       __syncthreads();
@@ -485,7 +502,10 @@ extern "C" int cn_field_eval(const cn_field_params* params, const cn_scene* scen
     hipLaunchKernelGGL(cn::gm::field_eval_mfma_kernel, dim3(cn::grid_for(ntiles, 1, 256)), dim3(cn::gm::NT), lds_mfma,
                        cn::as_stream(stream), cn::make_field_dev(*params), cn::make_scene_dev(*scene), app_mode,
                        sh_unit_dir, origins, directions, camera_indices, starts, ends, (long long)num_rays, num_samples,
-                       density, rgb, semantics, positions);
+                       density, rgb, semantics, positions, [] {
+                         const char* e = getenv("CN_DEBUG_SKIP");  // profiling aid: 32 no MFMA loops, 64 no gathers
+                         return e ? atoi(e) : 0;
+                       }());
     return cn::check_launch("cn_field_eval");
   }
   long long nblk = (num_rays * (long long)num_samples + 63) / 64;

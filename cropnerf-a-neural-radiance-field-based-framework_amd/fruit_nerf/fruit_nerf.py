@@ -110,7 +110,7 @@ class FruitModel:
                              and fs.hidden_dim_semantics == 64 and fs.hidden_dim_transient == 64
                              and fs.hidden_dim_color == 64 and fs.num_layers_color == 3
                              and fs.appearance_embedding_dim == 32)
-        self.general_rays_per_call = 8192
+        self.general_rays_per_call = 32768
 
     def state_dict(self) -> Dict[str, Tensor]:
         return dict(self.params)
