@@ -142,6 +142,9 @@ __device__ __forceinline__ bool row_run_reduce(unsigned key, float& v0, float& v
   return last;
 }
 
+#ifndef CN_QUAD_ATOMICS
+#define CN_QUAD_ATOMICS 1
+#endif
 #ifndef CN_PAIRED_ATOMICS
 #define CN_PAIRED_ATOMICS 1
 #endif
@@ -165,6 +168,49 @@ __device__ __forceinline__ void hash_level_backward(float* __restrict__ gtab, co
   float wx[2] = {1.f - ox, ox}, wy[2] = {1.f - oy, oy}, wz[2] = {1.f - oz, oz};  // index 1 = ceil corner
   const int row_lane = lane & 15;
   float ax = 0.f, ay = 0.f, az = 0.f;
+#if CN_QUAD_ATOMICS
+  // The two corners of an x-edge hash to e and e ^ 1 when ix is even (level offsets are even): their four floats are
+  // one aligned 16-byte slot.  Each atomic instruction therefore serves ONE x-edge of one source lane from FOUR adjacent
+  // lanes (entry = lane & 2 ? x1 corner : x0 corner, feature = lane & 1); the four source lanes of a quad take turns.
+  // Even ix: 4 requests per sample and level instead of 8; odd ix: 8 as before.
+#pragma unroll
+  for (int bd = 0; bd < 4; ++bd) {
+    const int b = bd & 1, d = bd >> 1;
+    unsigned eu[2];
+    float v0[2], v1[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const float w = wx[a] * wy[b] * wz[d];
+      const unsigned e = ((hx[a] ^ hy[b] ^ hz[d]) & mask) + level_off;
+      if constexpr (POS) {
+        const float2 t = hash_gather(table, e);
+        const float tg = t.x * g0 + t.y * g1;
+        ax += (a ? tg : -tg) * (wy[b] * wz[d]);
+        ay += (b ? tg : -tg) * (wx[a] * wz[d]);
+        az += (d ? tg : -tg) * (wx[a] * wy[b]);
+      }
+      v0[a] = w * g0;
+      v1[a] = w * g1;
+      const bool issue = row_run_reduce(e, v0[a], v1[a], row_lane);
+      eu[a] = issue && (v0[a] != 0.f || v1[a] != 0.f) ? e : 0xffffffffu;
+    }
+    const int ql = lane & 3;
+#define CN_QUAD_ROUND(CTRL)                                                                          \
+  {                                                                                                  \
+    const unsigned e0 = dpp_u32<CTRL>(eu[0]), e1 = dpp_u32<CTRL>(eu[1]);                             \
+    const float a00 = dpp_f32<CTRL>(v0[0]), a01 = dpp_f32<CTRL>(v1[0]);                              \
+    const float a10 = dpp_f32<CTRL>(v0[1]), a11 = dpp_f32<CTRL>(v1[1]);                              \
+    const unsigned es = (ql & 2) ? e1 : e0;                                                          \
+    const float val = (ql & 2) ? ((ql & 1) ? a11 : a10) : ((ql & 1) ? a01 : a00);                    \
+    if (es != 0xffffffffu) atomicAdd(gtab + 2 * (size_t)es + (ql & 1), val);                         \
+  }
+    CN_QUAD_ROUND(0x00)  // quad_perm [0,0,0,0]
+    CN_QUAD_ROUND(0x55)  // [1,1,1,1]
+    CN_QUAD_ROUND(0xAA)  // [2,2,2,2]
+    CN_QUAD_ROUND(0xFF)  // [3,3,3,3]
+#undef CN_QUAD_ROUND
+  }
+#else
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const int a = c & 1, b = (c >> 1) & 1, d = c >> 2;
@@ -198,6 +244,7 @@ __device__ __forceinline__ void hash_level_backward(float* __restrict__ gtab, co
     }
 #endif
   }
+#endif
   if constexpr (POS) {
     dpx = fmaf(ax, scale, dpx);
     dpy = fmaf(ay, scale, dpy);
