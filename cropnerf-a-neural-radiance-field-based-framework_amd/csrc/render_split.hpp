@@ -137,7 +137,8 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
     float4* dst = reinterpret_cast<float4*>(lds);
     for (int i = threadIdx.x; i < BLOB_FLOATS / 4; i += SPLIT_THREADS) dst[i] = src[i];
     if (threadIdx.x < SPLIT_PAIRS * 4)
-      reinterpret_cast<int*>(lds + BLOB_FLOATS + (threadIdx.x >> 2) * PAIR_SCRATCH + PAIR_FLAGS)[threadIdx.x & 3] = 0;
+      reinterpret_cast<int*>(lds + BLOB_FLOATS + (threadIdx.x >> 2) * PAIR_SCRATCH + PAIR_FLAGS)[threadIdx.x & 3] =
+          (threadIdx.x & 3) == 2 ? -1 : 0;  // [0,1]: slot flags (flag-sync build); [2]: schedule slot of a terminated ray
   }
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -182,6 +183,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
   for (int m = 0; m < SPLIT_MPG; ++m) gray[m].valid = false;
   CompositeState st;
   float my_dlogit = 0.f, my_sel = 0.f, my_sem = 0.f, my_r = 0.f, my_g = 0.f, my_b = 0.f;
+  bool ray_stopped = false;  // matrix wave: this ray was terminated early (cn_render_opts.early_stop_transmittance)
 
   // The two roles run separate loops (same trip count, one barrier per iteration) so that neither role's registers are
   // live in the other's code.
@@ -208,7 +210,12 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
           float* tb_g = gring + 2 * XCH_FLOATS + 64 + 68;
           if (k == 0)
             split_ray_setup(A, q_first + pair + m + qi * stride, items, xcd, striped, rows, cw, first_row, per_xcd, chunks_per_item_ray, gr);
-          if (gr.valid) {
+          // early termination: the matrix wave publishes the schedule slot of a ray it has finished early; the rest of
+          // that ray's half-steps are then idle for the pair (the workgroup still runs them in lock-step: the time is
+          // saved when the 8 rays in flight -- neighbouring pixels -- go opaque at about the same depth)
+          const bool stopped_g = !PER_SAMPLE && A.early_stop > 0.f &&
+                                 reinterpret_cast<volatile int*>(gring + PAIR_FLAGS)[2] == (int)qi;
+          if (gr.valid && !stopped_g) {
             const int chunk = PER_SAMPLE ? gr.chunk : (k >> 1), half = k & 1;
 #if CN_SPLIT_SYNC_FLAGS
             // wait for the slot BEFORE the gathers are issued: nothing but the ray state is live across the spin
@@ -328,6 +335,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
       if (k == 0) {
         split_ray_setup(A, q_first + pair + qi * stride, items, xcd, striped, rows, cw, first_row, per_xcd, chunks_per_item_ray, ray);
         st = CompositeState();
+        ray_stopped = false;
         if (ray.valid) {
           // per-ray colour bias: bc0 + Wc0[:, sh].SH(d) + Wc0[:, app].app  (lane n = neuron n)
           float sx = ray.dx, sy = ray.dy, sz = ray.dz;
@@ -355,7 +363,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
           __builtin_amdgcn_wave_barrier();
         }
       }
-      if (ray.valid) {
+      if (ray.valid && !ray_stopped) {
         const int chunk = PER_SAMPLE ? ray.chunk : (k >> 1), half = k & 1;
         const int c0 = chunk * 64;
         if (half == 0) {
@@ -526,7 +534,21 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
           } else {
           const float w = composite_chunk(st, valid, i == S - 1, e1 - e0, density, mid, cr, cg, cb, sem, A.eval_clamp != 0);
           if (A.out_w && valid) A.out_w[ray.r * (long long)S + i] = w;
-          if (k == nhalf - 1) {
+          bool finish = k == nhalf - 1;
+          if (!finish && A.early_stop > 0.f && __expf(-st.carry_dd) < A.early_stop) {  // wave-uniform
+            // the samples behind this chunk carry less than the threshold in total weight: drop them (same rule and same
+            // "last sample" stand-in as render_fused_kernel)
+            st.last_r = wave_read(A.eval_clamp ? nan_to_num(cr) : cr, 63);
+            st.last_g = wave_read(A.eval_clamp ? nan_to_num(cg) : cg, 63);
+            st.last_b = wave_read(A.eval_clamp ? nan_to_num(cb) : cb, 63);
+            st.last_mid = wave_read(mid, 63);
+            if (A.out_w)
+              for (int kk = c0 + 64 + lane; kk < S; kk += 64) A.out_w[ray.r * (long long)S + kk] = 0.f;
+            if (lane == 0) reinterpret_cast<volatile int*>(ring + PAIR_FLAGS)[2] = (int)qi;
+            ray_stopped = true;
+            finish = true;
+          }
+          if (finish) {
             const CompositeOut o = composite_finish(st, A.bg_mode, A.bg[0], A.bg[1], A.bg[2], A.eval_clamp != 0);
             if (lane == 0) {
               const long long r = ray.r;

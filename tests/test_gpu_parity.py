@@ -539,11 +539,13 @@ def test_image_width_hint_changes_schedule_not_results(scene, ops, handles, widt
         assert torch.equal(base[k], hinted[k]), k
 
 
+@pytest.mark.parametrize("split", ["0", "2"])  # single-wave kernel / producer-consumer kernel (forced for a small batch)
 @pytest.mark.parametrize("eps", [1e-2, 1e-4])
-def test_early_stop_is_off_by_default_and_bounded_when_on(scene, ops, eps):
+def test_early_stop_is_off_by_default_and_bounded_when_on(scene, ops, eps, split, monkeypatch):
     """cn_render_opts.early_stop_transmittance (an extension; the reference composites every sample): 0 is bit-identical
     to the plain render, > 0 on an opaque medium changes every output by less than the threshold and really stops
     (the weights behind the cut are exactly 0)."""
+    monkeypatch.setenv("CN_FUSED_SPLIT", split)
     fspec, _ = product_specs(scene)
     dp = dev_params(scene)
     dp = {k: v.clone() for k, v in dp.items()}
