@@ -17,6 +17,7 @@
 //
 // Shapes: the default fruit_nerf_method field (16 levels, 32->64->16, 15->64->64->1, 63->64->64->3, appearance 32)
 // and {5|7}-level 2L->16->1 proposal nets; other shapes return CN_ERR_UNSUPPORTED.
+#include <algorithm>
 #include <cstring>
 #include <cstdlib>
 
@@ -569,6 +570,10 @@ __global__ void __launch_bounds__(TB) field_backward_kernel(FieldBwdArgs A) {
 #include "train_field_mfma.hpp"
 namespace cn {
 
+}  // namespace cn
+#include "train_field_general.hpp"
+namespace cn {
+
 // ------------------------------------------------------------------------------------------------------------------------
 // proposal network backward
 // ------------------------------------------------------------------------------------------------------------------------
@@ -854,4 +859,158 @@ extern "C" int cn_proposal_backward(const cn_density_params* params, const cn_de
   else
     hipLaunchKernelGGL(cn::proposal_backward_kernel<7>, grid, dim3(cn::TB), 0, cn::as_stream(stream), A);
   return cn::check_launch("cn_proposal_backward");
+}
+
+// ---- shape-generic field backward ------------------------------------------------------------------------------------------
+namespace cn {
+static bool general_family_ok(const cn_field_params& p) {
+  auto w128 = [](const cn_mlp& m) {
+    for (int l = 0; l <= m.num_layers; ++l)
+      if (m.dims[l] > 128) return false;
+    return true;
+  };
+  return p.base.num_layers == 2 && (p.semantics.num_layers == 2 || p.semantics.num_layers == 3) &&
+         p.color.num_layers == 3 && w128(p.base) && w128(p.semantics) && w128(p.color) && p.geo_feat_dim <= 30 &&
+         2 * p.grid.num_levels <= 32 && 16 + p.geo_feat_dim + p.app_dim <= 128;
+}
+static int general_param_count(const cn_field_params& p) {
+  auto mlp = [](const cn_mlp& m) {
+    int n = 0;
+    for (int l = 0; l < m.num_layers; ++l) n += m.dims[l] * m.dims[l + 1] + m.dims[l + 1];
+    return n;
+  };
+  return mlp(p.base) + mlp(p.semantics) + mlp(p.color) + p.semantics.dims[p.semantics.num_layers] + 1;
+}
+static int general_blocks() {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  return cus;
+}
+}  // namespace cn
+
+extern "C" size_t cn_field_backward_general_workspace_bytes(const cn_field_params* params) {
+  if (!params) return 0;
+  return (size_t)cn::general_blocks() * ((cn::general_param_count(*params) + 3) / 4 * 4) * sizeof(float);
+}
+
+extern "C" int cn_field_backward_general(const cn_field_params* params, const cn_field_params* grads,
+                                         const cn_scene* scene, int32_t app_mode, int32_t sh_unit_dir,
+                                         const float* app_mean, const float* origins, const float* directions,
+                                         const int64_t* camera_indices, const float* starts, const float* ends,
+                                         const float* d_density, const float* d_rgb, const float* d_semantics,
+                                         int64_t num_rays, int32_t num_samples, void* workspace,
+                                         size_t workspace_bytes, cn_stream_t stream) {
+  CN_REQUIRE(params && grads && scene && origins && directions && starts && ends && d_density && d_rgb && d_semantics,
+             CN_ERR_INVALID, "cn_field_backward_general: null argument");
+  CN_REQUIRE(app_mode != CN_APP_PER_CAMERA || camera_indices, CN_ERR_INVALID, "Camera indices are not provided.");
+  CN_REQUIRE(app_mode != CN_APP_MEAN || app_mean, CN_ERR_INVALID, "cn_field_backward_general: app_mean required");
+  int rc = cn::validate_field(*params);
+  if (rc) return rc;
+  if ((rc = cn::validate_field(*grads))) return rc;
+  CN_REQUIRE(cn::general_family_ok(*params), CN_ERR_UNSUPPORTED,
+             "cn_field_backward_general: base 2 layers, semantics 2-3 layers, colour 3 layers, widths <= 128");
+  CN_REQUIRE(grads->grid.log2_table_size == params->grid.log2_table_size, CN_ERR_INVALID,
+             "cn_field_backward_general: gradient table size differs");
+  if (num_rays <= 0) return CN_OK;
+  const int nblk = cn::general_blocks();
+  const int ppb = (cn::general_param_count(*params) + 3) / 4 * 4;
+  CN_REQUIRE(workspace && workspace_bytes >= (size_t)nblk * ppb * sizeof(float), CN_ERR_WORKSPACE,
+             "cn_field_backward_general: workspace %zu B < %zu B", workspace_bytes, (size_t)nblk * ppb * sizeof(float));
+  hipStream_t s = cn::as_stream(stream);
+  cn::gb::GenArgs A{};
+  int off = 0;
+  struct Target { float* g; int off, n; };
+  Target targets[24];
+  int nt = 0;
+  auto fill = [&](cn::gb::GenLayer* dst, const cn_mlp& m, const cn_mlp& gm) {
+    for (int l = 0; l < m.num_layers; ++l) {
+      dst[l].W = m.weight[l];
+      dst[l].b = m.bias[l];
+      dst[l].K = m.dims[l];
+      dst[l].N = m.dims[l + 1];
+      dst[l].off_w = off;
+      targets[nt++] = {const_cast<float*>(gm.weight[l]), off, m.dims[l] * m.dims[l + 1]};
+      off += m.dims[l] * m.dims[l + 1];
+      dst[l].off_b = off;
+      targets[nt++] = {const_cast<float*>(gm.bias[l]), off, m.dims[l + 1]};
+      off += m.dims[l + 1];
+    }
+  };
+  fill(A.base, params->base, grads->base);
+  fill(A.sem, params->semantics, grads->semantics);
+  fill(A.col, params->color, grads->color);
+  A.ns = params->semantics.num_layers;
+  const int ht = params->semantics.dims[A.ns];
+  A.wh = params->sem_head_weight;
+  A.off_wh = off;
+  targets[nt++] = {const_cast<float*>(grads->sem_head_weight), off, ht};
+  off += ht;
+  A.off_bh = off;
+  targets[nt++] = {const_cast<float*>(grads->sem_head_bias), off, 1};
+  off += 1;
+  for (int i = 0; i < nt; ++i) CN_REQUIRE(targets[i].g, CN_ERR_INVALID, "cn_field_backward_general: null gradient buffer");
+  A.params_per_block = ppb;
+  A.scratch = static_cast<float*>(workspace);
+  auto p16 = [](int n) { return (n + 15) & ~15; };
+  int rows = 0, wmax = 16;
+  auto take = [&](int n) { int r = rows; rows += n; return r; };
+  const int enc = 2 * params->grid.num_levels, cin = 16 + params->geo_feat_dim + params->app_dim;
+  for (const cn_mlp* m : {&params->base, &params->semantics, &params->color})
+    for (int l = 0; l <= m->num_layers; ++l) wmax = std::max(wmax, p16(m->dims[l]));
+  A.r_enc = take(p16(enc));
+  A.r_h1 = take(p16(params->base.dims[1]));
+  A.r_g = take(48);
+  for (int l = 0; l < A.ns; ++l) A.r_s[l] = take(p16(params->semantics.dims[l + 1]));
+  A.r_cin = take(p16(cin));
+  A.r_c1 = take(p16(params->color.dims[1]));
+  A.r_c2 = take(p16(params->color.dims[2]));
+  A.r_rgb = take(16);
+  A.r_da = take(wmax);
+  A.r_db = take(wmax);
+  A.r_dcin = take(p16(cin));
+  A.r_dg = take(32);
+  A.r_drgb = take(16);
+  A.r_dsem = take(16);
+  A.rows = rows;
+  const size_t lds = ((size_t)rows * cn::gb::LDG + 16) * sizeof(float);
+  CN_REQUIRE(lds <= 160 * 1024, CN_ERR_UNSUPPORTED,
+             "cn_field_backward_general: the activations of one 32-sample tile need %zu B of LDS (max 163840)", lds);
+  A.table = params->grid.table;
+  A.g_table = const_cast<float*>(grads->grid.table);
+  A.emb = params->appearance;
+  A.g_emb = const_cast<float*>(grads->appearance);
+  A.app_mean = app_mode == CN_APP_MEAN ? app_mean : nullptr;
+  A.level_stride = 1u << params->grid.log2_table_size;
+  A.mask = A.level_stride - 1u;
+  A.num_levels = params->grid.num_levels;
+  A.geo = params->geo_feat_dim;
+  A.app_dim = params->app_dim;
+  A.app_per_camera = app_mode == CN_APP_PER_CAMERA;
+  A.sh_unit = sh_unit_dir;
+  for (int i = 0; i < CN_MAX_LEVELS; ++i) A.scale[i] = params->grid.scalings[i];
+  A.scene = cn::make_scene_dev(*scene);
+  A.origins = origins;
+  A.directions = directions;
+  A.starts = starts;
+  A.ends = ends;
+  A.cam_idx = camera_indices;
+  A.d_density = d_density;
+  A.d_rgb = d_rgb;
+  A.d_sem = d_semantics;
+  A.R = num_rays;
+  A.S = num_samples;
+  CN_REQUIRE(A.g_table && (!A.app_per_camera || A.g_emb), CN_ERR_INVALID, "cn_field_backward_general: null gradient buffer");
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::gb::field_backward_general_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  CN_REQUIRE(hipMemsetAsync(workspace, 0, (size_t)nblk * ppb * sizeof(float), s) == hipSuccess, CN_ERR_LAUNCH,
+             "cn_field_backward_general: hipMemsetAsync failed");
+  const long long ntiles = (num_rays * (long long)num_samples + cn::gb::TSG - 1) / cn::gb::TSG;
+  const int grid = (int)std::min<long long>(ntiles, nblk);
+  hipLaunchKernelGGL(cn::gb::field_backward_general_kernel, dim3(grid), dim3(cn::gb::NTG), lds, s, A);
+  rc = cn::check_launch("cn_field_backward_general");
+  if (rc) return rc;
+  for (int i = 0; i < nt; ++i)
+    hipLaunchKernelGGL(cn::gb::field_backward_reduce_kernel, dim3(cn::grid_for(targets[i].n, 256, 64)), dim3(256), 0, s,
+                       A.scratch, grid, ppb, targets[i].off, targets[i].n, targets[i].g);
+  return cn::check_launch("cn_field_backward_general reduce");
 }

@@ -1,0 +1,321 @@
+// Shape-generic FruitField backward on the fp32 matrix cores (included by train_field.hip): the training path of the
+// field shapes the specialised kernel (train_field_mfma.hpp) is not built for -- fruit_nerf_method_big / _huge
+// (geo_feat_dim 30, 3 x 128 semantic layers; fruit_nerf/fruit_nerf_config.py:66-172).
+//
+// Supported family (every config of the reference): base MLP 2 layers, semantic MLP 2 or 3 layers + Linear(Ht, 1),
+// colour MLP 3 layers, all widths <= 128, as long as the per-tile activations fit LDS.  One 512-thread workgroup per CU
+// walks 32-sample tiles; activations and deltas live in LDS as [feature][36] with every row count padded to 16 (pad rows
+// hold exact zeros); weights are read straight from global memory (L2) as MFMA A operands, with guards instead of
+// padding.  Weight and bias gradients are added, tile by tile and without atomics, into a scratch area PRIVATE to the
+// workgroup ([workgroups][parameters] floats in the caller's workspace); field_backward_reduce_kernel folds the scratch
+// into the gradient tensors afterwards.  Hash-table and appearance-embedding gradients are scatter-adds as in the
+// specialised kernel.  The position / direction gradients for the camera pose refinement are not produced here.
+#pragma once
+
+namespace cn {
+namespace gb {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int TSG = 32, LDG = 36, NTG = 512;
+
+struct GenLayer {
+  const float* W;
+  const float* b;
+  int K, N;
+  int off_w, off_b;  // offsets (floats) of dW / db inside a workgroup's scratch slice
+};
+
+struct GenArgs {
+  GenLayer base[2], sem[3], col[3];
+  int ns;                    // semantic layers (2 or 3)
+  const float* wh;           // semantic head [Ht]
+  int off_wh, off_bh;
+  int params_per_block;      // floats of one workgroup's scratch slice
+  float* scratch;            // [gridDim.x][params_per_block], zeroed by the caller
+  // LDS row offsets (rows of LDG floats)
+  int r_enc, r_h1, r_g, r_s[3], r_cin, r_c1, r_c2, r_rgb, r_da, r_db, r_dcin, r_dg, r_drgb, r_dsem, rows;
+  // field
+  const float* table;
+  float* g_table;
+  const float* emb;
+  float* g_emb;
+  const float* app_mean;
+  unsigned mask, level_stride;
+  int num_levels, geo, app_dim, app_per_camera, sh_unit;
+  float scale[CN_MAX_LEVELS];
+  SceneDev scene;
+  const float *origins, *directions, *starts, *ends;
+  const int64_t* cam_idx;
+  const float *d_density, *d_rgb, *d_sem;
+  long long R;
+  int S;
+};
+
+__device__ __forceinline__ int opaque_i(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// out[n][s] = act(b[n] + sum_k W[n][k] in[k][s]) for all n < pad16(N); rows >= N come out as zeros
+__device__ __forceinline__ void gen_fwd(const GenLayer& L, const float* in, float* out, bool relu, int tid) {
+  const int lane = opaque_i(tid) & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+  const int Kp = (L.K + 15) & ~15, Np = (L.N + 15) & ~15;
+  for (int blk = wave; blk < (Np >> 4) * 2; blk += NTG / 64) {
+    const int n0 = (blk >> 1) * 16, s0 = (blk & 1) * 16;
+    f32x4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 4 * q + r;
+      acc[r] = n < L.N ? L.b[n] : 0.f;
+    }
+    const int nrow = n0 + i;
+    for (int kb = 0; kb < Kp; kb += 16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = kb + 4 * q + e;
+        const float a = (nrow < L.N && k < L.K) ? L.W[(size_t)nrow * L.K + k] : 0.f;
+        const float b = in[k * LDG + s0 + i];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = acc[r];
+      if (relu) v = fmaxf(v, 0.f);
+      out[(n0 + 4 * q + r) * LDG + s0 + i] = v;
+    }
+  }
+}
+
+// dx[k][s] = (sum_n W[n][k] dy[n][s]) * (mask ? mask[k][s] > 0 : 1) for all k < pad16(K)
+__device__ __forceinline__ void gen_bwd(const GenLayer& L, const float* dy, float* dx, const float* mask, int tid) {
+  const int lane = opaque_i(tid) & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+  const int Kp = (L.K + 15) & ~15, Np = (L.N + 15) & ~15;
+  for (int blk = wave; blk < (Kp >> 4) * 2; blk += NTG / 64) {
+    const int k0 = (blk >> 1) * 16, s0 = (blk & 1) * 16;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int kcol = k0 + i;
+    for (int nb = 0; nb < Np; nb += 16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = nb + 4 * q + e;
+        const float a = (n < L.N && kcol < L.K) ? L.W[(size_t)n * L.K + kcol] : 0.f;
+        const float b = dy[n * LDG + s0 + i];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = k0 + 4 * q + r;
+      float v = acc[r];
+      if (mask) v = mask[k * LDG + s0 + i] > 0.f ? v : 0.f;
+      dx[k * LDG + s0 + i] = v;
+    }
+  }
+}
+
+// scratch dW[n][k] += sum_s dy[n][s] x[k][s];  scratch db[n] += sum_s dy[n][s]   (workgroup-private, no atomics)
+__device__ __forceinline__ void gen_dw(const GenLayer& L, const float* dy, const float* x, float* scratch, int tid) {
+  const int lane = opaque_i(tid) & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+  const int Kp = (L.K + 15) & ~15, Np = (L.N + 15) & ~15;
+  const int nkt = Kp >> 4;
+  for (int blk = wave; blk < (Np >> 4) * nkt; blk += NTG / 64) {
+    const int n0 = (blk / nkt) * 16, k0 = (blk % nkt) * 16;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sb = 0; sb < TSG; sb += 16) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(dy + (n0 + i) * LDG + sb + 4 * q);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(x + (k0 + i) * LDG + sb + 4 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float av = a[e], bv = b[e];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 4 * q + r, k = k0 + i;
+      if (n < L.N && k < L.K) scratch[L.off_w + n * L.K + k] += acc[r];
+    }
+  }
+  for (int n = tid; n < L.N; n += NTG) {
+    float sum = 0.f;
+    for (int s = 0; s < TSG; ++s) sum += dy[n * LDG + s];
+    scratch[L.off_b + n] += sum;
+  }
+}
+
+__global__ void __launch_bounds__(NTG) field_backward_general_kernel(GenArgs A) {
+  extern __shared__ __align__(16) float lds[];
+  const int tid = threadIdx.x;
+  for (int e = tid; e < A.rows * LDG; e += NTG) lds[e] = 0.f;
+  float* SCL = lds + A.rows * LDG;  // level scales (a per-lane index into the kernarg array would go to scratch)
+  if (tid < CN_MAX_LEVELS) SCL[tid] = A.scale[tid];
+  __syncthreads();
+  float* ENC = lds + A.r_enc * LDG;
+  float* H1 = lds + A.r_h1 * LDG;
+  float* G = lds + A.r_g * LDG;
+  float* CIN = lds + A.r_cin * LDG;
+  float* C1 = lds + A.r_c1 * LDG;
+  float* C2 = lds + A.r_c2 * LDG;
+  float* RGB = lds + A.r_rgb * LDG;
+  float* DA = lds + A.r_da * LDG;
+  float* DB = lds + A.r_db * LDG;
+  float* DCIN = lds + A.r_dcin * LDG;
+  float* DG = lds + A.r_dg * LDG;
+  float* DRGB = lds + A.r_drgb * LDG;
+  float* DSEM = lds + A.r_dsem * LDG;
+  float* scratch = A.scratch + (size_t)blockIdx.x * A.params_per_block;
+  const int s = tid & 31, grp = tid >> 5;  // 16 groups of 32 samples
+  const int lane = tid & 63;
+  const int cin_dim = 16 + A.geo + A.app_dim;
+  const long long total = A.R * (long long)A.S;
+  const long long ntiles = (total + TSG - 1) / TSG;
+  const GenLayer& lastsem = A.sem[A.ns - 1];
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long ismp = tile * TSG + s;
+    const bool valid = ismp < total;
+    const long long ic = valid ? ismp : total - 1;
+    const long long r = ic / A.S;
+    const float mid = (A.starts[ic] + A.ends[ic]) / 2.f;
+    const float dirx = A.directions[3 * r], diry = A.directions[3 * r + 1], dirz = A.directions[3 * r + 2];
+    float px = A.origins[3 * r] + dirx * mid, py = A.origins[3 * r + 1] + diry * mid, pz = A.origins[3 * r + 2] + dirz * mid;
+    const float self = normalize_position(A.scene, px, py, pz) ? 1.f : 0.f;
+    // ---- inputs ---------------------------------------------------------------------------------------------------------
+    for (int l = grp; l < A.num_levels; l += 16) {
+      const float2 f = hash_level(A.table, (unsigned)l * A.level_stride, A.mask, SCL[l], px, py, pz);
+      ENC[(2 * l) * LDG + s] = f.x;
+      ENC[(2 * l + 1) * LDG + s] = f.y;
+    }
+    if (grp == 0) DSEM[s] = valid ? A.d_sem[ic] : 0.f;
+    if (grp == 1) {
+      float dx = dirx, dy = diry, dz = dirz;
+      if (!A.sh_unit) {
+        dx = (dx + 1.f) / 2.f;
+        dy = (dy + 1.f) / 2.f;
+        dz = (dz + 1.f) / 2.f;
+      }
+      float sh[16];
+      sh_deg4(dx, dy, dz, sh);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) CIN[k * LDG + s] = sh[k];
+    }
+    {
+      const float* a = A.app_per_camera ? A.emb + A.cam_idx[r] * (long long)A.app_dim : A.app_mean;
+      for (int k = grp; k < A.app_dim; k += 16) CIN[(16 + A.geo + k) * LDG + s] = a ? a[k] : 0.f;
+    }
+    __syncthreads();
+    // ---- forward ---------------------------------------------------------------------------------------------------------
+    gen_fwd(A.base[0], ENC, H1, true, tid);
+    __syncthreads();
+    gen_fwd(A.base[1], H1, G, false, tid);
+    __syncthreads();
+    for (int k = grp; k < A.geo; k += 16) CIN[(16 + k) * LDG + s] = G[(1 + k) * LDG + s];
+    {
+      const float* x = G + LDG;  // geo rows (detached input of the semantic MLP)
+      for (int l = 0; l < A.ns; ++l) {
+        float* y = lds + A.r_s[l] * LDG;
+        gen_fwd(A.sem[l], x, y, l < A.ns - 1, tid);
+        __syncthreads();
+        x = y;
+      }
+    }
+    gen_fwd(A.col[0], CIN, C1, true, tid);
+    __syncthreads();
+    gen_fwd(A.col[1], C1, C2, true, tid);
+    __syncthreads();
+    gen_fwd(A.col[2], C2, RGB, false, tid);
+    __syncthreads();
+    // ---- semantic branch backward (stops at the detached geo features) ------------------------------------------------------
+    {
+      const float* sout = lds + A.r_s[A.ns - 1] * LDG;
+      const int ht = lastsem.N;
+      // head: d_sout[k][s] = wh[k] d_sem[s];  dWh[k] += sum_s d_sem[s] sout[k][s];  dbh += sum_s d_sem[s]
+      for (int k = grp; k < ((ht + 15) & ~15); k += 16) DA[k * LDG + s] = k < ht ? A.wh[k] * DSEM[s] : 0.f;
+      for (int k = tid; k < ht; k += NTG) {
+        float sum = 0.f;
+        for (int j = 0; j < TSG; ++j) sum += DSEM[j] * sout[k * LDG + j];
+        scratch[A.off_wh + k] += sum;
+      }
+      if (tid == 0) {
+        float sum = 0.f;
+        for (int j = 0; j < TSG; ++j) sum += DSEM[j];
+        scratch[A.off_bh] += sum;
+      }
+      __syncthreads();
+      float* dcur = DA;
+      float* dnext = DB;
+      for (int l = A.ns - 1; l >= 0; --l) {
+        const float* xin = l == 0 ? G + LDG : lds + A.r_s[l - 1] * LDG;
+        gen_dw(A.sem[l], dcur, xin, scratch, tid);
+        if (l > 0) gen_bwd(A.sem[l], dcur, dnext, xin, tid);  // gate: the input is a post-ReLU activation
+        __syncthreads();
+        float* t = dcur;
+        dcur = dnext;
+        dnext = t;
+      }
+    }
+    // ---- colour branch backward -------------------------------------------------------------------------------------------
+    if (tid < 96) {  // d_rgb_pre = d_rgb * rgb * (1 - rgb), rows 0..2 (rows 3..15 of DRGB stay zero)
+      const int row = tid >> 5;
+      const float sg = 1.f / (1.f + expf(-RGB[row * LDG + s]));
+      DRGB[row * LDG + s] = valid ? A.d_rgb[3 * ic + row] * sg * (1.f - sg) : 0.f;
+    }
+    __syncthreads();
+    gen_dw(A.col[2], DRGB, C2, scratch, tid);
+    gen_bwd(A.col[2], DRGB, DA, C2, tid);
+    __syncthreads();
+    gen_dw(A.col[1], DA, C1, scratch, tid);
+    gen_bwd(A.col[1], DA, DB, C1, tid);
+    __syncthreads();
+    gen_dw(A.col[0], DB, CIN, scratch, tid);
+    gen_bwd(A.col[0], DB, DCIN, nullptr, tid);
+    __syncthreads();
+    // ---- d(base output): row 0 = density logit through trunc_exp and the selector, rows 1..geo from the colour input ----
+    for (int row = grp; row < 32; row += 16) {
+      float v = 0.f;
+      if (row == 0) {
+        const float dd = valid ? A.d_density[ic] : 0.f;
+        v = dd * self * expf(fminf(fmaxf(G[s], -15.f), 15.f));
+      } else if (row <= A.geo) {
+        v = DCIN[(15 + row) * LDG + s];
+      }
+      DG[row * LDG + s] = v;
+    }
+    if (A.app_per_camera && valid)
+      for (int k = grp; k < A.app_dim; k += 16)
+        atomicAdd(A.g_emb + A.cam_idx[r] * (long long)A.app_dim + k, DCIN[(16 + A.geo + k) * LDG + s]);
+    __syncthreads();
+    gen_dw(A.base[1], DG, H1, scratch, tid);
+    gen_bwd(A.base[1], DG, DA, H1, tid);
+    __syncthreads();
+    gen_dw(A.base[0], DA, ENC, scratch, tid);
+    gen_bwd(A.base[0], DA, DB, nullptr, tid);
+    __syncthreads();
+    // ---- hash-table gradient (16 consecutive lanes = 16 consecutive samples of one level: run-length pre-reduction) ----
+    for (int l0 = 0; l0 < A.num_levels; l0 += 16) {
+      const int l = l0 + grp;
+      const bool on = l < A.num_levels;
+      const int lc = on ? l : 0;
+      float gpx = 0.f, gpy = 0.f, gpz = 0.f;
+      hash_level_backward<false>(A.g_table, A.table, (unsigned)lc * A.level_stride, A.mask, SCL[lc], px, py, pz,
+                                 on && valid ? DB[(2 * lc) * LDG + s] : 0.f,
+                                 on && valid ? DB[(2 * lc + 1) * LDG + s] : 0.f, lane, gpx, gpy, gpz);
+    }
+    __syncthreads();
+  }
+}
+
+// grads[e] += sum over workgroups of scratch[b][e] for one parameter tensor at scratch offset `off`
+__global__ void __launch_bounds__(256)
+field_backward_reduce_kernel(const float* __restrict__ scratch, int nblocks, int params_per_block, int off, int n,
+                             float* __restrict__ grad) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    float sum = 0.f;
+    for (int b = 0; b < nblocks; ++b) sum += scratch[(size_t)b * params_per_block + off + e];
+    grad[e] += sum;
+  }
+}
+
+}  // namespace gb
+}  // namespace cn

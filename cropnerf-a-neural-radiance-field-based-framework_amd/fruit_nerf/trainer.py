@@ -6,7 +6,8 @@ per-camera appearance) -> ``get_loss_dict`` (``fruit_nerf/fruit_nerf.py:601-615`
 -> backward -> Adam with exponential LR decay (``fruit_nerf/fruit_nerf_config.py:45-60``) -> anneal callback
 (``fruit_nerf.py:198-232``).
 
-The camera pose refinement (``camera_opt`` group, ``fruit_nerf.py:195``) is trained too: the field / proposal backward
+``fruit_nerf_method_big`` / ``_huge`` (other field shapes) train through the shape-generic kernels with the camera
+poses frozen.  The camera pose refinement (``camera_opt`` group, ``fruit_nerf.py:195``) is trained too: the field / proposal backward
 kernels return d loss / d sample position (and the SH-input gradient of the colour branch), ``cn_ray_backward`` reduces
 them per ray and ``cn_pose_adjustment_backward`` chains through exp_map_SO3xR3; ``camera_opt_regularizer``
 (``fruit_nerf.py:614``) is added by ``cn_pose_regularizer``.  The proposal networks follow the reference's update
@@ -47,14 +48,15 @@ class OptimGroup:
 
 class FruitTrainer:
     def __init__(self, model: FruitModel, groups: Optional[Dict[str, OptimGroup]] = None, seed: int = 0):
-        if not model._fused_shape:
-            raise NotImplementedError(
-                "training is built for the default fruit_nerf_method field shape; the _big / _huge shapes "
-                "(geo_feat_dim 30, 3 x 128 semantic layers) render through the shape-generic kernels but have no "
-                "backward kernels yet")
         self.model = model
+        # fruit_nerf_method_big / _huge field shapes train through the shape-generic kernels (cn_field_eval +
+        # cn_field_backward_general); those do not produce the position gradients, so the camera poses stay frozen there
+        self.general = not model._fused_shape
         self.groups = groups or {"proposal_networks": OptimGroup(), "fields": OptimGroup(),
                                  "camera_opt": OptimGroup(1e-3, 1e-15, 1e-4, 5000)}
+        if self.general:
+            self.groups = {k: v for k, v in self.groups.items() if k != "camera_opt"}
+        self._general_ws = None
         dev = model.device
         # a group that is not listed is frozen (its gradients are still computed for "fields"/"proposal_networks")
         self.train_pose = "camera_opt" in self.groups
@@ -158,8 +160,12 @@ class FruitTrainer:
             starts, ends = eu[:, :-1].contiguous(), eu[:, 1:].contiguous()
         # ---- field forward (fused kernel, per-sample outputs) --------------------------------------------------------
         S = cfg.num_nerf_samples_per_ray
-        opts = ops.render_opts(S, app_mode=L.APP_PER_CAMERA, sh_unit_dir=cfg.sh_input == "unit", eval_clamp=False)
-        fo = ops.render_samples(m.field, scene, opts, o, d, nears, fars, camera_indices=cam, bins=eu.contiguous())
+        if self.general:
+            fo = ops.field_eval(m.field, scene, o, d, cam, starts, ends, app_mode=L.APP_PER_CAMERA,
+                                sh_unit_dir=cfg.sh_input == "unit")
+        else:
+            opts = ops.render_opts(S, app_mode=L.APP_PER_CAMERA, sh_unit_dir=cfg.sh_input == "unit", eval_clamp=False)
+            fo = ops.render_samples(m.field, scene, opts, o, d, nears, fars, camera_indices=cam, bins=eu.contiguous())
         # ---- renderer + losses + their backward ------------------------------------------------------------------------
         self.loss_sums.zero_()
         image = batch["image"].to(dev)[:, :3].to(torch.float32).contiguous()
@@ -168,9 +174,15 @@ class FruitTrainer:
                                            cfg.semantic_loss_weight, self.loss_sums)
         dpos = torch.empty(R, S, 3, device=dev) if self.train_pose else None
         ddir = torch.empty(R, S, 3, device=dev) if self.train_pose else None
-        ops.field_backward(m.field, self.grad_field, scene, o, d, cam, starts, ends, rb_out["d_density"],
-                           rb_out["d_rgb"], rb_out["d_semantics"], app_mode=L.APP_PER_CAMERA,
-                           sh_unit_dir=cfg.sh_input == "unit", d_positions=dpos, d_directions=ddir)
+        if self.general:
+            self._general_ws = ops.field_backward_general(
+                m.field, self.grad_field, scene, o, d, cam, starts, ends, rb_out["d_density"], rb_out["d_rgb"],
+                rb_out["d_semantics"], app_mode=L.APP_PER_CAMERA, sh_unit_dir=cfg.sh_input == "unit",
+                workspace=self._general_ws)
+        else:
+            ops.field_backward(m.field, self.grad_field, scene, o, d, cam, starts, ends, rb_out["d_density"],
+                               rb_out["d_rgb"], rb_out["d_semantics"], app_mode=L.APP_PER_CAMERA,
+                               sh_unit_dir=cfg.sh_input == "unit", d_positions=dpos, d_directions=ddir)
         if self.train_pose:
             ops.ray_backward(dpos, ddir, starts, ends, d_o, d_d)
         for lvl, lv in enumerate(levels):

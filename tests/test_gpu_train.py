@@ -222,3 +222,123 @@ def test_fit_analytic_plant_end_to_end():
     chk = fit_scene.oracle_check(pipe, data, res_small=32)
     assert chk["psnr_hip_vs_oracle"] > 60.0, chk
     assert abs(chk["psnr_hip_vs_gt"] - chk["psnr_oracle_vs_gt"]) < 0.1, chk
+
+
+@pytest.mark.parametrize("shape", ["default", "big", "huge_like"])
+def test_general_field_backward_matches_autograd(shape):
+    """cn_field_backward_general (any field shape of the reference's configs; the training path of fruit_nerf_method_big
+    / _huge) against torch autograd on the oracle: every parameter gradient, the hash table and the appearance embedding.
+    On the default shape it must also agree with the specialised kernel."""
+    from cropnerf_amd import config as PC
+    from cropnerf_amd import ops
+    from oracle import field as OF
+    from oracle import samplers as OSM
+
+    kw = {"default": dict(geo_feat_dim=15, num_layers_semantic=2, hidden_dim_semantics=64, max_res=2048),
+          "big": dict(geo_feat_dim=30, num_layers_semantic=3, hidden_dim_semantics=128, max_res=4096),
+          "huge_like": dict(geo_feat_dim=30, num_layers_semantic=3, hidden_dim_semantics=128, max_res=8192)}[shape]
+    n_img, R, S = 5, 41, 13  # 533 samples: 16 full 32-sample tiles and a ragged one
+    ospec = OF.FieldSpec(grid=OF.GridSpec(16, 16, kw["max_res"], 12, 2), geo_feat_dim=kw["geo_feat_dim"],
+                         num_layers_semantic=kw["num_layers_semantic"], hidden_dim_semantics=kw["hidden_dim_semantics"],
+                         num_images=n_img)
+    params = {k: v for k, v in OF.random_params(ospec, [], seed=21, grid_scale=0.1).items() if k.startswith("field.")}
+    sc = make_scene(seed=2, log2_T=12, num_images=n_img, height=12, width=12, focal=16.0, prop_log2_T=10)
+    rb = ORY.with_aabb_near_far(ORY.image_rays(sc.c2w, sc.intr, 1, 12, 12), sc.aabb.reshape(-1)).slice(0, R)
+    g = torch.Generator().manual_seed(4)
+    cam = torch.randint(0, n_img, (R, 1), generator=g)
+    rs = OSM.spaced_sampler(rb, S, "uniform")
+    gd, grgb, gsem = (torch.randn(R, S, generator=g), torch.randn(R, S, 3, generator=g), torch.randn(R, S, generator=g))
+    # ---- oracle + autograd (semantic MLP on detached geo features, fruit_field.py:264-266) --------------------------------
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    fo = OF.field_forward(rs.positions(), rb.directions, cam, p, ospec, sc.aabb, True, "val", training=True)
+    geo = OF.field_density(rs.positions(), p, ospec, sc.aabb, True)[1].detach()
+    x = OF.mlp(geo.reshape(-1, ospec.geo_feat_dim), p, "field.mlp_semantics", ospec.num_layers_semantic)
+    sem = torch.nn.functional.linear(x, p["field.field_head_semantics.net.weight"],
+                                     p["field.field_head_semantics.net.bias"]).view(R, S)
+    ((fo["density"][..., 0] * gd).sum() + (fo["rgb"] * grgb).sum() + (sem * gsem).sum()).backward()
+    # ---- HIP ---------------------------------------------------------------------------------------------------------------
+    pspec = PC.FieldSpec(grid=PC.GridSpec(16, 16, kw["max_res"], 12, 2), geo_feat_dim=kw["geo_feat_dim"],
+                         num_layers_semantic=kw["num_layers_semantic"], hidden_dim_semantics=kw["hidden_dim_semantics"],
+                         num_images=n_img)
+    dp = {k: to_dev(v) for k, v in params.items()}
+    grads = {k: torch.zeros_like(v) for k, v in dp.items()}
+    fh, gh = ops.FieldHandle(dp, pspec), ops.FieldHandle(grads, pspec)
+    scene = ops.scene_struct(sc.aabb, True)
+    args = (scene, to_dev(rb.origins), to_dev(rb.directions), to_dev(cam[:, 0]), to_dev(rs.starts[..., 0]),
+            to_dev(rs.ends[..., 0]), to_dev(gd), to_dev(grgb), to_dev(gsem))
+    ops.field_backward_general(fh, gh, *args)
+    worst = {}
+    for k, v in p.items():
+        ref = v.grad
+        assert ref is not None and ref.abs().sum() > 0, k
+        worst[k] = (grads[k].cpu() - ref).norm().item() / (ref.norm().item() + 1e-12)
+    bad = {k: e for k, e in worst.items() if e > 3e-3}
+    assert not bad, bad
+    if shape == "default":
+        grads2 = {k: torch.zeros_like(v) for k, v in dp.items()}
+        ops.field_backward(fh, ops.FieldHandle(grads2, pspec), *args)
+        for k in grads:
+            rel = (grads[k] - grads2[k]).norm().item() / (grads2[k].norm().item() + 1e-12)
+            assert rel < 1e-4, (k, rel)
+
+
+def test_big_method_trains():
+    """A fruit_nerf_method_big-shaped model (geo 30, 3 x 128 semantic layers, a 7-level second proposal net as in
+    _huge) through FruitTrainer: losses and every field / proposal gradient against the oracle's autograd, then a few
+    optimiser steps reduce the loss."""
+    from cropnerf_amd import synthetic
+    from cropnerf_amd.config import FruitNerfModelConfig
+    from cropnerf_amd.fruit_nerf.fruit_nerf import FruitModel, Semantics
+    from cropnerf_amd.fruit_nerf.trainer import FruitTrainer, OptimGroup
+    from cropnerf_amd.rays import Cameras, SceneBox
+    from oracle import field as OF
+
+    n_img, H, R = 4, 16, 80
+    fspec = OF.FieldSpec(grid=OF.GridSpec(16, 16, 4096, 12, 2), geo_feat_dim=30, num_layers_semantic=3,
+                         hidden_dim_semantics=128, num_images=n_img)
+    pspecs = [OF.ProposalSpec(OF.GridSpec(5, 16, 512, 10)), OF.ProposalSpec(OF.GridSpec(7, 16, 2048, 10))]
+    params = OF.random_params(fspec, pspecs, seed=31, grid_scale=0.1)
+    c2w, intr = synthetic.orbit_cameras(n_img, height=H, width=H, focal=22.0)
+    aabb = torch.tensor(synthetic.SCENE_AABB, dtype=torch.float32)
+    pl = [{"hidden_dim": 16, "log2_hashmap_size": 10, "num_levels": 5, "max_res": 512},
+          {"hidden_dim": 16, "log2_hashmap_size": 10, "num_levels": 7, "max_res": 2048}]
+    cfg = FruitNerfModelConfig(geo_feat_dim=30, num_layers_semantic=3, hidden_dim_semantics=128, max_res=4096,
+                               log2_hashmap_size=12, proposal_net_args_list=pl, num_proposal_samples_per_ray=S_PROP,
+                               num_nerf_samples_per_ray=S_FINAL)
+    g = torch.Generator().manual_seed(9)
+    idx = torch.stack([torch.randint(0, n_img, (R,), generator=g), torch.randint(0, H, (R,), generator=g),
+                       torch.randint(0, H, (R,), generator=g)], -1)
+    jitter = [torch.rand(R, 1, generator=g) for _ in range(3)]
+    image = torch.rand(R, 3, generator=g)
+    mask = (torch.rand(R, 1, generator=g) > 0.5).float()
+    # oracle
+    p = {k: v.clone().requires_grad_(not k.startswith("camera_optimizer")) for k, v in params.items()}
+    rb = ORY.pinhole_rays(c2w, intr, idx[:, 0], idx[:, 1], idx[:, 2])
+    out_ref = OL.train_forward(rb, p, fspec, pspecs, aabb, S_PROP, S_FINAL, jitter)
+    ld_ref = OL.loss_dict(out_ref, image, mask)
+    sum(ld_ref.values()).backward()
+    # HIP
+    model = FruitModel(cfg, SceneBox(aabb), n_img, {"semantics": Semantics()}, device="cuda", test_mode="val", params=params)
+    model.training = True
+    groups = {"proposal_networks": OptimGroup(1e-2, 1e-15, 1e-4, 1000), "fields": OptimGroup(1e-2, 1e-15, 1e-4, 1000)}
+    tr = FruitTrainer(model, groups)
+    assert tr.general and not tr.train_pose
+    cams = Cameras(c2w, intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], H, H).to("cuda")
+    rays = cams.generate_rays(idx.cuda())
+    out = tr.forward_backward(rays, {"image": image, "fruit_mask": mask}, jitter=jitter)
+    for k, v in ld_ref.items():
+        assert abs(float(out["loss_dict"][k]) - float(v)) <= 2e-4 * abs(float(v)) + 1e-7, k
+    bad = {}
+    for k, v in p.items():
+        if v.grad is None:
+            continue
+        rel = (tr.grads[k].cpu() - v.grad).norm().item() / (v.grad.norm().item() + 1e-12)
+        if rel > 3e-3:
+            bad[k] = rel
+    assert not bad, bad
+    losses = []
+    for _ in range(6):
+        o2 = tr.forward_backward(rays, {"image": image, "fruit_mask": mask}, jitter=jitter)
+        losses.append(sum(float(v) for v in o2["loss_dict"].values()))
+        tr.optimizer_step()
+    assert losses[-1] < losses[0], losses

@@ -28,3 +28,23 @@ S = cfg.num_nerf_samples_per_ray
 print(json.dumps({"rays": R, "field_samples_per_ray": S, "proposal_samples_per_ray": list(cfg.num_proposal_samples_per_ray),
                   "ms_per_call": round(dt * 1e3, 2), "rays_per_sec": R / dt, "field_samples_per_sec": R * S / dt,
                   "finite": bool(torch.isfinite(out["rgb"]).all())}))
+
+# training iteration of the big method: 8192 rays (train_num_rays_per_batch = 4096 * 2, fruit_nerf_config.py)
+from cropnerf_amd.fruit_nerf.trainer import FruitTrainer
+m.training = True
+tr = FruitTrainer(m)
+g = torch.Generator().manual_seed(0)
+Rt = 8192
+idx = torch.stack([torch.randint(0, 8, (Rt,), generator=g), torch.randint(0, 800, (Rt,), generator=g),
+                   torch.randint(0, 800, (Rt,), generator=g)], -1)
+rays = cams.generate_rays(idx.cuda())
+batch = {"image": torch.rand(Rt, 3, generator=g).cuda(), "fruit_mask": (torch.rand(Rt, 1, generator=g) > 0.5).float().cuda()}
+for _ in range(2):
+    tr.train_iteration(rays, batch)
+torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(5):
+    tr.train_iteration(rays, batch)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t) / 5
+print(json.dumps({"train_rays": Rt, "ms_per_iter": round(dt * 1e3, 2), "rays_per_sec": Rt / dt}))
