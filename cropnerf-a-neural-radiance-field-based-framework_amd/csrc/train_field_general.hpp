@@ -69,13 +69,22 @@ __device__ __forceinline__ void gen_fwd(const GenLayer& L, const float* in, floa
       acc[r] = n < L.N ? L.b[n] : 0.f;
     }
     const int nrow = n0 + i;
-    for (int kb = 0; kb < Kp; kb += 16) {
+    // all A operands of the block (one weight row per lane, <= 128 columns) are requested up front: the L2 latency is
+    // paid once per 16x16 block instead of once per MFMA
+    float areg[32];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int k = kb + 4 * q + e;
-        const float a = (nrow < L.N && k < L.K) ? L.W[(size_t)nrow * L.K + k] : 0.f;
-        const float b = in[k * LDG + s0 + i];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    for (int j = 0; j < 32; ++j) {
+      const int k = 16 * (j >> 2) + 4 * q + (j & 3);
+      areg[j] = (nrow < L.N && k < L.K) ? L.W[(size_t)nrow * L.K + k] : 0.f;
+    }
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+      if (16 * kb < Kp) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float b = in[(16 * kb + 4 * q + e) * LDG + s0 + i];
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[4 * kb + e], b, acc, 0, 0, 0);
+        }
       }
     }
 #pragma unroll
@@ -95,13 +104,20 @@ __device__ __forceinline__ void gen_bwd(const GenLayer& L, const float* dy, floa
     const int k0 = (blk >> 1) * 16, s0 = (blk & 1) * 16;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int kcol = k0 + i;
-    for (int nb = 0; nb < Np; nb += 16) {
+    float areg[32];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int n = nb + 4 * q + e;
-        const float a = (n < L.N && kcol < L.K) ? L.W[(size_t)n * L.K + kcol] : 0.f;
-        const float b = dy[n * LDG + s0 + i];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    for (int j = 0; j < 32; ++j) {
+      const int n = 16 * (j >> 2) + 4 * q + (j & 3);
+      areg[j] = (n < L.N && kcol < L.K) ? L.W[(size_t)n * L.K + kcol] : 0.f;
+    }
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb) {
+      if (16 * nb < Np) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float b = dy[(16 * nb + 4 * q + e) * LDG + s0 + i];
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[4 * nb + e], b, acc, 0, 0, 0);
+        }
       }
     }
 #pragma unroll
@@ -282,9 +298,23 @@ __global__ void __launch_bounds__(NTG) field_backward_general_kernel(GenArgs A) 
       }
       DG[row * LDG + s] = v;
     }
-    if (A.app_per_camera && valid)
-      for (int k = grp; k < A.app_dim; k += 16)
-        atomicAdd(A.g_emb + A.cam_idx[r] * (long long)A.app_dim + k, DCIN[(16 + A.geo + k) * LDG + s]);
+    if (A.app_per_camera) {
+      // the 32 samples of a tile are almost always one ray (one camera row): sum them in the wave first, otherwise the
+      // same 32 addresses take 32-way conflicting atomics from every tile of every workgroup
+      const long long i_first = tile * TSG, i_last = (i_first + TSG - 1 < total ? i_first + TSG - 1 : total - 1);
+      const bool one_ray = (i_first / A.S) == (i_last / A.S);  // workgroup-uniform
+      for (int k0 = 0; k0 < A.app_dim; k0 += 16) {             // uniform trip count: every lane runs the DPP ops
+        const int k = k0 + grp;
+        float gsum = (valid && k < A.app_dim) ? DCIN[(16 + A.geo + k) * LDG + s] : 0.f;
+        if (one_ray) {
+          gsum = cn::mf::row16_sum(gsum);
+          const float other = __shfl_up(gsum, 16, 32);
+          if (s == 31 && k < A.app_dim) atomicAdd(A.g_emb + A.cam_idx[r] * (long long)A.app_dim + k, gsum + other);
+        } else if (valid && k < A.app_dim) {
+          atomicAdd(A.g_emb + A.cam_idx[r] * (long long)A.app_dim + k, gsum);
+        }
+      }
+    }
     __syncthreads();
     gen_dw(A.base[1], DG, H1, scratch, tid);
     gen_bwd(A.base[1], DG, DA, H1, tid);
