@@ -898,8 +898,9 @@ extern "C" int cn_field_backward_general(const cn_field_params* params, const cn
                                          const float* app_mean, const float* origins, const float* directions,
                                          const int64_t* camera_indices, const float* starts, const float* ends,
                                          const float* d_density, const float* d_rgb, const float* d_semantics,
-                                         int64_t num_rays, int32_t num_samples, void* workspace,
-                                         size_t workspace_bytes, cn_stream_t stream) {
+                                         int64_t num_rays, int32_t num_samples, float* d_positions,
+                                         float* d_directions, void* workspace, size_t workspace_bytes,
+                                         cn_stream_t stream) {
   CN_REQUIRE(params && grads && scene && origins && directions && starts && ends && d_density && d_rgb && d_semantics,
              CN_ERR_INVALID, "cn_field_backward_general: null argument");
   CN_REQUIRE(app_mode != CN_APP_PER_CAMERA || camera_indices, CN_ERR_INVALID, "Camera indices are not provided.");
@@ -965,7 +966,7 @@ extern "C" int cn_field_backward_general(const cn_field_params* params, const cn
   A.r_c1 = take(p16(params->color.dims[1]));
   A.r_c2 = take(p16(params->color.dims[2]));
   A.r_rgb = take(16);
-  A.r_da = take(wmax);
+  A.r_da = take(std::max(wmax, 48));  // also the 16 x 3 position-gradient partials
   A.r_db = take(wmax);
   A.r_dcin = take(p16(cin));
   A.r_dg = take(32);
@@ -997,6 +998,8 @@ extern "C" int cn_field_backward_general(const cn_field_params* params, const cn
   A.d_density = d_density;
   A.d_rgb = d_rgb;
   A.d_sem = d_semantics;
+  A.d_pos = d_positions;
+  A.d_dir = d_directions;
   A.R = num_rays;
   A.S = num_samples;
   CN_REQUIRE(A.g_table && (!A.app_per_camera || A.g_emb), CN_ERR_INVALID, "cn_field_backward_general: null gradient buffer");

@@ -9,7 +9,7 @@
 // padding.  Weight and bias gradients are added, tile by tile and without atomics, into a scratch area PRIVATE to the
 // workgroup ([workgroups][parameters] floats in the caller's workspace); field_backward_reduce_kernel folds the scratch
 // into the gradient tensors afterwards.  Hash-table and appearance-embedding gradients are scatter-adds as in the
-// specialised kernel.  The position / direction gradients for the camera pose refinement are not produced here.
+// specialised kernel, and so are the optional position / direction gradients for the camera pose refinement.
 #pragma once
 
 namespace cn {
@@ -47,6 +47,7 @@ struct GenArgs {
   const float *origins, *directions, *starts, *ends;
   const int64_t* cam_idx;
   const float *d_density, *d_rgb, *d_sem;
+  float *d_pos, *d_dir;  // optional [R*S,3]: gradients w.r.t. the sample position / the ray direction (pose refinement)
   long long R;
   int S;
 };
@@ -195,7 +196,9 @@ __global__ void __launch_bounds__(NTG) field_backward_general_kernel(GenArgs A) 
     const long long r = ic / A.S;
     const float mid = (A.starts[ic] + A.ends[ic]) / 2.f;
     const float dirx = A.directions[3 * r], diry = A.directions[3 * r + 1], dirz = A.directions[3 * r + 2];
-    float px = A.origins[3 * r] + dirx * mid, py = A.origins[3 * r + 1] + diry * mid, pz = A.origins[3 * r + 2] + dirz * mid;
+    const float wx = A.origins[3 * r] + dirx * mid, wy = A.origins[3 * r + 1] + diry * mid,
+                wz = A.origins[3 * r + 2] + dirz * mid;
+    float px = wx, py = wy, pz = wz;
     const float self = normalize_position(A.scene, px, py, pz) ? 1.f : 0.f;
     // ---- inputs ---------------------------------------------------------------------------------------------------------
     for (int l = grp; l < A.num_levels; l += 16) {
@@ -298,6 +301,23 @@ __global__ void __launch_bounds__(NTG) field_backward_general_kernel(GenArgs A) 
       }
       DG[row * LDG + s] = v;
     }
+    if (A.d_dir && grp == 2 && valid) {
+      float gsh[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) gsh[k] = DCIN[k * LDG + s];
+      float dx = dirx, dy = diry, dz = dirz;
+      const float chain = A.sh_unit ? 1.f : 0.5f;
+      if (!A.sh_unit) {
+        dx = (dx + 1.f) / 2.f;
+        dy = (dy + 1.f) / 2.f;
+        dz = (dz + 1.f) / 2.f;
+      }
+      float gx, gy, gz;
+      sh_deg4_backward(dx, dy, dz, gsh, gx, gy, gz);
+      A.d_dir[3 * ismp] = gx * chain;
+      A.d_dir[3 * ismp + 1] = gy * chain;
+      A.d_dir[3 * ismp + 2] = gz * chain;
+    }
     if (A.app_per_camera) {
       // the 32 samples of a tile are almost always one ray (one camera row): sum them in the wave first, otherwise the
       // same 32 addresses take 32-way conflicting atomics from every tile of every workgroup
@@ -323,14 +343,38 @@ __global__ void __launch_bounds__(NTG) field_backward_general_kernel(GenArgs A) 
     gen_bwd(A.base[0], DA, DB, nullptr, tid);
     __syncthreads();
     // ---- hash-table gradient (16 consecutive lanes = 16 consecutive samples of one level: run-length pre-reduction) ----
+    float gpx = 0.f, gpy = 0.f, gpz = 0.f;
     for (int l0 = 0; l0 < A.num_levels; l0 += 16) {
       const int l = l0 + grp;
       const bool on = l < A.num_levels;
       const int lc = on ? l : 0;
-      float gpx = 0.f, gpy = 0.f, gpz = 0.f;
-      hash_level_backward<false>(A.g_table, A.table, (unsigned)lc * A.level_stride, A.mask, SCL[lc], px, py, pz,
-                                 on && valid ? DB[(2 * lc) * LDG + s] : 0.f,
-                                 on && valid ? DB[(2 * lc + 1) * LDG + s] : 0.f, lane, gpx, gpy, gpz);
+      const float g0 = on && valid ? DB[(2 * lc) * LDG + s] : 0.f, g1 = on && valid ? DB[(2 * lc + 1) * LDG + s] : 0.f;
+      if (A.d_pos)
+        hash_level_backward<true>(A.g_table, A.table, (unsigned)lc * A.level_stride, A.mask, SCL[lc], px, py, pz, g0, g1,
+                                  lane, gpx, gpy, gpz);
+      else
+        hash_level_backward<false>(A.g_table, A.table, (unsigned)lc * A.level_stride, A.mask, SCL[lc], px, py, pz, g0,
+                                   g1, lane, gpx, gpy, gpz);
+    }
+    if (A.d_pos) {  // per-group partials -> LDS (DA is dead by now) -> one thread per sample sums the 16 groups
+      __syncthreads();
+      DA[(3 * grp + 0) * LDG + s] = gpx;
+      DA[(3 * grp + 1) * LDG + s] = gpy;
+      DA[(3 * grp + 2) * LDG + s] = gpz;
+      __syncthreads();
+      if (grp == 0 && valid) {
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) {
+          gx += DA[(3 * l + 0) * LDG + s];
+          gy += DA[(3 * l + 1) * LDG + s];
+          gz += DA[(3 * l + 2) * LDG + s];
+        }
+        normalize_position_backward(A.scene, wx, wy, wz, self, gx, gy, gz);
+        A.d_pos[3 * ismp] = gx;
+        A.d_pos[3 * ismp + 1] = gy;
+        A.d_pos[3 * ismp + 2] = gz;
+      }
     }
     __syncthreads();
   }

@@ -6,8 +6,7 @@ per-camera appearance) -> ``get_loss_dict`` (``fruit_nerf/fruit_nerf.py:601-615`
 -> backward -> Adam with exponential LR decay (``fruit_nerf/fruit_nerf_config.py:45-60``) -> anneal callback
 (``fruit_nerf.py:198-232``).
 
-``fruit_nerf_method_big`` / ``_huge`` (other field shapes) train through the shape-generic kernels with the camera
-poses frozen.  The camera pose refinement (``camera_opt`` group, ``fruit_nerf.py:195``) is trained too: the field / proposal backward
+``fruit_nerf_method_big`` / ``_huge`` (other field shapes) train through the shape-generic kernels.  The camera pose refinement (``camera_opt`` group, ``fruit_nerf.py:195``) is trained too: the field / proposal backward
 kernels return d loss / d sample position (and the SH-input gradient of the colour branch), ``cn_ray_backward`` reduces
 them per ray and ``cn_pose_adjustment_backward`` chains through exp_map_SO3xR3; ``camera_opt_regularizer``
 (``fruit_nerf.py:614``) is added by ``cn_pose_regularizer``.  The proposal networks follow the reference's update
@@ -50,12 +49,10 @@ class FruitTrainer:
     def __init__(self, model: FruitModel, groups: Optional[Dict[str, OptimGroup]] = None, seed: int = 0):
         self.model = model
         # fruit_nerf_method_big / _huge field shapes train through the shape-generic kernels (cn_field_eval +
-        # cn_field_backward_general); those do not produce the position gradients, so the camera poses stay frozen there
+        # cn_field_backward_general)
         self.general = not model._fused_shape
         self.groups = groups or {"proposal_networks": OptimGroup(), "fields": OptimGroup(),
                                  "camera_opt": OptimGroup(1e-3, 1e-15, 1e-4, 5000)}
-        if self.general:
-            self.groups = {k: v for k, v in self.groups.items() if k != "camera_opt"}
         self._general_ws = None
         dev = model.device
         # a group that is not listed is frozen (its gradients are still computed for "fields"/"proposal_networks")
@@ -178,7 +175,7 @@ class FruitTrainer:
             self._general_ws = ops.field_backward_general(
                 m.field, self.grad_field, scene, o, d, cam, starts, ends, rb_out["d_density"], rb_out["d_rgb"],
                 rb_out["d_semantics"], app_mode=L.APP_PER_CAMERA, sh_unit_dir=cfg.sh_input == "unit",
-                workspace=self._general_ws)
+                workspace=self._general_ws, d_positions=dpos, d_directions=ddir)
         else:
             ops.field_backward(m.field, self.grad_field, scene, o, d, cam, starts, ends, rb_out["d_density"],
                                rb_out["d_rgb"], rb_out["d_semantics"], app_mode=L.APP_PER_CAMERA,

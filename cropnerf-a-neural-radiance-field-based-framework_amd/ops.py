@@ -487,7 +487,8 @@ def field_backward_general(fh: FieldHandle, gh: FieldHandle, scene: L.Scene, ori
                            camera_indices: Optional[Tensor], starts: Tensor, ends: Tensor, d_density: Tensor,
                            d_rgb: Tensor, d_semantics: Tensor, app_mode: int = L.APP_PER_CAMERA,
                            sh_unit_dir: bool = True, app_mean: Optional[Tensor] = None,
-                           workspace: Optional[Tensor] = None) -> Tensor:
+                           workspace: Optional[Tensor] = None, d_positions: Optional[Tensor] = None,
+                           d_directions: Optional[Tensor] = None) -> Tensor:
     """``cn_field_backward_general``: parameter gradients for any field shape of the reference's configs (accumulated
     into the tensors behind ``gh``).  Returns the workspace so the caller can reuse it."""
     lib = L.load()
@@ -500,6 +501,7 @@ def field_backward_general(fh: FieldHandle, gh: FieldHandle, scene: L.Scene, ori
         _p(_f32(app_mean, "app_mean")), _p(_f32(origins, "origins")), _p(_f32(directions, "directions")),
         _p(_i64(camera_indices, "camera_indices")), _p(_f32(starts, "starts")), _p(_f32(ends, "ends")),
         _p(_f32(d_density, "d_density")), _p(_f32(d_rgb, "d_rgb")), _p(_f32(d_semantics, "d_semantics")), R, S,
+        _p(_f32(d_positions, "d_positions")), _p(_f32(d_directions, "d_directions")),
         C.c_void_p(workspace.data_ptr()), workspace.numel(), _stream(starts)))
     return workspace
 

@@ -324,14 +324,15 @@ int cn_field_backward(const cn_field_params* params, const cn_field_params* grad
 /* The same for the other field shapes of the reference's method configs (fruit_nerf_method_big / _huge:
  * fruit_nerf/fruit_nerf_config.py:66-172): base MLP 2 layers, semantic MLP 2-3 layers, colour MLP 3 layers, widths
  * <= 128.  Needs a zero-initialised-by-the-callee workspace of cn_field_backward_general_workspace_bytes(params)
- * (per-workgroup partial weight gradients); does not produce the pose-refinement gradients. */
+ * (per-workgroup partial weight gradients); d_positions / d_directions as for cn_field_backward. */
 size_t cn_field_backward_general_workspace_bytes(const cn_field_params* params);
 int cn_field_backward_general(const cn_field_params* params, const cn_field_params* grads, const cn_scene* scene,
                               int32_t app_mode, int32_t sh_unit_dir, const float* app_mean, const float* origins,
                               const float* directions, const int64_t* camera_indices, const float* starts,
                               const float* ends, const float* d_density, const float* d_rgb,
-                              const float* d_semantics, int64_t num_rays, int32_t num_samples, void* workspace,
-                              size_t workspace_bytes, cn_stream_t stream);
+                              const float* d_semantics, int64_t num_rays, int32_t num_samples,
+                              float* d_positions /*[R,S,3] or NULL*/, float* d_directions /*[R,S,3] or NULL*/,
+                              void* workspace, size_t workspace_bytes, cn_stream_t stream);
 
 /* Parameter gradients of one proposal network from d loss / d density [R,S]; d_positions as above. */
 int cn_proposal_backward(const cn_density_params* params, const cn_density_params* grads, const cn_scene* scene,

@@ -312,17 +312,20 @@ def test_big_method_trains():
     image = torch.rand(R, 3, generator=g)
     mask = (torch.rand(R, 1, generator=g) > 0.5).float()
     # oracle
-    p = {k: v.clone().requires_grad_(not k.startswith("camera_optimizer")) for k, v in params.items()}
+    params["camera_optimizer.pose_adjustment"] = (torch.rand(n_img, 6, generator=g) - 0.5) * 0.03
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     rb = ORY.pinhole_rays(c2w, intr, idx[:, 0], idx[:, 1], idx[:, 2])
     out_ref = OL.train_forward(rb, p, fspec, pspecs, aabb, S_PROP, S_FINAL, jitter)
     ld_ref = OL.loss_dict(out_ref, image, mask)
+    ld_ref["camera_opt_regularizer"] = OL.camera_opt_regularizer(p["camera_optimizer.pose_adjustment"])
     sum(ld_ref.values()).backward()
     # HIP
     model = FruitModel(cfg, SceneBox(aabb), n_img, {"semantics": Semantics()}, device="cuda", test_mode="val", params=params)
     model.training = True
-    groups = {"proposal_networks": OptimGroup(1e-2, 1e-15, 1e-4, 1000), "fields": OptimGroup(1e-2, 1e-15, 1e-4, 1000)}
+    groups = {"proposal_networks": OptimGroup(1e-2, 1e-15, 1e-4, 1000), "fields": OptimGroup(1e-2, 1e-15, 1e-4, 1000),
+              "camera_opt": OptimGroup(1e-3, 1e-15, 1e-4, 1000)}
     tr = FruitTrainer(model, groups)
-    assert tr.general and not tr.train_pose
+    assert tr.general and tr.train_pose
     cams = Cameras(c2w, intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], H, H).to("cuda")
     rays = cams.generate_rays(idx.cuda())
     out = tr.forward_backward(rays, {"image": image, "fruit_mask": mask}, jitter=jitter)
@@ -333,7 +336,9 @@ def test_big_method_trains():
         if v.grad is None:
             continue
         rel = (tr.grads[k].cpu() - v.grad).norm().item() / (v.grad.norm().item() + 1e-12)
-        if rel > 3e-3:
+        # the pose gradient sums position derivatives of up to 4096 cells per unit length over all samples of a camera,
+        # with heavy cancellation: fp32 summation order shows at the 4e-3 level here
+        if rel > (1e-2 if k.startswith("camera_optimizer") else 3e-3):
             bad[k] = rel
     assert not bad, bad
     losses = []
