@@ -260,7 +260,7 @@ class FruitModel:
     def get_outputs(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:
         """``fruit_nerf.py:543-599`` (eval): the camera-optimizer tweak is applied also outside training."""
         if self.training:
-            raise NotImplementedError("training forward (weights_list / ray_samples_list + backward) is not built yet")
+            return self._training_outputs(ray_bundle)
         rb = ray_bundle
         if rb.camera_indices is None:
             raise AttributeError("Camera indices are not provided.")
@@ -268,6 +268,89 @@ class FruitModel:
         ops.apply_pose_adjustment(self.params["camera_optimizer.pose_adjustment"], self._cam_idx(rb), rb.origins,
                                   rb.directions)
         return self._finish(self._sample_and_render(rb))
+
+    def _training_outputs(self, ray_bundle: RayBundle, jitter: Optional[List[Tensor]] = None) -> Dict:
+        """``get_outputs`` with ``self.training`` (``fruit_nerf.py:543-599``): stratified single-jitter proposal sampling,
+        per-camera appearance, no clamp, plus ``weights_list`` / ``ray_samples_list`` for ``get_loss_dict``.  Forward
+        only -- gradients come from ``FruitTrainer.forward_backward``, which runs the same kernels."""
+        from ..rays import RaySamples
+
+        cfg, dev = self.config, self.device
+        rb = ray_bundle
+        if rb.camera_indices is None:
+            raise AttributeError("Camera indices are not provided.")
+        R = rb.origins.shape[0]
+        cam = self._cam_idx(rb)
+        o, d = rb.origins.clone(), rb.directions.clone()
+        ops.apply_pose_adjustment(self.params["camera_optimizer.pose_adjustment"], cam, o, d)
+        n, f = rb.nears, rb.fars
+        n_lvl = len(self.proposal_networks)
+        if jitter is None:
+            jitter = [torch.rand(R, 1, device=dev) for _ in range(n_lvl + 1)]
+        jitter = [j.to(dev).contiguous() for j in jitter]
+        scene = self._scene(True)
+        weights_list, samples_list = [], []
+        sm = ops.sample_spaced(n, f, cfg.num_proposal_samples_per_ray[0], L.SPACING_PIECEWISE, jitter[0])
+        bins = torch.cat([sm["spacing_starts"], sm["spacing_ends"][:, -1:]], -1).contiguous()
+        starts, ends = sm["starts"], sm["ends"]
+
+        def samples(starts, ends, bins):
+            return RaySamples(o, d, starts[..., None], ends[..., None], bins[:, :-1, None], bins[:, 1:, None],
+                              rb.camera_indices)
+
+        out: Dict = {}
+        for lvl in range(n_lvl):
+            den = ops.proposal_density(self.proposal_networks[lvl], scene, o, d, starts, ends)
+            comp = ops.composite(starts, ends, den, want_weights=True, eval_clamp=False)
+            weights_list.append(comp["weights"][..., None])
+            rs_l = samples(starts, ends, bins)
+            rs_l.density = den  # kept for the interlevel term of get_loss_dict
+            samples_list.append(rs_l)
+            out[f"prop_depth_{lvl}"] = comp["depth"]
+            s_next = cfg.num_proposal_samples_per_ray[lvl + 1] if lvl + 1 < n_lvl else cfg.num_nerf_samples_per_ray
+            bins, eu = ops.sample_pdf(bins, comp["weights"], n, f, s_next, anneal=self._anneal, u_rand=jitter[lvl + 1])
+            starts, ends = eu[:, :-1].contiguous(), eu[:, 1:].contiguous()
+        if self._fused_shape:
+            opts = ops.render_opts(cfg.num_nerf_samples_per_ray, app_mode=L.APP_PER_CAMERA,
+                                   sh_unit_dir=cfg.sh_input == "unit", eval_clamp=False)
+            fo = ops.render_samples(self.field, scene, opts, o, d, n, f, camera_indices=cam, bins=eu.contiguous())
+        else:
+            fo = ops.field_eval(self.field, scene, o, d, cam, starts, ends, app_mode=L.APP_PER_CAMERA,
+                                sh_unit_dir=cfg.sh_input == "unit")
+        bg_mode, bg = self._background()
+        comp = ops.composite(starts, ends, fo["density"], fo["rgb"], fo["semantics"], bg_mode, bg, eval_clamp=False,
+                             want_weights=True)
+        weights_list.append(comp["weights"][..., None])
+        samples_list.append(samples(starts, ends, bins))
+        out.update({"rgb": comp["rgb"], "accumulation": comp["accumulation"], "depth": comp["depth"],
+                    "semantics": comp["semantics"], "semantics_colormap": comp["semantics_colormap"],
+                    "weights_list": weights_list, "ray_samples_list": samples_list})
+        return out
+
+    def get_loss_dict(self, outputs: Dict, batch: Dict[str, Tensor], metrics_dict=None) -> Dict[str, Tensor]:
+        """``fruit_nerf.py:601-615``: values only (the optimisation path is ``FruitTrainer``, which fuses these losses
+        with their backward)."""
+        cfg = self.config
+        image = batch["image"].to(self.device)[:, :3].to(torch.float32)
+        loss = {"rgb_loss": torch.mean((image - outputs["rgb"]) ** 2)}
+        x, y = outputs["semantics"], batch["fruit_mask"].to(self.device).to(torch.float32).reshape(-1, 1)
+        bce = torch.clamp(x, min=0) - x * y + torch.log1p(torch.exp(-x.abs()))
+        loss["semantics_loss"] = cfg.semantic_loss_weight * bce.mean()
+        if self.training and "weights_list" in outputs:
+            final = outputs["ray_samples_list"][-1]
+            fbins = torch.cat([final.spacing_starts[..., 0], final.spacing_ends[:, -1:, 0]], -1).contiguous()
+            fw = outputs["weights_list"][-1][..., 0].contiguous()
+            total = torch.zeros(1, device=self.device)
+            for w, rs in zip(outputs["weights_list"][:-1], outputs["ray_samples_list"][:-1]):
+                pb = torch.cat([rs.spacing_starts[..., 0], rs.spacing_ends[:, -1:, 0]], -1).contiguous()
+                # cn_interlevel_backward evaluates the term from the level's density (kept on the sample list); only its
+                # loss sum is used here
+                ops.interlevel_backward(fbins, fw, pb, rs.starts[..., 0].contiguous(), rs.ends[..., 0].contiguous(),
+                                        rs.density, 1.0, total)
+            loss["interlevel_loss"] = cfg.interlevel_loss_mult * total[0] / fw.numel()
+        pose = self.params["camera_optimizer.pose_adjustment"]
+        loss["camera_opt_regularizer"] = (pose[:, :3].norm(dim=-1).mean() * 1e-2 + pose[:, 3:].norm(dim=-1).mean() * 1e-3)
+        return loss
 
     def get_inference_outputs(self, ray_bundle: RayBundle) -> Dict[str, Tensor]:
         """``fruit_nerf.py:497-541``: no pose tweak, mean appearance."""

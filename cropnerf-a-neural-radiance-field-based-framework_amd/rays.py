@@ -76,6 +76,7 @@ class RaySamples:
     spacing_starts: Optional[Tensor] = None
     spacing_ends: Optional[Tensor] = None
     camera_indices: Optional[Tensor] = None
+    density: Optional[Tensor] = None  # [R,S] proposal density at these samples (training lists only)
 
     @property
     def deltas(self) -> Tensor:

@@ -80,6 +80,20 @@ def test_gradients_match_autograd():
         assert g_ref.abs().sum() > 0, k
     bad = {k: v for k, v in worst.items() if v > 3e-3}
     assert not bad, f"relative gradient error too large: {bad}"
+    # the model's own training-mode forward + get_loss_dict (fruit_nerf.py:543-615): same values, same keys
+    fwd = model._training_outputs(model._prepared(_hip_rays(sc, idx)), jitter)
+    assert {"rgb", "accumulation", "depth", "semantics", "semantics_colormap", "prop_depth_0", "prop_depth_1",
+            "weights_list", "ray_samples_list"} <= set(fwd)
+    assert_close(fwd["rgb"], ref_out["rgb"].detach(), 2e-4, 2e-5, "training forward rgb")
+    for w, w_ref in zip(fwd["weights_list"], ref_out["weights_list"]):
+        assert_close(w, w_ref.detach(), 2e-4, 2e-6, "weights_list")
+    for rs, rs_ref in zip(fwd["ray_samples_list"], ref_out["ray_samples_list"]):
+        assert_close(rs.starts, rs_ref.starts, 1e-5, 1e-6, "ray_samples_list starts")
+    ld = model.get_loss_dict(fwd, {"image": image, "fruit_mask": mask})
+    assert set(ld) == set(ref_loss)
+    for k, v in ref_loss.items():
+        assert abs(float(ld[k]) - v) <= 2e-4 * abs(v) + 1e-7, f"get_loss_dict {k}: {float(ld[k])} vs {v}"
+    assert model(_hip_rays(sc, idx))["rgb"].shape == (idx.shape[0], 3)  # forward() draws its own jitter
     # metrics (fruit_nerf.py:639-645)
     md = tr.get_metrics_dict(out)
     ref_dist = OL.distortion_loss([w.detach() for w in ref_out["weights_list"]], ref_out["ray_samples_list"])
