@@ -1,0 +1,28 @@
+"""Whole-image render of the default fruit_nerf_method in eval (proposal sampler (256, 96) + 48 field samples per ray,
+chunks of eval_num_rays_per_chunk = 32768, fruit_nerf.py:377-404) at 800 x 800.  Profiling aid:  python tools/image_probe.py"""
+import json, os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cropnerf_amd import config as PC, synthetic
+from cropnerf_amd.fruit_nerf.fruit_nerf import FruitModel, Semantics
+from cropnerf_amd.rays import Cameras, SceneBox
+
+cfg = PC.FruitNerfModelConfig()
+params = synthetic.p_rand(cfg.field_spec(100), cfg.proposal_specs(), seed=0, device="cuda")
+c2w, intr = synthetic.orbit_cameras(100)
+cams = Cameras(c2w, intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], 800, 800).to("cuda")
+res = {}
+for chunk in (1 << 15, 1 << 16, 1 << 18):
+    cfg.eval_num_rays_per_chunk = chunk
+    m = FruitModel(cfg, SceneBox(torch.tensor(synthetic.SCENE_AABB)), 100, {"semantics": Semantics()}, device="cuda",
+                   test_mode="test", params=params)
+    rb = cams.generate_rays(3, keep_shape=True)
+    out = m.get_outputs_for_camera_ray_bundle(rb)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for i in range(5):
+        out = m.get_outputs_for_camera_ray_bundle(cams.generate_rays(i, keep_shape=True))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / 5
+    res[f"chunk_{chunk}"] = {"ms_per_image": round(dt * 1e3, 2), "images_per_sec": round(1 / dt, 1),
+                             "rays_per_sec": 640000 / dt, "keys": sorted(out)}
+print(json.dumps(res))
