@@ -499,6 +499,10 @@ static bool mfma_generic_ok(const cn_field_params& p) {
 }
 }  // namespace gm
 
+}  // namespace cn
+#include "field_regw.hpp"
+namespace cn {
+
 int validate_field(const cn_field_params& p) {
   int rc = validate_grid(p.grid, "field grid");
   if (rc) return rc;
@@ -553,9 +557,38 @@ extern "C" int cn_field_eval(const cn_field_params* params, const cn_scene* scen
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma);
     attr_set = true;
   }
-  // default: the matrix-core kernel whenever the layer widths fit it; CN_FIELD_EVAL_IMPL=scalar forces the scalar one
-  // (kept as an independent implementation: the tests compare the two)
+  // Implementations, fastest first (CN_FIELD_EVAL_IMPL = regw | mfma | scalar forces one; the tests compare them):
+  //   regw   weights resident in registers, the two field shapes of the reference's configs (field_regw.hpp)
+  //   mfma   any widths <= 128, weights staged through LDS per tile
+  //   scalar any widths <= 176, scalar FMAs
   const char* impl = getenv("CN_FIELD_EVAL_IMPL");
+  const bool want = impl != nullptr;
+  if (!want || std::strcmp(impl, "regw") == 0) {
+    const bool def = cn::rw::regw_shape_matches<15, 2, 64>(*params), big = cn::rw::regw_shape_matches<30, 3, 128>(*params);
+    if (def || big) {
+      static bool regw_attr = false;
+      if (!regw_attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::rw::field_eval_regw_kernel<15, 2, 64>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)cn::rw::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::rw::field_eval_regw_kernel<30, 3, 128>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)cn::rw::LDS_BYTES);
+        regw_attr = true;
+      }
+      const long long ntiles = (num_rays * (long long)num_samples + cn::rw::TS - 1) / cn::rw::TS;
+      const dim3 grid(cn::grid_for(ntiles, 1, 256)), block(cn::rw::NT);
+      if (def)
+        hipLaunchKernelGGL((cn::rw::field_eval_regw_kernel<15, 2, 64>), grid, block, cn::rw::LDS_BYTES,
+                           cn::as_stream(stream), cn::make_field_dev(*params), cn::make_scene_dev(*scene), app_mode,
+                           sh_unit_dir, origins, directions, camera_indices, starts, ends, (long long)num_rays,
+                           num_samples, density, rgb, semantics, positions);
+      else
+        hipLaunchKernelGGL((cn::rw::field_eval_regw_kernel<30, 3, 128>), grid, block, cn::rw::LDS_BYTES,
+                           cn::as_stream(stream), cn::make_field_dev(*params), cn::make_scene_dev(*scene), app_mode,
+                           sh_unit_dir, origins, directions, camera_indices, starts, ends, (long long)num_rays,
+                           num_samples, density, rgb, semantics, positions);
+      return cn::check_launch("cn_field_eval");
+    }
+  }
   if (cn::gm::mfma_generic_ok(*params) && !(impl && std::strcmp(impl, "scalar") == 0)) {
     long long ntiles = (num_rays * (long long)num_samples + cn::gm::TS - 1) / cn::gm::TS;
     hipLaunchKernelGGL(cn::gm::field_eval_mfma_kernel, dim3(cn::grid_for(ntiles, 1, 256)), dim3(cn::gm::NT), lds_mfma,
