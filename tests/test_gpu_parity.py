@@ -619,7 +619,7 @@ def test_split_kernel_per_sample_outputs_match_fused(scene, ops, handles, S, con
 
 
 def test_generic_field_kernels_agree(scene, ops, monkeypatch):
-    """cn_field_eval has two device implementations (matrix-core, default; scalar, CN_FIELD_EVAL_IMPL=scalar): same
+    """cn_field_eval has three device implementations (register-resident weights, LDS-staged weights, scalar): same
     results on the default shape and on the fruit_nerf_method_big shape, per-camera appearance, ragged sample counts."""
     from cropnerf_amd import config as PC
 
@@ -634,9 +634,10 @@ def test_generic_field_kernels_agree(scene, ops, monkeypatch):
         params = PC.init_params(spec, [], seed=3, grid_scale=0.1, device="cuda")
         fh = ops.FieldHandle(params, spec)
         outs = {}
-        for impl in ("mfma", "scalar"):
+        for impl in ("regw", "mfma", "scalar"):
             monkeypatch.setenv("CN_FIELD_EVAL_IMPL", impl)
             outs[impl] = ops.field_eval(fh, ops.scene_struct(scene.aabb, True), o, d, cam, sm["starts"], sm["ends"],
                                         app_mode=2, want_positions=True)
-        for k in outs["mfma"]:
-            assert_close(outs["mfma"][k], outs["scalar"][k], 2e-5, 2e-6, f"{'big' if big else 'default'} {k}")
+        for impl in ("regw", "mfma"):
+            for k in outs[impl]:
+                assert_close(outs[impl][k], outs["scalar"][k], 2e-5, 2e-6, f"{impl} {'big' if big else 'default'} {k}")
