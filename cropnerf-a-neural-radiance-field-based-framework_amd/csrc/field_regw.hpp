@@ -51,12 +51,22 @@ __device__ __forceinline__ void layer(const RowTile<K>& rt, const float* __restr
 #pragma unroll 1  // (unrolled, hipcc hoists the LDS reads of all four column tiles and spills the resident weights)
   for (int ct = 0; ct < 4; ++ct) {
     f32x4 acc = {b4[0], b4[1], b4[2], b4[3]};
+    // B operands of round kb + 1 are read from LDS while the four MFMAs of round kb run
+    float b[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) b[e] = in[(4 * q + e) * LDA + 16 * ct + i];
 #pragma unroll
     for (int kb = 0; kb < RowTile<K>::KP / 16; ++kb) {
+      float bn[4];
+      if (kb + 1 < RowTile<K>::KP / 16) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float b = in[(16 * kb + 4 * q + e) * LDA + 16 * ct + i];
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rt.a[4 * kb + e], b, acc, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) bn[e] = in[(16 * (kb + 1) + 4 * q + e) * LDA + 16 * ct + i];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(rt.a[4 * kb + e], b[e], acc, 0, 0, 0);
+      if (kb + 1 < RowTile<K>::KP / 16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = bn[e];
       }
     }
 #pragma unroll
