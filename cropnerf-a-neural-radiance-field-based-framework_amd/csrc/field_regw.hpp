@@ -20,13 +20,17 @@ constexpr int TS = 64, LDA = 68, NT = 512, NW = 8;
 
 constexpr int pad16(int n) { return (n + 15) & ~15; }
 
-// A operands of this wave's row tile: lane (i = lane & 15, q = lane >> 4) holds W[16 * wave + i][16 * kb + 4 * q + e]
+// A layer with N outputs has NT_ = pad16(N) / 16 row tiles (1, 2, 4 or 8).  The 8 waves form 8 / NT_ groups: wave w owns
+// row tile w % NT_ and, of the four 16-sample column tiles, those of its group w / NT_ -- so that every wave has work
+// in every layer with at least 32 (row tile, column tile) blocks, at the price of holding the same rows in 8 / NT_ waves.
+// A operands of the row tile: lane (i = lane & 15, q = lane >> 4) holds W[16 * rt + i][16 * kb + 4 * q + e].
 template <int K>
 struct RowTile {
   static constexpr int KP = pad16(K);
   float a[KP / 4];
   __device__ __forceinline__ void load(const float* __restrict__ W, int N, int wave, int lane) {
-    const int i = lane & 15, q = lane >> 4, n = 16 * wave + i;
+    const int ntiles = pad16(N) / 16;
+    const int i = lane & 15, q = lane >> 4, n = 16 * (wave % ntiles) + i;
 #pragma unroll
     for (int j = 0; j < KP / 4; ++j) {
       const int k = 16 * (j >> 2) + 4 * q + (j & 3);
@@ -35,21 +39,23 @@ struct RowTile {
   }
 };
 
-// out rows [16 wave, 16 wave + 16) of all four column tiles: out = act(b + W in); waves without rows (16 wave >= pad16(N))
-// skip.  Rows >= N come out as zeros (zero weights and bias), which is what the next layer's pad inputs must be.
+// out = act(b + W in) for this wave's (row tile, column tiles).  Rows >= N come out as zeros (zero weights and bias),
+// which is what the next layer's pad inputs must be.
 template <int K, bool RELU>
 __device__ __forceinline__ void layer(const RowTile<K>& rt, const float* __restrict__ bias, int N, const float* in,
                                       float* out, int wave, int lane) {
-  if (16 * wave >= pad16(N)) return;
+  const int ntiles = pad16(N) / 16, groups = NW / ntiles, grp = wave / ntiles, rt0 = 16 * (wave % ntiles);
+  // column tiles of this wave's group: 4 / groups each (groups <= 4), or one for the first four groups (groups == 8)
+  const int ct_lo = groups <= 4 ? grp * (4 / groups) : grp, ct_hi = groups <= 4 ? ct_lo + 4 / groups : (grp < 4 ? grp + 1 : grp);
   const int i = lane & 15, q = lane >> 4;
   float b4[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int n = 16 * wave + 4 * q + r;
+    const int n = rt0 + 4 * q + r;
     b4[r] = n < N ? bias[n] : 0.f;
   }
 #pragma unroll 1  // (unrolled, hipcc hoists the LDS reads of all four column tiles and spills the resident weights)
-  for (int ct = 0; ct < 4; ++ct) {
+  for (int ct = ct_lo; ct < ct_hi; ++ct) {
     f32x4 acc = {b4[0], b4[1], b4[2], b4[3]};
     // B operands of round kb + 1 are read from LDS while the four MFMAs of round kb run
     float b[4];
@@ -73,7 +79,7 @@ __device__ __forceinline__ void layer(const RowTile<K>& rt, const float* __restr
     for (int r = 0; r < 4; ++r) {
       float v = acc[r];
       if (RELU) v = fmaxf(v, 0.f);
-      out[(16 * wave + 4 * q + r) * LDA + 16 * ct + i] = v;
+      out[(rt0 + 4 * q + r) * LDA + 16 * ct + i] = v;
     }
   }
 }
