@@ -104,6 +104,10 @@ SIGNATURES = {
     "cn_pose_adjustment_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P]),
     "cn_pose_regularizer": (C.c_int, [_P, _I32, _F, _F, _P, _P, _P]),
     "cn_distortion_metric": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
+    "cn_depth_project": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P]),
+    "cn_zbuffer_workspace_bytes": (C.c_size_t, [_I32, _I32]),
+    "cn_zbuffer_update_large": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P, C.c_size_t, _P]),
+    "cn_zbuffer_update": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, C.c_size_t, _P]),
     "cn_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _I32, C.c_double, C.c_double, C.c_double, C.c_double, _I32, _P]),
 }
 

@@ -569,3 +569,48 @@ def distortion_metric(spacing_bins: Tensor, weights: Tensor) -> Tensor:
     L.check(lib.cn_distortion_metric(_p(_f32(spacing_bins, "spacing_bins")), _p(_f32(weights, "weights")), R, S, _p(acc),
                                      _stream(weights)))
     return acc[0] / R
+
+
+# --------------------------------------------------------------------------------------------------------------
+# depth-based semantic projection (scripts/depth_based_semantic_projection.py)
+# --------------------------------------------------------------------------------------------------------------
+
+def _dev(t: Tensor, dtype, name: str) -> Tensor:
+    if t.dtype != dtype or not t.is_contiguous() or not t.is_cuda:
+        raise TypeError(f"{name}: expected a contiguous {dtype} device tensor, got {t.dtype} {t.device}")
+    return t
+
+
+def depth_project(P: Tensor, points: Tensor, height: int, width: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """``get_projection`` + pixel rounding / clipping of ``update_buffer``: (xs rows, ys columns, zs), float64 in."""
+    lib = L.load()
+    n = points.shape[0]
+    dev = points.device
+    xs = torch.empty(n, dtype=torch.int32, device=dev)
+    ys = torch.empty(n, dtype=torch.int32, device=dev)
+    zs = torch.empty(n, dtype=torch.float64, device=dev)
+    L.check(lib.cn_depth_project(_p(_dev(P, torch.float64, "P")), _p(_dev(points, torch.float64, "points")), n, height,
+                                 width, _p(xs), _p(ys), _p(zs), _stream(points)))
+    return xs, ys, zs
+
+
+def zbuffer_update(z_buffer: Tensor, img: Tensor, xs: Tensor, ys: Tensor, zs: Tensor, label: int, large: bool = False,
+                   want_visible: bool = True) -> Optional[Tensor]:
+    """``update_buffer`` in place on ``z_buffer`` [H,W] float32 and ``img`` [H,W] uint8; returns the visible mask
+    [H,W] uint8 (255 where a point was accepted) for ``large=False``."""
+    lib = L.load()
+    H, W = z_buffer.shape
+    _dev(z_buffer, torch.float32, "z_buffer")
+    _dev(img, torch.uint8, "img")
+    ws = torch.empty(lib.cn_zbuffer_workspace_bytes(H, W), dtype=torch.uint8, device=z_buffer.device)
+    n = xs.shape[0]
+    if large:
+        L.check(lib.cn_zbuffer_update_large(_p(_dev(xs, torch.int32, "xs")), _p(_dev(ys, torch.int32, "ys")),
+                                            _p(_dev(zs, torch.float64, "zs")), n, int(label), H, W, _p(z_buffer),
+                                            _p(img), C.c_void_p(ws.data_ptr()), ws.numel(), _stream(z_buffer)))
+        return None
+    vis = torch.empty(H, W, dtype=torch.uint8, device=z_buffer.device) if want_visible else None
+    L.check(lib.cn_zbuffer_update(_p(_dev(xs, torch.int32, "xs")), _p(_dev(ys, torch.int32, "ys")),
+                                  _p(_dev(zs, torch.float64, "zs")), n, int(label), H, W, _p(z_buffer), _p(img), _p(vis),
+                                  C.c_void_p(ws.data_ptr()), ws.numel(), _stream(z_buffer)))
+    return vis

@@ -369,6 +369,32 @@ int cn_distortion_metric(const float* spacing_bins /*[R,S+1]*/, const float* wei
 int cn_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step, double lr,
                  double beta1, double beta2, double eps, int32_t zero_grad, cn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Depth-based semantic projection (the alternative to the NeRF projection:
+ * fruit_nerf/scripts/depth_based_semantic_projection.py).  float64 geometry, float32 z-buffer, uint8 label
+ * image, all [height, width] row-major -- the reference's 1440 x 1920 arrays.
+ * ------------------------------------------------------------------------------------------- */
+
+/* get_projection (:45-49) + the pixel arithmetic of update_buffer (:85-89): im = P @ [p, 1];
+ * yx = round(im[:2] / -im[2]) half-to-even; ys = clip(yx[0], 0, width-1) (column), xs = clip(yx[1], 0, height-1)
+ * (row); zs = -im[2].  P [3,4] and points [N,3] are float64 device arrays. */
+int cn_depth_project(const double* P, const double* points, int64_t num_points, int32_t height, int32_t width,
+                     int32_t* xs, int32_t* ys, double* zs, cn_stream_t stream);
+
+size_t cn_zbuffer_workspace_bytes(int32_t height, int32_t width);
+
+/* update_buffer(large=True) (:90-94): img[xs, ys] = label; z_buffer[xs, ys] = zs -- the LAST point of a pixel wins. */
+int cn_zbuffer_update_large(const int32_t* xs, const int32_t* ys, const double* zs, int64_t num_points, int32_t label,
+                            int32_t height, int32_t width, float* z_buffer, uint8_t* img, void* workspace,
+                            size_t workspace_bytes, cn_stream_t stream);
+
+/* update_buffer(large=False) (:95-105): a point is accepted when z <= z_buffer at its pixel; accepted pixels take the
+ * point's z and the label.  visible (optional) = 255 on the accepted pixels, 0 elsewhere (what the caller paints into
+ * occ_free_*.png, :159-161). */
+int cn_zbuffer_update(const int32_t* xs, const int32_t* ys, const double* zs, int64_t num_points, int32_t label,
+                      int32_t height, int32_t width, float* z_buffer, uint8_t* img, uint8_t* visible, void* workspace,
+                      size_t workspace_bytes, cn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,8 @@ path and cannot be imported here (``nerfstudio``,
 ``jaxtyping``, ``open3d`` ... are ordinary ``ModuleNotFoundError``s; no
 permission denial occurred).  The oracle is therefore pinned only by the
 analytic known-answer tests of SURVEY.md section 8(c) (``tests/test_oracle_kat.py``).
+Exception: ``oracle/zbuffer.py`` (the depth-based projection, a "next" row) follows numpy code that IS in the
+reference (``scripts/depth_based_semantic_projection.py:31-105``) statement by statement.
 """
 
 from . import field, model, rays, render, samplers  # noqa: F401
