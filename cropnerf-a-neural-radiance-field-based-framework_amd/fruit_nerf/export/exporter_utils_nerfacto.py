@@ -2,8 +2,10 @@
 (``crop_nerf/fruit_nerf/export/exporter_utils_nerfacto.py:83-227``): random train rays -> model forward ->
 ``point = o + d * depth`` kept where ``semantics_colormap[:, 0] > 0`` (``:156-166``) -> optional OBB crop -> accumulate
 until ``num_points``.  Mask, point computation and compaction run in ``cn_pointcloud_compact``; kept points leave the
-device once.  open3d's statistical outlier removal / normal estimation (``:194-225``) are CPU post-processing outside the
-hot path and are applied only when open3d is importable."""
+device once.  The statistical outlier removal (``:194-199``, open3d ``remove_statistical_outlier(nb_neighbors=20,
+std_ratio)``, on by default) runs on the device too (``ops.statistical_outlier_mask``: uniform-grid k-nearest search,
+``cn_knn_mean_distance``).  Normal estimation / re-orientation (``:200-225``) stays open3d CPU post-processing and is
+applied only when open3d is importable."""
 
 from __future__ import annotations
 
@@ -44,25 +46,29 @@ def generate_point_cloud(pipeline, num_points: int = 1000000, remove_outliers: b
                 break
     pts, cols, dirs, count = buffers
     n = min(int(count.item()), cap)
-    points = pts[:n].double().cpu().numpy()
-    colors = cols[:n].double().cpu().numpy()
-    view_dirs = dirs[:n].cpu().numpy()
+    pts, cols, dirs = pts[:n], cols[:n], dirs[:n]
     if crop_obb is not None:
-        m = crop_obb.within(torch.from_numpy(points).float()).numpy()
-        points, colors, view_dirs = points[m], colors[m], view_dirs[m]
+        m = crop_obb.within(pts.float().cpu()).to(pts.device)
+        pts, cols, dirs = pts[m], cols[m], dirs[m]
+    if remove_outliers and pts.shape[0] > 0:
+        # on the device, before the points leave it.  open3d works on the float64 cloud; the search here is float32
+        # (positions of a +-1 scene: mean neighbour distances agree to ~1e-5 relative, so only points sitting on the
+        # threshold can flip)
+        keep = ops.statistical_outlier_mask(pts.contiguous(), 20, std_ratio)
+        pts, cols, dirs = pts[keep], cols[keep], dirs[keep]
+    points = pts.double().cpu().numpy()
+    colors = cols.double().cpu().numpy()
+    view_dirs = dirs.cpu().numpy()
     result = {"points": points, "colors": colors, "view_directions": view_dirs}
-    if remove_outliers or estimate_normals:
+    if estimate_normals:
         try:
             import open3d as o3d  # noqa: F401
         except ImportError:
-            result["note"] = "open3d not installed: statistical outlier removal / normal estimation skipped"
+            result["note"] = "open3d not installed: normal estimation skipped"
             return result
         pcd = o3d.geometry.PointCloud()
         pcd.points = o3d.utility.Vector3dVector(points)
         pcd.colors = o3d.utility.Vector3dVector(colors)
-        if remove_outliers:
-            pcd, ind = pcd.remove_statistical_outlier(nb_neighbors=20, std_ratio=std_ratio)
-            view_dirs = view_dirs[ind]
         if estimate_normals:
             pcd.estimate_normals()
             result["normals"] = np.asarray(pcd.normals)

@@ -614,3 +614,54 @@ def zbuffer_update(z_buffer: Tensor, img: Tensor, xs: Tensor, ys: Tensor, zs: Te
                                   _p(_dev(zs, torch.float64, "zs")), n, int(label), H, W, _p(z_buffer), _p(img), _p(vis),
                                   C.c_void_p(ws.data_ptr()), ws.numel(), _stream(z_buffer)))
     return vis
+
+
+# --------------------------------------------------------------------------------------------------------------
+# statistical outlier removal (open3d remove_statistical_outlier as used by the point-cloud exporter)
+# --------------------------------------------------------------------------------------------------------------
+
+def knn_mean_distance(points: Tensor, nb_neighbors: int = 20, points_per_cell: float = 6.0) -> Tensor:
+    """Mean distance of every point to its ``nb_neighbors`` nearest points (itself included), [N] float32, on a uniform
+    grid sized for about ``points_per_cell`` points per cell.  The binning (cell keys, sort, offsets) is torch plumbing;
+    the search is ``cn_knn_mean_distance``."""
+    lib = L.load()
+    pts = _f32(points.contiguous(), "points")
+    n = pts.shape[0]
+    if n == 0:
+        return torch.empty(0, device=pts.device)
+    lo, hi = pts.min(dim=0).values, pts.max(dim=0).values
+    ext = (hi - lo).clamp(min=1e-12).double()
+    h = float((ext.prod() * points_per_cell / n) ** (1.0 / 3.0))
+    h = max(h, float(ext.max()) / 1024.0)
+    dims = [max(1, min(1024, int(float(e) / h) + 1)) for e in ext]
+    while dims[0] * dims[1] * dims[2] > (1 << 27):
+        h *= 1.26
+        dims = [max(1, min(1024, int(float(e) / h) + 1)) for e in ext]
+    gx, gy, gz = dims
+    cell = ((pts - lo) / h).floor().to(torch.int64)
+    cell[:, 0].clamp_(0, gx - 1)
+    cell[:, 1].clamp_(0, gy - 1)
+    cell[:, 2].clamp_(0, gz - 1)
+    key = (cell[:, 2] * gy + cell[:, 1]) * gx + cell[:, 0]
+    key_sorted, order = torch.sort(key)
+    pts_sorted = pts[order].contiguous()
+    cell_start = torch.searchsorted(key_sorted, torch.arange(gx * gy * gz + 1, device=pts.device)).to(torch.int32).contiguous()
+    mean_sorted = torch.empty(n, device=pts.device)
+    L.check(lib.cn_knn_mean_distance(_p(pts_sorted), _p(cell_start), gx, gy, gz, float(lo[0]), float(lo[1]), float(lo[2]),
+                                     h, n, int(nb_neighbors), _p(mean_sorted), _stream(pts)))
+    out = torch.empty_like(mean_sorted)
+    out[order] = mean_sorted
+    return out
+
+
+def statistical_outlier_mask(points: Tensor, nb_neighbors: int = 20, std_ratio: float = 2.0) -> Tensor:
+    """open3d ``PointCloud::RemoveStatisticalOutliers``: keep a point when its mean neighbour distance is below
+    cloud mean + std_ratio * cloud std (sample std, N - 1).  Returns the boolean inlier mask [N]."""
+    avg = knn_mean_distance(points, nb_neighbors).double()
+    valid = avg > 0
+    nv = int(valid.sum())
+    if nv < 2:
+        return valid
+    mean = avg[valid].sum() / nv
+    std = torch.sqrt(((avg[valid] - mean) ** 2).sum() / (nv - 1))
+    return valid & (avg < mean + std_ratio * std)

@@ -395,6 +395,17 @@ int cn_zbuffer_update(const int32_t* xs, const int32_t* ys, const double* zs, in
                       int32_t height, int32_t width, float* z_buffer, uint8_t* img, uint8_t* visible, void* workspace,
                       size_t workspace_bytes, cn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Statistical outlier removal of the point-cloud exporter: the k-nearest-neighbour pass of open3d's
+ * remove_statistical_outlier(nb_neighbors=20, std_ratio) as called at
+ * fruit_nerf/export/exporter_utils_nerfacto.py:194-199.  The caller bins the points on a uniform grid
+ * (points sorted by linear cell index (z*gy + y)*gx + x; cell_start [gx*gy*gz + 1] offsets); mean_distance[i]
+ * = mean of the distances from sorted point i to its nb_neighbors nearest points, itself (0) included.
+ * ------------------------------------------------------------------------------------------- */
+int cn_knn_mean_distance(const float* points_sorted, const int32_t* cell_start, int32_t gx, int32_t gy, int32_t gz,
+                         float origin_x, float origin_y, float origin_z, float cell_size, int64_t num_points,
+                         int32_t nb_neighbors, float* mean_distance, cn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

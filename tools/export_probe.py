@@ -39,8 +39,10 @@ res["dense_export"] = {"rays": n_rays, "samples_per_ray": 3000, "rays_per_call":
 # (a17) semantic point cloud: 2048-ray calls until 1e6 kept points
 pipe2 = FruitPipeline(FruitPipelineConfig(FruitDataManagerConfig(2048, 2048), cfg), dev, cams, box, test_mode="test", params=params)
 t, pcd = sync_time(lambda: generate_point_cloud(pipe2, num_points=1_000_000, remove_outliers=False))
+t_sor, pcd_sor = sync_time(lambda: generate_point_cloud(pipe2, num_points=1_000_000, remove_outliers=True))
 res["pointcloud_export"] = {"kept_points": int(pcd["points"].shape[0]), "seconds": round(t, 3),
                             "train_batches": pipe2.datamanager.train_count, "rays_per_sec": pipe2.datamanager.train_count * 2048 / t}
+res["pointcloud_export_with_outlier_removal"] = {"seconds": round(t_sor, 3), "kept_after_removal": int(pcd_sor["points"].shape[0])}
 # (a15) projection: one (camera, sub-cluster AABB) job at 800x800 = AABB-restricted render + occlusion pass
 m = pipe2.model
 m.config.eval_num_rays_per_chunk = 4096
