@@ -195,109 +195,9 @@ __device__ __forceinline__ float2 hash_level_sc(const float* __restrict__ table,
   return r;
 }
 
-// hash_level with the x-neighbour pairs fetched together where the table layout allows it (device-only, gfx950).
-// The two corners that differ only in x hash to e and e' = e ^ (ix ^ (ix+1)); for even ix that is e ^ 1, i.e. the
-// two entries share one aligned 16-byte slot, so ONE 16-byte gather returns both (4 instead of 8 lane-requests per
-// sample and level); for odd ix the ceil-x corner needs its own 8-byte gather.  On average 6 instead of 8
-// lane-requests -- the fused kernel is bound by the rate at which the texture-address unit takes divergent lanes.
-//
-// The gathers are buffer loads through a resource (V#) over the whole table: lanes that do not need the second
-// gather present an out-of-range offset, which the range check drops before the cache -- predication without a
-// divergent branch (an `if (odd)` around the loads makes hipcc spill ~700 B per lane in the fused kernel).
-//
-// hipcc pitfall (ROCm 7.2): __builtin_bit_cast(float, v.y) on an ext_vector element reads element 0 -- always copy
-// the element into a scalar first (as_f32 below takes it by value).
-typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float as_f32(unsigned v) { return __builtin_bit_cast(float, v); }
-
-// The loads are issued from inline asm so that exactly 4 x 16-byte + 4 x 8-byte gathers per sample and level reach
-// the memory pipe, in that order, with the registers we choose (through the raw_buffer_load builtins hipcc hoists all
-// eight levels' loads and spills ~450 B per lane in the fused kernel).  Inline-asm loads are invisible to the compiler's
-// vmcnt accounting, so the results pass through xpair_wait() (an `s_waitcnt vmcnt(0)` that takes the destination
-// registers as in/out operands) before anything reads them.
-__device__ __forceinline__ u32x4_t table_rsrc(const float* table, unsigned bytes) {
-  const unsigned long long a = (unsigned long long)table;
-  u32x4_t r;
-  r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);  // the descriptor must sit in SGPRs
-  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);  // base[47:32], stride 0
-  r[2] = __builtin_amdgcn_readfirstlane(bytes);                          // num_records (bytes for a raw buffer)
-  r[3] = 0x00020000u;                                                    // DATA_FORMAT = 32
-  return r;
-}
-
-struct XPairLoads {
-  u32x4_t pair[4];   // aligned slot holding the floor-x corner (and, for even ix, the ceil-x corner)
-  u32x2_t extra[4];  // ceil-x corner when ix is odd (zeros otherwise)
-};
-
-__device__ __forceinline__ void xpair_issue(XPairLoads& L, u32x4_t rsrc, unsigned level_off, unsigned mask,
-                                            float scale, float px, float py, float pz) {
-  const unsigned ix = (unsigned)(int)floorf(px * scale), iy = (unsigned)(int)floorf(py * scale),
-                 iz = (unsigned)(int)floorf(pz * scale);
-  const unsigned hy0 = iy * CN_P1, hy1 = hy0 + CN_P1;
-  const unsigned hz0 = iz * CN_P2, hz1 = hz0 + CN_P2;
-  const unsigned yz[4] = {hy1 ^ hz1, hy0 ^ hz1, hy1 ^ hz0, hy0 ^ hz0};  // (c,c) (f,c) (c,f) (f,f) in (y,z)
-  const bool odd = (ix & 1u) != 0u;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const unsigned off = ((((ix ^ yz[k]) & mask) & ~1u) + level_off) << 3;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(L.pair[k]) : "v"(off), "s"(rsrc) : "memory");
-  }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const unsigned off = odd ? ((((ix + 1u) ^ yz[k]) & mask) + level_off) << 3 : 0xfffffff0u;
-    asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(L.extra[k]) : "v"(off), "s"(rsrc) : "memory");
-  }
-}
-
-// every read of A / B must come after this
-__device__ __forceinline__ void xpair_wait(XPairLoads& A, XPairLoads& B) {
-  asm volatile("s_waitcnt vmcnt(0)"
-               : "+v"(A.pair[0]), "+v"(A.pair[1]), "+v"(A.pair[2]), "+v"(A.pair[3]), "+v"(A.extra[0]), "+v"(A.extra[1]),
-                 "+v"(A.extra[2]), "+v"(A.extra[3]), "+v"(B.pair[0]), "+v"(B.pair[1]), "+v"(B.pair[2]), "+v"(B.pair[3]),
-                 "+v"(B.extra[0]), "+v"(B.extra[1]), "+v"(B.extra[2]), "+v"(B.extra[3])
-               :
-               : "memory");
-}
-
-__device__ __forceinline__ float2 xpair_blend(const XPairLoads& L, float scale, float px, float py, float pz) {
-  float sx = px * scale, sy = py * scale, sz = pz * scale;
-  float fx = floorf(sx), fy = floorf(sy), fz = floorf(sz);
-  float ox = sx - fx, oy = sy - fy, oz = sz - fz;
-  unsigned ix = (unsigned)(int)fx, iy = (unsigned)(int)fy, iz = (unsigned)(int)fz;
-  const unsigned hy0 = iy * CN_P1, hy1 = hy0 + CN_P1;
-  const unsigned hz0 = iz * CN_P2, hz1 = hz0 + CN_P2;
-  const unsigned yz[4] = {hy1 ^ hz1, hy0 ^ hz1, hy1 ^ hz0, hy0 ^ hz0};
-  const bool odd = (ix & 1u) != 0u;
-  float2 lo[4], hi[4];  // floor-x / ceil-x corner of each (y,z) combination
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const bool upper = ((ix ^ yz[k]) & 1u) != 0u;  // which half of the slot is the floor-x entry (mask keeps bit 0)
-    const float ax = as_f32(L.pair[k][0]), ay = as_f32(L.pair[k][1]);
-    const float bx = as_f32(L.pair[k][2]), by = as_f32(L.pair[k][3]);
-    lo[k].x = upper ? bx : ax;
-    lo[k].y = upper ? by : ay;
-    hi[k].x = odd ? as_f32(L.extra[k][0]) : (upper ? ax : bx);
-    hi[k].y = odd ? as_f32(L.extra[k][1]) : (upper ? ay : by);
-  }
-  // reference blend order: x toward the ceil corner, then y, then z  (f_0..f_7 = ccc cfc ffc fcc ccf cff fff fcf)
-  const float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
-  float2 r;
-  {
-    float f03 = hi[0].x * ox + lo[0].x * mx, f12 = hi[1].x * ox + lo[1].x * mx;
-    float f47 = hi[2].x * ox + lo[2].x * mx, f56 = hi[3].x * ox + lo[3].x * mx;
-    float a = f03 * oy + f12 * my, b = f47 * oy + f56 * my;
-    r.x = a * oz + b * mz;
-  }
-  {
-    float f03 = hi[0].y * ox + lo[0].y * mx, f12 = hi[1].y * ox + lo[1].y * mx;
-    float f47 = hi[2].y * ox + lo[2].y * mx, f56 = hi[3].y * ox + lo[3].y * mx;
-    float a = f03 * oy + f12 * my, b = f47 * oy + f56 * my;
-    r.y = a * oz + b * mz;
-  }
-  return r;
-}
+// hipcc pitfall (ROCm 7.2), found while building a 16-byte "x-pair" gather variant (measured slower and removed:
+// 3.69 vs 3.86 Gsamples/s): __builtin_bit_cast(float, v.y) applied directly to an ext_vector element reads element 0 --
+// copy the element into a scalar first.
 
 // torch.linspace(0,1,steps)[i] (CPU kernel: symmetric around the midpoint)
 __device__ __forceinline__ float linspace01(int i, int steps) {

@@ -43,22 +43,9 @@ constexpr int OFF_SCALE = 10712;  // [16] hash-grid level scalings (lane group g
 constexpr int BLOB_FLOATS = 10712 + 16;
 static_assert(BLOB_FLOATS % 4 == 0, "blob is copied as float4");
 constexpr int WAVE_SCRATCH = 200;  // floats of per-wave LDS scratch: colour bias [64] | 2 x 66 chunk bin edges
-// Build-time variant: software-pipeline the next half-step's gathers under the current half-step's MFMAs.  Correct
-// (same tests) but needs ~256 VGPRs -> 2 waves/SIMD, and measured no faster than the plain loop at 3 waves/SIMD
-// (3.18 vs 3.32 Gsamples/s on C2; with 3 waves/SIMD it spills: 1.76).  Off by default; kept for the next round's tuning.
-#ifndef CN_FUSED_PIPELINE
-#define CN_FUSED_PIPELINE 0
-#endif
 // timing-only ablations (outputs are wrong): 1 = skip the hash-grid gathers / skip the MLPs
 #ifndef CN_ABLATE_GATHER
 #define CN_ABLATE_GATHER 0
-#endif
-// Build-time variant: fetch the two x-neighbour corners with one 16-byte gather where they share an aligned slot
-// (cn_common.hpp: 6 instead of 8 lane-requests per sample and level).  Correct (same tests), but measured slower than
-// eight plain 8-byte gathers: 3.69 vs 3.86 Gsamples/s on C2 -- the wider requests, the extra selects and the asm-side
-// vmcnt(0) cost more than the saved requests.  Off by default.
-#ifndef CN_XPAIR_GATHER
-#define CN_XPAIR_GATHER 0
 #endif
 #ifndef CN_ABLATE_MLP
 #define CN_ABLATE_MLP 0
@@ -219,46 +206,6 @@ struct FusedArgs {
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #endif
 
-// hash_level split in two for software pipelining: issue the 8 corner gathers now, blend them later
-struct HashCorners {
-  float2 v[8];  // ccc cfc ffc fcc ccf cff fff fcf (f_0 .. f_7 of HashEncoding.pytorch_fwd)
-};
-__device__ __forceinline__ void hash_issue(HashCorners& hc, const float* __restrict__ table, unsigned level_off,
-                                           unsigned mask, float scale, float px, float py, float pz) {
-  const unsigned ix = (unsigned)(int)floorf(px * scale), iy = (unsigned)(int)floorf(py * scale),
-                 iz = (unsigned)(int)floorf(pz * scale);
-  const unsigned hx0 = ix, hx1 = ix + 1u;
-  const unsigned hy0 = iy * CN_P1, hy1 = hy0 + CN_P1;
-  const unsigned hz0 = iz * CN_P2, hz1 = hz0 + CN_P2;
-  hc.v[0] = hash_gather(table, ((hx1 ^ hy1 ^ hz1) & mask) + level_off);
-  hc.v[1] = hash_gather(table, ((hx1 ^ hy0 ^ hz1) & mask) + level_off);
-  hc.v[2] = hash_gather(table, ((hx0 ^ hy0 ^ hz1) & mask) + level_off);
-  hc.v[3] = hash_gather(table, ((hx0 ^ hy1 ^ hz1) & mask) + level_off);
-  hc.v[4] = hash_gather(table, ((hx1 ^ hy1 ^ hz0) & mask) + level_off);
-  hc.v[5] = hash_gather(table, ((hx1 ^ hy0 ^ hz0) & mask) + level_off);
-  hc.v[6] = hash_gather(table, ((hx0 ^ hy0 ^ hz0) & mask) + level_off);
-  hc.v[7] = hash_gather(table, ((hx0 ^ hy1 ^ hz0) & mask) + level_off);
-}
-__device__ __forceinline__ float2 hash_blend(const HashCorners& hc, float scale, float px, float py, float pz) {
-  const float sx = px * scale, sy = py * scale, sz = pz * scale;
-  const float ox = sx - floorf(sx), oy = sy - floorf(sy), oz = sz - floorf(sz);
-  const float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
-  float2 r;
-  {
-    float f03 = hc.v[0].x * ox + hc.v[3].x * mx, f12 = hc.v[1].x * ox + hc.v[2].x * mx;
-    float f56 = hc.v[5].x * ox + hc.v[6].x * mx, f47 = hc.v[4].x * ox + hc.v[7].x * mx;
-    float a = f03 * oy + f12 * my, b = f47 * oy + f56 * my;
-    r.x = a * oz + b * mz;
-  }
-  {
-    float f03 = hc.v[0].y * ox + hc.v[3].y * mx, f12 = hc.v[1].y * ox + hc.v[2].y * mx;
-    float f56 = hc.v[5].y * ox + hc.v[6].y * mx, f47 = hc.v[4].y * ox + hc.v[7].y * mx;
-    float a = f03 * oy + f12 * my, b = f47 * oy + f56 * my;
-    r.y = a * oz + b * mz;
-  }
-  return r;
-}
-
 // ReLU as a signed-integer max on the float bits: one v_max_i32 per value.  fmaxf(x, 0) costs two VALU ops here
 // (hipcc inserts a canonicalising v_max_f32 x, x in front); on the bit pattern, every negative float (sign bit set,
 // -0.0 included) is a negative int -> 0, every non-negative float is unchanged.
@@ -301,9 +248,8 @@ __global__ void __launch_bounds__(FUSED_THREADS, CN_FUSED_MIN_WAVES_PER_SIMD) re
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const int g = lane >> 4, j = lane & 15;
   float* scratch = lds + BLOB_FLOATS + wave * WAVE_SCRATCH;  // [0,64): per-ray colour bias, [64,129): chunk bin edges
-  float* tbuf = scratch + 64;  // two buffers of 66 floats in the pipelined build
+  float* tbuf = scratch + 64;
   const int S = A.S;
-  const u32x4_t tab_rsrc = table_rsrc(A.grid.table, (unsigned)A.grid.num_levels * A.grid.level_stride * 8u);
 
   // XCD-aware ray ownership: blocks b, b+8, ... share an XCD (round-robin dispatch) and therefore an L2.
   //  * unknown ray order: each XCD sweeps one contiguous eighth of the batch;
@@ -373,253 +319,6 @@ __global__ void __launch_bounds__(FUSED_THREADS, CN_FUSED_MIN_WAVES_PER_SIMD) re
     }
 
     CompositeState st;
-#if CN_FUSED_PIPELINE
-    // ---- software pipeline over half-steps (32 samples each): while the MFMAs of half-step hs run, the 64 gathers of
-    //      half-step hs+1 are in flight, one level (16 loads, 32 VGPRs) at a time -- the gather latency hides under this
-    //      wave's own matrix work instead of depending on what the other waves of the SIMD happen to be doing --------
-    const int nchunks = (S + 63) >> 6;
-    const int nhs = nchunks * 2;
-    auto fill_edges = [&](int chunk, float* tb) {
-      const float e_lo = edge(chunk * 64 + lane);
-      const float e_top = edge(chunk * 64 + 64);
-      tb[lane] = e_lo;
-      if (lane == 0) tb[64] = e_top;
-    };
-    auto positions = [&](int hstep, float (&px)[2], float (&py)[2], float (&pz)[2], float (&sl)[2]) {
-      const float* tb = tbuf + ((hstep >> 1) & 1) * 66;
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int k = 32 * (hstep & 1) + 16 * c + j;
-        const float mid = (tb[k] + tb[k + 1]) / 2.f;
-        px[c] = ox + dx * mid;
-        py[c] = oy + dy * mid;
-        pz[c] = oz + dz * mid;
-        sl[c] = normalize_position(A.scene, px[c], py[c], pz[c]) ? 1.f : 0.f;
-      }
-    };
-    const f32x4 lvl_scale = *reinterpret_cast<const f32x4*>(lds + OFF_SCALE + 4 * g);
-    const unsigned lvl_base = (unsigned)(4 * g) * A.grid.level_stride;
-    __builtin_amdgcn_wave_barrier();
-    fill_edges(0, tbuf);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    f32x4 feat[2][2];
-    float csel[2];
-    {
-      float px[2], py[2], pz[2];
-      positions(0, px, py, pz, csel);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          float2 f = hash_level_sc(A.grid.table, lvl_base + q * A.grid.level_stride, A.grid.mask, lvl_scale[q], px[c],
-                                py[c], pz[c]);
-          feat[c][q >> 1][2 * (q & 1)] = f.x;
-          feat[c][q >> 1][2 * (q & 1) + 1] = f.y;
-        }
-      }
-    }
-    float my_dlogit = 0.f, my_sel = 0.f, my_sem = 0.f, my_r = 0.f, my_g = 0.f, my_b = 0.f;
-#pragma unroll 1
-    for (int hs = 0; hs < nhs; ++hs) {
-      const int chunk = hs >> 1, half = hs & 1;
-      const float* tb = tbuf + (chunk & 1) * 66;
-      const bool has_next = hs + 1 < nhs;
-      if (half == 0 && chunk + 1 < nchunks) {  // edges of the next chunk, needed by the prefetch of its first half
-        __builtin_amdgcn_wave_barrier();
-        fill_edges(chunk + 1, tbuf + ((chunk + 1) & 1) * 66);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
-      float nx[2], ny[2], nz[2], nsel[2];
-      positions(has_next ? hs + 1 : hs, nx, ny, nz, nsel);
-      HashCorners hc[2];
-      f32x4 featn[2][2];
-#define CN_ISSUE(q)                                                                                                  \
-  _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                                       \
-      hash_issue(hc[c], A.grid.table, lvl_base + (q) * A.grid.level_stride, A.grid.mask, lvl_scale[q], nx[c], ny[c], \
-                 nz[c]);
-#define CN_CONSUME(q)                                                      \
-  _Pragma("unroll") for (int c = 0; c < 2; ++c) {                          \
-    float2 f = hash_blend(hc[c], lvl_scale[q], nx[c], ny[c], nz[c]);       \
-    featn[c][(q) >> 1][2 * ((q) & 1)] = f.x;                               \
-    featn[c][(q) >> 1][2 * ((q) & 1) + 1] = f.y;                           \
-  }
-      if (has_next) { CN_ISSUE(0) }
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- base MLP layer 0: 32 -> 64, ReLU ------------------------------------------------------------------
-      f32x4 h[4][2];
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B0 + 16 * mt + 4 * g);
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(lds + OFF_A0 + ((mt * 2 + 0) * 64 + lane) * 4);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(lds + OFF_A0 + ((mt * 2 + 1) * 64 + lane) * 4);
-        f32x4 acc[2] = {b, b};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int c = 0; c < 2; ++c) acc[c] = MFMA(a0[e], feat[c][0][e], acc[c]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int c = 0; c < 2; ++c) acc[c] = MFMA(a1[e], feat[c][1][e], acc[c]);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) h[mt][c] = relu4(acc[c]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (has_next) { CN_CONSUME(0) CN_ISSUE(1) }
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- base MLP layer 1: 64 -> 16 (neuron 0 = density logit, 1..15 = geo features) ---------------------------
-      f32x4 o16[2];
-      {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B1 + 4 * g);
-        f32x4 acc[2] = {b, b};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_A1 + (t * 64 + lane) * 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) acc[c] = MFMA(a[e], h[t][c][e], acc[c]);
-        }
-        o16[0] = acc[0];
-        o16[1] = acc[1];
-      }
-      const bool mine = (g >> 1) == half;  // this half holds lane l's own sample in column tile g&1
-      const bool odd = (g & 1) != 0;
-      {
-        float d0 = row0_broadcast(o16[0].x), d1 = row0_broadcast(o16[1].x);
-        my_dlogit = mine ? (odd ? d1 : d0) : my_dlogit;
-        my_sel = mine ? (odd ? csel[1] : csel[0]) : my_sel;
-      }
-      float sem_part[2] = {0.f, 0.f};
-      float rgb_part[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-      f32x4 c1[4][2];
-      if (!DENSITY_ONLY) {
-        // ---- semantics: relu(Ws0 geo + bs0) . (Wh Ws1) + folded bias --------------------------------------------
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_BS0 + 16 * mt + 4 * g);
-          const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_AS0 + (mt * 64 + lane) * 4);
-          const f32x4 wf = *reinterpret_cast<const f32x4*>(lds + OFF_WF + 16 * mt + 4 * g);
-          f32x4 acc[2] = {b, b};
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) acc[c] = MFMA(a[e], o16[c][e], acc[c]);
-#pragma unroll
-          for (int c = 0; c < 2; ++c) sem_part[c] = dot4(wf, relu4(acc[c]), sem_part[c]);
-        }
-        // ---- colour layer 0: geo columns on the MFMA, SH + appearance columns pre-summed in the ray bias ---------
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_AC0 + (mt * 64 + lane) * 4);
-          const f32x4 cb = *reinterpret_cast<const f32x4*>(scratch + 16 * mt + 4 * g);
-          f32x4 acc[2] = {cb, cb};
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) acc[c] = MFMA(a[e], o16[c][e], acc[c]);
-#pragma unroll
-          for (int c = 0; c < 2; ++c) c1[mt][c] = relu4(acc[c]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (has_next) { CN_CONSUME(1) CN_ISSUE(2) }
-      __builtin_amdgcn_sched_barrier(0);
-      if (!DENSITY_ONLY) {
-        // ---- colour layer 1 (64 -> 64, ReLU) with the 64 -> 3 head folded into the row-tile loop ------------------
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_BC1 + 16 * mt + 4 * g);
-          f32x4 acc[2] = {b, b};
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_AC1 + ((mt * 4 + t) * 64 + lane) * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-              for (int c = 0; c < 2; ++c) acc[c] = MFMA(a[e], c1[t][c][e], acc[c]);
-          }
-          const f32x4 w0 = *reinterpret_cast<const f32x4*>(lds + OFF_WRGB + 0 * 64 + 16 * mt + 4 * g);
-          const f32x4 w1 = *reinterpret_cast<const f32x4*>(lds + OFF_WRGB + 1 * 64 + 16 * mt + 4 * g);
-          const f32x4 w2 = *reinterpret_cast<const f32x4*>(lds + OFF_WRGB + 2 * 64 + 16 * mt + 4 * g);
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            f32x4 v = relu4(acc[c]);
-            rgb_part[c][0] = dot4(w0, v, rgb_part[c][0]);
-            rgb_part[c][1] = dot4(w1, v, rgb_part[c][1]);
-            rgb_part[c][2] = dot4(w2, v, rgb_part[c][2]);
-          }
-          if (mt == 1) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (has_next) { CN_CONSUME(2) CN_ISSUE(3) }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        // ---- reduce the heads over the four lane groups and keep the column tile this lane owns ---------------
-        float s0 = group_sum(sem_part[0]), s1 = group_sum(sem_part[1]);
-        my_sem = mine ? (odd ? s1 : s0) : my_sem;
-        float r0 = group_sum(rgb_part[0][0]), r1 = group_sum(rgb_part[1][0]);
-        my_r = mine ? (odd ? r1 : r0) : my_r;
-        float g0 = group_sum(rgb_part[0][1]), g1 = group_sum(rgb_part[1][1]);
-        my_g = mine ? (odd ? g1 : g0) : my_g;
-        float b0 = group_sum(rgb_part[0][2]), b1 = group_sum(rgb_part[1][2]);
-        my_b = mine ? (odd ? b1 : b0) : my_b;
-      } else {
-        if (has_next) { CN_CONSUME(2) CN_ISSUE(3) }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (has_next) {
-        CN_CONSUME(3)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          feat[c][0] = featn[c][0];
-          feat[c][1] = featn[c][1];
-          csel[c] = nsel[c];
-        }
-      }
-#undef CN_ISSUE
-#undef CN_CONSUME
-      if (half == 1) {
-        // ---- lane l now holds sample c0 + l of this chunk -----------------------------------------------------------
-        const int c0 = chunk * 64;
-        float density = expf(my_dlogit) * my_sel;
-        float sem = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
-        if (!DENSITY_ONLY) {
-          sem = my_sem + lds[OFF_MISC + 0];
-          cr = sigmoidf(my_r + lds[OFF_MISC + 1]);
-          cg = sigmoidf(my_g + lds[OFF_MISC + 2]);
-          cb = sigmoidf(my_b + lds[OFF_MISC + 3]);
-        }
-        const int i = c0 + lane;
-        const bool valid = i < S;
-        const float e0 = tb[lane], e1 = tb[lane + 1];
-        const float mid = (e0 + e1) / 2.f;
-        if (PER_SAMPLE) {
-          if (valid) {
-            const long long o = r * (long long)S + i;
-            if (A.s_density) A.s_density[o] = density;
-            if (A.s_sem) A.s_sem[o] = sem;
-            if (A.s_label) A.s_label[o] = (int64_t)semantics_label(sem);
-            if (A.s_rgb) {
-              A.s_rgb[3 * o + 0] = cr;
-              A.s_rgb[3 * o + 1] = cg;
-              A.s_rgb[3 * o + 2] = cb;
-            }
-            if (A.s_pos) {
-              A.s_pos[3 * o + 0] = ox + dx * mid;
-              A.s_pos[3 * o + 1] = oy + dy * mid;
-              A.s_pos[3 * o + 2] = oz + dz * mid;
-            }
-          }
-        } else {
-          float w = composite_chunk(st, valid, i == S - 1, e1 - e0, density, mid, cr, cg, cb, sem, A.eval_clamp != 0);
-          if (A.out_w && valid) A.out_w[r * (long long)S + i] = w;
-        }
-      }
-    }
-#else
     for (int c0 = 0; c0 < S; c0 += 64) {
       // ---- bin edges of the chunk: lane l owns edge c0+l, edge c0+64 is wave-uniform; staged in LDS so that the
       //      gather lanes (sample 32h+16c+j) and the compositing lanes (sample l) read the same values ----------
@@ -658,18 +357,10 @@ __global__ void __launch_bounds__(FUSED_THREADS, CN_FUSED_MIN_WAVES_PER_SIMD) re
           for (int q = 0; q < 4; ++q) {
             const unsigned level_off = (unsigned)(4 * g + q) * A.grid.level_stride;
             const float scale = lvl_scale[q];
-#if CN_XPAIR_GATHER && !CN_ABLATE_GATHER
-            XPairLoads ld0, ld1;
-            xpair_issue(ld0, tab_rsrc, level_off, A.grid.mask, scale, px[0], py[0], pz[0]);
-            xpair_issue(ld1, tab_rsrc, level_off, A.grid.mask, scale, px[1], py[1], pz[1]);
-            xpair_wait(ld0, ld1);
-#endif
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
 #if CN_ABLATE_GATHER  // timing-only build: no table reads (positions still feed the MLP so nothing is dead code)
               float2 f = make_float2(px[c] * scale, py[c] + pz[c]);
-#elif CN_XPAIR_GATHER
-              float2 f = xpair_blend(c == 0 ? ld0 : ld1, scale, px[c], py[c], pz[c]);
 #else
               float2 f = hash_level_sc(A.grid.table, level_off, A.grid.mask, scale, px[c], py[c], pz[c]);
 #endif
@@ -843,7 +534,6 @@ __global__ void __launch_bounds__(FUSED_THREADS, CN_FUSED_MIN_WAVES_PER_SIMD) re
         }
       }
     }
-#endif
     if (!PER_SAMPLE) {
       CompositeOut o = composite_finish(st, A.bg_mode, A.bg[0], A.bg[1], A.bg[2], A.eval_clamp != 0);
       if (lane == 0) {
