@@ -21,23 +21,17 @@ namespace cn {
 #ifndef CN_SPLIT_LEVELS_IN_FLIGHT
 #define CN_SPLIT_LEVELS_IN_FLIGHT 4
 #endif
-// CN_SPLIT_G gather waves, each feeding CN_SPLIT_MPG matrix waves ("pairs" below = matrix waves = rays in flight)
-#ifndef CN_SPLIT_SEPARATE_LOOPS
-#define CN_SPLIT_SEPARATE_LOOPS 0
-#endif
-// Build variants that were measured and lost (kept for A/B runs), C2 workload, Gsamples/s:
-//   CN_SPLIT_SYNC_FLAGS=1     per-pair full/empty flags in LDS instead of the workgroup barrier     4.31 vs 4.89
-//   CN_SPLIT_SEPARATE_LOOPS=1 one loop per role instead of one loop with a role branch             4.65 vs 4.93
-//   CN_SPLIT_G x CN_SPLIT_MPG 4x3 / 5x2 / 4x2 / 6x1 (fewer gather waves, more matrix waves each)    3.49 / 3.82 / 4.43 / 4.17
-//   (8x1 = 4.93: with fewer gather waves the gather side becomes the bound, with 8x1 the matrix pipe is ~66 % busy)
-//   deferring the compositing of one of the two matrix waves of a SIMD to its next half-step (so that the two do not
-//   reach that VALU-only tail together): 4.88 vs 4.89 -- no gain, removed again
-// Ablation builds of this kernel (timing only): -DCN_ABLATE_GATHER=1 2.12 ms, -DCN_ABLATE_MLP=1 1.81 ms, both 1.36 ms
-// per C2 batch against 2.56 ms for the real thing: the matrix side (2.12) is the longer one, and ~1 ms of every variant
-// is the non-gather, non-MFMA work (addresses, blends, activations, compositing, LDS traffic, barriers).
-#ifndef CN_SPLIT_SYNC_FLAGS
-#define CN_SPLIT_SYNC_FLAGS 0
-#endif
+// CN_SPLIT_G gather waves, each feeding CN_SPLIT_MPG matrix waves ("pairs" below = matrix waves = rays in flight).
+// Measured at C2 (Gsamples/s), then removed from the source again (the commits are in the history):
+//   G x MPG = 4x3 / 5x2 / 4x2 / 6x1 instead of 8x1                                                   3.49 / 3.82 / 4.43 / 4.17 vs 4.93
+//   per-pair full/empty flags in LDS instead of the workgroup barrier                              4.31 vs 4.89
+//   one loop per role instead of one loop with a role branch                                        4.65 vs 4.93
+//   the gather waves also run the base MLP (96 of the 288 MFMAs) and hand over its 16 outputs        4.29 vs 4.87
+//   one of the two matrix waves of a SIMD defers its compositing to its next half-step               4.88 vs 4.89
+// (with fewer gather waves the gather side becomes the bound; at 8x1 the matrix pipe is ~66 % busy and, MFMA and VALU
+//  cycles being additive on a SIMD, the kernel sits at ~98 % of its issue bound -- DESIGN.md section 4.1)
+// Ablation builds (timing only): -DCN_ABLATE_GATHER=1 2.12 ms, -DCN_ABLATE_MLP=1 1.81 ms, both 1.36 ms per C2 batch
+// against 2.56 ms for the real thing.
 #ifndef CN_SPLIT_G
 #define CN_SPLIT_G 8
 #endif
@@ -48,14 +42,9 @@ constexpr int SPLIT_G = CN_SPLIT_G, SPLIT_MPG = CN_SPLIT_MPG;
 constexpr int SPLIT_PAIRS = SPLIT_G * SPLIT_MPG;
 constexpr int SPLIT_THREADS = (SPLIT_G + SPLIT_PAIRS) * 64;
 static_assert(SPLIT_THREADS <= 1024, "at most 16 waves per workgroup");
-// 1: the gather waves also run the base MLP (96 of the 288 MFMAs of a half-step) and hand over its 16 outputs.  Measured
-// slower (4.29 vs 4.87 Gsamples/s): the MFMAs extend the gather wave's serial chain behind the gather latency.
-#ifndef CN_SPLIT_BASE_IN_GATHER
-#define CN_SPLIT_BASE_IN_GATHER 0
-#endif
-// one half-step in the ring: per lane 16 feature floats (or the 8 base-MLP outputs) + selector bits
-constexpr int XCH_FLOATS = (CN_SPLIT_BASE_IN_GATHER ? 8 : 16) * 64 + 64;
-constexpr int PAIR_SCRATCH = 2 * XCH_FLOATS + 64 + 68 + 68 + 4;  // ring | per-ray colour bias | matrix edges | gather edges | slot flags
+// one half-step in the ring: per lane 16 feature floats + selector bits
+constexpr int XCH_FLOATS = 16 * 64 + 64;
+constexpr int PAIR_SCRATCH = 2 * XCH_FLOATS + 64 + 68 + 68 + 4;  // ring | per-ray colour bias | matrix edges | gather edges | flags
 constexpr int PAIR_FLAGS = 2 * XCH_FLOATS + 64 + 68 + 68;
 constexpr size_t SPLIT_LDS_BYTES = (size_t)(BLOB_FLOATS + SPLIT_PAIRS * PAIR_SCRATCH) * sizeof(float);
 
@@ -118,17 +107,6 @@ __device__ __forceinline__ void split_fill_edges(const FusedArgs& A, const Split
   __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ void split_wait_flag(int* flag, int want) {
-  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != want) __builtin_amdgcn_s_sleep(1);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  asm volatile("" ::: "memory");  // also keeps the (loop-invariant) weight reads of the MFMA chain from being hoisted
-}
-__device__ __forceinline__ void split_set_flag(int* flag, int v) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __hip_atomic_store(flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  asm volatile("" ::: "memory");
-}
-
 template <bool PER_SAMPLE>
 __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A) {
   extern __shared__ __align__(16) float lds[];
@@ -138,7 +116,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
     for (int i = threadIdx.x; i < BLOB_FLOATS / 4; i += SPLIT_THREADS) dst[i] = src[i];
     if (threadIdx.x < SPLIT_PAIRS * 4)
       reinterpret_cast<int*>(lds + BLOB_FLOATS + (threadIdx.x >> 2) * PAIR_SCRATCH + PAIR_FLAGS)[threadIdx.x & 3] =
-          (threadIdx.x & 3) == 2 ? -1 : 0;  // [0,1]: slot flags (flag-sync build); [2]: schedule slot of a terminated ray
+          (threadIdx.x & 3) == 2 ? -1 : 0;  // [2]: schedule slot of a ray its matrix wave has terminated early
   }
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -185,15 +163,9 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
   float my_dlogit = 0.f, my_sel = 0.f, my_sem = 0.f, my_r = 0.f, my_g = 0.f, my_b = 0.f;
   bool ray_stopped = false;  // matrix wave: this ray was terminated early (cn_render_opts.early_stop_transmittance)
 
-  // The two roles run separate loops (same trip count, one barrier per iteration) so that neither role's registers are
-  // live in the other's code.
-#if CN_SPLIT_SEPARATE_LOOPS
-  if (!matrix_role) {
-    for (long long step = 0; step <= total; ++step) {
-#else
+  // One loop for both roles (same trip count, one workgroup barrier per half-step at its end).
   for (long long step = 0; step <= total; ++step) {
     if (!matrix_role) {
-#endif
       // ================= gather wave: produce half-step `step` =======================================================
       // (lane coordinates through an empty volatile asm per iteration: keeps LICM from hoisting every lane-dependent
       //  LDS address out of the loop and spilling them)
@@ -217,11 +189,6 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
                                  reinterpret_cast<volatile int*>(gring + PAIR_FLAGS)[2] == (int)qi;
           if (gr.valid && !stopped_g) {
             const int chunk = PER_SAMPLE ? gr.chunk : (k >> 1), half = k & 1;
-#if CN_SPLIT_SYNC_FLAGS
-            // wait for the slot BEFORE the gathers are issued: nothing but the ray state is live across the spin
-            int* flag = reinterpret_cast<int*>(gring + PAIR_FLAGS) + (int)(step & 1);
-            split_wait_flag(flag, 0);
-#endif
             if (half == 0) split_fill_edges(A, gr, chunk * 64, tb_g, lane);
             float px[2], py[2], pz[2];
             bool sel[2];
@@ -257,73 +224,16 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
             }
             float* xs = gring + (int)(step & 1) * XCH_FLOATS;
             f32x4* xv = reinterpret_cast<f32x4*>(xs);
-#if CN_SPLIT_BASE_IN_GATHER
-            // the base MLP (96 of the 288 MFMAs of a half-step) runs here: the matrix pipe gets work from four waves per
-            // SIMD instead of two, the two sides of the hand-off are closer in length, and the slot shrinks to 16 floats
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- base MLP layer 0: 32 -> 64, ReLU ------------------------------------------------------------------------
-            f32x4 h[4][2];
-    #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-              const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B0 + 16 * mt + 4 * g);
-              const f32x4 a0 = *reinterpret_cast<const f32x4*>(lds + OFF_A0 + ((mt * 2 + 0) * 64 + lane) * 4);
-              const f32x4 a1 = *reinterpret_cast<const f32x4*>(lds + OFF_A0 + ((mt * 2 + 1) * 64 + lane) * 4);
-              f32x4 acc[2] = {b, b};
-    #pragma unroll
-              for (int e = 0; e < 4; ++e)
-    #pragma unroll
-                for (int c = 0; c < 2; ++c) acc[c] = MFMA(a0[e], feat[c][0][e], acc[c]);
-    #pragma unroll
-              for (int e = 0; e < 4; ++e)
-    #pragma unroll
-                for (int c = 0; c < 2; ++c) acc[c] = MFMA(a1[e], feat[c][1][e], acc[c]);
-    #pragma unroll
-              for (int c = 0; c < 2; ++c) h[mt][c] = relu4(acc[c]);
-            }
-            // ---- base MLP layer 1: 64 -> 16 ---------------------------------------------------------------------------------
-            f32x4 o16[2];
-            {
-              const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B1 + 4 * g);
-              f32x4 acc[2] = {b, b};
-    #pragma unroll
-              for (int t = 0; t < 4; ++t) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_A1 + (t * 64 + lane) * 4);
-    #pragma unroll
-                for (int e = 0; e < 4; ++e)
-    #pragma unroll
-                  for (int c = 0; c < 2; ++c) acc[c] = MFMA(a[e], h[t][c][e], acc[c]);
-              }
-              o16[0] = acc[0];
-              o16[1] = acc[1];
-            }
-            xv[0 * 64 + lane] = o16[0];
-            xv[1 * 64 + lane] = o16[1];
-#else
             xv[0 * 64 + lane] = feat[0][0];
             xv[1 * 64 + lane] = feat[0][1];
             xv[2 * 64 + lane] = feat[1][0];
             xv[3 * 64 + lane] = feat[1][1];
-#endif
             xs[XCH_FLOATS - 64 + lane] = (sel[0] ? 1.f : 0.f) + (sel[1] ? 2.f : 0.f);
-#if CN_SPLIT_SYNC_FLAGS
-            split_set_flag(flag, 1);
-#endif
           }
           __builtin_amdgcn_sched_barrier(0);  // one consumer's half-step at a time
         }
       }
-#if CN_SPLIT_SEPARATE_LOOPS
-#if !CN_SPLIT_SYNC_FLAGS
-      __syncthreads();
-#endif
-    }
-    return;
-  }
-  for (long long step = 0; step <= total; ++step) {
-    if (step >= 1) {
-#else
     } else if (step >= 1) {
-#endif
       // ================= matrix wave: consume half-step `step - 1` ===================================================
       int lane = lane0;
       asm volatile("" : "+v"(lane));
@@ -372,25 +282,12 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
         }
         const float* xs = ring + (int)(hs & 1) * XCH_FLOATS;
         const f32x4* xv = reinterpret_cast<const f32x4*>(xs);
-#if CN_SPLIT_SYNC_FLAGS
-        split_wait_flag(reinterpret_cast<int*>(ring + PAIR_FLAGS) + (int)(hs & 1), 1);
-#endif
-#if !CN_SPLIT_BASE_IN_GATHER
         f32x4 feat[2][2];
         feat[0][0] = xv[0 * 64 + lane];
         feat[0][1] = xv[1 * 64 + lane];
         feat[1][0] = xv[2 * 64 + lane];
         feat[1][1] = xv[3 * 64 + lane];
-#endif
         const int selbits = (int)xs[XCH_FLOATS - 64 + lane];
-#if CN_SPLIT_SYNC_FLAGS
-        split_set_flag(reinterpret_cast<int*>(ring + PAIR_FLAGS) + (int)(hs & 1), 0);  // slot read: the gather wave may refill it
-#endif
-#if CN_SPLIT_BASE_IN_GATHER
-        f32x4 o16[2];  // the gather wave has run the base MLP: the slot holds its 16 outputs per sample
-        o16[0] = xv[0 * 64 + lane];
-        o16[1] = xv[1 * 64 + lane];
-#else
         // ---- base MLP layer 0: 32 -> 64, ReLU ------------------------------------------------------------------------
         f32x4 h[4][2];
 #pragma unroll
@@ -426,7 +323,6 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
           o16[0] = acc[0];
           o16[1] = acc[1];
         }
-#endif
         __builtin_amdgcn_sched_barrier(0);
         const bool mine = (g >> 1) == half;
         const bool odd = (g & 1) != 0;
@@ -572,9 +468,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
         }
       }
     }
-#if !CN_SPLIT_SYNC_FLAGS
     __syncthreads();
-#endif
   }
 }
 
