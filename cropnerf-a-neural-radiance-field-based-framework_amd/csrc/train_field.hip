@@ -781,10 +781,8 @@ extern "C" int cn_field_backward(const cn_field_params* params, const cn_field_p
   }
   // default: the matrix-core kernel; CN_FIELD_BACKWARD_IMPL=scalar selects the first (scalar-FMA) implementation,
   // kept as an independent device implementation for cross-checks
-  static const bool use_scalar = [] {
-    const char* e = getenv("CN_FIELD_BACKWARD_IMPL");
-    return e && std::strcmp(e, "scalar") == 0;
-  }();
+  const char* impl_env = getenv("CN_FIELD_BACKWARD_IMPL");  // read per call: one process can compare both
+  const bool use_scalar = impl_env && std::strcmp(impl_env, "scalar") == 0;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::field_backward_kernel),

@@ -294,11 +294,19 @@ def test_general_field_backward_matches_autograd(shape):
     bad = {k: e for k, e in worst.items() if e > 3e-3}
     assert not bad, bad
     if shape == "default":
-        grads2 = {k: torch.zeros_like(v) for k, v in dp.items()}
-        ops.field_backward(fh, ops.FieldHandle(grads2, pspec), *args)
-        for k in grads:
-            rel = (grads[k] - grads2[k]).norm().item() / (grads2[k].norm().item() + 1e-12)
-            assert rel < 1e-4, (k, rel)
+        # ... and the two implementations of the specialised kernel (matrix-core, default; scalar, the first version)
+        import os
+
+        for impl in ("mfma", "scalar"):
+            os.environ["CN_FIELD_BACKWARD_IMPL"] = impl
+            try:
+                grads2 = {k: torch.zeros_like(v) for k, v in dp.items()}
+                ops.field_backward(fh, ops.FieldHandle(grads2, pspec), *args)
+            finally:
+                del os.environ["CN_FIELD_BACKWARD_IMPL"]
+            for k in grads:
+                rel = (grads[k] - grads2[k]).norm().item() / (grads2[k].norm().item() + 1e-12)
+                assert rel < 1e-4, (impl, k, rel)
 
 
 def test_big_method_trains():
