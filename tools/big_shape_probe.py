@@ -4,10 +4,10 @@ import json, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cropnerf_amd import synthetic
 from cropnerf_amd.fruit_nerf.fruit_nerf import FruitModel, Semantics
-from cropnerf_amd.fruit_nerf.fruit_nerf_config import fruit_nerf_method_big
+from cropnerf_amd.fruit_nerf import fruit_nerf_config as FC
 from cropnerf_amd.rays import Cameras, SceneBox
 
-cfg = fruit_nerf_method_big.config.pipeline.model
+cfg = getattr(FC, os.environ.get("METHOD", "fruit_nerf_method_big")).config.pipeline.model
 c2w, intr = synthetic.orbit_cameras(8, height=800, width=800)
 cams = Cameras(c2w, intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], 800, 800).to("cuda")
 m = FruitModel(cfg, SceneBox(torch.tensor(synthetic.SCENE_AABB)), 8, {"semantics": Semantics()}, device="cuda", test_mode="inference")
@@ -34,7 +34,7 @@ from cropnerf_amd.fruit_nerf.trainer import FruitTrainer
 m.training = True
 tr = FruitTrainer(m)
 g = torch.Generator().manual_seed(0)
-Rt = 8192
+Rt = int(os.environ.get("TRAIN_RAYS", "8192"))
 idx = torch.stack([torch.randint(0, 8, (Rt,), generator=g), torch.randint(0, 800, (Rt,), generator=g),
                    torch.randint(0, 800, (Rt,), generator=g)], -1)
 rays = cams.generate_rays(idx.cuda())
