@@ -665,3 +665,89 @@ def statistical_outlier_mask(points: Tensor, nb_neighbors: int = 20, std_ratio: 
     mean = avg[valid].sum() / nv
     std = torch.sqrt(((avg[valid] - mean) ** 2).sum() / (nv - 1))
     return valid & (avg < mean + std_ratio * std)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# super-cluster stage of the segmenter (segmentation/segmenter.py:69-86)
+# --------------------------------------------------------------------------------------------------------------
+
+def _bin_points(pts: Tensor, h: float, lo: Optional[Tensor] = None):
+    """Uniform-grid binning (torch plumbing): returns (sorted points, cell_start int32, dims, origin, order)."""
+    lo = pts.min(dim=0).values if lo is None else lo
+    hi = pts.max(dim=0).values
+    dims = [max(1, int(float((hi[a] - lo[a]) / h)) + 1) for a in range(3)]
+    if dims[0] * dims[1] * dims[2] > (1 << 28):
+        raise ValueError(f"grid of {dims} cells is too fine for this cloud")
+    cell = ((pts - lo) / h).floor().to(torch.int64)
+    for a in range(3):
+        cell[:, a].clamp_(0, dims[a] - 1)
+    key = (cell[:, 2] * dims[1] + cell[:, 1]) * dims[0] + cell[:, 0]
+    key_sorted, order = torch.sort(key)
+    cell_start = torch.searchsorted(key_sorted, torch.arange(dims[0] * dims[1] * dims[2] + 1, device=pts.device))
+    return pts[order].contiguous(), cell_start.to(torch.int32).contiguous(), dims, lo, order.contiguous()
+
+
+def voxel_down_sample(points: Tensor, voxel_size: float, colors: Optional[Tensor] = None):
+    """open3d ``voxel_down_sample``: voxel index = floor((p - (min_bound - voxel_size / 2)) / voxel_size); the points (and
+    colours) of a voxel are averaged.  Output order: ascending voxel key (open3d's is unspecified)."""
+    lib = L.load()
+    pts = _f32(points.contiguous(), "points")
+    if pts.shape[0] == 0:
+        return pts, colors
+    vmin = pts.min(dim=0).values - voxel_size * 0.5
+    cell = ((pts - vmin) / voxel_size).floor().to(torch.int64)
+    dims = cell.max(dim=0).values + 1
+    key = (cell[:, 2] * dims[1] + cell[:, 1]) * dims[0] + cell[:, 0]
+    key_sorted, order = torch.sort(key)
+    _, counts = torch.unique_consecutive(key_sorted, return_counts=True)
+    seg = torch.zeros(counts.numel() + 1, dtype=torch.int32, device=pts.device)
+    seg[1:] = counts.cumsum(0).to(torch.int32)
+    vals = pts[order] if colors is None else torch.cat([pts[order], _f32(colors.contiguous(), "colors")[order]], dim=1)
+    vals = vals.contiguous()
+    out = torch.empty(counts.numel(), vals.shape[1], device=pts.device)
+    L.check(lib.cn_segment_mean(_p(vals), _p(seg), counts.numel(), vals.shape[1], _p(out), _stream(pts)))
+    return (out[:, :3].contiguous(), None) if colors is None else (out[:, :3].contiguous(), out[:, 3:].contiguous())
+
+
+def dbscan(points: Tensor, eps: float, min_points: int) -> Tuple[Tensor, Tensor]:
+    """``cluster_dbscan(eps, min_points)``: labels [N] int64 (-1 = noise; clusters numbered by their smallest core point
+    index, as a scan in point order discovers them) and the core mask [N]."""
+    lib = L.load()
+    pts = _f32(points.contiguous(), "points")
+    n = pts.shape[0]
+    if n == 0:
+        return torch.empty(0, dtype=torch.int64, device=pts.device), torch.empty(0, dtype=torch.bool, device=pts.device)
+    ext = float((pts.max(dim=0).values - pts.min(dim=0).values).max())
+    h = max(float(eps), ext / 512.0)
+    ps, cell_start, dims, lo, order = _bin_points(pts, h)
+    count = torch.empty(n, dtype=torch.int32, device=pts.device)
+    parent = torch.empty(n, dtype=torch.int32, device=pts.device)
+    root = torch.empty(n, dtype=torch.int32, device=pts.device)
+    L.check(lib.cn_dbscan(_p(ps), _p(cell_start), dims[0], dims[1], dims[2], float(lo[0]), float(lo[1]), float(lo[2]), h,
+                          float(eps), int(min_points), _p(order), n, _p(count), _p(parent), _p(root), _stream(pts)))
+    core_sorted = count >= min_points
+    # cluster ids in order of the smallest ORIGINAL index among each cluster's core points
+    big = torch.iinfo(torch.int64).max
+    first = torch.full((n,), big, dtype=torch.int64, device=pts.device)
+    cs = core_sorted.nonzero().squeeze(1)
+    first.scatter_reduce_(0, root[cs].to(torch.int64), order[cs], reduce="amin")
+    roots = (first < big).nonzero().squeeze(1)
+    rank = torch.empty_like(first)
+    rank[roots[torch.argsort(first[roots])]] = torch.arange(roots.numel(), device=pts.device)
+    lab_sorted = torch.where(root >= 0, rank[root.clamp(min=0).to(torch.int64)], torch.full_like(first, -1))
+    labels = torch.empty(n, dtype=torch.int64, device=pts.device)
+    labels[order] = lab_sorted
+    core = torch.empty(n, dtype=torch.bool, device=pts.device)
+    core[order] = core_sorted
+    return labels, core
+
+
+def get_super_clusters(points: Tensor, vx_size: float = 10e-5, colors: Optional[Tensor] = None):
+    """``segmentation/segmenter.py:69-86``: voxel down-sample, DBSCAN(eps = 20 voxels, min_points = 30), drop the noise,
+    statistical outlier removal (20 neighbours, std_ratio 2).  Returns (points, labels)."""
+    pts, _ = voxel_down_sample(points, vx_size, colors)
+    labels, _ = dbscan(pts, 20 * vx_size, 30)
+    keep = labels >= 0
+    pts, labels = pts[keep].contiguous(), labels[keep]
+    inl = statistical_outlier_mask(pts, 20, 2.0)
+    return pts[inl].contiguous(), labels[inl]

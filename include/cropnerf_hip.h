@@ -406,6 +406,26 @@ int cn_knn_mean_distance(const float* points_sorted, const int32_t* cell_start, 
                          float origin_x, float origin_y, float origin_z, float cell_size, int64_t num_points,
                          int32_t nb_neighbors, float* mean_distance, cn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Super-cluster stage of the segmenter (segmentation/segmenter.py:69-86, get_super_clusters):
+ * voxel_down_sample -> cluster_dbscan(eps, min_points) -> remove_statistical_outlier (cn_knn_mean_distance).
+ * The caller bins the points on a uniform grid as for cn_knn_mean_distance.
+ * ------------------------------------------------------------------------------------------- */
+
+/* open3d voxel_down_sample: out[s] = mean of the rows [segment_start[s], segment_start[s+1]) of
+ * values_sorted [N, channels] (rows sorted by voxel). */
+int cn_segment_mean(const float* values_sorted, const int32_t* segment_start, int64_t num_segments, int32_t channels,
+                    float* out, cn_stream_t stream);
+
+/* DBSCAN with grid cells >= eps wide.  order [N] = original index of each sorted point (ties between clusters
+ * for a border point go to the core neighbour with the smallest original index).  neighbour_count [N] and
+ * parent [N] are work arrays (neighbour_count[i] >= min_points marks the core points afterwards);
+ * root [N] = sorted index of the representative of the point's cluster, -1 for noise. */
+int cn_dbscan(const float* points_sorted, const int32_t* cell_start, int32_t gx, int32_t gy, int32_t gz,
+              float origin_x, float origin_y, float origin_z, float cell_size, float eps, int32_t min_points,
+              const int64_t* order, int64_t num_points, int32_t* neighbour_count, int32_t* parent, int32_t* root,
+              cn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
