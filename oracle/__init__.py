@@ -26,6 +26,8 @@ permission denial occurred).  The oracle is therefore pinned only by the
 analytic known-answer tests of SURVEY.md section 8(c) (``tests/test_oracle_kat.py``).
 Exception: ``oracle/zbuffer.py`` (the depth-based projection, a "next" row) follows numpy code that IS in the
 reference (``scripts/depth_based_semantic_projection.py:31-105``) statement by statement.
+``oracle/outliers.py`` and ``oracle/clustering.py`` (the segmenter's super-cluster stage) restate open3d's published
+algorithms with scipy / scikit-learn -- open3d is absent, so they too are unpinned.
 """
 
 from . import field, model, rays, render, samplers  # noqa: F401
