@@ -1,7 +1,6 @@
 // Super-cluster stage of the segmenter (segmentation/segmenter.py:69-86: get_super_clusters =
 // voxel_down_sample -> cluster_dbscan(eps = 20 voxels, min_points = 30) -> drop noise -> remove_statistical_outlier
-// (csrc/knn.hip)).  The caller bins the points on a uniform grid with cell size >= eps (sorted by cell, cell offsets);
-// everything here is one thread per point over the 3x3x3 block of cells around it.
+// (csrc/knn.hip)).  The caller bins the points (sorted by cell); everything here is one thread per point.
 //
 //   cn_segment_mean   open3d voxel_down_sample: the points (any number of channels) of one voxel are averaged
 //   cn_dbscan         density-based clustering with DBSCAN's definitions: a point is a CORE point when at least
@@ -27,38 +26,85 @@ segment_mean_kernel(const float* __restrict__ vals, const int* __restrict__ seg_
   }
 }
 
-struct GridArgs {
-  const float* pts;
-  const int* cell_start;
-  int gx, gy, gz;
-  float ox, oy, oz, inv_h;
+// ---------------------------------------------------------------------------------------------------------------
+// DBSCAN on a sparse grid whose cells have a diagonal <= eps (cell size <= eps / sqrt 3): any two points of a cell are
+// within eps of each other, and everything within eps of a point lies in the 5x5x5 block of cells around its own.
+//   * a cell holding >= min_points points makes all of them core points of ONE cluster without a single distance;
+//   * connectivity needs ONE core-core link per pair of neighbouring cells, not one per pair of points: a core point
+//     links to its cell's representative, then looks into each neighbouring cell whose representative is not yet in its
+//     component and stops at the first core point within eps.  With eps = 20 voxels (segmenter.py:76) a point has
+//     thousands of neighbours; this does ~10^2 operations per point instead.
+// The caller sorts the points by cell key ((z*dim_y + y)*dim_x + x, 64 bit) and passes the occupied cells only.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int DB_ROWS = 25;            // (dy, dz) in [-2, 2]^2; the 5 cells of a row are consecutive keys
+constexpr unsigned DB_FIRST_MASK = 0x1FFFFFFFu;  // row entry = first occupied cell | (number of occupied cells << 29)
+constexpr int DB_NONE = 0x7FFFFFFF;
+
+struct SparseGrid {
+  const float* pts;              // [n,3] sorted by cell
+  const long long* cell_keys;    // [m] ascending
+  const int* cell_start;         // [m+1]
+  const int* point_cell;         // [n]
+  unsigned* rows;                // [m, 25]
+  int* rep;                      // [m] smallest sorted index of a core point of the cell, DB_NONE if none
+  long long dim_x, dim_y, dim_z;
+  int m;
   long long n;
 };
 
-template <typename F>
-__device__ __forceinline__ void for_each_neighbour(const GridArgs& G, long long i, float eps2, F&& f) {
-  const float px = G.pts[3 * i], py = G.pts[3 * i + 1], pz = G.pts[3 * i + 2];
-  const int cx = min(max((int)floorf((px - G.ox) * G.inv_h), 0), G.gx - 1);
-  const int cy = min(max((int)floorf((py - G.oy) * G.inv_h), 0), G.gy - 1);
-  const int cz = min(max((int)floorf((pz - G.oz) * G.inv_h), 0), G.gz - 1);
-  for (int z = max(cz - 1, 0); z <= min(cz + 1, G.gz - 1); ++z)
-    for (int y = max(cy - 1, 0); y <= min(cy + 1, G.gy - 1); ++y)
-      for (int x = max(cx - 1, 0); x <= min(cx + 1, G.gx - 1); ++x) {
-        const long long c = ((long long)z * G.gy + y) * G.gx + x;
-        const int lo = G.cell_start[c], hi = G.cell_start[c + 1];
-        for (int q = lo; q < hi; ++q) {
-          const float ex = G.pts[3 * q] - px, ey = G.pts[3 * q + 1] - py, ez = G.pts[3 * q + 2] - pz;
-          if (ex * ex + ey * ey + ez * ez <= eps2) f(q);
-        }
+// per (occupied cell, row): the occupied cells of the row, found by binary search over the sorted keys
+__global__ void __launch_bounds__(256) dbscan_rows_kernel(SparseGrid G) {
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < (long long)G.m * DB_ROWS;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(t / DB_ROWS), r = (int)(t - (long long)c * DB_ROWS);
+    if (r == 0) G.rep[c] = DB_NONE;
+    const long long key = G.cell_keys[c];
+    const long long x = key % G.dim_x, yz = key / G.dim_x, y = yz % G.dim_y, z = yz / G.dim_y;
+    const long long yy = y + (r % 5) - 2, zz = z + (r / 5) - 2;
+    unsigned entry = 0;
+    if (yy >= 0 && yy < G.dim_y && zz >= 0 && zz < G.dim_z) {
+      const long long base = (zz * G.dim_y + yy) * G.dim_x;
+      const long long klo = base + (x - 2 > 0 ? x - 2 : 0), khi = base + (x + 2 < G.dim_x - 1 ? x + 2 : G.dim_x - 1);
+      int lo = 0, hi = G.m;  // lower bound of klo
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (G.cell_keys[mid] < klo) lo = mid + 1; else hi = mid;
       }
+      unsigned cnt = 0;
+      while (cnt < 5 && lo + (int)cnt < G.m && G.cell_keys[lo + cnt] <= khi) ++cnt;
+      entry = (unsigned)lo | (cnt << 29);
+    }
+    G.rows[t] = entry;
+  }
 }
 
-__global__ void __launch_bounds__(256) dbscan_count_kernel(GridArgs G, float eps2, int* __restrict__ count, int* __restrict__ parent) {
+__device__ __forceinline__ bool within(const float* __restrict__ pts, int q, float px, float py, float pz, float eps2) {
+  const float ex = pts[3 * q] - px, ey = pts[3 * q + 1] - py, ez = pts[3 * q + 2] - pz;
+  return ex * ex + ey * ey + ez * ez <= eps2;
+}
+
+// neighbour_count saturates at min_points (all DBSCAN needs); core points announce themselves as cell representative
+__global__ void __launch_bounds__(256)
+dbscan_count_kernel(SparseGrid G, float eps2, int min_points, int* __restrict__ count, int* __restrict__ parent) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < G.n; i += (long long)gridDim.x * blockDim.x) {
-    int c = 0;
-    for_each_neighbour(G, i, eps2, [&](int) { ++c; });
-    count[i] = c;
+    const int c = G.point_cell[i];
+    int cnt = G.cell_start[c + 1] - G.cell_start[c];  // the whole cell is within eps
+    if (cnt < min_points) {
+      const float px = G.pts[3 * i], py = G.pts[3 * i + 1], pz = G.pts[3 * i + 2];
+      for (int r = 0; r < DB_ROWS && cnt < min_points; ++r) {
+        const unsigned e = G.rows[(long long)c * DB_ROWS + r];
+        const int first = (int)(e & DB_FIRST_MASK), ncell = (int)(e >> 29);
+        for (int cc = first; cc < first + ncell && cnt < min_points; ++cc) {
+          if (cc == c) continue;
+          const int hi = G.cell_start[cc + 1];
+          for (int q = G.cell_start[cc]; q < hi && cnt < min_points; ++q) cnt += within(G.pts, q, px, py, pz, eps2) ? 1 : 0;
+        }
+      }
+    }
+    cnt = min(cnt, min_points);
+    count[i] = cnt;
     parent[i] = (int)i;
+    if (cnt >= min_points) atomicMin(G.rep + c, (int)i);
   }
 }
 
@@ -86,33 +132,60 @@ __device__ __forceinline__ void uf_union(int* parent, int a, int b) {
   }
 }
 
+// every core point: link to the cell representative, then one link into each EARLIER neighbouring cell (the later ones
+// look back at this one) unless that cell's representative is already in the same component
 __global__ void __launch_bounds__(256)
-dbscan_union_kernel(GridArgs G, float eps2, int min_points, const int* __restrict__ count, int* __restrict__ parent) {
+dbscan_union_kernel(SparseGrid G, float eps2, int min_points, const int* __restrict__ count, int* __restrict__ parent) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < G.n; i += (long long)gridDim.x * blockDim.x) {
     if (count[i] < min_points) continue;
-    for_each_neighbour(G, i, eps2, [&](int q) {
-      if (q < (int)i && count[q] >= min_points) uf_union(parent, (int)i, q);
-    });
+    const int c = G.point_cell[i];
+    const int own = G.rep[c];
+    if (own != (int)i) uf_union(parent, (int)i, own);
+    const float px = G.pts[3 * i], py = G.pts[3 * i + 1], pz = G.pts[3 * i + 2];
+    for (int r = 0; r <= DB_ROWS / 2; ++r) {  // rows of smaller keys, and the own row up to the own cell
+      const unsigned e = G.rows[(long long)c * DB_ROWS + r];
+      const int first = (int)(e & DB_FIRST_MASK), ncell = (int)(e >> 29);
+      for (int cc = first; cc < first + ncell && cc < c; ++cc) {
+        const int rq = G.rep[cc];
+        if (rq == DB_NONE) continue;
+        if (uf_find(parent, rq) == uf_find(parent, (int)i)) continue;
+        const int hi = G.cell_start[cc + 1];
+        for (int q = G.cell_start[cc]; q < hi; ++q)
+          if (count[q] >= min_points && within(G.pts, q, px, py, pz, eps2)) {
+            uf_union(parent, (int)i, q);
+            break;
+          }
+      }
+    }
   }
 }
 
 // root (sorted index) of every point's cluster, -1 for noise
 __global__ void __launch_bounds__(256)
-dbscan_assign_kernel(GridArgs G, float eps2, int min_points, const int* __restrict__ count, int* __restrict__ parent,
+dbscan_assign_kernel(SparseGrid G, float eps2, int min_points, const int* __restrict__ count, int* __restrict__ parent,
                      const int64_t* __restrict__ order, int* __restrict__ root) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < G.n; i += (long long)gridDim.x * blockDim.x) {
     if (count[i] >= min_points) {
       root[i] = uf_find(parent, (int)i);
       continue;
     }
+    const int c = G.point_cell[i];
+    const float px = G.pts[3 * i], py = G.pts[3 * i + 1], pz = G.pts[3 * i + 2];
     long long best = -1;
     int best_q = -1;
-    for_each_neighbour(G, i, eps2, [&](int q) {
-      if (count[q] >= min_points && (best < 0 || order[q] < best)) {
-        best = order[q];
-        best_q = q;
+    for (int r = 0; r < DB_ROWS; ++r) {
+      const unsigned e = G.rows[(long long)c * DB_ROWS + r];
+      const int first = (int)(e & DB_FIRST_MASK), ncell = (int)(e >> 29);
+      for (int cc = first; cc < first + ncell; ++cc) {
+        if (G.rep[cc] == DB_NONE) continue;  // no core point there
+        const int hi = G.cell_start[cc + 1];
+        for (int q = G.cell_start[cc]; q < hi; ++q)
+          if (count[q] >= min_points && (best < 0 || order[q] < best) && within(G.pts, q, px, py, pz, eps2)) {
+            best = order[q];
+            best_q = q;
+          }
       }
-    });
+    }
     root[i] = best_q >= 0 ? uf_find(parent, best_q) : -1;
   }
 }
@@ -129,22 +202,34 @@ extern "C" int cn_segment_mean(const float* values_sorted, const int32_t* segmen
   return cn::check_launch("cn_segment_mean");
 }
 
-extern "C" int cn_dbscan(const float* points_sorted, const int32_t* cell_start, int32_t gx, int32_t gy, int32_t gz,
-                         float origin_x, float origin_y, float origin_z, float cell_size, float eps, int32_t min_points,
-                         const int64_t* order, int64_t num_points, int32_t* neighbour_count, int32_t* parent,
-                         int32_t* root, cn_stream_t stream) {
-  CN_REQUIRE(gx > 0 && gy > 0 && gz > 0 && cell_size > 0.f && eps > 0.f && min_points >= 1, CN_ERR_INVALID,
-             "cn_dbscan: bad argument");
-  CN_REQUIRE(cell_size >= eps, CN_ERR_INVALID, "cn_dbscan: the grid cells must be at least eps wide");
+extern "C" size_t cn_dbscan_workspace_bytes(int64_t num_cells) {
+  return num_cells <= 0 ? 0 : (size_t)num_cells * (cn::DB_ROWS + 1) * sizeof(int32_t);
+}
+
+extern "C" int cn_dbscan(const float* points_sorted, const int64_t* cell_keys, const int32_t* cell_start,
+                         const int32_t* point_cell, int64_t num_cells, int64_t dim_x, int64_t dim_y, int64_t dim_z,
+                         float cell_size, float eps, int32_t min_points, const int64_t* order, int64_t num_points,
+                         int32_t* neighbour_count, int32_t* parent, int32_t* root, void* workspace, size_t workspace_bytes,
+                         cn_stream_t stream) {
+  CN_REQUIRE(cell_size > 0.f && eps > 0.f && min_points >= 1, CN_ERR_INVALID, "cn_dbscan: bad argument");
+  CN_REQUIRE(cell_size * 1.7320508f <= eps, CN_ERR_INVALID, "cn_dbscan: the diagonal of a grid cell must not exceed eps");
   if (num_points <= 0) return CN_OK;
   CN_REQUIRE(num_points < (1LL << 31), CN_ERR_INVALID, "cn_dbscan: at most 2^31-1 points");
-  CN_REQUIRE(points_sorted && cell_start && order && neighbour_count && parent && root, CN_ERR_INVALID,
-             "cn_dbscan: null argument");
-  cn::GridArgs G{points_sorted, cell_start, gx, gy, gz, origin_x, origin_y, origin_z, 1.f / cell_size, (long long)num_points};
+  CN_REQUIRE(num_cells >= 1 && num_cells <= num_points && num_cells < (1LL << 29), CN_ERR_INVALID, "cn_dbscan: bad cell count");
+  CN_REQUIRE(dim_x >= 1 && dim_y >= 1 && dim_z >= 1 && dim_x < (1LL << 20) && dim_y < (1LL << 20) && dim_z < (1LL << 20),
+             CN_ERR_INVALID, "cn_dbscan: grid dimensions must be in [1, 2^20)");
+  CN_REQUIRE(points_sorted && cell_keys && cell_start && point_cell && order && neighbour_count && parent && root && workspace,
+             CN_ERR_INVALID, "cn_dbscan: null argument");
+  CN_REQUIRE(workspace_bytes >= cn_dbscan_workspace_bytes(num_cells), CN_ERR_WORKSPACE, "cn_dbscan: workspace too small");
+  unsigned* rows = reinterpret_cast<unsigned*>(workspace);
+  int* rep = reinterpret_cast<int*>(rows + (size_t)num_cells * cn::DB_ROWS);
+  cn::SparseGrid G{points_sorted, reinterpret_cast<const long long*>(cell_keys), cell_start, point_cell, rows, rep,
+                   (long long)dim_x, (long long)dim_y, (long long)dim_z, (int)num_cells, (long long)num_points};
   const float eps2 = eps * eps;
   hipStream_t s = cn::as_stream(stream);
   const dim3 grid(cn::grid_for(num_points, 256, 1 << 16)), block(256);
-  hipLaunchKernelGGL(cn::dbscan_count_kernel, grid, block, 0, s, G, eps2, neighbour_count, parent);
+  hipLaunchKernelGGL(cn::dbscan_rows_kernel, dim3(cn::grid_for(num_cells * cn::DB_ROWS, 256, 1 << 16)), block, 0, s, G);
+  hipLaunchKernelGGL(cn::dbscan_count_kernel, grid, block, 0, s, G, eps2, (int)min_points, neighbour_count, parent);
   hipLaunchKernelGGL(cn::dbscan_union_kernel, grid, block, 0, s, G, eps2, (int)min_points, neighbour_count, parent);
   hipLaunchKernelGGL(cn::dbscan_assign_kernel, grid, block, 0, s, G, eps2, (int)min_points, neighbour_count, parent, order,
                      root);

@@ -8,6 +8,7 @@ tensors on the ROCm device; a missing library or a failed call raises.
 from __future__ import annotations
 
 import ctypes as C
+import math
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -199,6 +200,8 @@ def raygen_ortho(surface_points: Tensor, plane_vector: Sequence[float], start: i
     out = {"origins": torch.empty(num_rays, 3, device=dev), "directions": torch.empty(num_rays, 3, device=dev),
            "pixel_area": torch.empty(num_rays, 1, device=dev), "nears": torch.empty(num_rays, 1, device=dev),
            "fars": torch.empty(num_rays, 1, device=dev)}
+    if num_rays == 0:  # past the end of the surface grid: an empty bundle, as slicing gives the reference
+        return out
     L.check(lib.cn_raygen_ortho(_p(_f32(surface_points, "surface_points")), _farr(plane_vector), start, num_rays,
                                 _p(out["origins"]), _p(out["directions"]), _p(out["pixel_area"]), _p(out["nears"]),
                                 _p(out["fars"]), _stream(surface_points)))
@@ -717,14 +720,27 @@ def dbscan(points: Tensor, eps: float, min_points: int) -> Tuple[Tensor, Tensor]
     n = pts.shape[0]
     if n == 0:
         return torch.empty(0, dtype=torch.int64, device=pts.device), torch.empty(0, dtype=torch.bool, device=pts.device)
-    ext = float((pts.max(dim=0).values - pts.min(dim=0).values).max())
-    h = max(float(eps), ext / 512.0)
-    ps, cell_start, dims, lo, order = _bin_points(pts, h)
+    # sparse grid with cell diagonal <= eps (torch plumbing: keys, sort, run lengths)
+    h = 0.99 * float(eps) / math.sqrt(3.0)
+    lo = pts.min(dim=0).values
+    cell = ((pts - lo) / h).floor().to(torch.int64)
+    dims = [int(v) + 1 for v in cell.max(dim=0).values.tolist()]
+    if max(dims) >= (1 << 20):
+        raise ValueError(f"eps = {eps} is too small for a cloud of this extent (grid {dims})")
+    key = (cell[:, 2] * dims[1] + cell[:, 1]) * dims[0] + cell[:, 0]
+    key_sorted, order = torch.sort(key)
+    cell_keys, point_cell, counts = torch.unique_consecutive(key_sorted, return_inverse=True, return_counts=True)
+    m = cell_keys.numel()
+    cell_start = torch.zeros(m + 1, dtype=torch.int32, device=pts.device)
+    cell_start[1:] = torch.cumsum(counts, 0)
+    ps = pts[order].contiguous()
+    point_cell = point_cell.to(torch.int32)
     count = torch.empty(n, dtype=torch.int32, device=pts.device)
     parent = torch.empty(n, dtype=torch.int32, device=pts.device)
     root = torch.empty(n, dtype=torch.int32, device=pts.device)
-    L.check(lib.cn_dbscan(_p(ps), _p(cell_start), dims[0], dims[1], dims[2], float(lo[0]), float(lo[1]), float(lo[2]), h,
-                          float(eps), int(min_points), _p(order), n, _p(count), _p(parent), _p(root), _stream(pts)))
+    ws = torch.empty(lib.cn_dbscan_workspace_bytes(m), dtype=torch.uint8, device=pts.device)
+    L.check(lib.cn_dbscan(_p(ps), _p(cell_keys), _p(cell_start), _p(point_cell), m, dims[0], dims[1], dims[2], h, float(eps),
+                          int(min_points), _p(order), n, _p(count), _p(parent), _p(root), _p(ws), ws.numel(), _stream(pts)))
     core_sorted = count >= min_points
     # cluster ids in order of the smallest ORIGINAL index among each cluster's core points
     big = torch.iinfo(torch.int64).max

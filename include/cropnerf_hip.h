@@ -409,7 +409,7 @@ int cn_knn_mean_distance(const float* points_sorted, const int32_t* cell_start, 
 /* ---------------------------------------------------------------------------------------------
  * Super-cluster stage of the segmenter (segmentation/segmenter.py:69-86, get_super_clusters):
  * voxel_down_sample -> cluster_dbscan(eps, min_points) -> remove_statistical_outlier (cn_knn_mean_distance).
- * The caller bins the points on a uniform grid as for cn_knn_mean_distance.
+ * The caller bins (sorts) the points; see each entry point.
  * ------------------------------------------------------------------------------------------- */
 
 /* open3d voxel_down_sample: out[s] = mean of the rows [segment_start[s], segment_start[s+1]) of
@@ -417,14 +417,19 @@ int cn_knn_mean_distance(const float* points_sorted, const int32_t* cell_start, 
 int cn_segment_mean(const float* values_sorted, const int32_t* segment_start, int64_t num_segments, int32_t channels,
                     float* out, cn_stream_t stream);
 
-/* DBSCAN with grid cells >= eps wide.  order [N] = original index of each sorted point (ties between clusters
- * for a border point go to the core neighbour with the smallest original index).  neighbour_count [N] and
- * parent [N] are work arrays (neighbour_count[i] >= min_points marks the core points afterwards);
- * root [N] = sorted index of the representative of the point's cluster, -1 for noise. */
-int cn_dbscan(const float* points_sorted, const int32_t* cell_start, int32_t gx, int32_t gy, int32_t gz,
-              float origin_x, float origin_y, float origin_z, float cell_size, float eps, int32_t min_points,
-              const int64_t* order, int64_t num_points, int32_t* neighbour_count, int32_t* parent, int32_t* root,
-              cn_stream_t stream);
+/* DBSCAN (open3d cluster_dbscan(eps, min_points) as called at segmentation/segmenter.py:76-77) on a sparse grid whose
+ * cells have a diagonal <= eps (cell_size * sqrt(3) <= eps; grid dimensions < 2^20 per axis).  The caller sorts the
+ * points by cell key (z*dim_y + y)*dim_x + x and passes the OCCUPIED cells: cell_keys [num_cells] ascending,
+ * cell_start [num_cells + 1] offsets into the sorted points, point_cell [N] = occupied-cell index of each sorted point.
+ * order [N] = original index of each sorted point (ties between clusters for a border point go to the core neighbour
+ * with the smallest original index).  neighbour_count [N] (number of points within eps, itself included, saturated at
+ * min_points: == min_points marks the core points) and parent [N] are work arrays; root [N] = sorted index of the
+ * representative of the point's cluster, -1 for noise. */
+size_t cn_dbscan_workspace_bytes(int64_t num_cells);
+int cn_dbscan(const float* points_sorted, const int64_t* cell_keys, const int32_t* cell_start, const int32_t* point_cell,
+              int64_t num_cells, int64_t dim_x, int64_t dim_y, int64_t dim_z, float cell_size, float eps,
+              int32_t min_points, const int64_t* order, int64_t num_points, int32_t* neighbour_count, int32_t* parent,
+              int32_t* root, void* workspace, size_t workspace_bytes, cn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -43,13 +43,23 @@ def test_hip_voxel_down_sample():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,eps,mp", [(30000, 0.03, 30), (5000, 0.05, 8), (40, 0.5, 3)])
+@pytest.mark.parametrize("n,eps,mp", [(30000, 0.03, 30), (5000, 0.05, 8), (40, 0.5, 3),
+                                      (16000, 0.12, 30),       # a whole blob within eps: thousands of neighbours per point
+                                      (-20000, 0.3, 30), (-20001, 0.3, 30)])  # dense slabs a gap of 0.9 / 1.1 eps apart
 def test_hip_dbscan_matches_sklearn(n, eps, mp):
     from scipy.spatial import cKDTree
 
     from cropnerf_amd import ops
 
-    pts = _blobs(n, n)
+    if n < 0:  # two uniformly filled unit cubes (cells of >= min_points points) that do / do not link up
+        rng = np.random.default_rng(-n)
+        gap = eps * (0.9 if n % 2 == 0 else 1.1)
+        a = rng.uniform(0, 1, size=(-n // 2, 3))
+        b = rng.uniform(0, 1, size=(-n // 2, 3)) + [1.0 + gap, 0.0, 0.0]
+        pts = np.concatenate([a, b, rng.uniform(-3, 4, size=(200, 3))]).astype(np.float32)
+        pts = pts[rng.permutation(len(pts))]
+    else:
+        pts = _blobs(n, n)
     ref_labels, ref_core = OC.dbscan(pts, eps, mp)
     labels, core = ops.dbscan(torch.from_numpy(pts).cuda(), eps, mp)
     labels, core = labels.cpu().numpy(), core.cpu().numpy()

@@ -5,11 +5,11 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cropnerf_amd import ops
 
-n = int(os.environ.get("N", 1_000_000)); vx = float(os.environ.get("VX", 1e-3)); blobs = int(os.environ.get("BLOBS", 300))
+n = int(os.environ.get("N", 1_000_000)); vx = float(os.environ.get("VX", 1e-3)); blobs = int(os.environ.get("BLOBS", 300)); sigma = float(os.environ.get("SIGMA", 0.012))
 g = torch.Generator(device="cuda").manual_seed(0)
 centres = torch.rand(blobs, 3, device="cuda", generator=g) * 2 - 1
 which = torch.randint(0, blobs, (n - n // 20,), device="cuda", generator=g)
-pts = torch.cat([centres[which] + torch.randn(len(which), 3, device="cuda", generator=g) * 0.012,
+pts = torch.cat([centres[which] + torch.randn(len(which), 3, device="cuda", generator=g) * sigma,
                  torch.rand(n // 20, 3, device="cuda", generator=g) * 2.4 - 1.2]).contiguous()
 def timed(f, reps=3):
     out = f(); torch.cuda.synchronize(); t = time.perf_counter()

@@ -121,5 +121,5 @@ if __name__ == "__main__":
         out["oracle"] = oracle_check(pipe, data)
     if a.save:
         from cropnerf_amd.fruit_nerf.checkpoint import save_run
-        save_run(a.save, pipe)
+        save_run(a.save, pipe.model.config, pipe.datamanager.cameras.to("cpu"), pipe.model.scene_box, pipe.model.params, step=a.iters)
     print(json.dumps(out))
