@@ -11,6 +11,7 @@ from cropnerf_amd.fruit_nerf.fruit_pipeline import FruitPipeline, FruitPipelineC
 from cropnerf_amd.rays import Cameras, SceneBox
 
 dev = "cuda"
+NUM_POINTS = int(os.environ.get("NUM_POINTS", 1_000_000))  # BASELINE.json configs[3]: NUM_POINTS=10000000
 H = W = 800
 cfg = PC.FruitNerfModelConfig()
 fspec = cfg.field_spec(100)
@@ -38,8 +39,8 @@ res["dense_export"] = {"rays": n_rays, "samples_per_ray": 3000, "rays_per_call":
                        "full_3000x3000_estimate_s": round(t * (3000 * 3000) / n_rays, 1)}
 # (a17) semantic point cloud: 2048-ray calls until 1e6 kept points
 pipe2 = FruitPipeline(FruitPipelineConfig(FruitDataManagerConfig(2048, 2048), cfg), dev, cams, box, test_mode="test", params=params)
-t, pcd = sync_time(lambda: generate_point_cloud(pipe2, num_points=1_000_000, remove_outliers=False))
-t_sor, pcd_sor = sync_time(lambda: generate_point_cloud(pipe2, num_points=1_000_000, remove_outliers=True))
+t, pcd = sync_time(lambda: generate_point_cloud(pipe2, num_points=NUM_POINTS, remove_outliers=False))
+t_sor, pcd_sor = sync_time(lambda: generate_point_cloud(pipe2, num_points=NUM_POINTS, remove_outliers=True))
 res["pointcloud_export"] = {"kept_points": int(pcd["points"].shape[0]), "seconds": round(t, 3),
                             "train_batches": pipe2.datamanager.train_count, "rays_per_sec": pipe2.datamanager.train_count * 2048 / t}
 res["pointcloud_export_with_outlier_removal"] = {"seconds": round(t_sor, 3), "kept_after_removal": int(pcd_sor["points"].shape[0])}
