@@ -1,4 +1,4 @@
-"""Times the default fruit_nerf training iteration (4096 random rays) on cuda:0; CN_DEBUG_SKIP ablates parts of
+"""Times the default fruit_nerf training iteration (TRAIN_RAYS random rays, default 4096) on cuda:0; CN_DEBUG_SKIP ablates parts of
 cn_field_backward (1 hash atomics, 2 embedding atomics, 4 weight-gradient dots).  Profiling aid, not a test."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,7 +16,7 @@ tr = FruitTrainer(model)
 c2w, intr = synthetic.orbit_cameras(100)
 cams = Cameras(c2w, intr[:,0], intr[:,1], intr[:,2], intr[:,3], 800, 800).to(dev)
 g = torch.Generator().manual_seed(0)
-R = 4096
+R = int(os.environ.get("TRAIN_RAYS", "4096"))
 idx = torch.stack([torch.randint(0,100,(R,),generator=g), torch.randint(0,800,(R,),generator=g), torch.randint(0,800,(R,),generator=g)],-1)
 rb = cams.generate_rays(idx.to(dev))
 batch = {"image": torch.rand(R,3,generator=g).to(dev), "fruit_mask": (torch.rand(R,1,generator=g)>0.5).float().to(dev)}
