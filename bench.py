@@ -133,7 +133,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        gather_buf = torch.empty(world * R, 6, device=device)  # concatenated along dim 0 (valid for RCCL and gloo)
+        # concatenated along dim 0 (valid for RCCL and gloo); two buffers: the all-gather of step i runs on RCCL's stream
+        # under the render of step i+1
+        gather_bufs = [torch.empty(world * R, 6, device=device) for _ in range(2)]
+        gather_buf = gather_bufs[0]
+    pending = []
 
     def step(i: int):
         o, d, n, f, cam, start = batches[i % DISTINCT_BATCHES]
@@ -149,10 +153,15 @@ def main():
                 dist.all_gather_into_tensor(host, packed.cpu())
                 gather_buf.copy_(host)
             else:
-                dist.all_gather_into_tensor(gather_buf, packed)
+                if len(pending) == 2:
+                    pending.pop(0).wait()  # stream-side wait: the buffer about to be reused has been filled
+                pending.append(dist.all_gather_into_tensor(gather_bufs[i % 2], packed, async_op=True))
         return out
 
     def barrier():
+        while pending:
+            pending.pop(0).wait()
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -119,3 +119,34 @@ def test_shard_helpers_single_process():
     assert D.shard_jobs(list(range(7)), 1, 3) == [1, 4]
     t = torch.arange(6.0).reshape(3, 2)
     assert D.all_gather_points(t) is t  # world size 1: no communication
+
+
+@pytest.mark.gpu
+def test_rccl_async_all_gather_single_rank():
+    """The collective pattern of bench.py's N > 1 path (double-buffered ``all_gather_into_tensor(async_op=True)`` over
+    RCCL, stream-side waits) on a one-rank RCCL group: checks that RCCL loads and the pattern is valid on this box.  The
+    multi-rank arithmetic is covered by the gloo tests above."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        bufs = [torch.empty(1024, 6, device="cuda") for _ in range(2)]
+        pending, sent = [], []
+        for i in range(5):
+            packed = torch.full((1024, 6), float(i), device="cuda")
+            if len(pending) == 2:
+                pending.pop(0).wait()
+            pending.append(dist.all_gather_into_tensor(bufs[i % 2], packed, async_op=True))
+            sent.append(packed)
+        while pending:
+            pending.pop(0).wait()
+        torch.cuda.synchronize()
+        dist.barrier()
+        assert float(bufs[0][0, 0]) == 4.0 and float(bufs[1][0, 0]) == 3.0
+        t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t) == 1.5
+    finally:
+        dist.destroy_process_group()
