@@ -5,6 +5,7 @@
 //   cn_interlevel_backward    : interlevel_loss term (:609-612; nerfstudio losses.interlevel_loss / lossfun_outer / outer)
 //                               of one proposal level: loss and d(loss)/d(proposal density).
 //   cn_adam_step              : torch.optim.Adam update (fruit_nerf/fruit_nerf_config.py:45-60), elementwise.
+//   cn_radam_step             : torch.optim.RAdam update (the _big / _huge methods, fruit_nerf_config.py:101-167).
 // Gradients w.r.t. per-sample field outputs leave as [R,S] arrays; train_field.hip turns them into parameter gradients.
 #include "composite_dev.hpp"
 
@@ -374,6 +375,24 @@ adam_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict
   }
 }
 
+// torch.optim.RAdam (the optimiser of fruit_nerf_method_big / _huge, fruit_nerf_config.py:101-117,151-167): the Adam
+// moments, then either the variance-rectified step m_hat * lr * rect * sqrt(bc2) / (sqrt(v) + eps) or, while the variance
+// estimate is not yet tractable (rho_t <= 5, the first steps), the plain momentum step m_hat * lr.
+__global__ void __launch_bounds__(256)
+radam_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                  long long n, float step_size, float beta1, float beta2, float omb1, float omb2, float eps,
+                  int rectified, int zero_grad) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = beta1 * m[i] + omb1 * gi;
+    const float vi = beta2 * v[i] + omb2 * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= rectified ? step_size * mi / (sqrtf(vi) + eps) : step_size * mi;
+    if (zero_grad) g[i] = 0.f;
+  }
+}
+
 }  // namespace cn
 
 extern "C" int cn_train_render_backward(const float* starts, const float* ends, const float* density,
@@ -425,6 +444,23 @@ extern "C" int cn_adam_step(float* param, float* grad, float* exp_avg, float* ex
                      grad, exp_avg, exp_avg_sq, (long long)n, (float)(lr / bc1), (float)beta1, (float)beta2,
                      (float)(1.0 - beta1), (float)(1.0 - beta2), (float)(1.0 / sqrt(bc2)), (float)eps, zero_grad);
   return cn::check_launch("cn_adam_step");
+}
+
+extern "C" int cn_radam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
+                             double lr, double beta1, double beta2, double eps, int32_t zero_grad, cn_stream_t stream) {
+  CN_REQUIRE(param && grad && exp_avg && exp_avg_sq, CN_ERR_INVALID, "cn_radam_step: null argument");
+  CN_REQUIRE(step >= 1, CN_ERR_INVALID, "cn_radam_step: step is 1-based");
+  if (n <= 0) return CN_OK;
+  const double b2t = pow(beta2, (double)step), bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - b2t;
+  const double rho_inf = 2.0 / (1.0 - beta2) - 1.0, rho_t = rho_inf - 2.0 * step * b2t / bc2;
+  const int rectified = rho_t > 5.0;
+  double step_size = lr / bc1;
+  if (rectified)
+    step_size *= sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t)) * sqrt(bc2);
+  hipLaunchKernelGGL(cn::radam_step_kernel, dim3(cn::grid_for(n, 256, 4096)), dim3(256), 0, cn::as_stream(stream), param,
+                     grad, exp_avg, exp_avg_sq, (long long)n, (float)step_size, (float)beta1, (float)beta2,
+                     (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, rectified, zero_grad);
+  return cn::check_launch("cn_radam_step");
 }
 
 extern "C" int cn_distortion_metric(const float* spacing_bins, const float* weights, int64_t num_rays,

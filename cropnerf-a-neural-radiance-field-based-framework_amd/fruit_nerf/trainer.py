@@ -36,6 +36,7 @@ class OptimGroup:
     eps: float = 1e-15
     lr_final: Optional[float] = 1e-4
     max_steps: Optional[int] = 200000
+    optimizer: str = "adam"  # "adam" | "radam" (fruit_nerf_config.py: RAdam for the _big / _huge methods)
 
     def lr_at(self, step: int) -> float:
         """nerfstudio ExponentialDecayScheduler (no warm-up)."""
@@ -43,6 +44,11 @@ class OptimGroup:
             return self.lr
         t = min(max(step / self.max_steps, 0.0), 1.0)
         return math.exp(math.log(self.lr) * (1 - t) + math.log(self.lr_final) * t)
+
+
+def groups_from_spec(optimizers) -> Dict[str, "OptimGroup"]:
+    """Optimiser groups of a method specification (``fruit_nerf_config.py``: name -> OptimizerSpec)."""
+    return {k: OptimGroup(o.lr, o.eps, o.lr_final, o.max_steps, o.optimizer) for k, o in optimizers.items()}
 
 
 class FruitTrainer:
@@ -218,8 +224,9 @@ class FruitTrainer:
                 self.flat_grads[lo:hi].zero_()
                 continue
             grp = self.groups[g]
-            ops.adam_step(self.flat_params[lo:hi], self.flat_grads[lo:hi], self.flat_exp_avg[lo:hi],
-                          self.flat_exp_avg_sq[lo:hi], self.step, grp.lr_at(self.step - 1), eps=grp.eps, zero_grad=True)
+            step_fn = {"adam": ops.adam_step, "radam": ops.radam_step}[grp.optimizer]
+            step_fn(self.flat_params[lo:hi], self.flat_grads[lo:hi], self.flat_exp_avg[lo:hi],
+                    self.flat_exp_avg_sq[lo:hi], self.step, grp.lr_at(self.step - 1), eps=grp.eps, zero_grad=True)
 
     def train_iteration(self, ray_bundle: RayBundle, batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
         self.set_anneal(self.step)

@@ -564,6 +564,15 @@ def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, 
                              eps, 1 if zero_grad else 0, _stream(param)))
 
 
+def radam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step: int, lr: float,
+               beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-15, zero_grad: bool = True) -> None:
+    """``torch.optim.RAdam`` (the ``_big`` / ``_huge`` methods' optimiser)."""
+    lib = L.load()
+    L.check(lib.cn_radam_step(_p(_f32(param, "param")), _p(_f32(grad, "grad")), _p(_f32(exp_avg, "exp_avg")),
+                              _p(_f32(exp_avg_sq, "exp_avg_sq")), param.numel(), int(step), float(lr), beta1, beta2,
+                              eps, 1 if zero_grad else 0, _stream(param)))
+
+
 def distortion_metric(spacing_bins: Tensor, weights: Tensor) -> Tensor:
     """mean over rays of nerfstudio's distortion loss (get_metrics_dict "distortion")."""
     lib = L.load()

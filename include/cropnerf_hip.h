@@ -369,6 +369,11 @@ int cn_distortion_metric(const float* spacing_bins /*[R,S+1]*/, const float* wei
 int cn_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step, double lr,
                  double beta1, double beta2, double eps, int32_t zero_grad, cn_stream_t stream);
 
+/* torch.optim.RAdam step (fruit_nerf_method_big / _huge: fruit_nerf/fruit_nerf_config.py:101-117,151-167; no weight
+ * decay), same arguments as cn_adam_step. */
+int cn_radam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step, double lr,
+                 double beta1, double beta2, double eps, int32_t zero_grad, cn_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Depth-based semantic projection (the alternative to the NeRF projection:
  * fruit_nerf/scripts/depth_based_semantic_projection.py).  float64 geometry, float32 z-buffer, uint8 label

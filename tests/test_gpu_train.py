@@ -186,6 +186,31 @@ def test_adam_step_matches_torch_semantics():
     assert_close(dv, v, 1e-5, 1e-12, "adam exp_avg_sq")
 
 
+def test_radam_step_matches_torch_optim():
+    """cn_radam_step (the _big / _huge methods' optimiser) against torch.optim.RAdam itself on the CPU: the first steps
+    take the un-rectified branch (rho_t <= 5), the later ones the rectified one."""
+    from cropnerf_amd import ops
+
+    g = torch.Generator().manual_seed(2)
+    p = torch.nn.Parameter(torch.randn(5003, generator=g))
+    opt = torch.optim.RAdam([p], lr=1e-2, eps=1e-15)
+    dp = to_dev(p.detach()).clone()
+    dm, dv = torch.zeros_like(dp), torch.zeros_like(dp)
+    for step in range(1, 13):
+        grad = torch.randn(5003, generator=g) * (10.0 ** torch.randint(-4, 1, (5003,), generator=g).float())
+        grad[::13] = 0.0
+        lr = OL.exponential_decay_lr(step - 1, 1e-2, 1e-4, 50)
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+        p.grad = grad.clone()
+        opt.step()
+        ops.radam_step(dp, to_dev(grad).clone(), dm, dv, step, lr)
+        assert_close(dp, p.detach(), 2e-5, 1e-6, f"radam params after step {step}")
+    st = opt.state[p]
+    assert_close(dm, st["exp_avg"], 1e-5, 2e-7, "radam exp_avg")  # torch lerps, the kernel multiplies out
+    assert_close(dv, st["exp_avg_sq"], 1e-5, 1e-12, "radam exp_avg_sq")
+
+
 def test_training_reduces_loss_like_the_oracle():
     """Ten iterations on one fixed batch: the loss trajectory follows the oracle's (autograd + Adam) and goes down."""
     from cropnerf_amd.fruit_nerf.trainer import FruitTrainer, OptimGroup
