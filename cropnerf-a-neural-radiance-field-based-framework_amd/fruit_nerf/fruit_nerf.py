@@ -59,7 +59,8 @@ class Semantics:
 
 
 class FruitModel:
-    """Eval / export side of the reference's ``FruitModel`` (training backward is not built in this round)."""
+    """The reference's ``FruitModel`` (``fruit_nerf.py:73-700``) on the HIP kernels: every forward variant, the chunked
+    image / projection renders and the loss / metric dictionaries; the backward pass lives in ``trainer.FruitTrainer``."""
 
     def __init__(self, config: FruitNerfModelConfig, scene_box: SceneBox, num_train_data: int, metadata: Dict,
                  device: Union[str, torch.device] = "cuda", grad_scaler=None, test_mode: str = "val",

@@ -1,0 +1,158 @@
+"""``ns-train fruit_nerf --data <dir>`` for this package: trains one of the three method specifications of
+``fruit_nerf_config.py`` (``fruit_nerf``, ``fruit_nerf_big``, ``fruit_nerf_huge``) on a nerfstudio-format capture with a
+``semantics/`` mask folder (``data/cotton_nerf_dataparser.py``) and writes the run directory the exporters read:
+
+    outputs/<experiment>/<method>/<timestamp>/config.json
+                                              dataparser_transforms.json
+                                              nerfstudio_models/step-000001999.pt
+
+    python cropnerf-a-neural-radiance-field-based-framework_amd/fruit_nerf/scripts/train.py fruit_nerf --data plant_1 \\
+        [--output-dir outputs] [--max-num-iterations 40000] [--steps-per-save 2000] [--downscale-factor 2]
+
+The loop is nerfstudio's ``Trainer.train`` reduced to what the method needs: ``next_train`` -> ``FruitTrainer.train_iteration``
+(forward, losses, backward, one optimiser step per parameter group with its exponential-decay schedule), a checkpoint
+every ``steps_per_save`` iterations and at the end, PSNR of the eval split at the end.  Multi-GPU: launch with
+``torch.distributed.run`` (one rank per GPU): every rank draws its own ray batch and the gradients are averaged with one
+all-reduce (``FruitTrainer.all_reduce_gradients``)."""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from datetime import datetime
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
+
+
+def _psnr(a, b) -> float:
+    return float(-10.0 * torch.log10(((a - b) ** 2).mean().clamp_min(1e-12)))
+
+
+def train(method: str, data: Path, output_dir: Path = Path("outputs"), max_num_iterations=None, steps_per_save=None,
+          downscale_factor=None, experiment_name=None, timestamp=None, seed: int = 0, log_every: int = 100,
+          train_split_fraction=None, device: str = "cuda", quiet: bool = False):
+    from cropnerf_amd.fruit_nerf import fruit_nerf_config as FC
+    from cropnerf_amd.fruit_nerf.checkpoint import save_run
+    from cropnerf_amd.fruit_nerf.data.cotton_dataset import FruitDataset
+    from cropnerf_amd.fruit_nerf.data.cotton_nerf_dataparser import CottonNerfDataParserConfig
+    from cropnerf_amd.fruit_nerf.data.fruit_datamanager import FruitDataManager
+    from cropnerf_amd.fruit_nerf.fruit_nerf import FruitModel
+    from cropnerf_amd.fruit_nerf.trainer import FruitTrainer, groups_from_spec
+
+    specs = {"fruit_nerf": FC.fruit_nerf_method, "fruit_nerf_big": FC.fruit_nerf_method_big,
+             "fruit_nerf_huge": FC.fruit_nerf_method_huge}
+    if method not in specs:
+        raise SystemExit(f"unknown method {method!r}; choose from {sorted(specs)}")
+    tc = specs[method].config
+    iters = max_num_iterations if max_num_iterations is not None else tc.max_num_iterations
+    save_every = steps_per_save if steps_per_save is not None else tc.steps_per_save
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        device = f"cuda:{local}"
+        dist.init_process_group("nccl", device_id=torch.device(device))
+    say = (lambda *a: None) if (quiet or rank != 0) else (lambda *a: print(*a, flush=True))
+
+    pc = CottonNerfDataParserConfig(data=Path(data), downscale_factor=downscale_factor)
+    if train_split_fraction is not None:
+        pc.train_split_fraction = train_split_fraction
+    parser = pc.setup()
+    train_out = parser.get_dataparser_outputs("train")
+    eval_out = parser.get_dataparser_outputs("val")
+    train_set = FruitDataset(train_out, tc.pipeline.datamanager.camera_res_scale_factor)
+    say(f"[data] {len(train_set)} training / {len(eval_out.image_filenames)} eval images of "
+        f"{train_out.cameras.height} x {train_out.cameras.width}, dataparser scale {train_out.dataparser_scale:.5f}")
+    dm = FruitDataManager.from_dataset(tc.pipeline.datamanager, train_set, device=device, seed=seed, world_size=world,
+                                       local_rank=rank)
+    model = FruitModel(tc.pipeline.model, scene_box=train_out.scene_box, num_train_data=len(train_set),
+                       metadata=train_out.metadata, device=device, test_mode="val", seed=seed)
+    model.training = True
+    trainer = FruitTrainer(model, groups_from_spec(tc.optimizers), seed=seed + rank)
+
+    run_dir = Path(output_dir) / (experiment_name or Path(data).name) / tc.method_name / (
+        timestamp or datetime.now().strftime("%Y-%m-%d_%H%M%S"))
+
+    def checkpoint(step: int) -> Path:
+        if rank != 0:
+            return run_dir / "config.json"
+        cfg_path = save_run(run_dir, model.config, dm.cameras.to("cpu"), train_out.scene_box, model.params, step=step,
+                            transform=train_out.dataparser_transform.tolist(), scale=train_out.dataparser_scale,
+                            method_name=tc.method_name)
+        for old in sorted((run_dir / "nerfstudio_models").glob("step-*.pt"))[:-1]:
+            old.unlink()  # nerfstudio's save_only_latest_checkpoint
+        return cfg_path
+
+    t0 = time.perf_counter()
+    t_log, cfg_path = t0, run_dir / "config.json"
+    for step in range(iters):
+        ray_bundle, batch = dm.next_train(step)
+        if world > 1:
+            out = trainer.forward_backward(ray_bundle, batch, update_proposals=trainer.proposal_update_due(step))
+            trainer.all_reduce_gradients()
+            trainer.optimizer_step()
+        else:
+            out = trainer.train_iteration(ray_bundle, batch)
+        if step % log_every == 0 or step == iters - 1:
+            ld = {k: float(v) for k, v in out["loss_dict"].items()}
+            now = time.perf_counter()
+            rate = log_every * dm.config.train_num_rays_per_batch * world / max(now - t_log, 1e-9) if step else 0.0
+            t_log = now
+            say(f"[{step:6d}] " + " ".join(f"{k} {v:.5f}" for k, v in ld.items()) +
+                f" psnr {float(out['metrics_dict']['psnr']):.2f} rays/s {rate:.3g}")
+        if save_every and step and step % save_every == 0:
+            cfg_path = checkpoint(step)
+    torch.cuda.synchronize()
+    seconds = time.perf_counter() - t0
+    cfg_path = checkpoint(max(iters - 1, 0))
+
+    # eval split: full-image PSNR (get_image_metrics_and_images' psnr, fruit_nerf.py:647-700)
+    result = {"config": str(cfg_path), "iterations": iters, "train_seconds": round(seconds, 2),
+              "rays_per_sec": iters * dm.config.train_num_rays_per_batch * world / max(seconds, 1e-9)}
+    if rank == 0 and len(eval_out.image_filenames) > 0:
+        model.eval()
+        eval_set = FruitDataset(eval_out)
+        cams = eval_out.cameras.to(device)
+        vals = []
+        for i in range(len(eval_set)):
+            rb = cams.generate_rays(i, keep_shape=True)
+            rb.camera_indices = torch.zeros_like(rb.camera_indices)  # unseen view: pose tweak / embedding of camera 0
+            pred = model.get_outputs_for_camera_ray_bundle(rb)["rgb"].to(device)
+            vals.append(_psnr(pred, eval_set.get_data(i)["image"].to(device=device, dtype=torch.float32)))
+        result["eval_psnr"] = round(sum(vals) / len(vals), 3)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    say(json.dumps(result))
+    return result
+
+
+def entrypoint(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("method", choices=["fruit_nerf", "fruit_nerf_big", "fruit_nerf_huge"])
+    ap.add_argument("--data", type=Path, required=True)
+    ap.add_argument("--output-dir", type=Path, default=Path("outputs"))
+    ap.add_argument("--max-num-iterations", type=int, default=None)
+    ap.add_argument("--steps-per-save", type=int, default=None)
+    ap.add_argument("--downscale-factor", type=int, default=None)
+    ap.add_argument("--experiment-name", default=None)
+    ap.add_argument("--timestamp", default=None)
+    ap.add_argument("--train-split-fraction", type=float, default=None)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--log-every", type=int, default=100)
+    a = ap.parse_args(argv)
+    return train(a.method, a.data, a.output_dir, a.max_num_iterations, a.steps_per_save, a.downscale_factor,
+                 a.experiment_name, a.timestamp, a.seed, a.log_every, a.train_split_fraction)
+
+
+if __name__ == "__main__":
+    entrypoint()

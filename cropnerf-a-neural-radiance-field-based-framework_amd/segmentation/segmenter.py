@@ -73,3 +73,24 @@ def process_and_save_all(points, k: int, save_path=None, vx_size: float = 10e-5,
     if save_path is not None:
         np.save(save_path, np.asarray(res, dtype=object), allow_pickle=True)
     return res
+
+
+def process_for_pipeline(input_path, dataname: str = "semantics_pc.ply", k: int = 2, vx_size: float = 10e-5) -> str:
+    """``:183-185``: ``<input_path>/<dataname>`` (a PLY written by the exporters) -> ``<input_path>/all_super_cluster_info_nsub_2.npy``."""
+    import os
+
+    from ..fruit_nerf.ply import read_ply
+
+    save_path = os.path.join(input_path, "all_super_cluster_info_nsub_2.npy")
+    points, _ = read_ply(os.path.join(input_path, dataname))
+    res = process_and_save_all(points, k=k, save_path=save_path, vx_size=vx_size)
+    print(f"{len(res)} super-clusters -> {save_path}")
+    return save_path
+
+
+if __name__ == "__main__":  # python segmenter.py <pcd dir> [ply name] [k] [voxel size]  (the reference hard-codes these, :206-218)
+    import sys
+
+    a = sys.argv[1:]
+    process_for_pipeline(a[0], a[1] if len(a) > 1 else "semantics_pc.ply", int(a[2]) if len(a) > 2 else 2,
+                         float(a[3]) if len(a) > 3 else 10e-5)

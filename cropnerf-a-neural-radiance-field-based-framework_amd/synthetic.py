@@ -117,3 +117,43 @@ def analytic_dataset(cameras, device="cuda") -> Tuple[torch.Tensor, torch.Tensor
         images.append(rgb)
         masks.append(m)
     return torch.stack(images), torch.stack(masks)
+
+
+def write_capture(path, num: int = 24, res: int = 64, radius: float = 0.8, world_shift=(0.3, -0.2, 0.1),
+                  world_scale: float = 2.5) -> str:
+    """Writes the analytic plant as a nerfstudio-format capture (what ``CottonNerf`` parses, ``data/cotton_nerf_dataparser.py``):
+    ``transforms.json`` (shared intrinsics, one 4x4 ``transform_matrix`` per frame), ``images/frame_%05d.png`` and
+    ``semantics/frame_%05d.png`` (fruit = 255).  The poses are written in a shifted, scaled world frame so that the
+    dataparser's centring and auto-scaling have something to undo.  CPU only (closed-form renderer + PIL)."""
+    import json
+    import os
+
+    import numpy as np
+    from PIL import Image
+
+    focal = 1111.1 * res / 800.0
+    c2w, _ = orbit_cameras(num, radius=radius, height=res, width=res, focal=focal)
+    os.makedirs(os.path.join(path, "images"), exist_ok=True)
+    os.makedirs(os.path.join(path, "semantics"), exist_ok=True)
+    ys, xs = torch.meshgrid(torch.arange(res, dtype=torch.float32), torch.arange(res, dtype=torch.float32), indexing="ij")
+    cam_dirs = torch.stack([(xs + 0.5 - res / 2.0) / focal, -(ys + 0.5 - res / 2.0) / focal, -torch.ones_like(xs)], -1)
+    frames = []
+    shift = torch.tensor(world_shift, dtype=torch.float32)
+    for i in range(num):
+        d = cam_dirs @ c2w[i, :, :3].T
+        d = d / d.norm(dim=-1, keepdim=True)
+        o = c2w[i, :, 3].expand_as(d)
+        rgb, mask, _ = analytic_render(o.reshape(-1, 3), d.reshape(-1, 3))
+        img = (rgb.reshape(res, res, 3).clamp(0, 1) * 255.0 + 0.5).to(torch.uint8).numpy()
+        Image.fromarray(img, "RGB").save(os.path.join(path, "images", f"frame_{i + 1:05d}.png"))
+        m = (mask.reshape(res, res) > 0.5).to(torch.uint8).numpy() * 255
+        Image.fromarray(m, "L").save(os.path.join(path, "semantics", f"frame_{i + 1:05d}.png"))
+        pose = torch.eye(4)
+        pose[:3, :3] = c2w[i, :, :3]
+        pose[:3, 3] = c2w[i, :, 3] * world_scale + shift
+        frames.append({"file_path": f"images/frame_{i + 1:05d}.png", "transform_matrix": pose.tolist()})
+    meta = {"fl_x": focal, "fl_y": focal, "cx": res / 2.0, "cy": res / 2.0, "w": res, "h": res, "k1": 0, "k2": 0, "p1": 0,
+            "p2": 0, "frames": frames}
+    with open(os.path.join(path, "transforms.json"), "w", encoding="UTF-8") as f:
+        json.dump(meta, f)
+    return str(path)

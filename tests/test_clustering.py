@@ -145,3 +145,16 @@ def test_clustering_edge_cases():
     # the segmenter skips super-clusters that have no more points than sub-clusters (segmenter.py:163-164)
     few = np.concatenate([ball[:60] * 0.01, ball[:60] * 0.01 + 5.0])
     assert SG.process_and_save_all(few, k=100, vx_size=1e-4) == []
+
+
+@pytest.mark.gpu
+def test_segmenter_process_for_pipeline(tmp_path):
+    """segmenter.py's entry point: exported PLY in, all_super_cluster_info_nsub_2.npy out (segmenter.py:183-185)."""
+    from cropnerf_amd.fruit_nerf.ply import write_ply
+    from cropnerf_amd.segmentation import segmenter as SG
+
+    pts = (_blobs(7, 30000) * 0.4).astype(np.float64)
+    write_ply(str(tmp_path / "semantics_pc.ply"), pts, np.full_like(pts, 0.5))
+    out = SG.process_for_pipeline(str(tmp_path), "semantics_pc.ply", k=2, vx_size=0.002)
+    info = np.load(out, allow_pickle=True)
+    assert out.endswith("all_super_cluster_info_nsub_2.npy") and len(info) >= 4 and info[0]["aabb"].shape == (2, 2, 3)

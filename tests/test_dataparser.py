@@ -1,0 +1,139 @@
+"""Host-side wire formats in front of the path: the CottonNerf dataparser and FruitDataset mirrors
+on a synthetic capture written by ``synthetic.write_capture``; the train CLI end to end on the GPU."""
+
+import json
+import math
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from cropnerf_amd import synthetic
+from cropnerf_amd.fruit_nerf.data import cotton_dataset as CD
+from cropnerf_amd.fruit_nerf.data import cotton_nerf_dataparser as DP
+
+
+@pytest.fixture(scope="module")
+def capture(tmp_path_factory):
+    return Path(synthetic.write_capture(tmp_path_factory.mktemp("capture"), num=20, res=32))
+
+
+def test_rotation_matrix_and_orientation():
+    a, b = torch.tensor([0.3, -0.5, 0.8]), torch.tensor([0.0, 0.0, 1.0])
+    R = DP.rotation_matrix(a, b)
+    assert torch.allclose(R @ (a / a.norm()), b, atol=1e-6) and torch.allclose(R @ R.T, torch.eye(3), atol=1e-6)
+    assert abs(float(torch.linalg.det(R)) - 1.0) < 1e-6
+    poses = torch.eye(4).repeat(5, 1, 1)
+    poses[:, :3, 3] = torch.randn(5, 3)
+    out, T = DP.auto_orient_and_center_poses(poses, "none", "poses")
+    assert out.shape == (5, 3, 4) and torch.allclose(out[:, :, 3].mean(0), torch.zeros(3), atol=1e-6)
+    assert torch.allclose(T[:, :3], torch.eye(3))
+    with pytest.raises(NotImplementedError):
+        DP.auto_orient_and_center_poses(poses, "pca", "poses")
+
+
+def test_dataparser_outputs(capture):
+    parser = DP.CottonNerfDataParserConfig(data=capture).setup()
+    tr, ev = parser.get_dataparser_outputs("train"), parser.get_dataparser_outputs("val")
+    # 95 % split: ceil(20 * .95) = 19 equally spaced training images, the rest evaluates (:170-181)
+    assert len(tr.image_filenames) == 19 and len(ev.image_filenames) == 1
+    assert not set(tr.image_filenames) & set(ev.image_filenames)
+    assert tr.cameras.height == tr.cameras.width == 32 and len(tr.cameras) == 19
+    assert all(p.exists() for p in tr.image_filenames) and all(Path(p).exists() for p in tr.metadata["semantics"].filenames)
+    assert Path(tr.metadata["semantics"].filenames[0]).parent.name == "semantics"
+    # "up" + "poses" + auto-scale over ALL frames: mean camera up -> +z, origins centred, largest |coordinate| = 1
+    both = torch.cat([tr.cameras.camera_to_worlds, ev.cameras.camera_to_worlds])
+    up = both[:, :, 1].mean(0)
+    assert torch.allclose(up / up.norm(), torch.tensor([0.0, 0.0, 1.0]), atol=1e-5)
+    assert torch.allclose(both[:, :, 3].mean(0), torch.zeros(3), atol=1e-5)
+    assert abs(float(both[:, :, 3].abs().max()) - 1.0) < 1e-6
+    # the capture was written at 2.5 x the plant's frame with an orbit radius of 0.8: the scale undoes that
+    assert abs(tr.dataparser_scale - 1.0 / (2.5 * float(synthetic.orbit_cameras(20)[0][:, :, 3].abs().max()))) < 1e-5
+    assert tr.scene_box.aabb.tolist() == [[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]]
+    out = capture / "run" / "dataparser_transforms.json"
+    tr.save_dataparser_transform(out)
+    saved = json.loads(out.read_text())
+    assert np.asarray(saved["transform"]).shape == (3, 4) and saved["scale"] == pytest.approx(tr.dataparser_scale)
+
+
+def test_dataparser_overrides_and_errors(capture, tmp_path):
+    meta = json.loads((capture / "transforms.json").read_text())
+    # orientation_override "none" (what the 3DCotton captures carry): rotation stays the identity
+    meta["orientation_override"] = "none"
+    alt = tmp_path / "alt.json"
+    (tmp_path / "images").symlink_to(capture / "images")
+    (tmp_path / "semantics").symlink_to(capture / "semantics")
+    alt.write_text(json.dumps(meta))
+    out = DP.CottonNerfDataParserConfig(data=alt).setup().get_dataparser_outputs("train")
+    assert torch.allclose(out.dataparser_transform[:, :3], torch.eye(3))
+    # explicit split lists
+    meta["train_filenames"] = [f["file_path"] for f in meta["frames"][:5]]
+    alt.write_text(json.dumps(meta))
+    parser = DP.CottonNerfDataParserConfig(data=alt).setup()
+    assert len(parser.get_dataparser_outputs("train").image_filenames) == 5
+    with pytest.raises(RuntimeError):
+        parser.get_dataparser_outputs("val")
+    # distortion and unknown splits are refused
+    meta.pop("train_filenames")
+    meta["k1"] = 0.1
+    alt.write_text(json.dumps(meta))
+    with pytest.raises(NotImplementedError):
+        DP.CottonNerfDataParserConfig(data=alt).setup().get_dataparser_outputs("train")
+    with pytest.raises(ValueError):
+        DP.CottonNerfDataParserConfig(data=capture).setup().get_dataparser_outputs("bogus")
+    with pytest.raises(AssertionError):
+        DP.CottonNerfDataParserConfig(data=tmp_path / "missing").setup().get_dataparser_outputs("train")
+
+
+def test_downscale_folder_rule(capture, tmp_path):
+    parser = DP.CottonNerfDataParserConfig(data=capture, downscale_factor=2).setup()
+    assert parser._get_fname(Path("images/frame_00001.png"), capture) == capture / "images_2" / "frame_00001.png"
+    out_cfg = DP.CottonNerfDataParserConfig(data=capture, downscale_factor=2)
+    cams = out_cfg.setup().get_dataparser_outputs("train").cameras
+    assert cams.height == 16 and float(cams.fx[0]) == pytest.approx(0.5 * 1111.1 * 32 / 800.0)
+
+
+def test_fruit_dataset(capture, tmp_path):
+    from PIL import Image
+
+    out = DP.CottonNerfDataParserConfig(data=capture).setup().get_dataparser_outputs("train")
+    ds = CD.FruitDataset(out)
+    d = ds.get_data(3)
+    assert d["image"].dtype == torch.float16 and d["image"].shape == (32, 32, 3)
+    assert d["fruit_mask"].shape == (32, 32, 1) and set(d["fruit_mask"].unique().tolist()) <= {0.0, 1.0}
+    raw = np.array(Image.open(out.image_filenames[3]))
+    assert torch.equal(d["image"], torch.from_numpy(raw.astype("float16") / 255.0))
+    # grey levels up to 3 are background, RGB masks go through cv2's fixed-point grey conversion
+    Image.fromarray(np.array([[0, 3, 4, 255]], dtype=np.uint8), "L").save(tmp_path / "m.png")
+    assert CD.get_semantics_and_mask_tensors_from_path(tmp_path / "m.png").tolist() == [[0.0, 0.0, 1.0, 1.0]]
+    rgb = np.zeros((1, 3, 3), dtype=np.uint8)
+    rgb[0, 0] = (10, 0, 0)      # 0.299 * 10 = 2.99 -> 3 -> background
+    rgb[0, 1] = (0, 7, 0)       # 0.587 * 7 = 4.1 -> 4 -> fruit
+    rgb[0, 2] = (255, 255, 255)
+    Image.fromarray(rgb, "RGB").save(tmp_path / "c.png")
+    assert CD.get_semantics_and_mask_tensors_from_path(tmp_path / "c.png").tolist() == [[0.0, 1.0, 1.0]]
+    Image.fromarray(np.zeros((2, 2), dtype=np.uint8), "L").save(tmp_path / "z.png")
+    with pytest.raises(ValueError):  # an all-background mask cannot be normalised (cotton_dataset.py:75-76)
+        CD.get_semantics_and_mask_tensors_from_path(tmp_path / "z.png")
+    with pytest.raises(AssertionError):
+        CD.FruitDataset(DP.DataparserOutputs(out.image_filenames, out.cameras, out.scene_box, 1.0, out.dataparser_transform, {}))
+
+
+@pytest.mark.gpu
+def test_train_cli_then_export_cli(tmp_path):
+    """ns-train -> ns-export on a written capture: the run directory of the train CLI is what the exporter CLIs load."""
+    from cropnerf_amd.fruit_nerf.scripts import exporter, train
+
+    cap = synthetic.write_capture(tmp_path / "plant", num=16, res=48)
+    res = train.train("fruit_nerf", Path(cap), tmp_path / "outputs", max_num_iterations=60, steps_per_save=25,
+                      timestamp="t0", log_every=20, quiet=True, train_split_fraction=0.8)
+    cfg = Path(res["config"])
+    assert cfg.exists() and cfg.parent == tmp_path / "outputs" / "plant" / "fruit_nerf" / "t0"
+    assert (cfg.parent / "dataparser_transforms.json").exists()
+    ckpts = sorted((cfg.parent / "nerfstudio_models").glob("step-*.pt"))
+    assert [c.name for c in ckpts] == ["step-000000059.pt"]
+    assert math.isfinite(res["eval_psnr"]) and res["eval_psnr"] > 5.0
+    exporter.entrypoint(["semantic-pointcloud", "--load-config", str(cfg), "--output-dir", str(tmp_path / "pcd"),
+                         "--num-points-per-side", "40", "--num-rays-per-batch", "512"])
+    assert (tmp_path / "pcd" / "fruit_nerf" / "density.ply").exists()  # output_dir / load_dir.parts[-3] (exporter.py:104)
