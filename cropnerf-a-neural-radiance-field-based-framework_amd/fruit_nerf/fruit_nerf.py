@@ -487,6 +487,12 @@ class FruitModel:
         mse = torch.mean((outputs["rgb"] - image[:, :3]) ** 2)
         return {"psnr": -10.0 * torch.log10(mse)}
 
+    def get_image_metrics_and_images(self, outputs: Dict[str, Tensor], batch: Dict[str, Tensor], lpips_fn=None):
+        """``fruit_nerf.py:647-700``: (psnr, ssim, lpips, iou) and the logged images for one rendered view."""
+        from .image_metrics import get_image_metrics_and_images
+
+        return get_image_metrics_and_images(self, outputs, batch, lpips_fn)
+
 
 def save_image(img_hw3: Tensor, path: str) -> None:
     """``torchvision.utils.save_image`` semantics for one [H,W,3] image: clamp to [0,1], x255 + 0.5, uint8 PNG."""

@@ -30,10 +30,6 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
 
 
-def _psnr(a, b) -> float:
-    return float(-10.0 * torch.log10(((a - b) ** 2).mean().clamp_min(1e-12)))
-
-
 def train(method: str, data: Path, output_dir: Path = Path("outputs"), max_num_iterations=None, steps_per_save=None,
           downscale_factor=None, experiment_name=None, timestamp=None, seed: int = 0, log_every: int = 100,
           train_split_fraction=None, device: str = "cuda", quiet: bool = False):
@@ -115,20 +111,24 @@ def train(method: str, data: Path, output_dir: Path = Path("outputs"), max_num_i
     seconds = time.perf_counter() - t0
     cfg_path = checkpoint(max(iters - 1, 0))
 
-    # eval split: full-image PSNR (get_image_metrics_and_images' psnr, fruit_nerf.py:647-700)
+    # eval split: get_image_metrics_and_images (fruit_nerf.py:647-700) averaged over the eval images
     result = {"config": str(cfg_path), "iterations": iters, "train_seconds": round(seconds, 2),
               "rays_per_sec": iters * dm.config.train_num_rays_per_batch * world / max(seconds, 1e-9)}
     if rank == 0 and len(eval_out.image_filenames) > 0:
         model.eval()
         eval_set = FruitDataset(eval_out)
         cams = eval_out.cameras.to(device)
-        vals = []
+        sums: dict = {}
         for i in range(len(eval_set)):
             rb = cams.generate_rays(i, keep_shape=True)
             rb.camera_indices = torch.zeros_like(rb.camera_indices)  # unseen view: pose tweak / embedding of camera 0
-            pred = model.get_outputs_for_camera_ray_bundle(rb)["rgb"].to(device)
-            vals.append(_psnr(pred, eval_set.get_data(i)["image"].to(device=device, dtype=torch.float32)))
-        result["eval_psnr"] = round(sum(vals) / len(vals), 3)
+            outputs = model.get_outputs_for_camera_ray_bundle(rb)
+            metrics, _ = model.get_image_metrics_and_images(outputs, eval_set.get_data(i))
+            for k, v in metrics.items():
+                sums[k] = sums.get(k, 0.0) + v
+        for k, v in sums.items():
+            if v == v:  # lpips is NaN without its pretrained network
+                result[f"eval_{k}"] = round(v / len(eval_set), 4)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

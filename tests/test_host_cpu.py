@@ -1,6 +1,9 @@
 """CPU-side checks of host logic that needs no GPU: plugin config objects, PLY I/O, run-directory config."""
 
+import math
+
 import numpy as np
+import pytest
 import torch
 
 
@@ -62,3 +65,52 @@ def test_raybundle_container_semantics():
     m = torch.tensor([[True, False, False, True], [False, True, False, False]])
     sub = rb[m]
     assert sub.origins.shape == (3, 3) and sub.nears.shape == (3, 1)
+
+
+def test_image_metrics_restatements():
+    """get_image_metrics_and_images' upstream pieces (fruit_nerf.py:647-700): SSIM against a direct float64 evaluation of
+    its definition, PSNR, the colormaps' end points and the reference's softmax-over-one-channel IoU."""
+    import numpy as np
+
+    from cropnerf_amd.fruit_nerf import image_metrics as IM
+
+    g = torch.Generator().manual_seed(0)
+    a = torch.rand(1, 3, 24, 20, generator=g)
+    b = (a + 0.1 * torch.randn(1, 3, 24, 20, generator=g)).clamp(0, 1)
+    assert abs(float(IM.ssim(a, a)) - 1.0) < 1e-6
+    # direct evaluation: Gaussian-weighted statistics of every 11 x 11 window inside the image
+    x = np.arange(11) - 5.0
+    w = np.exp(-(x / 1.5) ** 2 / 2)
+    w = np.outer(w / w.sum(), w / w.sum())
+    A, B = a[0].double().numpy(), b[0].double().numpy()
+    vals = []
+    for c in range(3):
+        for i in range(24 - 10):
+            for j in range(20 - 10):
+                p, t = A[c, i:i + 11, j:j + 11], B[c, i:i + 11, j:j + 11]
+                mp, mt = (w * p).sum(), (w * t).sum()
+                spp, stt, spt = (w * p * p).sum() - mp * mp, (w * t * t).sum() - mt * mt, (w * p * t).sum() - mp * mt
+                vals.append(((2 * mp * mt + 1e-4) * (2 * spt + 9e-4)) / ((mp * mp + mt * mt + 1e-4) * (spp + stt + 9e-4)))
+    assert abs(float(IM.ssim(a, b)) - float(np.mean(vals))) < 2e-5
+    assert abs(float(IM.psnr(a, b)) + 10 * math.log10(float(((a - b) ** 2).mean()))) < 1e-5
+    lo, hi = IM.apply_colormap(torch.zeros(2, 2, 1)), IM.apply_colormap(torch.ones(2, 2, 1))
+    assert lo.shape == (2, 2, 3) and torch.allclose(lo[0, 0], torch.tensor([0.18995, 0.07176, 0.23217]), atol=1e-5)
+    assert torch.allclose(hi[0, 0], torch.tensor([0.4796, 0.01583, 0.01055]), atol=1e-5)
+    depth = torch.tensor([[[1.0], [3.0]]])
+    faded = IM.apply_depth_colormap(depth, accumulation=torch.tensor([[[1.0], [0.0]]]))
+    assert torch.allclose(faded[0, 0], lo[0, 0], atol=1e-5) and torch.allclose(faded[0, 1], torch.ones(3))
+
+    class _M:
+        device = torch.device("cpu")
+        proposal_networks = [None, None]
+
+    H, W = 16, 16
+    mask = (torch.rand(H, W, 1, generator=g) > 0.7).float()
+    outs = {"rgb": torch.rand(H, W, 3, generator=g) * 1.2, "accumulation": torch.rand(H, W, 1, generator=g),
+            "depth": torch.rand(H, W, 1, generator=g) * 4, "prop_depth_0": torch.rand(H, W, 1, generator=g),
+            "prop_depth_1": torch.rand(H, W, 1, generator=g), "semantics": torch.randn(H, W, 1, generator=g) * 5}
+    metrics, images = IM.get_image_metrics_and_images(_M(), outs, {"image": torch.rand(H, W, 3, generator=g), "fruit_mask": mask})
+    assert set(metrics) == {"psnr", "ssim", "lpips", "iou"} and math.isnan(metrics["lpips"])
+    assert metrics["iou"] == pytest.approx(float(mask.mean()))     # softmax over one channel == 1 everywhere
+    assert images["img"].shape == (H, 2 * W, 3) and images["fruit_mask"].shape == (H, W, 3)
+    assert set(images) == {"img", "accumulation", "depth", "prop_depth_0", "prop_depth_1", "semantics_colormap", "fruit_mask"}
