@@ -47,6 +47,22 @@ __global__ void __launch_bounds__(256) k(float* table, unsigned slot_mask, int p
     for (int i = threadIdx.x; i < 16384; i += 256) table[i] += win[i];
   }
 }
+// random 8-byte gathers (float2, the hash grid's read) for comparison: one 64-byte segment request per lane
+__global__ void __launch_bounds__(256) gather_k(const float2* table, unsigned entry_mask, int iters, float* out) {
+  unsigned h = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 777u;
+  float acc = 0.f;
+  for (int it = 0; it < iters; it += 4) {
+    float2 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      h = mix(h + it + j);
+      v[j] = table[h & entry_mask];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc += v[j].x + v[j].y;
+  }
+  if (acc == 123.456f) out[0] = acc;
+}
 int main() {
   const size_t max_bytes = 512u << 20;
   float* table;
@@ -79,6 +95,18 @@ int main() {
     float ms; (void)hipEventElapsedTime(&ms, a, b); ms /= 3;
     const double groups = (double)blocks * 256 / g * iters;
     printf("%-36s %8.3f ms  %7.2f G groups/s  %7.1f G floats/s\n", c.name, ms, groups / ms * 1e-6, c.active * groups / ms * 1e-6);
+  }
+  for (size_t bytes : {(size_t)1 << 20, (size_t)16 << 20, (size_t)64 << 20, (size_t)512 << 20}) {
+    const unsigned entry_mask = (unsigned)(bytes / 8) - 1;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    hipLaunchKernelGGL(gather_k, dim3(blocks), dim3(256), 0, 0, (const float2*)table, entry_mask, iters, table);
+    (void)hipEventRecord(a, 0);
+    for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(gather_k, dim3(blocks), dim3(256), 0, 0, (const float2*)table, entry_mask, iters, table);
+    (void)hipEventRecord(b, 0);
+    (void)hipEventSynchronize(b);
+    float ms; (void)hipEventElapsedTime(&ms, a, b); ms /= 3;
+    printf("random float2 gathers, %4zu MB table   %8.3f ms  %7.2f G gathers/s\n", bytes >> 20, ms, (double)blocks * 256 * iters / ms * 1e-6);
   }
   return 0;
 }
