@@ -1,0 +1,1 @@
+"""Dataparser, dataset and datamanager (capture on disk -> rays and pixels resident on the device)."""

@@ -1,0 +1,1 @@
+"""Dense-volume and surface point-cloud exporters."""

@@ -1,0 +1,1 @@
+"""Command-line entry points: train, exporter, semantic_projection, depth_based_semantic_projection."""
