@@ -24,28 +24,44 @@ def generate_point_cloud(pipeline, num_points: int = 1000000, remove_outliers: b
                          std_ratio: float = 10.0, only_semantics: bool = True, max_batches: Optional[int] = None
                          ) -> Dict[str, np.ndarray]:
     model, dm = pipeline.model, pipeline.datamanager
-    cap = int(num_points + dm.config.train_num_rays_per_batch)
+    # The reference reads the kept-point count back after every 2048-ray call (``while num_points < total``).  Here up to
+    # ``lookahead`` calls are enqueued before one read-back of their running counts; the cloud is then cut at the count of
+    # the first call that reached ``num_points``, so the result is exactly the reference's (calls append in order), without
+    # a host round trip per call.
+    lookahead = 16
+    rays_per_call = dm.config.train_num_rays_per_batch
+    cap = int(num_points + (lookahead + 1) * rays_per_call)
     buffers = None
     kept = 0
     batches = 0
     with torch.no_grad():
-        while kept < num_points:
-            ray_bundle, _ = dm.next_train(0)
-            outputs = model(ray_bundle)
-            for name in (rgb_output_name, depth_output_name):
-                if name not in outputs:  # :133-142
-                    print(f"Could not find {name} in the model outputs; choose one of: {list(outputs.keys())}",
-                          file=sys.stderr)
-                    sys.exit(1)
-            cmap = outputs["semantics_colormap"] if only_semantics else torch.ones_like(outputs["rgb"])
-            buffers = ops.pointcloud_compact(ray_bundle.origins, ray_bundle.directions, outputs[depth_output_name],
-                                             outputs[rgb_output_name], cmap.contiguous(), cap, buffers)
-            kept = int(buffers[3].item())
-            batches += 1
+        history = torch.zeros(lookahead, dtype=torch.int64, device=model.device)
+        done = False
+        while not done:
+            group = lookahead if max_batches is None else min(lookahead, max_batches - batches)
+            for j in range(group):
+                ray_bundle, _ = dm.next_train(0)
+                outputs = model(ray_bundle)
+                for name in (rgb_output_name, depth_output_name):
+                    if name not in outputs:  # :133-142
+                        print(f"Could not find {name} in the model outputs; choose one of: {list(outputs.keys())}",
+                              file=sys.stderr)
+                        sys.exit(1)
+                cmap = outputs["semantics_colormap"] if only_semantics else torch.ones_like(outputs["rgb"])
+                buffers = ops.pointcloud_compact(ray_bundle.origins, ray_bundle.directions, outputs[depth_output_name],
+                                                 outputs[rgb_output_name], cmap.contiguous(), cap, buffers)
+                history[j].copy_(buffers[3].reshape(()))
+            counts = history[:group].tolist()  # the one synchronisation per group
+            batches += group
+            kept = counts[-1]
+            for c in counts:
+                if c >= num_points:
+                    kept, done = c, True
+                    break
             if max_batches is not None and batches >= max_batches:
-                break
+                done = True
     pts, cols, dirs, count = buffers
-    n = min(int(count.item()), cap)
+    n = min(kept, cap)
     pts, cols, dirs = pts[:n], cols[:n], dirs[:n]
     if crop_obb is not None:
         m = crop_obb.within(pts.float().cpu()).to(pts.device)
