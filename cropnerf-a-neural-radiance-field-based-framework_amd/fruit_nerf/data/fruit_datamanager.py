@@ -104,6 +104,17 @@ class FruitDataManager:
         self.train_count += 1
         return self._sample(self.config.train_num_rays_per_batch)
 
+    def next_train_device(self, step: int) -> Tuple[RayBundle, Dict]:
+        """``next_train`` with the pixel indices drawn on the device (torch's device generator, as nerfstudio's
+        ``PixelSampler`` does): no host-to-device copy, so the call can be captured in a HIP graph.  Ray bundle only --
+        the exporters do not read the pixels."""
+        self.train_count += 1
+        n, h, w = len(self.cameras), self.cameras.height, self.cameras.width
+        num_rays, dev = self.config.train_num_rays_per_batch, self.device
+        idx = torch.stack([torch.randint(0, n, (num_rays,), device=dev), torch.randint(0, h, (num_rays,), device=dev),
+                           torch.randint(0, w, (num_rays,), device=dev)], dim=-1)
+        return self.cameras.generate_rays(idx), {"indices": idx}
+
     def next_eval(self, step: int) -> Tuple[RayBundle, Dict]:
         self.eval_count += 1
         return self._sample(self.config.eval_num_rays_per_batch)

@@ -21,8 +21,8 @@ from ... import ops
 def generate_point_cloud(pipeline, num_points: int = 1000000, remove_outliers: bool = True,
                          estimate_normals: bool = False, reorient_normals: bool = False, rgb_output_name: str = "rgb",
                          depth_output_name: str = "depth", normal_output_name: Optional[str] = None, crop_obb=None,
-                         std_ratio: float = 10.0, only_semantics: bool = True, max_batches: Optional[int] = None
-                         ) -> Dict[str, np.ndarray]:
+                         std_ratio: float = 10.0, only_semantics: bool = True, max_batches: Optional[int] = None,
+                         use_graph: bool = True) -> Dict[str, np.ndarray]:
     model, dm = pipeline.model, pipeline.datamanager
     # The reference reads the kept-point count back after every 2048-ray call (``while num_points < total``).  Here up to
     # ``lookahead`` calls are enqueued before one read-back of their running counts; the cloud is then cut at the count of
@@ -30,27 +30,56 @@ def generate_point_cloud(pipeline, num_points: int = 1000000, remove_outliers: b
     # a host round trip per call.
     lookahead = 16
     rays_per_call = dm.config.train_num_rays_per_batch
-    cap = int(num_points + (lookahead + 1) * rays_per_call)
-    buffers = None
+    cap = int(num_points + (lookahead + 4) * rays_per_call)
+    state = {"buffers": None}
+
+    def one_call(next_rays):
+        ray_bundle, _ = next_rays(0)
+        outputs = model(ray_bundle)
+        for name in (rgb_output_name, depth_output_name):
+            if name not in outputs:  # :133-142
+                print(f"Could not find {name} in the model outputs; choose one of: {list(outputs.keys())}", file=sys.stderr)
+                sys.exit(1)
+        cmap = outputs["semantics_colormap"] if only_semantics else torch.ones_like(outputs["rgb"])
+        state["buffers"] = ops.pointcloud_compact(ray_bundle.origins, ray_bundle.directions, outputs[depth_output_name],
+                                                  outputs[rgb_output_name], cmap.contiguous(), cap, state["buffers"])
+
     kept = 0
     batches = 0
     with torch.no_grad():
         history = torch.zeros(lookahead, dtype=torch.int64, device=model.device)
-        done = False
+        # One call is ~15 small launches for 2048 rays: the loop is bound by the host.  After three eager calls (they
+        # count, and they run every first-call initialisation) the call is captured into a HIP graph -- pixel indices from
+        # the device generator, every intermediate in the graph's memory pool -- and replayed.
+        graph = None
+        replay = None
+        if use_graph and max_batches is None:
+            for j in range(3):
+                one_call(dm.next_train_device)
+                history[j].copy_(state["buffers"][3].reshape(()))
+            batches = 3
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    one_call(dm.next_train_device)
+                replay = graph.replay
+                dm.train_count -= 1  # the capture pass enqueued nothing
+            except Exception as e:  # capture is an optimisation: fall back to eager launches, loudly
+                print(f"[generate_point_cloud] HIP graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+                graph, replay = None, None
+                torch.cuda.synchronize()
+            counts = history[:3].tolist()
+            kept = next((c for c in counts if c >= num_points), counts[-1])
+        done = kept >= num_points
         while not done:
             group = lookahead if max_batches is None else min(lookahead, max_batches - batches)
             for j in range(group):
-                ray_bundle, _ = dm.next_train(0)
-                outputs = model(ray_bundle)
-                for name in (rgb_output_name, depth_output_name):
-                    if name not in outputs:  # :133-142
-                        print(f"Could not find {name} in the model outputs; choose one of: {list(outputs.keys())}",
-                              file=sys.stderr)
-                        sys.exit(1)
-                cmap = outputs["semantics_colormap"] if only_semantics else torch.ones_like(outputs["rgb"])
-                buffers = ops.pointcloud_compact(ray_bundle.origins, ray_bundle.directions, outputs[depth_output_name],
-                                                 outputs[rgb_output_name], cmap.contiguous(), cap, buffers)
-                history[j].copy_(buffers[3].reshape(()))
+                if replay is not None:
+                    replay()
+                    dm.train_count += 1
+                else:
+                    one_call(dm.next_train)
+                history[j].copy_(state["buffers"][3].reshape(()))
             counts = history[:group].tolist()  # the one synchronisation per group
             batches += group
             kept = counts[-1]
@@ -60,6 +89,7 @@ def generate_point_cloud(pipeline, num_points: int = 1000000, remove_outliers: b
                     break
             if max_batches is not None and batches >= max_batches:
                 done = True
+    buffers = state["buffers"]
     pts, cols, dirs, count = buffers
     n = min(kept, cap)
     pts, cols, dirs = pts[:n], cols[:n], dirs[:n]

@@ -306,3 +306,21 @@ def test_big_method_shape_runs_through_the_generic_kernels():
     assert_close(out["rgb"], ref["rgb"], RTOL, ATOL, "export rgb")
     assert_close(out["semantics"], ref["semantics"], RTOL, 5e-5, "export semantics")
     assert torch.equal(out["semantics_colormap"].cpu(), ref["semantics_colormap"].reshape(out["semantics_colormap"].shape))
+
+
+def test_point_cloud_export_graph_replay_matches_eager_semantics():
+    """generate_point_cloud replays one captured call (HIP graph) per 512-ray batch.  Same stopping rule as the eager loop:
+    the cloud ends with the first call that reaches num_points; a tiny target is met inside the eager warm-up calls."""
+    from cropnerf_amd.fruit_nerf.export.exporter_utils_nerfacto import generate_point_cloud
+
+    sc = make_scene(seed=4, log2_T=16, num_images=5, height=24, width=24, focal=33.0, prop_log2_T=13)
+    sc.params["field.field_head_semantics.net.bias"] += 6.0
+    sc.params["field.mlp_base_mlp.layers.1.bias"][0] += 4.0
+    pipe = _pipeline(sc, "test")
+    for use_graph in (True, False):
+        pcd = generate_point_cloud(pipe, num_points=5000, remove_outliers=False, use_graph=use_graph)
+        n = pcd["points"].shape[0]
+        assert 5000 <= n < 5000 + 512 and pcd["colors"].shape == (n, 3) and np.isfinite(pcd["points"]).all()
+        assert pcd["colors"].min() >= 0 and pcd["colors"].max() <= 1 and np.abs(pcd["points"]).max() < 1e4
+    small = generate_point_cloud(pipe, num_points=10, remove_outliers=False)
+    assert 10 <= small["points"].shape[0] <= 512
