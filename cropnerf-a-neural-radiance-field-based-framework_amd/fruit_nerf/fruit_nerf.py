@@ -58,6 +58,24 @@ class Semantics:
         self.mask_classes = list(mask_classes)
 
 
+class TrainingCallback:
+    """nerfstudio ``TrainingCallback``: ``func(step)`` at the named locations, every ``update_every_num_iters`` steps."""
+
+    def __init__(self, where_to_run: Sequence[str], update_every_num_iters: Optional[int], func, iters=None):
+        self.where_to_run, self.update_every_num_iters, self.func, self.iters = list(where_to_run), update_every_num_iters, func, iters
+
+    def run_callback(self, step: int) -> None:
+        if self.update_every_num_iters is not None:
+            if step % self.update_every_num_iters == 0:
+                self.func(step)
+        elif self.iters is not None and step in self.iters:
+            self.func(step)
+
+    def run_callback_at_location(self, step: int, location: str) -> None:
+        if location in self.where_to_run:
+            self.run_callback(step)
+
+
 class FruitModel:
     """The reference's ``FruitModel`` (``fruit_nerf.py:73-700``) on the HIP kernels: every forward variant, the chunked
     image / projection renders and the loss / metric dictionaries; the backward pass lives in ``trainer.FruitTrainer``."""
@@ -127,6 +145,29 @@ class FruitModel:
             "fields": [v for k, v in self.params.items() if k.startswith("field.")],
             "camera_opt": [self.params["camera_optimizer.pose_adjustment"]],
         }
+
+    def get_training_callbacks(self, training_callback_attributes=None) -> List["TrainingCallback"]:
+        """``fruit_nerf.py:198-232``: the two callbacks a nerfstudio ``Trainer`` runs around every iteration -- the
+        proposal-weight annealing (arXiv 2111.12077 eq. 18) before it and the proposal sampler's ``step_cb`` after it.
+        ``FruitTrainer.train_iteration`` performs the same two updates itself; these objects are for a foreign loop."""
+        callbacks: List[TrainingCallback] = []
+        cfg = self.config
+        if cfg.use_proposal_weight_anneal:
+            N = cfg.proposal_weights_anneal_max_num_iters
+
+            def set_anneal(step):
+                self.step = step
+                train_frac = float(np.clip(step / N, 0, 1))
+                b = cfg.proposal_weights_anneal_slope
+                self.set_anneal(b * train_frac / ((b - 1) * train_frac + 1))
+
+            def step_cb(step):  # ProposalNetworkSampler.step_cb
+                self._sampler_step = step
+                self._steps_since_update = getattr(self, "_steps_since_update", 0) + 1
+
+            callbacks.append(TrainingCallback(["before_train_iteration"], 1, set_anneal))
+            callbacks.append(TrainingCallback(["after_train_iteration"], 1, step_cb))
+        return callbacks
 
     def eval(self):
         self.training = False

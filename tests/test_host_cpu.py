@@ -114,3 +114,31 @@ def test_image_metrics_restatements():
     assert metrics["iou"] == pytest.approx(float(mask.mean()))     # softmax over one channel == 1 everywhere
     assert images["img"].shape == (H, 2 * W, 3) and images["fruit_mask"].shape == (H, W, 3)
     assert set(images) == {"img", "accumulation", "depth", "prop_depth_0", "prop_depth_1", "semantics_colormap", "fruit_mask"}
+
+
+def test_training_callbacks_surface():
+    """get_training_callbacks (fruit_nerf.py:198-232): annealing before, sampler step after every iteration."""
+    from cropnerf_amd.config import FruitNerfModelConfig
+    from cropnerf_amd.fruit_nerf.fruit_nerf import FruitModel
+
+    class _M:  # the method only touches config, set_anneal and two counters
+        config = FruitNerfModelConfig()
+        anneal = None
+
+        def set_anneal(self, a):
+            self.anneal = a
+
+    m = _M()
+    cbs = FruitModel.get_training_callbacks(m)
+    assert [c.where_to_run for c in cbs] == [["before_train_iteration"], ["after_train_iteration"]]
+    for step in (0, 500, 5000):
+        for c in cbs:
+            c.run_callback_at_location(step, "before_train_iteration")
+        frac = min(step / m.config.proposal_weights_anneal_max_num_iters, 1.0)
+        b = m.config.proposal_weights_anneal_slope
+        assert m.anneal == pytest.approx(b * frac / ((b - 1) * frac + 1)) and m.step == step
+        for c in cbs:
+            c.run_callback_at_location(step, "after_train_iteration")
+    assert m._steps_since_update == 3 and m._sampler_step == 5000
+    m.config.use_proposal_weight_anneal = False
+    assert FruitModel.get_training_callbacks(m) == []
