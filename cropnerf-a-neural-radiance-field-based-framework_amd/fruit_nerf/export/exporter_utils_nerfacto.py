@@ -1,6 +1,7 @@
 """Semantic point-cloud export -- mirror of ``generate_point_cloud``
 (``crop_nerf/fruit_nerf/export/exporter_utils_nerfacto.py:83-227``): random train rays -> model forward ->
-``point = o + d * depth`` kept where ``semantics_colormap[:, 0] > 0`` (``:156-166``) -> optional OBB crop -> accumulate
+``point = o + d * depth`` kept where ``semantics_colormap[:, 0] > 0`` (``:156-166``) and inside the optional oriented
+box (``:168-174``, folded into the same mask) -> accumulate
 until ``num_points``.  Mask, point computation and compaction run in ``cn_pointcloud_compact``; kept points leave the
 device once.  The statistical outlier removal (``:194-199``, open3d ``remove_statistical_outlier(nb_neighbors=20,
 std_ratio)``, on by default) runs on the device too (``ops.statistical_outlier_mask``: uniform-grid k-nearest search,
@@ -41,6 +42,9 @@ def generate_point_cloud(pipeline, num_points: int = 1000000, remove_outliers: b
                 print(f"Could not find {name} in the model outputs; choose one of: {list(outputs.keys())}", file=sys.stderr)
                 sys.exit(1)
         cmap = outputs["semantics_colormap"] if only_semantics else torch.ones_like(outputs["rgb"])
+        if crop_obb is not None:  # :168-174: cropped points do not count towards num_points
+            inside = crop_obb.within(ray_bundle.origins + ray_bundle.directions * outputs[depth_output_name])
+            cmap = cmap * inside[:, None].to(cmap.dtype)
         state["buffers"] = ops.pointcloud_compact(ray_bundle.origins, ray_bundle.directions, outputs[depth_output_name],
                                                   outputs[rgb_output_name], cmap.contiguous(), cap, state["buffers"])
 
@@ -93,9 +97,6 @@ def generate_point_cloud(pipeline, num_points: int = 1000000, remove_outliers: b
     pts, cols, dirs, count = buffers
     n = min(kept, cap)
     pts, cols, dirs = pts[:n], cols[:n], dirs[:n]
-    if crop_obb is not None:
-        m = crop_obb.within(pts.float().cpu()).to(pts.device)
-        pts, cols, dirs = pts[m], cols[m], dirs[m]
     if remove_outliers and pts.shape[0] > 0:
         # on the device, before the points leave it.  open3d works on the float64 cloud; the search here is float32
         # (positions of a +-1 scene: mean neighbour distances agree to ~1e-5 relative, so only points sitting on the

@@ -16,7 +16,7 @@ import os
 import sys
 from dataclasses import dataclass
 from pathlib import Path
-from typing import Tuple
+from typing import Optional, Tuple
 
 
 @dataclass
@@ -65,18 +65,25 @@ class ExportPointCloud:
     num_rays_per_batch: int = 2048
     std_ratio: float = 10.0
     save_world_frame: bool = False
+    obb_center: Optional[Tuple[float, float, float]] = None
+    obb_rotation: Optional[Tuple[float, float, float]] = None
+    obb_scale: Optional[Tuple[float, float, float]] = None
 
     def main(self) -> None:
         from cropnerf_amd.fruit_nerf.checkpoint import eval_setup
         from cropnerf_amd.fruit_nerf.export.exporter_utils_nerfacto import generate_point_cloud
+        from cropnerf_amd.rays import OrientedBox
         from cropnerf_amd.fruit_nerf.ply import write_ply
 
         if not self.output_dir.exists():
             self.output_dir.mkdir(parents=True)
         _, pipeline, _, _ = eval_setup(self.load_config, test_mode="test")
         pipeline.datamanager.config.train_num_rays_per_batch = self.num_rays_per_batch
+        crop_obb = None  # debug/exporter_nerfacto.py:119-121
+        if self.obb_center is not None and self.obb_rotation is not None and self.obb_scale is not None:
+            crop_obb = OrientedBox.from_params(self.obb_center, self.obb_rotation, self.obb_scale)
         pcd = generate_point_cloud(pipeline=pipeline, num_points=self.num_points, remove_outliers=self.remove_outliers,
-                                   std_ratio=self.std_ratio)
+                                   std_ratio=self.std_ratio, crop_obb=crop_obb)
         print("Saving Point Cloud...")
         write_ply(str(self.output_dir / "semantics_pc.ply"), pcd["points"], pcd["colors"], pcd.get("normals"))
         print("Saving Point Cloud: done")
@@ -107,13 +114,15 @@ def entrypoint(argv=None):
     pc.add_argument("--num-rays-per-batch", type=int, default=2048)
     pc.add_argument("--std-ratio", type=float, default=10.0)
     pc.add_argument("--save-world-frame", type=lambda s: s.lower() == "true", default=False)
+    for flag in ("--obb_center", "--obb_rotation", "--obb_scale"):  # ns-export pointcloud's spelling (README.md:125)
+        pc.add_argument(flag, type=float, nargs=3, default=None)
     a = ap.parse_args(argv)
     if a.cmd == "semantic-pointcloud":
         ExportSemanticPointCloud(a.load_config, a.output_dir, a.use_bounding_box, a.bounding_box_min,
                                  a.bounding_box_max, a.num_rays_per_batch, a.num_points_per_side).main()
     else:
         ExportPointCloud(a.load_config, a.output_dir, a.num_points, a.remove_outliers, a.num_rays_per_batch,
-                         a.std_ratio, a.save_world_frame).main()
+                         a.std_ratio, a.save_world_frame, a.obb_center, a.obb_rotation, a.obb_scale).main()
 
 
 if __name__ == "__main__":

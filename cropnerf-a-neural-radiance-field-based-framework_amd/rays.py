@@ -20,6 +20,33 @@ class SceneBox:
 
 
 @dataclass
+class OrientedBox:
+    """nerfstudio ``OrientedBox`` (the ``--obb_center / --obb_rotation / --obb_scale`` crop of ``ns-export pointcloud``,
+    ``debug/exporter_nerfacto.py:119-121``): rotation R [3,3], centre T [3], edge lengths S [3]."""
+
+    R: Tensor
+    T: Tensor
+    S: Tensor
+
+    @staticmethod
+    def from_params(pos, rpy, scale) -> "OrientedBox":
+        """Centre, roll-pitch-yaw in radians (R = Rz(yaw) Ry(pitch) Rx(roll), viser's ``SO3.from_rpy_radians``), scale."""
+        import math
+
+        r, p, y = (float(v) for v in rpy)
+        rx = torch.tensor([[1.0, 0, 0], [0, math.cos(r), -math.sin(r)], [0, math.sin(r), math.cos(r)]])
+        ry = torch.tensor([[math.cos(p), 0, math.sin(p)], [0, 1.0, 0], [-math.sin(p), 0, math.cos(p)]])
+        rz = torch.tensor([[math.cos(y), -math.sin(y), 0], [math.sin(y), math.cos(y), 0], [0, 0, 1.0]])
+        return OrientedBox(rz @ ry @ rx, torch.tensor([float(v) for v in pos]), torch.tensor([float(v) for v in scale]))
+
+    def within(self, pts: Tensor) -> Tensor:
+        """[N,3] -> [N] bool: strictly inside (both comparisons are strict upstream)."""
+        R, T, S = self.R.to(pts), self.T.to(pts), self.S.to(pts)
+        local = (pts - T) @ R  # R^T (p - T), row-vector form
+        return ((local > -S / 2) & (local < S / 2)).all(dim=-1)
+
+
+@dataclass
 class RayBundle:
     origins: Tensor  # [R,3] or [H,W,3]
     directions: Tensor

@@ -324,3 +324,10 @@ def test_point_cloud_export_graph_replay_matches_eager_semantics():
         assert pcd["colors"].min() >= 0 and pcd["colors"].max() <= 1 and np.abs(pcd["points"]).max() < 1e4
     small = generate_point_cloud(pipe, num_points=10, remove_outliers=False)
     assert 10 <= small["points"].shape[0] <= 512
+    # oriented-box crop (ns-export pointcloud --obb_*): folded into the keep mask, so cropped points do not count
+    from cropnerf_amd.rays import OrientedBox
+
+    box = OrientedBox.from_params((0.0, 0.0, 0.0), (0.0, 0.0, 0.3), (1.0, 1.2, 0.8))
+    cropped = generate_point_cloud(pipe, num_points=2000, remove_outliers=False, crop_obb=box)
+    pts = torch.from_numpy(cropped["points"]).float()
+    assert pts.shape[0] >= 2000 and bool(box.within(pts).all())

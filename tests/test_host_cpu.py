@@ -142,3 +142,17 @@ def test_training_callbacks_surface():
     assert m._steps_since_update == 3 and m._sampler_step == 5000
     m.config.use_proposal_weight_anneal = False
     assert FruitModel.get_training_callbacks(m) == []
+
+
+def test_oriented_box():
+    """nerfstudio OrientedBox.from_params / within (the ns-export pointcloud crop)."""
+    from cropnerf_amd.rays import OrientedBox
+
+    box = OrientedBox.from_params((0.5, 0.0, 0.0), (0.0, 0.0, math.pi / 2), (2.0, 1.0, 4.0))
+    # yaw 90 deg: the box's x edge (length 2) lies along world y, its y edge (length 1) along world -x
+    pts = torch.tensor([[0.5, 0.0, 0.0], [0.5, 0.9, 0.0], [0.5, 1.1, 0.0], [0.9, 0.0, 0.0], [1.1, 0.0, 0.0],
+                        [0.5, 0.0, 1.9], [0.5, 0.0, 2.0]])
+    assert box.within(pts).tolist() == [True, True, False, True, False, True, False]
+    assert torch.allclose(box.R @ box.R.T, torch.eye(3), atol=1e-6)
+    rpy = OrientedBox.from_params((0, 0, 0), (0.3, -0.2, 0.7), (1, 1, 1)).R
+    assert torch.allclose(rpy @ torch.tensor([0.0, 0.0, 1.0]), torch.tensor([0.04521531, -0.3482963, 0.93629336]), atol=1e-5)
