@@ -92,5 +92,10 @@ def all_reduce_mean(value: Tensor, group=None) -> Tensor:
     if ws == 1:
         return value
     v = value.clone()
-    dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
+    if v.is_cuda and dist.get_backend(group) == "gloo":  # rehearsal on a one-GPU box: gloo moves host memory
+        h = v.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        v.copy_(h)
+    else:
+        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
     return v / ws

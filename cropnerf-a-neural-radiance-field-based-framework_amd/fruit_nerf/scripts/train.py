@@ -54,9 +54,14 @@ def train(method: str, data: Path, output_dir: Path = Path("outputs"), max_num_i
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         local = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(local)
-        device = f"cuda:{local}"
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if os.environ.get("CROPNERF_REHEARSE_ON_ONE_GPU") == "1":  # every rank on cuda:0, gradients over gloo (tests only)
+            torch.cuda.set_device(0)
+            device = "cuda:0"
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            device = f"cuda:{local}"
+            dist.init_process_group("nccl", device_id=torch.device(device))
     say = (lambda *a: None) if (quiet or rank != 0) else (lambda *a: print(*a, flush=True))
 
     pc = CottonNerfDataParserConfig(data=Path(data), downscale_factor=downscale_factor)
@@ -92,12 +97,7 @@ def train(method: str, data: Path, output_dir: Path = Path("outputs"), max_num_i
     t_log, cfg_path = t0, run_dir / "config.json"
     for step in range(iters):
         ray_bundle, batch = dm.next_train(step)
-        if world > 1:
-            out = trainer.forward_backward(ray_bundle, batch, update_proposals=trainer.proposal_update_due(step))
-            trainer.all_reduce_gradients()
-            trainer.optimizer_step()
-        else:
-            out = trainer.train_iteration(ray_bundle, batch)
+        out = trainer.train_iteration(ray_bundle, batch)  # averages the gradients over the ranks when there are several
         if step % log_every == 0 or step == iters - 1:
             ld = {k: float(v) for k, v in out["loss_dict"].items()}
             now = time.perf_counter()
@@ -130,6 +130,14 @@ def train(method: str, data: Path, output_dir: Path = Path("outputs"), max_num_i
             if v == v:  # lpips is NaN without its pretrained network
                 result[f"eval_{k}"] = round(v / len(eval_set), 4)
     if world > 1:
+        # data-parallel invariant: every rank applied the same averaged gradients to the same initial parameters
+        from cropnerf_amd.distributed import all_reduce_mean
+
+        chk = trainer.flat_params.double().sum().reshape(1)
+        mean = all_reduce_mean(chk)
+        if abs(float(mean) - float(chk)) > 1e-6 * max(1.0, abs(float(chk))):
+            raise RuntimeError(f"rank {rank}: parameters diverged between ranks ({float(chk)!r} vs mean {float(mean)!r})")
+        result["ranks"] = world
         dist.barrier()
         dist.destroy_process_group()
     say(json.dumps(result))

@@ -137,3 +137,31 @@ def test_train_cli_then_export_cli(tmp_path):
     exporter.entrypoint(["semantic-pointcloud", "--load-config", str(cfg), "--output-dir", str(tmp_path / "pcd"),
                          "--num-points-per-side", "40", "--num-rays-per-batch", "512"])
     assert (tmp_path / "pcd" / "fruit_nerf" / "density.ply").exists()  # output_dir / load_dir.parts[-3] (exporter.py:104)
+
+
+@pytest.mark.gpu
+def test_train_cli_two_ranks_rehearsal(tmp_path):
+    """The N > 1 path of the train CLI -- one ray batch per rank, gradients averaged in ONE all-reduce of the flat buffer,
+    identical parameters on every rank afterwards (the CLI checks that itself) -- rehearsed with two ranks on this box's
+    single GPU over gloo (``CROPNERF_REHEARSE_ON_ONE_GPU``; on a multi-GPU node the same code runs over RCCL)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    cap = synthetic.write_capture(tmp_path / "plant", num=12, res=40)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = Path(__file__).resolve().parents[1]
+    script = root / "cropnerf-a-neural-radiance-field-based-framework_amd" / "fruit_nerf" / "scripts" / "train.py"
+    env = dict(os.environ, CROPNERF_REHEARSE_ON_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script), "fruit_nerf", "--data", cap, "--output-dir", str(tmp_path / "out"),
+           "--max-num-iterations", "30", "--log-every", "10", "--timestamp", "t", "--train-split-fraction", "0.8"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    last = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(last)
+    assert res["ranks"] == 2 and math.isfinite(res["eval_psnr"])
+    assert (tmp_path / "out" / "plant" / "fruit_nerf" / "t" / "nerfstudio_models" / "step-000000029.pt").exists()
