@@ -315,50 +315,9 @@ __device__ __forceinline__ void dense_mfma(const float* __restrict__ Wg, const f
   }
 }
 
-#ifndef CN_GENERIC_DIRECT_WEIGHTS
-#define CN_GENERIC_DIRECT_WEIGHTS 0
-#endif
-// Build variant (measured slower: 48 vs 29.5 ms per 65k big-method rays): the same layer with the weights read straight
-// from global memory (L2 / L1) as MFMA A operands -- all <= 128 operands of a 16x16 block requested up front -- instead
-// of being staged through LDS: one barrier per layer instead of two per 64-row pass, but 4 waves fetch each weight row.
-__device__ __forceinline__ void dense_direct(const float* __restrict__ Wg, const float* __restrict__ bg, int K, int N,
-                                             const float* in, float* out, bool relu, int tid, int debug_skip = 0) {
-  const int Kp = (K + 15) & ~15, Np = (N + 15) & ~15;
-  const int lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
-  __syncthreads();  // `in` is complete, `out` is free
-  for (int blk = wave; blk < (Np >> 4) * 4 && !(debug_skip & 32); blk += NW) {
-    const int n0 = (blk >> 2) * 16, s0 = (blk & 3) * 16;
-    const int nrow = n0 + i;
-    float areg[32];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      const int k = 16 * (j >> 2) + 4 * q + (j & 3);
-      areg[j] = (nrow < N && k < K) ? Wg[(size_t)nrow * K + k] : 0.f;
-    }
-    f32x4 acc;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = n0 + 4 * q + r;
-      acc[r] = n < N ? bg[n] : 0.f;
-    }
-#pragma unroll
-    for (int kb = 0; kb < 8; ++kb) {
-      if (16 * kb < Kp) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float b = in[(16 * kb + 4 * q + e) * LDA + s0 + i];
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[4 * kb + e], b, acc, 0, 0, 0);
-        }
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v = acc[r];
-      if (relu) v = fmaxf(v, 0.f);
-      out[(n0 + 4 * q + r) * LDA + s0 + i] = v;
-    }
-  }
-}
+// (A variant of dense_mfma that read the weights straight from global memory as MFMA A operands -- one barrier per layer
+// instead of two per 64-row pass, but four waves fetch each weight row -- measured 48 vs 29.5 ms per 65k big-method rays and
+// was removed.)
 
 __global__ void __launch_bounds__(NT)
 field_eval_mfma_kernel(FieldDev fp, SceneDev sc, int app_mode, int sh_unit, const float* __restrict__ origins,
@@ -433,11 +392,7 @@ field_eval_mfma_kernel(FieldDev fp, SceneDev sc, int app_mode, int sh_unit, cons
       for (int l = 0; l < fp.base.num_layers; ++l) {
         const bool last = l == fp.base.num_layers - 1;
         float* y = last ? bufG : (x == bufA ? bufB : bufA);
-#if CN_GENERIC_DIRECT_WEIGHTS
-        dense_direct(fp.base.w[l], fp.base.b[l], fp.base.dims[l], fp.base.dims[l + 1], x, y, !last, tid, debug_skip);
-#else
         dense_mfma(fp.base.w[l], fp.base.b[l], fp.base.dims[l], fp.base.dims[l + 1], x, y, !last, wbuf, tid, debug_skip);
-#endif
         x = y;
       }
     }
@@ -450,13 +405,8 @@ field_eval_mfma_kernel(FieldDev fp, SceneDev sc, int app_mode, int sh_unit, cons
       const float* x = bufG + LDA;
       for (int l = 0; l < fp.sem.num_layers; ++l) {
         float* y = (x == bufA) ? bufB : bufA;
-#if CN_GENERIC_DIRECT_WEIGHTS
-        dense_direct(fp.sem.w[l], fp.sem.b[l], fp.sem.dims[l], fp.sem.dims[l + 1], x, y, l < fp.sem.num_layers - 1, tid,
-                     debug_skip);
-#else
         dense_mfma(fp.sem.w[l], fp.sem.b[l], fp.sem.dims[l], fp.sem.dims[l + 1], x, y, l < fp.sem.num_layers - 1, wbuf, tid,
                    debug_skip);
-#endif
         x = y;
       }
       __syncthreads();
@@ -472,13 +422,8 @@ field_eval_mfma_kernel(FieldDev fp, SceneDev sc, int app_mode, int sh_unit, cons
       const float* x = bufC;
       for (int l = 0; l < fp.color.num_layers; ++l) {
         float* y = (x == bufA) ? bufB : bufA;
-#if CN_GENERIC_DIRECT_WEIGHTS
-        dense_direct(fp.color.w[l], fp.color.b[l], fp.color.dims[l], fp.color.dims[l + 1], x, y,
-                     l < fp.color.num_layers - 1, tid, debug_skip);
-#else
         dense_mfma(fp.color.w[l], fp.color.b[l], fp.color.dims[l], fp.color.dims[l + 1], x, y,
                    l < fp.color.num_layers - 1, wbuf, tid, debug_skip);
-#endif
         x = y;
       }
       __syncthreads();

@@ -143,12 +143,6 @@ __device__ __forceinline__ bool row_run_reduce(unsigned key, float& v0, float& v
   return last;
 }
 
-#ifndef CN_QUAD_ATOMICS
-#define CN_QUAD_ATOMICS 1
-#endif
-#ifndef CN_PAIRED_ATOMICS
-#define CN_PAIRED_ATOMICS 1
-#endif
 // scatter d(loss)/d(features of one level) into the table gradient with the forward's trilinear weights
 // (all 64 lanes call it; g0 = g1 = 0 for lanes without a sample).  POS: also accumulate d(loss)/d(normalised position)
 // -- the trilinear weights are linear in the in-cell offset, so d enc_f / d x = scale * sum_c (+-1) wy wz table[c].f
@@ -169,11 +163,12 @@ __device__ __forceinline__ void hash_level_backward(float* __restrict__ gtab, co
   float wx[2] = {1.f - ox, ox}, wy[2] = {1.f - oy, oy}, wz[2] = {1.f - oz, oz};  // index 1 = ceil corner
   const int row_lane = lane & 15;
   float ax = 0.f, ay = 0.f, az = 0.f;
-#if CN_QUAD_ATOMICS
-  // The two corners of an x-edge hash to e and e ^ 1 when ix is even (level offsets are even): their four floats are
-  // one aligned 16-byte slot.  Each atomic instruction therefore serves ONE x-edge of one source lane from FOUR adjacent
-  // lanes (entry = lane & 2 ? x1 corner : x0 corner, feature = lane & 1); the four source lanes of a quad take turns.
-  // Even ix: 4 requests per sample and level instead of 8; odd ix: 8 as before.
+  // The hash xors ix into the low bits, so the two corners of an x-edge lie in one aligned 64-byte segment of the table
+  // unless ix = 7 (mod 8) -- and the memory pipe takes everything ONE instruction sends to one 64-byte segment as ONE
+  // atomic request, whatever the lanes (tools/atomic_microbench.hip: 21e9 requests/s, the bound of this kernel).  Each
+  // atomic instruction therefore serves ONE x-edge of one source lane from FOUR adjacent lanes (entry = lane & 2 ? x1
+  // corner : x0 corner, feature = lane & 1); the four source lanes of a quad take turns: 4 requests per sample and
+  // level for 7 of 8 cells instead of 16 single floats.
 #pragma unroll
   for (int bd = 0; bd < 4; ++bd) {
     const int b = bd & 1, d = bd >> 1;
@@ -211,41 +206,8 @@ __device__ __forceinline__ void hash_level_backward(float* __restrict__ gtab, co
     CN_QUAD_ROUND(0xFF)  // [3,3,3,3]
 #undef CN_QUAD_ROUND
   }
-#else
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const int a = c & 1, b = (c >> 1) & 1, d = c >> 2;
-    const float w = wx[a] * wy[b] * wz[d];
-    const unsigned e = ((hx[a] ^ hy[b] ^ hz[d]) & mask) + level_off;
-    if constexpr (POS) {
-      const float2 t = hash_gather(table, e);
-      const float tg = t.x * g0 + t.y * g1;
-      ax += (a ? tg : -tg) * (wy[b] * wz[d]);
-      ay += (b ? tg : -tg) * (wx[a] * wz[d]);
-      az += (d ? tg : -tg) * (wx[a] * wy[b]);
-    }
-    float v0 = w * g0, v1 = w * g1;
-    const bool issue = row_run_reduce(e, v0, v1, row_lane);
-#if CN_PAIRED_ATOMICS
-    // The two features of an entry are adjacent dwords.  Issue them from ADJACENT LANES of one instruction (first the
-    // entries of the even lanes, then those of the odd lanes) instead of from the same lane in two instructions, so
-    // that the pair travels as one request.
-    const unsigned eu = issue && (v0 != 0.f || v1 != 0.f) ? e : 0xffffffffu;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const unsigned es = h ? dpp_u32<0xF5>(eu) : dpp_u32<0xA0>(eu);   // quad_perm [1,1,3,3] / [0,0,2,2]
-      const float a0 = h ? dpp_f32<0xF5>(v0) : dpp_f32<0xA0>(v0);
-      const float a1 = h ? dpp_f32<0xF5>(v1) : dpp_f32<0xA0>(v1);
-      if (es != 0xffffffffu) atomicAdd(gtab + 2 * (size_t)es + (lane & 1), (lane & 1) ? a1 : a0);
-    }
-#else
-    if (issue && (v0 != 0.f || v1 != 0.f)) {
-      atomicAdd(gtab + 2 * (size_t)e, v0);
-      atomicAdd(gtab + 2 * (size_t)e + 1, v1);
-    }
-#endif
-  }
-#endif
+  // (History, measured at 4096 rays: one atomic per float from the owning lane 2.73 ms; the two features of an entry from
+  // two adjacent lanes of one instruction 1.73 ms; this x-edge form 1.30 ms.  The earlier forms were removed.)
   if constexpr (POS) {
     dpx = fmaf(ax, scale, dpx);
     dpy = fmaf(ay, scale, dpy);
