@@ -84,3 +84,72 @@ def test_hip_reproduces_golden(gold):
     assert_close(out["positions"], gold["export/out/point_location"], 1e-6, 1e-6, "export positions")
     for k in ("rgb", "semantics", "density"):
         assert_close(out[k], gold[f"export/out/{k}"], RTOL, ATOL, f"export {k}")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# tests/golden/postprocess_small.npz (tests/golden/make_golden_postprocess.py): the stages either side of the path
+# ---------------------------------------------------------------------------------------------------------------------
+POST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "postprocess_small.npz")
+
+
+@pytest.fixture(scope="module")
+def post():
+    return dict(np.load(POST))
+
+
+def test_oracle_reproduces_postprocess_golden(post):
+    from oracle import clustering as OC
+    from oracle import outliers as OO
+    from oracle import zbuffer as OZ
+
+    H, W = (int(v) for v in post["zbuffer/hw"])
+    P = OZ.get_projection_mat(*post["zbuffer/intr"], post["zbuffer/c2w"])
+    z = np.full((H, W), np.inf, dtype=np.float32)
+    img = np.zeros((H, W), dtype=np.uint8)
+    z, img, _ = OZ.update_buffer(z, OZ.get_projection(P, post["zbuffer/tree"]), img, 0, large=True)
+    z, img, (vx, vy) = OZ.update_buffer(z, OZ.get_projection(P, post["zbuffer/fruit"]), img, 1)
+    vis = np.zeros((H, W), dtype=np.uint8)
+    vis[vx, vy] = 255
+    assert np.array_equal(z, post["zbuffer/out/z"]) and np.array_equal(img, post["zbuffer/out/img"])
+    assert np.array_equal(vis, post["zbuffer/out/visible"])
+    down = OC.voxel_down_sample(post["cluster/points"].astype(np.float64), float(post["cluster/voxel_size"]))
+    down = down[np.lexsort(np.round(down, 6).T[::-1])].astype(np.float32)
+    assert np.allclose(down, post["cluster/out/down"], atol=1e-7)
+    labels, core = OC.dbscan(post["cluster/out/down"], float(post["cluster/eps"]), int(post["cluster/min_points"]))
+    assert np.array_equal(labels, post["cluster/out/labels"]) and np.array_equal(core, post["cluster/out/core"])
+    assert np.allclose(OO.knn_mean_distance(post["cluster/out/down"].astype(np.float64), 20), post["outlier/out/mean_distance"])
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_postprocess_golden(post):
+    from cropnerf_amd import ops
+    from cropnerf_amd.fruit_nerf.scripts import depth_based_semantic_projection as M
+    from oracle import zbuffer as OZ
+
+    # depth-based projection: exact (labels, visibility) / fp32 (depths)
+    H, W = (int(v) for v in post["zbuffer/hw"])
+    P = OZ.get_projection_mat(*post["zbuffer/intr"], post["zbuffer/c2w"])  # 12 numbers of host arithmetic
+    z = torch.full((H, W), float("inf"), dtype=torch.float32, device="cuda")
+    img = torch.zeros(H, W, dtype=torch.uint8, device="cuda")
+    M.update_buffer(z, M.get_projection(P, post["zbuffer/tree"], H, W), img, label=0, large=True)
+    _, _, vis = M.update_buffer(z, M.get_projection(P, post["zbuffer/fruit"], H, W), img, label=1)
+    assert np.array_equal(img.cpu().numpy(), post["zbuffer/out/img"])
+    assert np.array_equal(vis.cpu().numpy(), post["zbuffer/out/visible"])
+    assert np.allclose(z.cpu().numpy(), post["zbuffer/out/z"], rtol=1e-6, equal_nan=True)
+    # voxel down-sampling, DBSCAN, statistical outliers
+    pts = torch.from_numpy(post["cluster/points"]).cuda()
+    down, _ = ops.voxel_down_sample(pts, float(post["cluster/voxel_size"]))
+    d = down.cpu().numpy()
+    d = d[np.lexsort(np.round(d, 6).T[::-1])]
+    assert d.shape == post["cluster/out/down"].shape and np.allclose(d, post["cluster/out/down"], atol=2e-6)
+    gd = torch.from_numpy(post["cluster/out/down"]).cuda()
+    labels, core = ops.dbscan(gd, float(post["cluster/eps"]), int(post["cluster/min_points"]))
+    labels, core = labels.cpu().numpy(), core.cpu().numpy()
+    ref_l, ref_c = post["cluster/out/labels"], post["cluster/out/core"]
+    assert np.array_equal(core, ref_c) and np.array_equal(labels == -1, ref_l == -1)
+    assert np.array_equal(labels[core], ref_l[core])   # border points may belong to either neighbouring cluster
+    mean_d = ops.knn_mean_distance(gd, 20).cpu().numpy()
+    assert np.allclose(mean_d, post["outlier/out/mean_distance"], rtol=2e-5, atol=1e-7)
+    mask = ops.statistical_outlier_mask(gd, 20, 2.0).cpu().numpy()
+    ref_m = post["outlier/out/mask"]
+    assert (mask != ref_m).sum() <= 2                   # only points sitting on the threshold can flip in fp32
