@@ -28,6 +28,8 @@ Exception: ``oracle/zbuffer.py`` (the depth-based projection, a "next" row) foll
 reference (``scripts/depth_based_semantic_projection.py:31-105``) statement by statement.
 ``oracle/outliers.py`` and ``oracle/clustering.py`` (the segmenter's super-cluster stage) restate open3d's published
 algorithms with scipy / scikit-learn -- open3d is absent, so they too are unpinned.
+The merger's label propagation needs no oracle: the reference's own ``segmentation/lpa.py`` imports here and produced
+``tests/golden/merger_small.npz`` (``tests/golden/make_golden_merger.py``).
 """
 
 from . import field, model, rays, render, samplers  # noqa: F401
