@@ -96,6 +96,9 @@ class CottonNerfDataParserConfig:
     train_split_fraction: float = 0.95
     semantic_dir: Optional[str] = "semantics"
     semantic_img_ext: Optional[str] = "png"
+    # False: <semantic_dir>/<image stem>.<ext> (this file).  True: every frame names its mask in "semantic_path", with
+    # ``semantics_<k>`` down-scale folders -- the one difference of ``data/fruitnerf_dataparser.py`` (``:141-148``).
+    semantics_from_frames: bool = False
 
     def setup(self) -> "CottonNerf":
         return CottonNerf(self)
@@ -131,7 +134,13 @@ class CottonNerf:
                 raise NotImplementedError("lens distortion is not supported (undistort the images first)")
             image_filenames.append(fname)
             poses.append(np.array(frame["transform_matrix"]))
-            semantic_filenames.append(self._get_semantic_filepath(fname, data_dir))
+            if not cfg.semantics_from_frames:
+                semantic_filenames.append(self._get_semantic_filepath(fname, data_dir))
+            elif "semantic_path" in frame:
+                semantic_filenames.append(self._get_fname(Path(str(frame["semantic_path"]).replace("\\", "/")), data_dir,
+                                                          downsample_folder_prefix="semantics_"))
+        assert len(semantic_filenames) == 0 or len(semantic_filenames) == len(image_filenames), \
+            "Different number of image and semantic filenames."  # :147-152
         if any(float(meta.get(k, 0.0)) != 0.0 for k in distort_keys):
             raise NotImplementedError("lens distortion is not supported (undistort the images first)")
         if meta.get("camera_model", "OPENCV") not in ("OPENCV", "PINHOLE", "SIMPLE_PINHOLE"):
@@ -171,7 +180,7 @@ class CottonNerf:
         poses_t[:, :3, 3] *= scale_factor
 
         image_filenames = [image_filenames[i] for i in indices]
-        semantic_filenames = [semantic_filenames[i] for i in indices]
+        semantic_filenames = [semantic_filenames[i] for i in indices] if len(semantic_filenames) > 0 else []
         idx = torch.tensor(np.asarray(indices), dtype=torch.long)
         poses_t = poses_t[idx]
         s = float(cfg.scene_scale)

@@ -23,6 +23,7 @@ class FruitDataManagerConfig:
     train_num_rays_per_batch: int = 4096
     eval_num_rays_per_batch: int = 4096
     camera_res_scale_factor: float = 1.0
+    dataparser: Optional[object] = None  # a CottonNerfDataParserConfig / FruitNerfDataParserConfig (None: CottonNerf defaults)
 
 
 def get_corners_of_aabb(aabb, device=None) -> Tensor:

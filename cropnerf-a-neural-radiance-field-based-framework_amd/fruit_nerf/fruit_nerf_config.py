@@ -11,7 +11,9 @@ from dataclasses import dataclass, field
 from typing import Any, Dict, Optional
 
 from ..config import FruitNerfModelConfig
+from .data.cotton_nerf_dataparser import CottonNerfDataParserConfig
 from .data.fruit_datamanager import FruitDataManagerConfig
+from .data.fruitnerf_dataparser import FruitNerfDataParserConfig
 from .fruit_pipeline import FruitPipelineConfig
 
 
@@ -58,7 +60,8 @@ fruit_nerf_method = MethodSpecification(
         method_name="fruit_nerf", steps_per_eval_batch=500, steps_per_save=2000, max_num_iterations=40000,
         mixed_precision=True,
         pipeline=FruitPipelineConfig(
-            datamanager=FruitDataManagerConfig(train_num_rays_per_batch=4096, eval_num_rays_per_batch=4096),
+            datamanager=FruitDataManagerConfig(train_num_rays_per_batch=4096, eval_num_rays_per_batch=4096,
+                                               dataparser=CottonNerfDataParserConfig()),
             model=FruitNerfModelConfig(eval_num_rays_per_chunk=1 << 15),
         ),
         optimizers=_optim("adam"),
@@ -70,7 +73,8 @@ fruit_nerf_method_big = MethodSpecification(
     config=TrainerConfig(
         method_name="fruit_nerf_big", max_num_iterations=100000,
         pipeline=FruitPipelineConfig(
-            datamanager=FruitDataManagerConfig(train_num_rays_per_batch=4096 * 2, eval_num_rays_per_batch=4096),
+            datamanager=FruitDataManagerConfig(train_num_rays_per_batch=4096 * 2, eval_num_rays_per_batch=4096,
+                                               dataparser=CottonNerfDataParserConfig(train_split_fraction=0.99)),
             model=FruitNerfModelConfig(
                 eval_num_rays_per_chunk=1 << 15, num_nerf_samples_per_ray=128,
                 num_proposal_samples_per_ray=(512, 256), geo_feat_dim=30, hidden_dim_semantics=128,
@@ -86,7 +90,8 @@ fruit_nerf_method_huge = MethodSpecification(
     config=TrainerConfig(
         method_name="fruit_nerf_huge", max_num_iterations=100000,
         pipeline=FruitPipelineConfig(
-            datamanager=FruitDataManagerConfig(train_num_rays_per_batch=4096 * 4, eval_num_rays_per_batch=4096),
+            datamanager=FruitDataManagerConfig(train_num_rays_per_batch=4096 * 4, eval_num_rays_per_batch=4096,
+                                               dataparser=FruitNerfDataParserConfig()),
             model=FruitNerfModelConfig(
                 eval_num_rays_per_chunk=1 << 15, num_nerf_samples_per_ray=64,
                 num_proposal_samples_per_ray=(512, 512),

@@ -64,7 +64,10 @@ def train(method: str, data: Path, output_dir: Path = Path("outputs"), max_num_i
             dist.init_process_group("nccl", device_id=torch.device(device))
     say = (lambda *a: None) if (quiet or rank != 0) else (lambda *a: print(*a, flush=True))
 
-    pc = CottonNerfDataParserConfig(data=Path(data), downscale_factor=downscale_factor)
+    import copy
+
+    pc = copy.deepcopy(tc.pipeline.datamanager.dataparser) or CottonNerfDataParserConfig()  # the method's dataparser
+    pc.data, pc.downscale_factor = Path(data), downscale_factor
     if train_split_fraction is not None:
         pc.train_split_fraction = train_split_fraction
     parser = pc.setup()

@@ -165,3 +165,31 @@ def test_train_cli_two_ranks_rehearsal(tmp_path):
     res = json.loads(last)
     assert res["ranks"] == 2 and math.isfinite(res["eval_psnr"])
     assert (tmp_path / "out" / "plant" / "fruit_nerf" / "t" / "nerfstudio_models" / "step-000000029.pt").exists()
+
+
+def test_fruitnerf_dataparser_variant_and_method_dataparsers(capture, tmp_path):
+    """data/fruitnerf_dataparser.py (the _huge method's parser): masks named per frame by "semantic_path", 0.9 split; and the
+    dataparser each method specification carries (fruit_nerf_config.py:38,79,130)."""
+    from cropnerf_amd.fruit_nerf import fruit_nerf_config as FC
+    from cropnerf_amd.fruit_nerf.data.fruitnerf_dataparser import FruitNerfDataParserConfig
+
+    meta = json.loads((capture / "transforms.json").read_text())
+    for f in meta["frames"]:
+        f["semantic_path"] = "semantics\\\\" + Path(f["file_path"]).name      # Windows separators occur in the real captures
+    alt = tmp_path / "transforms.json"
+    (tmp_path / "images").symlink_to(capture / "images")
+    (tmp_path / "semantics").symlink_to(capture / "semantics")
+    alt.write_text(json.dumps(meta))
+    out = FruitNerfDataParserConfig(data=tmp_path).setup().get_dataparser_outputs("train")
+    assert len(out.image_filenames) == 18                       # ceil(20 * 0.9)
+    names = out.metadata["semantics"].filenames
+    assert len(names) == 18 and all(Path(n).exists() and Path(n).parent.name == "semantics" for n in names)
+    assert [Path(n).name for n in names] == [Path(n).name for n in out.image_filenames]
+    # a frame without "semantic_path" breaks the one-mask-per-image rule
+    meta["frames"][3].pop("semantic_path")
+    alt.write_text(json.dumps(meta))
+    with pytest.raises(AssertionError):
+        FruitNerfDataParserConfig(data=tmp_path).setup().get_dataparser_outputs("train")
+    dp = [m.config.pipeline.datamanager.dataparser for m in (FC.fruit_nerf_method, FC.fruit_nerf_method_big, FC.fruit_nerf_method_huge)]
+    assert [type(d).__name__ for d in dp] == ["CottonNerfDataParserConfig", "CottonNerfDataParserConfig", "FruitNerfDataParserConfig"]
+    assert [d.train_split_fraction for d in dp] == [0.95, 0.99, 0.9]
