@@ -151,7 +151,8 @@ def write_capture(path, num: int = 24, res: int = 64, radius: float = 0.8, world
         pose = torch.eye(4)
         pose[:3, :3] = c2w[i, :, :3]
         pose[:3, 3] = c2w[i, :, 3] * world_scale + shift
-        frames.append({"file_path": f"images/frame_{i + 1:05d}.png", "transform_matrix": pose.tolist()})
+        frames.append({"file_path": f"images/frame_{i + 1:05d}.png", "semantic_path": f"semantics/frame_{i + 1:05d}.png",
+                       "transform_matrix": pose.tolist()})
     meta = {"fl_x": focal, "fl_y": focal, "cx": res / 2.0, "cy": res / 2.0, "w": res, "h": res, "k1": 0, "k2": 0, "p1": 0,
             "p2": 0, "frames": frames}
     with open(os.path.join(path, "transforms.json"), "w", encoding="UTF-8") as f:
