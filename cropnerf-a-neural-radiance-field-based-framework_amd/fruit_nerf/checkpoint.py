@@ -33,7 +33,7 @@ class RunConfig:
 
 def save_run(run_dir, model_config: FruitNerfModelConfig, cameras: Cameras, scene_box: SceneBox,
              params: Dict[str, torch.Tensor], step: int = 0, transform=None, scale: float = 1.0,
-             method_name: str = "fruit_nerf") -> pathlib.Path:
+             method_name: str = "fruit_nerf", optimizers: Optional[dict] = None) -> pathlib.Path:
     run_dir = pathlib.Path(run_dir)
     (run_dir / "nerfstudio_models").mkdir(parents=True, exist_ok=True)
     mc = asdict(model_config)
@@ -47,8 +47,10 @@ def save_run(run_dir, model_config: FruitNerfModelConfig, cameras: Cameras, scen
     (run_dir / "config.json").write_text(json.dumps(raw))
     t = transform if transform is not None else [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]]
     (run_dir / "dataparser_transforms.json").write_text(json.dumps({"transform": t, "scale": scale}))
-    torch.save({"step": step, "params": {k: v.detach().cpu() for k, v in params.items()}},
-               run_dir / "nerfstudio_models" / f"step-{step:09d}.pt")
+    ckpt = {"step": step, "params": {k: v.detach().cpu() for k, v in params.items()}}
+    if optimizers is not None:  # FruitTrainer.state_dict() (+ the datamanager's sampling state): what --load-dir resumes from
+        ckpt["optimizers"] = optimizers
+    torch.save(ckpt, run_dir / "nerfstudio_models" / f"step-{step:09d}.pt")
     return run_dir / "config.json"
 
 

@@ -32,7 +32,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
 
 def train(method: str, data: Path, output_dir: Path = Path("outputs"), max_num_iterations=None, steps_per_save=None,
           downscale_factor=None, experiment_name=None, timestamp=None, seed: int = 0, log_every: int = 100,
-          train_split_fraction=None, device: str = "cuda", quiet: bool = False):
+          train_split_fraction=None, device: str = "cuda", quiet: bool = False, load_dir=None):
     from cropnerf_amd.fruit_nerf import fruit_nerf_config as FC
     from cropnerf_amd.fruit_nerf.checkpoint import save_run
     from cropnerf_amd.fruit_nerf.data.cotton_dataset import FruitDataset
@@ -83,6 +83,21 @@ def train(method: str, data: Path, output_dir: Path = Path("outputs"), max_num_i
     model.training = True
     trainer = FruitTrainer(model, groups_from_spec(tc.optimizers), seed=seed + rank)
 
+    start = 0
+    if load_dir is not None:  # ns-train --load-dir: parameters, optimiser moments, schedules and sampling state
+        ckpts = sorted(Path(load_dir).glob("step-*.pt"))
+        if not ckpts:
+            raise FileNotFoundError(f"no checkpoint under {load_dir}")
+        state = torch.load(ckpts[-1], map_location="cpu", weights_only=False)
+        for k, v in state["params"].items():
+            model.params[k].copy_(v)
+        if "optimizers" in state:
+            trainer.load_state_dict(state["optimizers"])
+            dm._gen.set_state(state["optimizers"]["datamanager_generator"])
+            dm.train_count = int(state["optimizers"]["train_count"])
+        start = int(state["step"]) + 1
+        say(f"[resume] {ckpts[-1]} -> continuing at step {start}")
+
     run_dir = Path(output_dir) / (experiment_name or Path(data).name) / tc.method_name / (
         timestamp or datetime.now().strftime("%Y-%m-%d_%H%M%S"))
 
@@ -91,14 +106,16 @@ def train(method: str, data: Path, output_dir: Path = Path("outputs"), max_num_i
             return run_dir / "config.json"
         cfg_path = save_run(run_dir, model.config, dm.cameras.to("cpu"), train_out.scene_box, model.params, step=step,
                             transform=train_out.dataparser_transform.tolist(), scale=train_out.dataparser_scale,
-                            method_name=tc.method_name)
+                            method_name=tc.method_name,
+                            optimizers=dict(trainer.state_dict(), datamanager_generator=dm._gen.get_state(),
+                                            train_count=dm.train_count))
         for old in sorted((run_dir / "nerfstudio_models").glob("step-*.pt"))[:-1]:
             old.unlink()  # nerfstudio's save_only_latest_checkpoint
         return cfg_path
 
     t0 = time.perf_counter()
     t_log, cfg_path = t0, run_dir / "config.json"
-    for step in range(iters):
+    for step in range(start, iters):
         ray_bundle, batch = dm.next_train(step)
         out = trainer.train_iteration(ray_bundle, batch)  # averages the gradients over the ranks when there are several
         if step % log_every == 0 or step == iters - 1:
@@ -115,8 +132,9 @@ def train(method: str, data: Path, output_dir: Path = Path("outputs"), max_num_i
     cfg_path = checkpoint(max(iters - 1, 0))
 
     # eval split: get_image_metrics_and_images (fruit_nerf.py:647-700) averaged over the eval images
-    result = {"config": str(cfg_path), "iterations": iters, "train_seconds": round(seconds, 2),
-              "rays_per_sec": iters * dm.config.train_num_rays_per_batch * world / max(seconds, 1e-9)}
+    done = max(iters - start, 0)
+    result = {"config": str(cfg_path), "iterations": iters, "resumed_at": start, "train_seconds": round(seconds, 2),
+              "rays_per_sec": done * dm.config.train_num_rays_per_batch * world / max(seconds, 1e-9)}
     if rank == 0 and len(eval_out.image_filenames) > 0:
         model.eval()
         eval_set = FruitDataset(eval_out)
@@ -160,9 +178,10 @@ def entrypoint(argv=None):
     ap.add_argument("--train-split-fraction", type=float, default=None)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--log-every", type=int, default=100)
+    ap.add_argument("--load-dir", type=Path, default=None, help="a run's nerfstudio_models directory to resume from")
     a = ap.parse_args(argv)
     return train(a.method, a.data, a.output_dir, a.max_num_iterations, a.steps_per_save, a.downscale_factor,
-                 a.experiment_name, a.timestamp, a.seed, a.log_every, a.train_split_fraction)
+                 a.experiment_name, a.timestamp, a.seed, a.log_every, a.train_split_fraction, load_dir=a.load_dir)
 
 
 if __name__ == "__main__":

@@ -228,6 +228,22 @@ class FruitTrainer:
             step_fn(self.flat_params[lo:hi], self.flat_grads[lo:hi], self.flat_exp_avg[lo:hi],
                     self.flat_exp_avg_sq[lo:hi], self.step, grp.lr_at(self.step - 1), eps=grp.eps, zero_grad=True)
 
+    def state_dict(self) -> Dict[str, object]:
+        """What a resumed run needs beside the parameters (nerfstudio checkpoints carry "optimizers" too): the Adam
+        moments in flat-buffer order, the step, the proposal sampler's schedule state and the jitter generator."""
+        return {"step": self.step, "exp_avg": self.flat_exp_avg.detach().cpu(), "exp_avg_sq": self.flat_exp_avg_sq.detach().cpu(),
+                "steps_since_update": self._steps_since_update, "sampler_step": self._sampler_step,
+                "generator": self._gen.get_state()}
+
+    def load_state_dict(self, state: Dict[str, object]) -> None:
+        if tuple(state["exp_avg"].shape) != tuple(self.flat_exp_avg.shape):
+            raise ValueError("optimizer state of a different model / trainer configuration")
+        self.step = int(state["step"])
+        self.flat_exp_avg.copy_(state["exp_avg"])
+        self.flat_exp_avg_sq.copy_(state["exp_avg_sq"])
+        self._steps_since_update, self._sampler_step = int(state["steps_since_update"]), int(state["sampler_step"])
+        self._gen.set_state(state["generator"])
+
     def train_iteration(self, ray_bundle: RayBundle, batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
         self.set_anneal(self.step)
         it = self.step
