@@ -43,6 +43,16 @@ def shard_jobs(jobs: Sequence, rank: int, world_size: int) -> List:
     return list(jobs[rank::world_size])
 
 
+def _gather_into(out: Tensor, src: Tensor, group=None) -> None:
+    """``all_gather_into_tensor``; device tensors over gloo (rehearsals on a one-GPU box, CPU tests) go through the host."""
+    if src.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, src.cpu(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, src, group=group)
+
+
 def _all_gather_rows(local: Tensor, counts: List[int], group=None) -> Tensor:
     """All-gather of [n_r, k] row blocks of different lengths: pad to the longest, gather once, trim."""
     rank, ws = world(group)
@@ -51,7 +61,7 @@ def _all_gather_rows(local: Tensor, counts: List[int], group=None) -> Tensor:
     padded = torch.zeros(mx, k, dtype=local.dtype, device=local.device)
     padded[: local.shape[0]] = local
     out = torch.empty(ws * mx, k, dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, padded, group=group)
+    _gather_into(out, padded, group)
     out = out.view(ws, mx, k)
     return torch.cat([out[r, : counts[r]] for r in range(ws)], dim=0)
 
@@ -82,7 +92,7 @@ def all_gather_points(rows: Tensor, group=None) -> Tensor:
         return rows
     n = torch.tensor([rows.shape[0]], dtype=torch.int64, device=rows.device)
     all_n = torch.empty(ws, dtype=torch.int64, device=rows.device)
-    dist.all_gather_into_tensor(all_n, n, group=group)
+    _gather_into(all_n, n, group)
     return _all_gather_rows(rows.contiguous(), [int(v) for v in all_n.tolist()], group)
 
 

@@ -67,6 +67,8 @@ class FruitDataManager:
         self.train_count = 0
         self.eval_count = 0
         self._gen = torch.Generator(device="cpu").manual_seed(seed + 1000 * local_rank)
+        self._device_generator: Optional[torch.Generator] = None
+        self._seed = seed + 1000 * local_rank
         self.orthographic_ray_generator: Optional[OrthographicRayGenerator] = None
 
     @classmethod
@@ -105,6 +107,15 @@ class FruitDataManager:
         self.train_count += 1
         return self._sample(self.config.train_num_rays_per_batch)
 
+    @property
+    def device_generator(self) -> torch.Generator:
+        """The device-side random stream of ``next_train_device`` (seeded per rank; a HIP graph that captures the call must
+        register it: ``graph.register_generator_state``)."""
+        if self._device_generator is None:
+            self._device_generator = torch.Generator(device=self.device)
+            self._device_generator.manual_seed(self._seed)
+        return self._device_generator
+
     def next_train_device(self, step: int) -> Tuple[RayBundle, Dict]:
         """``next_train`` with the pixel indices drawn on the device (torch's device generator, as nerfstudio's
         ``PixelSampler`` does): no host-to-device copy, so the call can be captured in a HIP graph.  Ray bundle only --
@@ -112,8 +123,10 @@ class FruitDataManager:
         self.train_count += 1
         n, h, w = len(self.cameras), self.cameras.height, self.cameras.width
         num_rays, dev = self.config.train_num_rays_per_batch, self.device
-        idx = torch.stack([torch.randint(0, n, (num_rays,), device=dev), torch.randint(0, h, (num_rays,), device=dev),
-                           torch.randint(0, w, (num_rays,), device=dev)], dim=-1)
+        g = self.device_generator
+        idx = torch.stack([torch.randint(0, n, (num_rays,), device=dev, generator=g),
+                           torch.randint(0, h, (num_rays,), device=dev, generator=g),
+                           torch.randint(0, w, (num_rays,), device=dev, generator=g)], dim=-1)
         return self.cameras.generate_rays(idx), {"indices": idx}
 
     def next_eval(self, step: int) -> Tuple[RayBundle, Dict]:

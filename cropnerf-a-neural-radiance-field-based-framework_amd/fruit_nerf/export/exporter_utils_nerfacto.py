@@ -25,6 +25,13 @@ def generate_point_cloud(pipeline, num_points: int = 1000000, remove_outliers: b
                          std_ratio: float = 10.0, only_semantics: bool = True, max_batches: Optional[int] = None,
                          use_graph: bool = True) -> Dict[str, np.ndarray]:
     model, dm = pipeline.model, pipeline.datamanager
+    # several ranks (one per GPU): every rank collects its share of the target from its own random rays; the shares are
+    # concatenated with one variable-length all-gather (counts, then padded rows) before the outlier pass
+    from ...distributed import all_gather_points, world as _world
+
+    rank, world_size = _world()
+    if world_size > 1:
+        num_points = -(-num_points // world_size)
     # The reference reads the kept-point count back after every 2048-ray call (``while num_points < total``).  Here up to
     # ``lookahead`` calls are enqueued before one read-back of their running counts; the cloud is then cut at the count of
     # the first call that reached ``num_points``, so the result is exactly the reference's (calls append in order), without
@@ -64,6 +71,7 @@ def generate_point_cloud(pipeline, num_points: int = 1000000, remove_outliers: b
             batches = 3
             try:
                 graph = torch.cuda.CUDAGraph()
+                graph.register_generator_state(dm.device_generator)  # the pixel sampler's own (per-rank) random stream
                 with torch.cuda.graph(graph):
                     one_call(dm.next_train_device)
                 replay = graph.replay
@@ -97,6 +105,9 @@ def generate_point_cloud(pipeline, num_points: int = 1000000, remove_outliers: b
     pts, cols, dirs, count = buffers
     n = min(kept, cap)
     pts, cols, dirs = pts[:n], cols[:n], dirs[:n]
+    if world_size > 1:
+        rows = all_gather_points(torch.cat([pts, cols, dirs], dim=-1).contiguous())
+        pts, cols, dirs = rows[:, 0:3].contiguous(), rows[:, 3:6].contiguous(), rows[:, 6:9].contiguous()
     if remove_outliers and pts.shape[0] > 0:
         # on the device, before the points leave it.  open3d works on the float64 cloud; the search here is float32
         # (positions of a +-1 scene: mean neighbour distances agree to ~1e-5 relative, so only points sitting on the

@@ -473,6 +473,10 @@ class FruitModel:
         if pcd_data is None:
             pcd_data = np.load(pcd_path, allow_pickle=True)
         results = {}
+        from ..distributed import world as _world
+
+        rank, world_size = _world()  # (camera x sub-cluster) jobs are independent: dealt round-robin over the ranks,
+        job = -1                     # no communication (every rank writes its own PNGs / returns its own results)
         for i_sc in range(len(pcd_data)):
             cluster_aabb = np.asarray(pcd_data[i_sc]["aabb"])
             save_dir = os.path.join(output_root, f"super_cluster_{i_sc}")
@@ -483,6 +487,9 @@ class FruitModel:
                 if save:
                     os.makedirs(cam_dir, exist_ok=True)
                 for i in range(cluster_aabb.shape[0]):
+                    job += 1
+                    if job % world_size != rank:
+                        continue
                     aabb = SceneBox(torch.tensor(cluster_aabb[i], dtype=torch.float32))
                     wo_occ, visible = self.project_cluster(cam, aabb, cam_idx)
                     if save:

@@ -150,3 +150,19 @@ def test_rccl_async_all_gather_single_rank():
         assert float(t) == 1.5
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_exporters_two_ranks_rehearsal():
+    """The exporters' N > 1 paths on the product code: point-cloud export (every rank collects its share from its own random
+    stream -- also inside the captured HIP graph --, one variable-length all-gather) and projection jobs (dealt
+    round-robin, no communication).  Two ranks on this box's single GPU over gloo (tests/_dist_export_worker.py); on a
+    multi-GPU node the same code runs over RCCL."""
+    import subprocess
+
+    worker = os.path.join(ROOT, "tests", "_dist_export_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), worker]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "sharded export ok" in p.stdout, p.stdout[-1500:] + p.stderr[-2500:]
