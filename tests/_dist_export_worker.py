@@ -40,5 +40,21 @@ allkeys = [None] * ws
 dist.all_gather_object(allkeys, keys)
 flat = sorted(k for ks in allkeys for k in ks)
 assert len(flat) == 16 and len(set(flat)) == 16 and all(len(ks) == 8 for ks in allkeys), allkeys
+# dense volume export: batches dealt round-robin + gather == the single-rank export (same point sets)
+from unittest import mock
+from cropnerf_amd.fruit_nerf.export.exporter_utils import sample_volume
+pipe_e = FruitPipeline(FruitPipelineConfig(FruitDataManagerConfig(512, 100), cfg), "cuda", cams, SceneBox(torch.tensor([[-1.0,-1,-1],[1,1,1]])),
+                       test_mode="export", params=params, world_size=ws, local_rank=rank)
+pipe_e.model.setup_inference(True, 50)
+n_rays = pipe_e.datamanager.setup_inference(((-1, -1, -1), (1, 1, 1)), 21)
+with torch.no_grad():
+    sharded = sample_volume(pipe_e, n_rays, sem_thresh=0.5, den_thresh=5.0)
+    pipe_e.datamanager.train_count = 0
+    with mock.patch("cropnerf_amd.distributed.world", lambda group=None: (0, 1)):
+        single = sample_volume(pipe_e, n_rays, sem_thresh=0.5, den_thresh=5.0)
+for k in ("semantic_colormap", "semantic", "density"):
+    a, b = sharded[k]["points"], single[k]["points"]
+    assert a.shape == b.shape and a.shape[0] > 0, (k, a.shape, b.shape)
+    assert np.allclose(a[np.lexsort(a.T)], b[np.lexsort(b.T)], atol=1e-6), k
 if rank == 0: print("sharded export ok:", n, "points; projection jobs per rank", [len(k) for k in allkeys])
 dist.barrier(); dist.destroy_process_group()
