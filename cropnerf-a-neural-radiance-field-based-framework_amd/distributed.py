@@ -26,6 +26,28 @@ from torch import Tensor
 PACK_KEYS = (("rgb", 3), ("accumulation", 1), ("depth", 1), ("semantics", 1))
 
 
+def init_from_env() -> Tuple[int, int, str]:
+    """What the CLIs call first: under ``torch.distributed.run`` (WORLD_SIZE > 1) join the job -- one rank per GPU over
+    RCCL, device = LOCAL_RANK; ``CROPNERF_REHEARSE_ON_ONE_GPU=1`` puts every rank on cuda:0 over gloo (tests) -- and
+    return (rank, world size, device string).  A plain ``python script.py`` returns (0, 1, "cuda")."""
+    import os
+
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws <= 1:
+        return 0, 1, "cuda"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not dist.is_initialized():
+        if os.environ.get("CROPNERF_REHEARSE_ON_ONE_GPU") == "1":
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+            return dist.get_rank(), ws, "cuda:0"
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return dist.get_rank(), ws, f"cuda:{torch.cuda.current_device()}"
+
+
 def world(group=None) -> Tuple[int, int]:
     if not (dist.is_available() and dist.is_initialized()):
         return 0, 1

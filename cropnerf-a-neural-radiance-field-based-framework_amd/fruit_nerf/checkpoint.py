@@ -56,6 +56,11 @@ def save_run(run_dir, model_config: FruitNerfModelConfig, cameras: Cameras, scen
 
 def eval_setup(load_config, eval_num_rays_per_chunk: Optional[int] = None, test_mode: str = "test",
                device: str = "cuda") -> Tuple[RunConfig, FruitPipeline, pathlib.Path, int]:
+    from ..distributed import init_from_env
+
+    rank, world_size, dist_device = init_from_env()  # under torch.distributed.run: one rank per GPU
+    if world_size > 1:
+        device = dist_device
     load_config = pathlib.Path(load_config)
     raw = json.loads(load_config.read_text())
     cfg = RunConfig(load_config, raw)
@@ -76,6 +81,6 @@ def eval_setup(load_config, eval_num_rays_per_chunk: Optional[int] = None, test_
     state = torch.load(ckpts[-1], map_location="cpu")
     pipe = FruitPipeline(FruitPipelineConfig(FruitDataManagerConfig(), model_cfg), device=device, cameras=cams,
                          scene_box=SceneBox(torch.tensor(raw["scene_box"], dtype=torch.float32)), test_mode=test_mode,
-                         params=state["params"])
+                         params=state["params"], world_size=world_size, local_rank=rank)
     pipe.eval()
     return cfg, pipe, ckpts[-1], int(state["step"])

@@ -47,6 +47,8 @@ class ExportSemanticPointCloud:
             transform_json = json.load(fp)
         pcds = sample_volume(pipeline=pipeline, num_points=num_points, output_dir=self.output_dir, config=config,
                              transform_json=transform_json)
+        if pipeline.local_rank != 0:  # several ranks: everyone holds the gathered cloud, rank 0 writes it
+            return
         os.makedirs(str(self.output_dir / config.load_dir.parts[-3]), exist_ok=True)
         print("Saving Point Cloud...")
         for name, pcd in pcds.items():
@@ -84,6 +86,8 @@ class ExportPointCloud:
             crop_obb = OrientedBox.from_params(self.obb_center, self.obb_rotation, self.obb_scale)
         pcd = generate_point_cloud(pipeline=pipeline, num_points=self.num_points, remove_outliers=self.remove_outliers,
                                    std_ratio=self.std_ratio, crop_obb=crop_obb)
+        if pipeline.local_rank != 0:
+            return
         print("Saving Point Cloud...")
         write_ply(str(self.output_dir / "semantics_pc.ply"), pcd["points"], pcd["colors"], pcd.get("normals"))
         print("Saving Point Cloud: done")

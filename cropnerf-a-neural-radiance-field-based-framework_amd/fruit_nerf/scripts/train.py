@@ -48,20 +48,13 @@ def train(method: str, data: Path, output_dir: Path = Path("outputs"), max_num_i
     tc = specs[method].config
     iters = max_num_iterations if max_num_iterations is not None else tc.max_num_iterations
     save_every = steps_per_save if steps_per_save is not None else tc.steps_per_save
-    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    from cropnerf_amd.distributed import init_from_env
+
+    rank, world, dist_device = init_from_env()
     if world > 1:
         import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        local = int(os.environ.get("LOCAL_RANK", "0"))
-        if os.environ.get("CROPNERF_REHEARSE_ON_ONE_GPU") == "1":  # every rank on cuda:0, gradients over gloo (tests only)
-            torch.cuda.set_device(0)
-            device = "cuda:0"
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local)
-            device = f"cuda:{local}"
-            dist.init_process_group("nccl", device_id=torch.device(device))
+        device = dist_device
     say = (lambda *a: None) if (quiet or rank != 0) else (lambda *a: print(*a, flush=True))
 
     import copy

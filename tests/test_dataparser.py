@@ -164,7 +164,15 @@ def test_train_cli_two_ranks_rehearsal(tmp_path):
     last = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     res = json.loads(last)
     assert res["ranks"] == 2 and math.isfinite(res["eval_psnr"])
-    assert (tmp_path / "out" / "plant" / "fruit_nerf" / "t" / "nerfstudio_models" / "step-000000029.pt").exists()
+    run = tmp_path / "out" / "plant" / "fruit_nerf" / "t"
+    assert (run / "nerfstudio_models" / "step-000000029.pt").exists()
+    # ... and the exporter CLI under the same launcher: batches dealt over the ranks, rank 0 writes the gathered clouds
+    exp = root / "cropnerf-a-neural-radiance-field-based-framework_amd" / "fruit_nerf" / "scripts" / "exporter.py"
+    cmd = cmd[:10] + [str(exp), "semantic-pointcloud", "--load-config", str(run / "config.json"), "--output-dir",
+                      str(tmp_path / "pcd"), "--num-points-per-side", "30", "--num-rays-per-batch", "128"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert (tmp_path / "pcd" / "fruit_nerf" / "density.ply").exists() and p.stdout.count("Saving Point Cloud: done") == 1
 
 
 def test_fruitnerf_dataparser_variant_and_method_dataparsers(capture, tmp_path):
