@@ -425,7 +425,9 @@ class FruitModel:
     def _chunked(self, camera_ray_bundle: RayBundle, fn, image_width: int = 0) -> Dict[str, Tensor]:
         """``image_width`` > 0: the bundle is a whole row-major image, so every chunk is a pixel run -- passed to the
         renderer as a scheduling hint (cn_render_opts.image_width / pixel_start)."""
-        chunk = self.config.eval_num_rays_per_chunk
+        # the reference's chunk size bounds ITS memory (materialised [R,S,.] tensors); rays are independent, so any size
+        # gives the same image here and chunks below 32 768 rays (the projection CLI asks for 4096) only add launches
+        chunk = max(int(self.config.eval_num_rays_per_chunk), 1 << 15)
         flat = camera_ray_bundle.flatten()
         n = len(flat)
         lists: Dict[str, List[Tensor]] = {}
