@@ -290,6 +290,28 @@ def secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, o
         o_ = opts if args.no_image_hint else ops.render_opts(S, image_width=W, pixel_start=start)
         ops.render_rays(fh, scene_c, o_, o, d, n, f, bins=ps["euclidean_bins"])
 
+    # the headline workload with the optional split-bf16 matrix products (cn_render_opts.matrix_precision = 1; NOT the
+    # headline, which is exact fp32): same batches, same kernel, same parity bar against the oracle (tests)
+    from cropnerf_amd import _lib as L
+    from cropnerf_amd import ops as _ops
+
+    scene_u = _ops.scene_struct(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), contraction=False)
+
+    def split_bf16(i):
+        o, d, n, f, cam, start = batches[i % DISTINCT_BATCHES]
+        o_ = ops.render_opts(S, matrix_precision=L.MATRIX_SPLIT_BF16, **({} if args.no_image_hint else
+                                                                           {"image_width": W, "pixel_start": start}))
+        return ops.render_rays(fh, scene_u, o_, o, d, n, f)
+
+    t = timed(split_bf16, 20)
+    o, d, n, f, cam, start = batches[0]
+    exact = ops.render_rays(fh, scene_u, ops.render_opts(S, image_width=W, pixel_start=start), o, d, n, f)["rgb"]
+    mse = float(((split_bf16(0)["rgb"] - exact) ** 2).mean())
+    out["uniform_mode_split_bf16_matrix"] = {
+        "ms_per_batch": round(t * 1e3, 3), "samples_per_sec": R * S / t, "rays_per_sec": R / t,
+        "psnr_vs_fp32_render_db": round(-10.0 * math.log10(max(mse, 1e-30)), 1),
+        "note": "optional arithmetic (operands split into bf16 hi + lo, fp32 accumulation); the headline value is exact fp32"}
+
     t = timed(prop, 10)
     out["proposal_mode"] = {"ms_per_batch": round(t * 1e3, 3), "rays_per_sec": R / t, "field_samples_per_sec": R * S / t,
                             "network_evals_per_sec": R * (S + sum(cfg.num_proposal_samples_per_ray)) / t}

@@ -58,8 +58,10 @@ class RenderOpts(C.Structure):
     _fields_ = [("num_samples", C.c_int32), ("spacing", C.c_int32), ("bg_mode", C.c_int32),
                 ("bg_color", C.c_float * 3), ("app_mode", C.c_int32), ("sh_unit_dir", C.c_int32),
                 ("eval_clamp", C.c_int32), ("density_only", C.c_int32), ("image_width", C.c_int32),
-                ("pixel_start", C.c_int64), ("early_stop_transmittance", C.c_float)]
+                ("pixel_start", C.c_int64), ("early_stop_transmittance", C.c_float), ("matrix_precision", C.c_int32)]
 
+
+MATRIX_FP32, MATRIX_SPLIT_BF16 = 0, 1  # cn_render_opts.matrix_precision
 
 _P = C.c_void_p
 _I32, _I64, _F = C.c_int32, C.c_int64, C.c_float

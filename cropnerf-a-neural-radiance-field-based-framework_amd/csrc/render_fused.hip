@@ -42,6 +42,7 @@ constexpr int OFF_WSH = 9688;   // [64][16] Wc0[:, 0:16]
 constexpr int OFF_SCALE = 10712;  // [16] hash-grid level scalings (lane group g reads [4g, 4g+4))
 constexpr int BLOB_FLOATS = 10712 + 16;
 static_assert(BLOB_FLOATS % 4 == 0, "blob is copied as float4");
+static_assert(OFF_A0 == 0 && OFF_B0 == 18 * 512, "the split-bf16 images reuse the fp32 A-operand region block for block");
 constexpr int WAVE_SCRATCH = 200;  // floats of per-wave LDS scratch: colour bias [64] | 2 x 66 chunk bin edges
 // timing-only ablations (outputs are wrong): 1 = skip the hash-grid gathers / skip the MLPs
 #ifndef CN_ABLATE_GATHER
@@ -77,7 +78,42 @@ struct PrepArgs {
   int app_mode;
   int app_rows;
   float scale[CN_MAX_LEVELS];
+  int bf16;     // 1: the A-operand region holds split-bf16 images for v_mfma_f32_16x16x32_bf16 (render_split_kernel<.,true>)
+  float* ext;   // [BF16_EXT_FLOATS] the four image blocks that do not fit the fp32 region
 };
+
+// Split-bf16 A operands (cn_render_opts.matrix_precision = 1).  Block b = one (row tile, K block of 32): [hi | lo][lane 64][8 bf16];
+// lane (g, j) holds row 16 mt + j and the eight k values its B operand lane supplies.  B operands are the features of a
+// lane (k = 8 g + jj) or two accumulator tiles of the previous layer (jj = 4 (t & 1) + e  <->  k = 16 t + 4 g + e), so no
+// activation ever changes lane.  Blocks: 0-3 base L0, 4-5 base L1, 6-9 semantics L0, 10-13 colour L0 (K = 16 real + 16
+// zero), 14-21 colour L1.  18 blocks fill the fp32 A region exactly, 4 go to the extension.
+constexpr int BF16_BLOCKS = 22, BF16_BLOCK_FLOATS = 512, BF16_EXT_FLOATS = 4 * BF16_BLOCK_FLOATS;
+
+__device__ __forceinline__ float bf16_logical_weight(const PrepArgs& p, int b, int g, int j, int jj) {
+  if (b < 4) return p.w0[(16 * b + j) * 32 + 8 * g + jj];
+  if (b < 6) return p.w1[j * 64 + 16 * (2 * (b - 4) + (jj >> 2)) + 4 * g + (jj & 3)];
+  if (b < 14) {
+    if (jj >= 4) return 0.f;
+    const int m = 4 * g + jj;  // base output neuron; neuron 0 is the density logit, not a geo feature
+    if (m == 0) return 0.f;
+    return b < 10 ? p.ws0[(16 * (b - 6) + j) * 15 + (m - 1)] : p.wc0[(16 * (b - 10) + j) * 63 + 16 + (m - 1)];
+  }
+  const int mt = (b - 14) >> 1, kb = (b - 14) & 1;
+  return p.wc1[(16 * mt + j) * 64 + 16 * (2 * kb + (jj >> 2)) + 4 * g + (jj & 3)];
+}
+
+__device__ __forceinline__ float bf16_image_word(const PrepArgs& p, int q) {  // q: float index inside the 22-block image
+  const int b = q >> 9, half = (q >> 8) & 1, lane = (q >> 2) & 63, w = q & 3;
+  unsigned bits[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float x = bf16_logical_weight(p, b, lane >> 4, lane & 15, 2 * w + h);
+    const __bf16 hi = (__bf16)x;
+    const __bf16 v = half ? (__bf16)(x - (float)hi) : hi;
+    bits[h] = (unsigned)__builtin_bit_cast(unsigned short, v);
+  }
+  return __builtin_bit_cast(float, bits[0] | (bits[1] << 16));
+}
 
 // Embedding.mean(dim=0) for the 32-wide appearance embedding: 8 partial sums per column, combined through LDS
 __global__ void __launch_bounds__(256) prep_mean_kernel(const float* __restrict__ emb, int n, float* __restrict__ mean) {
@@ -97,9 +133,14 @@ __global__ void __launch_bounds__(256) prep_mean_kernel(const float* __restrict_
 
 __global__ void __launch_bounds__(256) prep_kernel(PrepArgs p, float* __restrict__ blob, float* __restrict__ app_bias) {
   const int total = BLOB_FLOATS + p.app_rows * 64;
+  if (p.bf16)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < BF16_EXT_FLOATS; i += gridDim.x * blockDim.x)
+      p.ext[i] = bf16_image_word(p, OFF_B0 + i);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     float v = 0.f;
-    if (i < OFF_A1) {
+    if (p.bf16 && i < OFF_B0) {
+      v = bf16_image_word(p, i);
+    } else if (i < OFF_A1) {
       int q = i - OFF_A0;
       int mt = q >> 9, sq = (q >> 8) & 1, lane = (q >> 2) & 63, e = q & 3;
       int g = lane >> 4, j = lane & 15;
@@ -174,6 +215,7 @@ struct FusedArgs {
   GridDev grid;
   SceneDev scene;
   const float* blob;
+  const float* blob_ext;  // split-bf16 mode: the image blocks beyond the fp32 region
   const float* app_bias;  // [rows][64]
   const float* origins;
   const float* directions;
@@ -580,7 +622,8 @@ static int check_fused_shape(const cn_field_params& p) {
 
 static size_t fused_workspace_bytes(const cn_field_params* p) {
   int rows = p && p->num_images > 0 ? p->num_images : 1;
-  return (size_t)(BLOB_FLOATS + rows * 64 + 32) * sizeof(float);  // weight image | appearance bias rows | mean
+  // weight image | appearance bias rows | mean | split-bf16 image extension
+  return (size_t)(BLOB_FLOATS + rows * 64 + 32 + BF16_EXT_FLOATS) * sizeof(float);
 }
 
 // Resident blocks of a kernel variant on this device (rounded down to a multiple of 8 = one group per XCD).  A grid
@@ -612,6 +655,8 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   CN_REQUIRE(opts->bg_mode == CN_BG_LAST_SAMPLE || opts->bg_mode == CN_BG_COLOR, CN_ERR_INVALID, "%s: bg_mode %d", who,
              opts->bg_mode);
   CN_REQUIRE(opts->image_width <= 0 || opts->pixel_start >= 0, CN_ERR_INVALID, "%s: negative pixel_start", who);
+  CN_REQUIRE(opts->matrix_precision == CN_MATRIX_FP32 || opts->matrix_precision == CN_MATRIX_SPLIT_BF16, CN_ERR_INVALID,
+             "%s: matrix_precision %d", who, opts->matrix_precision);
   int rc = check_fused_shape(*params);
   if (rc) return rc;
   CN_REQUIRE(workspace && workspace_bytes >= fused_workspace_bytes(params), CN_ERR_WORKSPACE,
@@ -623,7 +668,47 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   hipStream_t s = as_stream(stream);
   float* blob = static_cast<float*>(workspace);
   float* app_bias = blob + BLOB_FLOATS;
+  // ---- which kernel: the producer/consumer variant (render_split.hpp) or the single-wave one -----------------------------
+  // (the environment is read per call so that one process can compare both forms)
+  const char* split_env = getenv("CN_FUSED_SPLIT");
+  const int split_mode = split_env ? atoi(split_env) : CN_FUSED_SPLIT_DEFAULT;
+  const float early_stop = opts->early_stop_transmittance > 0.f ? opts->early_stop_transmittance : 0.f;
+  unsigned split_blocks = 0;  // 0: render_fused_kernel
+  // Early termination: both kernels implement it.  The workgroup of the split kernel runs its 8 rays in lock-step, so
+  // it only saves time when they all go opaque at a similar depth (C2 batch on an opaque medium: 2.53 -> 1.13 ms); the
+  // independent waves of the fused kernel save in proportion to the terminated rays (3.2 -> 0.87 ms), which suits real
+  // scenes (a mix of rays that hit a surface and rays that cross empty space) better -- so it is the default there and
+  // CN_FUSED_SPLIT=2 forces the split kernel.
+  if (!opts->density_only && split_mode && (PER_SAMPLE || early_stop == 0.f || split_mode > 1)) {
+    static int resident = 0;  // workgroups the device holds at once (a multiple of 8 = XCD teams)
+    if (!resident) {
+      int dev = 0, cus = 256, per_cu = 1;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<false, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<true, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS_BYTES);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS_BYTES_BF16);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<true, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS_BYTES_BF16);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_split_kernel<false, false>, SPLIT_THREADS,
+                                                       SPLIT_LDS_BYTES) != hipSuccess || per_cu < 1)
+        per_cu = 1;
+      resident = cus * per_cu;
+      resident = resident >= 8 ? (resident / 8) * 8 : 8;
+    }
+    const long long work = PER_SAMPLE ? num_rays * ((opts->num_samples + 63) / 64) : num_rays;  // (ray, chunk) items
+    const long long want_s = (((work + SPLIT_PAIRS - 1) / SPLIT_PAIRS) + 7) / 8 * 8;
+    // one workgroup per CU carries 8 rays at a time: with fewer rays than that fills the device (the exporters' 512-ray
+    // x 3000-sample calls) the 4-wave workgroups of render_fused_kernel spread over more CUs
+    if (want_s >= resident || split_mode > 1) split_blocks = (unsigned)(want_s < resident ? want_s : resident);
+  }
+  // split-bf16 matrix products: an option of the producer/consumer kernel only; elsewhere the products stay fp32
+  const bool bf16 = opts->matrix_precision == CN_MATRIX_SPLIT_BF16 && split_blocks > 0;
   PrepArgs P;
+  P.bf16 = bf16 ? 1 : 0;
+  P.ext = blob + BLOB_FLOATS + (size_t)(params->num_images > 0 ? params->num_images : 1) * 64 + 32;
   P.w0 = params->base.weight[0];
   P.b0 = params->base.bias[0];
   P.w1 = params->base.weight[1];
@@ -656,6 +741,7 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   A.grid = make_grid_dev(params->grid);
   A.scene = make_scene_dev(*scene);
   A.blob = blob;
+  A.blob_ext = P.ext;
   A.app_bias = app_bias;
   A.origins = origins;
   A.directions = directions;
@@ -673,7 +759,7 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   A.app_per_camera = opts->app_mode == CN_APP_PER_CAMERA;
   A.sh_unit = opts->sh_unit_dir;
   A.eval_clamp = opts->eval_clamp;
-  A.early_stop = opts->early_stop_transmittance > 0.f ? opts->early_stop_transmittance : 0.f;
+  A.early_stop = early_stop;
   A.image_width = opts->image_width > 0 ? opts->image_width : 0;
   // ~400 rays are in flight per XCD; a stripe about 24 pixels wide makes that patch roughly square (measured at
   // 800 px: 1/2/4/8 stripes per XCD -> 3.57 / 3.78 / 3.83 / 3.66 Gsamples/s)
@@ -688,39 +774,14 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   const long long cap = PER_SAMPLE ? res_sample : (opts->density_only ? res_density : res_full);
   const long long want = (((num_rays + FUSED_WAVES - 1) / FUSED_WAVES) + 7) / 8 * 8;
   const unsigned blocks = (unsigned)(want < cap ? want : cap);
-  // producer/consumer variant of the composited full render (render_split.hpp)
-  // (the environment is read per call so that one process can compare both forms)
-  const char* split_env = getenv("CN_FUSED_SPLIT");
-  const int split_mode = split_env ? atoi(split_env) : CN_FUSED_SPLIT_DEFAULT;
-  // Early termination: both kernels implement it.  The workgroup of the split kernel runs its 8 rays in lock-step, so
-  // it only saves time when they all go opaque at a similar depth (C2 batch on an opaque medium: 2.53 -> 1.13 ms); the
-  // independent waves of the fused kernel save in proportion to the terminated rays (3.2 -> 0.87 ms), which suits real
-  // scenes (a mix of rays that hit a surface and rays that cross empty space) better -- so it is the default there and
-  // CN_FUSED_SPLIT=2 forces the split kernel.
-  if (!opts->density_only && split_mode && (PER_SAMPLE || A.early_stop == 0.f || split_mode > 1)) {
-    static int resident = 0;  // workgroups the device holds at once (a multiple of 8 = XCD teams)
-    if (!resident) {
-      int dev = 0, cus = 256, per_cu = 1;
-      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS_BYTES);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS_BYTES);
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_split_kernel<false>, SPLIT_THREADS, SPLIT_LDS_BYTES) !=
-              hipSuccess || per_cu < 1)
-        per_cu = 1;
-      resident = cus * per_cu;
-      resident = resident >= 8 ? (resident / 8) * 8 : 8;
-    }
-    const long long work = PER_SAMPLE ? num_rays * ((opts->num_samples + 63) / 64) : num_rays;  // (ray, chunk) items
-    const long long want_s = (((work + SPLIT_PAIRS - 1) / SPLIT_PAIRS) + 7) / 8 * 8;
-    // one workgroup per CU carries 8 rays at a time: with fewer rays than that fills the device (the exporters' 512-ray
-    // x 3000-sample calls) the 4-wave workgroups of render_fused_kernel spread over more CUs
-    if (want_s >= resident || split_mode > 1) {
-      const unsigned nb = (unsigned)(want_s < resident ? want_s : resident);
-      hipLaunchKernelGGL(render_split_kernel<PER_SAMPLE>, dim3(nb), dim3(SPLIT_THREADS), SPLIT_LDS_BYTES, s, A);
-      return check_launch(who);
-    }
+  if (split_blocks) {
+    if (bf16)
+      hipLaunchKernelGGL((render_split_kernel<PER_SAMPLE, true>), dim3(split_blocks), dim3(SPLIT_THREADS),
+                         SPLIT_LDS_BYTES_BF16, s, A);
+    else
+      hipLaunchKernelGGL((render_split_kernel<PER_SAMPLE, false>), dim3(split_blocks), dim3(SPLIT_THREADS), SPLIT_LDS_BYTES,
+                         s, A);
+    return check_launch(who);
   }
   if (PER_SAMPLE) {
     hipLaunchKernelGGL((render_fused_kernel<true, false>), dim3(blocks), dim3(FUSED_THREADS), 0, s, A);

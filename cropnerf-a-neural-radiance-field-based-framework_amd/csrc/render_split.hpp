@@ -47,6 +47,27 @@ constexpr int XCH_FLOATS = 16 * 64 + 64;
 constexpr int PAIR_SCRATCH = 2 * XCH_FLOATS + 64 + 68 + 68 + 4;  // ring | per-ray colour bias | matrix edges | gather edges | flags
 constexpr int PAIR_FLAGS = 2 * XCH_FLOATS + 64 + 68 + 68;
 constexpr size_t SPLIT_LDS_BYTES = (size_t)(BLOB_FLOATS + SPLIT_PAIRS * PAIR_SCRATCH) * sizeof(float);
+constexpr size_t SPLIT_LDS_BYTES_BF16 = SPLIT_LDS_BYTES + (size_t)BF16_EXT_FLOATS * sizeof(float);
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// fp32 values -> bf16 hi + bf16 lo (x ~ hi + lo to ~16 mantissa bits): the B operands of the split-bf16 matrix path
+__device__ __forceinline__ void split_bf16(const f32x4& a, const f32x4& b, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = j < 4 ? a[j] : b[j - 4];
+    const __bf16 h = (__bf16)x;
+    hi[j] = h;
+    lo[j] = (__bf16)(x - (float)h);
+  }
+}
+// acc += A . B with A = ah + al, B = bh + bl, dropping al . bl (v_mfma_f32_16x16x32_bf16, fp32 accumulation)
+__device__ __forceinline__ f32x4 mfma_split(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+  return acc;
+}
 
 struct SplitRay {
   float ox, oy, oz, dx, dy, dz, sn, sf;
@@ -107,13 +128,21 @@ __device__ __forceinline__ void split_fill_edges(const FusedArgs& A, const Split
   __builtin_amdgcn_wave_barrier();
 }
 
-template <bool PER_SAMPLE>
+// BF16: the matrix waves run the MLPs on split-bf16 products (cn_render_opts.matrix_precision = 1; the weight images in the
+// blob are then the bf16 ones of prep_kernel, four more blocks of them behind the pair scratch).
+template <bool PER_SAMPLE, bool BF16 = false>
 __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A) {
   extern __shared__ __align__(16) float lds[];
+  constexpr int OFF_EXT = BLOB_FLOATS + SPLIT_PAIRS * PAIR_SCRATCH;  // BF16 only
   {
     const float4* src = reinterpret_cast<const float4*>(A.blob);
     float4* dst = reinterpret_cast<float4*>(lds);
     for (int i = threadIdx.x; i < BLOB_FLOATS / 4; i += SPLIT_THREADS) dst[i] = src[i];
+    if constexpr (BF16) {
+      const float4* esrc = reinterpret_cast<const float4*>(A.blob_ext);
+      float4* edst = reinterpret_cast<float4*>(lds + OFF_EXT);
+      for (int i = threadIdx.x; i < BF16_EXT_FLOATS / 4; i += SPLIT_THREADS) edst[i] = esrc[i];
+    }
     if (threadIdx.x < SPLIT_PAIRS * 4)
       reinterpret_cast<int*>(lds + BLOB_FLOATS + (threadIdx.x >> 2) * PAIR_SCRATCH + PAIR_FLAGS)[threadIdx.x & 3] =
           (threadIdx.x & 3) == 2 ? -1 : 0;  // [2]: schedule slot of a ray its matrix wave has terminated early
@@ -288,40 +317,70 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
         feat[1][0] = xv[2 * 64 + lane];
         feat[1][1] = xv[3 * 64 + lane];
         const int selbits = (int)xs[XCH_FLOATS - 64 + lane];
-        // ---- base MLP layer 0: 32 -> 64, ReLU ------------------------------------------------------------------------
+        // ---- base MLP (32 -> 64 ReLU -> 16) ---------------------------------------------------------------------------------
         f32x4 h[4][2];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B0 + 16 * mt + 4 * g);
-          const f32x4 a0 = *reinterpret_cast<const f32x4*>(lds + OFF_A0 + ((mt * 2 + 0) * 64 + lane) * 4);
-          const f32x4 a1 = *reinterpret_cast<const f32x4*>(lds + OFF_A0 + ((mt * 2 + 1) * 64 + lane) * 4);
-          f32x4 acc[2] = {b, b};
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) acc[c] = MFMA(a0[e], feat[c][0][e], acc[c]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) acc[c] = MFMA(a1[e], feat[c][1][e], acc[c]);
-#pragma unroll
-          for (int c = 0; c < 2; ++c) h[mt][c] = relu4(acc[c]);
-        }
-        // ---- base MLP layer 1: 64 -> 16 ---------------------------------------------------------------------------------
         f32x4 o16[2];
-        {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B1 + 4 * g);
-          f32x4 acc[2] = {b, b};
+        // image block b: [hi | lo][lane][8 bf16]; 18 blocks sit in the fp32 A region, 4 behind the pair scratch
+        auto blk = [&](int b) { return reinterpret_cast<const bf16x8*>(b < 18 ? lds + OFF_A0 + b * 512 : lds + OFF_EXT + (b - 18) * 512); };
+        if constexpr (BF16) {
+          bf16x8 fh[2], fl[2];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_A1 + (t * 64 + lane) * 4);
+          for (int c = 0; c < 2; ++c) split_bf16(feat[c][0], feat[c][1], fh[c], fl[c]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+          for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B0 + 16 * mt + 4 * g);
+            const bf16x8 ah = blk(mt)[lane], al = blk(mt)[64 + lane];
 #pragma unroll
-              for (int c = 0; c < 2; ++c) acc[c] = MFMA(a[e], h[t][c][e], acc[c]);
+            for (int c = 0; c < 2; ++c) h[mt][c] = relu4(mfma_split(ah, al, fh[c], fl[c], b));
+          }
+          const f32x4 b1 = *reinterpret_cast<const f32x4*>(lds + OFF_B1 + 4 * g);
+          f32x4 acc[2] = {b1, b1};
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+            const bf16x8 ah = blk(4 + kb)[lane], al = blk(4 + kb)[64 + lane];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              bf16x8 xh, xl;
+              split_bf16(h[2 * kb][c], h[2 * kb + 1][c], xh, xl);
+              acc[c] = mfma_split(ah, al, xh, xl, acc[c]);
+            }
           }
           o16[0] = acc[0];
           o16[1] = acc[1];
+        } else {
+          // ---- base MLP layer 0: 32 -> 64, ReLU ------------------------------------------------------------------------
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B0 + 16 * mt + 4 * g);
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(lds + OFF_A0 + ((mt * 2 + 0) * 64 + lane) * 4);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(lds + OFF_A0 + ((mt * 2 + 1) * 64 + lane) * 4);
+            f32x4 acc[2] = {b, b};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int c = 0; c < 2; ++c) acc[c] = MFMA(a0[e], feat[c][0][e], acc[c]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int c = 0; c < 2; ++c) acc[c] = MFMA(a1[e], feat[c][1][e], acc[c]);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) h[mt][c] = relu4(acc[c]);
+          }
+          // ---- base MLP layer 1: 64 -> 16 ---------------------------------------------------------------------------------
+          {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B1 + 4 * g);
+            f32x4 acc[2] = {b, b};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_A1 + (t * 64 + lane) * 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[c] = MFMA(a[e], h[t][c][e], acc[c]);
+            }
+            o16[0] = acc[0];
+            o16[1] = acc[1];
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
         const bool mine = (g >> 1) == half;
@@ -335,16 +394,28 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
         }
         // ---- semantics ------------------------------------------------------------------------------------------------------
         float sem_part[2] = {0.f, 0.f};
+        bf16x8 oh[2], ol[2];  // BF16: the 16 base outputs as a K block of 32 (upper half zero)
+        if constexpr (BF16) {
+          const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < 2; ++c) split_bf16(o16[c], zero4, oh[c], ol[c]);
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_BS0 + 16 * mt + 4 * g);
-          const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_AS0 + (mt * 64 + lane) * 4);
           const f32x4 wf = *reinterpret_cast<const f32x4*>(lds + OFF_WF + 16 * mt + 4 * g);
           f32x4 acc[2] = {b, b};
+          if constexpr (BF16) {
+            const bf16x8 ah = blk(6 + mt)[lane], al = blk(6 + mt)[64 + lane];
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
+            for (int c = 0; c < 2; ++c) acc[c] = mfma_split(ah, al, oh[c], ol[c], acc[c]);
+          } else {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_AS0 + (mt * 64 + lane) * 4);
 #pragma unroll
-            for (int c = 0; c < 2; ++c) acc[c] = MFMA(a[e], o16[c][e], acc[c]);
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int c = 0; c < 2; ++c) acc[c] = MFMA(a[e], o16[c][e], acc[c]);
+          }
 #pragma unroll
           for (int c = 0; c < 2; ++c) sem_part[c] = dot4(wf, relu4(acc[c]), sem_part[c]);
         }
@@ -352,30 +423,52 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
         f32x4 c1[4][2];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_AC0 + (mt * 64 + lane) * 4);
           const f32x4 cb = *reinterpret_cast<const f32x4*>(scratch + 16 * mt + 4 * g);
           f32x4 acc[2] = {cb, cb};
+          if constexpr (BF16) {
+            const bf16x8 ah = blk(10 + mt)[lane], al = blk(10 + mt)[64 + lane];
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
+            for (int c = 0; c < 2; ++c) acc[c] = mfma_split(ah, al, oh[c], ol[c], acc[c]);
+          } else {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_AC0 + (mt * 64 + lane) * 4);
 #pragma unroll
-            for (int c = 0; c < 2; ++c) acc[c] = MFMA(a[e], o16[c][e], acc[c]);
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int c = 0; c < 2; ++c) acc[c] = MFMA(a[e], o16[c][e], acc[c]);
+          }
 #pragma unroll
           for (int c = 0; c < 2; ++c) c1[mt][c] = relu4(acc[c]);
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- colour layer 1 + rgb head -------------------------------------------------------------------------------------------
         float rgb_part[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        bf16x8 ch[2][2], cl[2][2];  // BF16: [K block][column tile] operands of colour layer 1
+        if constexpr (BF16) {
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) split_bf16(c1[2 * kb][c], c1[2 * kb + 1][c], ch[kb][c], cl[kb][c]);
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_BC1 + 16 * mt + 4 * g);
           f32x4 acc[2] = {b, b};
+          if constexpr (BF16) {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_AC1 + ((mt * 4 + t) * 64 + lane) * 4);
+            for (int kb = 0; kb < 2; ++kb) {
+              const bf16x8 ah = blk(14 + 2 * mt + kb)[lane], al = blk(14 + 2 * mt + kb)[64 + lane];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+              for (int c = 0; c < 2; ++c) acc[c] = mfma_split(ah, al, ch[kb][c], cl[kb][c], acc[c]);
+            }
+          } else {
 #pragma unroll
-              for (int c = 0; c < 2; ++c) acc[c] = MFMA(a[e], c1[t][c][e], acc[c]);
+            for (int t = 0; t < 4; ++t) {
+              const f32x4 a = *reinterpret_cast<const f32x4*>(lds + OFF_AC1 + ((mt * 4 + t) * 64 + lane) * 4);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) acc[c] = MFMA(a[e], c1[t][c][e], acc[c]);
+            }
           }
           const f32x4 w0 = *reinterpret_cast<const f32x4*>(lds + OFF_WRGB + 0 * 64 + 16 * mt + 4 * g);
           const f32x4 w1 = *reinterpret_cast<const f32x4*>(lds + OFF_WRGB + 1 * 64 + 16 * mt + 4 * g);

@@ -132,7 +132,8 @@ def scene_struct(aabb: Tensor, contraction: bool) -> L.Scene:
 def render_opts(num_samples: int, spacing: int = L.SPACING_UNIFORM, bg_mode: int = L.BG_LAST_SAMPLE,
                 bg_color: Sequence[float] = (0.0, 0.0, 0.0), app_mode: int = L.APP_MEAN, sh_unit_dir: bool = True,
                 eval_clamp: bool = True, density_only: bool = False, image_width: int = 0,
-                pixel_start: int = 0, early_stop_transmittance: float = 0.0) -> L.RenderOpts:
+                pixel_start: int = 0, early_stop_transmittance: float = 0.0,
+                matrix_precision: int = L.MATRIX_FP32) -> L.RenderOpts:
     o = L.RenderOpts()
     o.num_samples = int(num_samples)
     o.spacing = spacing
@@ -146,6 +147,7 @@ def render_opts(num_samples: int, spacing: int = L.SPACING_UNIFORM, bg_mode: int
     o.image_width = int(image_width)
     o.pixel_start = int(pixel_start)
     o.early_stop_transmittance = float(early_stop_transmittance)
+    o.matrix_precision = int(matrix_precision)
     return o
 
 

@@ -53,6 +53,9 @@ typedef void* cn_stream_t; /* hipStream_t */
 #define CN_APP_PER_CAMERA 2
 
 /* background modes of RGBRenderer (fruit_nerf/fruit_nerf.py:170; scripts/semantic_projection.py:158,169) */
+#define CN_MATRIX_FP32 0
+#define CN_MATRIX_SPLIT_BF16 1
+
 #define CN_BG_LAST_SAMPLE 0
 #define CN_BG_COLOR 1
 
@@ -119,6 +122,12 @@ typedef struct cn_render_opts {
    * stop a ray after a 64-sample chunk once the transmittance behind it is below this value; every output
    * then differs from the full result by less than the threshold (times the value range).  0 = off. */
   float early_stop_transmittance;
+  /* Arithmetic of the MLP matrix products, an extension.  CN_MATRIX_FP32 (0, default): exact fp32 products
+   * (v_mfma_f32_16x16x4_f32).  CN_MATRIX_SPLIT_BF16 (1): every operand split into bf16 hi + lo, a.b ~ a_hi.b_hi +
+   * a_hi.b_lo + a_lo.b_hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- about 16 mantissa bits per product,
+   * i.e. between the reference's two own precisions (fp16 with tcnn, fp32 with torch), at a third of the matrix time.
+   * Honoured by the producer/consumer render kernel (batches that fill the device); elsewhere products stay fp32. */
+  int32_t matrix_precision;
 } cn_render_opts;
 
 const char* cn_last_error(void);

@@ -238,7 +238,8 @@ def test_composite_homogeneous_known_answer(ops):
 
 
 # ------------------------------------------------------------------------------------------------ fused renderer
-def _fused_vs_oracle(scene, ops, handles, S, contraction, n_rays, cam, bg_override=None, density_only=False):
+def _fused_vs_oracle(scene, ops, handles, S, contraction, n_rays, cam, bg_override=None, density_only=False,
+                     matrix_precision=0):
     from cropnerf_amd import _lib as L
 
     dp, fh, dh = handles
@@ -250,7 +251,7 @@ def _fused_vs_oracle(scene, ops, handles, S, contraction, n_rays, cam, bg_overri
     ref = m.forward(rb)
     sc = ops.scene_struct(scene.aabb, contraction)
     opts = ops.render_opts(S, bg_mode=L.BG_COLOR if bg_override is not None else L.BG_LAST_SAMPLE,
-                           bg_color=bg_override or (0, 0, 0), density_only=density_only)
+                           bg_color=bg_override or (0, 0, 0), density_only=density_only, matrix_precision=matrix_precision)
     out = ops.render_rays(fh, sc, opts, to_dev(rb.origins), to_dev(rb.directions), to_dev(rb.nears), to_dev(rb.fars),
                           want_weights=True)
     return ref, out
@@ -600,6 +601,31 @@ def test_split_kernel_matches_fused(scene, ops, handles, S, width, monkeypatch):
         else:
             assert_close(outs["1"][k], outs["0"][k], 2e-6, 1e-6, f"split vs fused {k}")
     assert torch.isfinite(outs["1"]["rgb"]).all()
+
+
+@pytest.mark.parametrize("S,contraction", [(192, False), (64, True), (100, False)])
+def test_split_bf16_matrix_option_meets_the_parity_bar(scene, ops, handles, S, contraction, monkeypatch):
+    """cn_render_opts.matrix_precision = CN_MATRIX_SPLIT_BF16: the MLP products on v_mfma_f32_16x16x32_bf16 with operands
+    split into bf16 hi + lo (the lo x lo term dropped, fp32 accumulation).  Held to the SAME bars against the oracle as the
+    exact-fp32 kernels (2e-4 relative + 2e-5); against the fp32 render of the same kernel it is within 5e-5.  The option is
+    honoured by the producer/consumer kernel only (forced here for the small batch): elsewhere it changes nothing."""
+    from cropnerf_amd import _lib as L
+
+    monkeypatch.setenv("CN_FUSED_SPLIT", "2")
+    ref, out = _fused_vs_oracle(scene, ops, handles, S, contraction, 600, 0, matrix_precision=L.MATRIX_SPLIT_BF16)
+    _, exact = _fused_vs_oracle(scene, ops, handles, S, contraction, 600, 0)
+    assert_close(out["weights"], ref["_weights"][..., 0], RTOL, 1e-6, "weights")
+    assert_close(out["accumulation"], ref["accumulation"], RTOL, ATOL, "accumulation")
+    assert_close(out["rgb"], ref["rgb"], RTOL, ATOL, "rgb")
+    assert_close(out["semantics"], ref["semantics"], RTOL, 5e-5, "semantics")
+    _depth_match(out["depth"], ref["depth"])
+    for k in ("rgb", "accumulation", "semantics"):
+        assert_close(out[k], exact[k], 5e-5, 5e-5, f"split-bf16 vs fp32 {k}")
+    assert not torch.equal(out["rgb"], exact["rgb"])       # it really is a different arithmetic
+    monkeypatch.setenv("CN_FUSED_SPLIT", "0")              # single-wave kernel: the option is ignored, products stay fp32
+    _, fused_opt = _fused_vs_oracle(scene, ops, handles, S, contraction, 600, 0, matrix_precision=L.MATRIX_SPLIT_BF16)
+    _, fused = _fused_vs_oracle(scene, ops, handles, S, contraction, 600, 0)
+    assert torch.equal(fused_opt["rgb"], fused["rgb"])
 
 
 @pytest.mark.parametrize("S,contraction", [(70, False), (128, True)])
