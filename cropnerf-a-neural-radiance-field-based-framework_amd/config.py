@@ -109,6 +109,9 @@ class FruitNerfModelConfig:
     # extension (not in the reference, which composites every sample): > 0 stops a ray in eval renders once its
     # transmittance falls below this value; 0 keeps the reference's behaviour
     early_stop_transmittance: float = 0.0
+    # extension: "fp32" = exact fp32 matrix products (default); "split_bf16" = operands as bf16 hi + lo on the bf16 matrix
+    # pipe with fp32 accumulation in the eval renders that fill the device (cn_render_opts.matrix_precision)
+    matrix_precision: str = "fp32"
 
     def field_spec(self, num_images: int) -> FieldSpec:
         # FruitModel.populate_modules forwards only these (fruit_nerf.py:97-112); the rest stay FruitField defaults.

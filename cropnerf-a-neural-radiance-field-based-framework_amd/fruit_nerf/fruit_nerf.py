@@ -224,6 +224,12 @@ class FruitModel:
             return None
         return rb.camera_indices.reshape(-1).to(torch.int64).contiguous()
 
+    def _matrix_precision(self) -> int:
+        mode = getattr(self.config, "matrix_precision", "fp32")
+        if mode not in ("fp32", "split_bf16"):
+            raise ValueError(f"matrix_precision {mode!r}: 'fp32' or 'split_bf16'")
+        return L.MATRIX_SPLIT_BF16 if (mode == "split_bf16" and not self.training) else L.MATRIX_FP32
+
     def _opts(self, num_samples: int, density_only: bool = False) -> L.RenderOpts:
         bg_mode, bg = self._background()
         return ops.render_opts(num_samples, spacing=L.SPACING_UNIFORM, bg_mode=bg_mode, bg_color=bg,
@@ -231,7 +237,8 @@ class FruitModel:
                                eval_clamp=not self.training, density_only=density_only,
                                image_width=self._image_hint[0], pixel_start=self._image_hint[1],
                                early_stop_transmittance=0.0 if self.training else
-                               getattr(self.config, "early_stop_transmittance", 0.0))
+                               getattr(self.config, "early_stop_transmittance", 0.0),
+                               matrix_precision=self._matrix_precision())
 
     def _sample_and_render(self, rb: RayBundle, density_only: bool = False) -> Dict[str, Tensor]:
         """proposal (or uniform) sampler -> field -> renderers, all on device."""

@@ -331,3 +331,23 @@ def test_point_cloud_export_graph_replay_matches_eager_semantics():
     cropped = generate_point_cloud(pipe, num_points=2000, remove_outliers=False, crop_obb=box)
     pts = torch.from_numpy(cropped["points"]).float()
     assert pts.shape[0] >= 2000 and bool(box.within(pts).all())
+
+
+def test_model_matrix_precision_option(scene):
+    """FruitNerfModelConfig.matrix_precision = "split_bf16": a whole-image eval render through the model differs from the
+    exact-fp32 one by less than the parity bar; an unknown value is refused."""
+    pipe = _pipeline(scene, "test")
+    m = pipe.model
+    rb = _cameras(scene).to("cuda").generate_rays(0, keep_shape=True)
+    exact = m.get_outputs_for_camera_ray_bundle(rb)
+    m.config.matrix_precision = "split_bf16"
+    try:
+        fast = m.get_outputs_for_camera_ray_bundle(rb)
+    finally:
+        m.config.matrix_precision = "fp32"
+    for k in ("rgb", "accumulation", "semantics"):
+        assert_close(fast[k], exact[k], 2e-4, 5e-5, k)
+    m.config.matrix_precision = "fp16"
+    with pytest.raises(ValueError):
+        m.get_outputs_for_camera_ray_bundle(rb)
+    m.config.matrix_precision = "fp32"
