@@ -642,6 +642,14 @@ def test_split_kernel_per_sample_outputs_match_fused(scene, ops, handles, S, con
     assert torch.equal(outs["0"]["semantics_colormap"], outs["1"]["semantics_colormap"])
     for k in ("density", "rgb", "semantics", "positions"):
         assert_close(outs["1"][k], outs["0"][k], 2e-6, 1e-6, f"split vs fused per-sample {k}")
+    # the split-bf16 matrix option of the per-sample form (densities are exp(logit): relative bar)
+    from cropnerf_amd import _lib as L
+
+    fast = ops.render_samples(fh, sc, ops.render_opts(S, matrix_precision=L.MATRIX_SPLIT_BF16), o, d, n, f)
+    assert torch.equal(fast["positions"], outs["1"]["positions"])
+    assert_close(fast["density"], outs["1"]["density"], 2e-4, 1e-6, "split-bf16 per-sample density")
+    assert_close(fast["rgb"], outs["1"]["rgb"], 5e-5, 5e-5, "split-bf16 per-sample rgb")
+    assert_close(fast["semantics"], outs["1"]["semantics"], 2e-4, 5e-5, "split-bf16 per-sample semantics")
 
 
 def test_generic_field_kernels_agree(scene, ops, monkeypatch):
