@@ -232,3 +232,28 @@ def test_train_cli_resume_continues_the_same_run(tmp_path):
         # of the atomic sums on rarely-hit entries); a resume that lost the moments or a schedule is off by far more
         assert rel < (0.25 if k.startswith("camera_optimizer") else 5e-2), (k, rel)  # the 12 x 6 pose tweaks are ~1e-4: noisiest
     assert abs(resumed["eval_psnr"] - full["eval_psnr"]) < 1.0
+
+
+def test_auto_downscale_picks_existing_folders(tmp_path):
+    """``_get_fname`` (cotton_nerf_dataparser.py:307-331): with no explicit factor the images are halved while the longer side
+    is >= 1200 px AND the ``images_<2^k>`` folder exists; masks follow into ``images_<k>/../semantics`` by the same rule."""
+    from PIL import Image
+
+    (tmp_path / "images").mkdir()
+    (tmp_path / "images_2").mkdir()
+    (tmp_path / "images_4").mkdir()
+    Image.fromarray(np.zeros((10, 2600, 3), dtype=np.uint8)).save(tmp_path / "images" / "frame_00001.png")
+    for d in ("images_2", "images_4"):
+        Image.fromarray(np.zeros((4, 4, 3), dtype=np.uint8)).save(tmp_path / d / "frame_00001.png")
+    parser = DP.CottonNerfDataParserConfig(data=tmp_path).setup()
+    # 2600 -> 1300 (>= 1200, images_2 exists) -> 650 (< 1200: stop): factor 4
+    assert parser._get_fname(Path("images/frame_00001.png"), tmp_path) == tmp_path / "images_4" / "frame_00001.png"
+    assert parser.downscale_factor == 4
+    # without the images_4 folder the search stops at 2
+    (tmp_path / "images_4" / "frame_00001.png").unlink()
+    parser = DP.CottonNerfDataParserConfig(data=tmp_path).setup()
+    assert parser._get_fname(Path("images/frame_00001.png"), tmp_path).parent.name == "images_2"
+    # small images are used as they are
+    Image.fromarray(np.zeros((10, 800, 3), dtype=np.uint8)).save(tmp_path / "images" / "frame_00001.png")
+    parser = DP.CottonNerfDataParserConfig(data=tmp_path).setup()
+    assert parser._get_fname(Path("images/frame_00001.png"), tmp_path) == tmp_path / "images" / "frame_00001.png"
