@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <mutex>
+
 #include "cn_common.hpp"
 #include "wave_ops.hpp"
 
@@ -494,14 +496,13 @@ extern "C" int cn_field_eval(const cn_field_params* params, const cn_scene* scen
   if (num_rays <= 0) return CN_OK;
   size_t lds = (size_t)(cn::GMAX + 2 * cn::KMAX) * 64 * sizeof(float) + 256 * sizeof(float);
   const size_t lds_mfma = cn::gm::LDS_FLOATS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;  // one-time kernel attributes (the entry points are re-entrant)
+  std::call_once(attr_once, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::field_eval_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::gm::field_eval_mfma_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma);
-    attr_set = true;
-  }
+  });
   // Implementations, fastest first (CN_FIELD_EVAL_IMPL = regw | mfma | scalar forces one; the tests compare them):
   //   regw   weights resident in registers, the two field shapes of the reference's configs (field_regw.hpp)
   //   mfma   any widths <= 128, weights staged through LDS per tile
@@ -511,14 +512,13 @@ extern "C" int cn_field_eval(const cn_field_params* params, const cn_scene* scen
   if (!want || std::strcmp(impl, "regw") == 0) {
     const bool def = cn::rw::regw_shape_matches<15, 2, 64>(*params), big = cn::rw::regw_shape_matches<30, 3, 128>(*params);
     if (def || big) {
-      static bool regw_attr = false;
-      if (!regw_attr) {
+      static std::once_flag regw_once;
+      std::call_once(regw_once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::rw::field_eval_regw_kernel<15, 2, 64>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)cn::rw::LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::rw::field_eval_regw_kernel<30, 3, 128>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)cn::rw::LDS_BYTES);
-        regw_attr = true;
-      }
+      });
       const long long ntiles = (num_rays * (long long)num_samples + cn::rw::TS - 1) / cn::rw::TS;
       const dim3 grid(cn::grid_for(ntiles, 1, 256)), block(cn::rw::NT);
       if (def)

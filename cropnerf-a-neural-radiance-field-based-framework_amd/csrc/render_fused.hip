@@ -680,8 +680,8 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   // scenes (a mix of rays that hit a surface and rays that cross empty space) better -- so it is the default there and
   // CN_FUSED_SPLIT=2 forces the split kernel.
   if (!opts->density_only && split_mode && (PER_SAMPLE || early_stop == 0.f || split_mode > 1)) {
-    static int resident = 0;  // workgroups the device holds at once (a multiple of 8 = XCD teams)
-    if (!resident) {
+    // workgroups the device holds at once (a multiple of 8 = XCD teams); computed once, thread-safely
+    static const int resident = [] {
       int dev = 0, cus = 256, per_cu = 1;
       if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<false, false>),
@@ -695,9 +695,9 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_split_kernel<false, false>, SPLIT_THREADS,
                                                        SPLIT_LDS_BYTES) != hipSuccess || per_cu < 1)
         per_cu = 1;
-      resident = cus * per_cu;
-      resident = resident >= 8 ? (resident / 8) * 8 : 8;
-    }
+      const int r = cus * per_cu;
+      return r >= 8 ? (r / 8) * 8 : 8;
+    }();
     const long long work = PER_SAMPLE ? num_rays * ((opts->num_samples + 63) / 64) : num_rays;  // (ray, chunk) items
     const long long want_s = (((work + SPLIT_PAIRS - 1) / SPLIT_PAIRS) + 7) / 8 * 8;
     // one workgroup per CU carries 8 rays at a time: with fewer rays than that fills the device (the exporters' 512-ray

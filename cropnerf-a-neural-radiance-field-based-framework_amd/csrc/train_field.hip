@@ -21,6 +21,8 @@
 #include <cstring>
 #include <cstdlib>
 
+#include <mutex>
+
 #include "cn_common.hpp"
 #include "wave_ops.hpp"
 
@@ -745,15 +747,14 @@ extern "C" int cn_field_backward(const cn_field_params* params, const cn_field_p
   // kept as an independent device implementation for cross-checks
   const char* impl_env = getenv("CN_FIELD_BACKWARD_IMPL");  // read per call: one process can compare both
   const bool use_scalar = impl_env && std::strcmp(impl_env, "scalar") == 0;
-  static bool attr = false;
-  if (!attr) {
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::field_backward_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)((size_t)cn::FIELD_ROWS * cn::LD * sizeof(float)));
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::mf::field_backward_mfma_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)cn::mf::LDS_BYTES);
-    attr = true;
-  }
+  });
   const long long nsamp = num_rays * (long long)num_samples;
   if (use_scalar) {
     size_t lds = (size_t)cn::FIELD_ROWS * cn::LD * sizeof(float);
