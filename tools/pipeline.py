@@ -32,6 +32,8 @@ def main(a):
     out["held_out_psnr"], out["held_out_fruit_iou"] = fit["held_out_psnr_mean"], fit["held_out_fruit_iou_mean"]
     model, dm = pipe.model, pipe.datamanager
     model.eval()
+    model.config.matrix_precision = a.matrix_precision  # eval renders only; training stays exact fp32
+    out["matrix_precision"] = a.matrix_precision
 
     # --- ns-export semantic point cloud (scripts/exporter.py:80-133): side^2 orthographic rays x side samples
     t = clock()
@@ -106,4 +108,5 @@ if __name__ == "__main__":
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--sem-thresh", type=float, default=3.0)
     ap.add_argument("--den-thresh", type=float, default=70.0)
+    ap.add_argument("--matrix-precision", choices=["fp32", "split_bf16"], default="fp32")
     main(ap.parse_args())
