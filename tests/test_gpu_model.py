@@ -351,3 +351,29 @@ def test_model_matrix_precision_option(scene):
     with pytest.raises(ValueError):
         m.get_outputs_for_camera_ray_bundle(rb)
     m.config.matrix_precision = "fp32"
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the driver's keys plus ``roofline`` and ``cpu_baseline`` (a short run here: few
+    steps, 3 s of CPU baseline, no secondary timings)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-secondary",
+                        "--cpu-baseline-seconds", "3"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "samples/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and 0 < r["frac"] <= 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["peak"] == 8000.0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    assert d["value"] > 1e9 and abs(d["ms_per_step"] * 1e-3 * d["value"] - 65536 * 192) / (65536 * 192) < 1e-6
