@@ -30,9 +30,21 @@ class CropNerfHipError(RuntimeError):
         self.message = message
 
 
+GRID_TORCH, GRID_TCNN = 0, 1  # cn_grid.layout
+TABLE_F32, TABLE_F16 = 0, 1  # cn_grid.table_dtype
+
+
 class Grid(C.Structure):
     _fields_ = [("table", C.c_void_p), ("num_levels", C.c_int32), ("log2_table_size", C.c_int32),
-                ("scalings", C.c_float * CN_MAX_LEVELS)]
+                ("scalings", C.c_float * CN_MAX_LEVELS), ("layout", C.c_int32), ("table_dtype", C.c_int32),
+                ("level_offset", C.c_uint32 * CN_MAX_LEVELS), ("level_bits", C.c_uint8 * CN_MAX_LEVELS)]
+
+
+class TcnnGridPlan(C.Structure):
+    _fields_ = [("num_levels", C.c_int32), ("log2_table_size", C.c_int32), ("base_resolution", C.c_int32),
+                ("per_level_scale", C.c_float), ("scalings", C.c_float * CN_MAX_LEVELS),
+                ("resolution", C.c_uint32 * CN_MAX_LEVELS), ("packed_offset", C.c_uint32 * (CN_MAX_LEVELS + 1)),
+                ("level_offset", C.c_uint32 * (CN_MAX_LEVELS + 1)), ("level_bits", C.c_uint8 * CN_MAX_LEVELS)]
 
 
 class Mlp(C.Structure):
@@ -70,6 +82,12 @@ _I32, _I64, _F = C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
     "cn_last_error": (C.c_char_p, []),
     "cn_version": (C.c_int, []),
+    "cn_tcnn_grid_plan_init": (C.c_int, [_I32, _I32, _I32, _F, C.POINTER(TcnnGridPlan)]),
+    "cn_tcnn_grid_describe": (C.c_int, [C.POINTER(TcnnGridPlan), _P, _I32, C.POINTER(Grid)]),
+    "cn_tcnn_grid_pack": (C.c_int, [C.POINTER(TcnnGridPlan), _P, _I32, _P, _I32, _P]),
+    "cn_tcnn_grid_unpack": (C.c_int, [C.POINTER(TcnnGridPlan), _P, _I32, _P, _I32, _P]),
+    "cn_tcnn_grid_tie_gradients": (C.c_int, [C.POINTER(TcnnGridPlan), _P, _P]),
+    "cn_tcnn_grid_tie_parameters": (C.c_int, [C.POINTER(TcnnGridPlan), _P, _P]),
     "cn_raygen_pinhole": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P]),
     "cn_intersect_aabb": (C.c_int, [_P, _P, C.POINTER(_F), _I64, _P, _P, _P]),
     "cn_raygen_ortho": (C.c_int, [_P, C.POINTER(_F), _I64, _I64, _P, _P, _P, _P, _P, _P]),

@@ -17,28 +17,73 @@ import torch
 
 @dataclass
 class GridSpec:
-    """nerfstudio ``HashEncoding`` hyper-parameters (``fruit_field.py:125-132``)."""
+    """nerfstudio ``HashEncoding`` hyper-parameters (``fruit_field.py:125-132``).
+
+    ``layout`` selects which of the reference's two implementations the table follows (``FruitField``'s
+    ``implementation`` argument, ``fruit_field.py:95``): ``"torch"`` = nerfstudio's torch ``HashEncoding`` (every level
+    hashed, ``[L * 2^k, 2]``), ``"tcnn"`` = tiny-cuda-nn's ``GridEncoding`` geometry (dense coarse levels, +0.5 cell
+    offset) in this library's table layout (``include/cropnerf_hip.h``: ``cn_tcnn_grid_plan``)."""
 
     num_levels: int = 16
     min_res: int = 16
     max_res: int = 2048
     log2_hashmap_size: int = 19
     features_per_level: int = 2
+    layout: str = "torch"
 
     @property
     def table_size(self) -> int:
         return 1 << self.log2_hashmap_size
 
+    def growth(self) -> float:
+        """nerfstudio ``HashEncoding.__init__``: exp((ln max_res - ln min_res) / (L - 1)) in float64."""
+        if self.num_levels <= 1:
+            return 1.0
+        return float(np.exp((np.log(self.max_res) - np.log(self.min_res)) / (self.num_levels - 1)))
+
+    def plan(self):
+        """``cn_tcnn_grid_plan`` of this grid (tcnn layout only); computed by the library (host code, no GPU needed)."""
+        if self.layout != "tcnn":
+            raise ValueError("GridSpec.plan() is defined for layout='tcnn'")
+        key = (self.num_levels, self.min_res, self.max_res, self.log2_hashmap_size)
+        plan = _PLAN_CACHE.get(key)
+        if plan is None:
+            import ctypes as C
+
+            from . import _lib as L
+
+            plan = L.TcnnGridPlan()
+            # tcnn reads "per_level_scale" from its JSON config as a float
+            L.check(L.load().cn_tcnn_grid_plan_init(self.num_levels, self.log2_hashmap_size, self.min_res,
+                                                    float(np.float32(self.growth())), C.byref(plan)))
+            _PLAN_CACHE[key] = plan
+        return plan
+
+    @property
+    def num_entries(self) -> int:
+        """Rows of the hash table."""
+        if self.layout == "tcnn":
+            return int(self.plan().level_offset[self.num_levels])
+        return self.table_size * self.num_levels
+
+    @property
+    def num_packed_entries(self) -> int:
+        """Entries of tcnn's own parameter vector for this grid (``n_params / features_per_level``)."""
+        return int(self.plan().packed_offset[self.num_levels])
+
     def scalings(self) -> List[float]:
-        """floor(min_res * growth**l).  Upstream evaluates ``np.float64 ** int64 Tensor`` through
+        """torch layout: floor(min_res * growth**l).  Upstream evaluates ``np.float64 ** int64 Tensor`` through
         ``Tensor.__rpow__``, i.e. in float32 (default 16..2048 grid: last level 2047, not 2048); reproduced with
-        the same expression."""
+        the same expression.  tcnn layout: grid.h ``grid_scale`` (from the plan)."""
+        if self.layout == "tcnn":
+            p = self.plan()
+            return [float(p.scalings[i]) for i in range(self.num_levels)]
         levels = torch.arange(self.num_levels)
-        growth = (
-            np.exp((np.log(self.max_res) - np.log(self.min_res)) / (self.num_levels - 1))
-            if self.num_levels > 1 else 1.0
-        )
-        return torch.floor(self.min_res * growth ** levels).to(torch.float32).tolist()
+        growth = self.growth() if self.num_levels > 1 else 1.0
+        return torch.floor(self.min_res * np.float64(growth) ** levels).to(torch.float32).tolist()
+
+
+_PLAN_CACHE: Dict[tuple, object] = {}
 
 
 @dataclass
@@ -112,11 +157,18 @@ class FruitNerfModelConfig:
     # extension: "fp32" = exact fp32 matrix products (default); "split_bf16" = operands as bf16 hi + lo on the bf16 matrix
     # pipe with fp32 accumulation in the eval renders that fill the device (cn_render_opts.matrix_precision)
     matrix_precision: str = "fp32"
+    # Which of the reference's two implementations the parameters follow (nerfacto's ``implementation``; FruitField's own
+    # default is "tcnn", fruit_field.py:95).  "torch": nerfstudio's torch HashEncoding / MLP (all levels hashed, biases).
+    # "tcnn": tiny-cuda-nn's grid geometry (dense coarse levels, +0.5 offset), bias-free MLPs (tcnn_params.py) -- the
+    # layout a reference-trained checkpoint has.  hash_table_dtype "float16" stores the tables as tcnn computes with
+    # them (inference only; training keeps float32 masters).
+    implementation: str = "torch"
+    hash_table_dtype: str = "float32"
 
     def field_spec(self, num_images: int) -> FieldSpec:
         # FruitModel.populate_modules forwards only these (fruit_nerf.py:97-112); the rest stay FruitField defaults.
         return FieldSpec(
-            grid=GridSpec(self.num_levels, 16, self.max_res, self.log2_hashmap_size, 2),
+            grid=GridSpec(self.num_levels, 16, self.max_res, self.log2_hashmap_size, 2, self.implementation),
             geo_feat_dim=self.geo_feat_dim, num_layers_semantic=self.num_layers_semantic,
             hidden_dim_semantics=self.hidden_dim_semantics, num_images=num_images,
             use_average_appearance_embedding=self.use_average_appearance_embedding, sh_input=self.sh_input,
@@ -127,7 +179,8 @@ class FruitNerfModelConfig:
         for i in range(self.num_proposal_iterations):
             a = self.proposal_net_args_list[min(i, len(self.proposal_net_args_list) - 1)]
             out.append(ProposalSpec(GridSpec(a["num_levels"], a.get("base_res", 16), a["max_res"],
-                                             a["log2_hashmap_size"], a.get("features_per_level", 2)),
+                                             a["log2_hashmap_size"], a.get("features_per_level", 2),
+                                             self.implementation),
                                     hidden_dim=a["hidden_dim"]))
         return out
 
@@ -136,7 +189,7 @@ def param_shapes(spec: FieldSpec, prop_specs: List[ProposalSpec]) -> Dict[str, T
     """Logical state-dict names -> shapes (``nn.Linear`` layout [out,in]; hash tables [L*T, F])."""
     g = spec.grid
     shapes: Dict[str, Tuple[int, ...]] = {}
-    shapes["field.mlp_base_grid.hash_table"] = (g.table_size * g.num_levels, g.features_per_level)
+    shapes["field.mlp_base_grid.hash_table"] = (g.num_entries, g.features_per_level)
 
     def add_mlp(prefix, in_dim, num_layers, width, out_dim):
         dims = [in_dim] + [width] * (num_layers - 1) + [out_dim]
@@ -154,7 +207,7 @@ def param_shapes(spec: FieldSpec, prop_specs: List[ProposalSpec]) -> Dict[str, T
     shapes["field.embedding_appearance.embedding.weight"] = (spec.num_images, spec.appearance_embedding_dim)
     for i, ps in enumerate(prop_specs):
         pg = ps.grid
-        shapes[f"proposal_networks.{i}.encoding.hash_table"] = (pg.table_size * pg.num_levels, pg.features_per_level)
+        shapes[f"proposal_networks.{i}.encoding.hash_table"] = (pg.num_entries, pg.features_per_level)
         add_mlp(f"proposal_networks.{i}.mlp", pg.num_levels * pg.features_per_level, 2, ps.hidden_dim, 1)
     shapes["camera_optimizer.pose_adjustment"] = (spec.num_images, 6)
     return shapes
@@ -163,11 +216,21 @@ def param_shapes(spec: FieldSpec, prop_specs: List[ProposalSpec]) -> Dict[str, T
 def init_params(spec: FieldSpec, prop_specs: List[ProposalSpec], seed: int = 0, grid_scale: float = 1e-3,
                 device: Union[str, torch.device] = "cpu") -> Dict[str, torch.Tensor]:
     """Random initialisation: hash tables U(-1,1)*grid_scale (reference: 1e-3), Linear layers the ``nn.Linear``
-    default (Kaiming-uniform a=sqrt 5 == U(+-1/sqrt(fan_in)) for weight and bias), embedding N(0,1), pose 0."""
+    default (Kaiming-uniform a=sqrt 5 == U(+-1/sqrt(fan_in)) for weight and bias), embedding N(0,1), pose 0.
+    tcnn layout: the biases a tcnn module cannot hold start (and are kept) at zero, and the caller ties the alias
+    entries of the tables (``ops.tcnn_grid_tie_parameters``; ``FruitModel`` does)."""
     gen = torch.Generator().manual_seed(seed)
     shapes = param_shapes(spec, prop_specs)
+    frozen = set()
+    if spec.grid.layout == "tcnn":
+        from .fruit_nerf.tcnn_params import frozen_parameter_names
+
+        frozen = set(frozen_parameter_names(spec, prop_specs))
     out: Dict[str, torch.Tensor] = {}
     for name, shape in shapes.items():
+        if name in frozen:
+            out[name] = torch.zeros(shape, device=device)
+            continue
         if name.endswith("hash_table"):
             t = (torch.rand(shape, generator=gen) * 2 - 1) * grid_scale
         elif name.endswith("embedding.weight"):

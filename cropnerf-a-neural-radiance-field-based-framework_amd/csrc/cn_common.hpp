@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 #include "../../include/cropnerf_hip.h"
 
@@ -34,6 +35,33 @@ inline int check_launch(const char* what) {
 
 inline hipStream_t as_stream(cn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// One-time, PER-DEVICE kernel setup (hipFuncSetAttribute(MaxDynamicSharedMemorySize), occupancy queries): a process that
+// uses several devices through the C ABI gets the attributes set on each of them, and a failed attribute call surfaces
+// as CN_ERR_LAUNCH with a message instead of a later opaque launch error.  init(device, value) returns a hipError_t.
+constexpr int CN_MAX_DEVICES = 64;
+template <typename T>
+struct PerDevice {
+  std::once_flag once[CN_MAX_DEVICES];
+  hipError_t err[CN_MAX_DEVICES] = {};
+  T value[CN_MAX_DEVICES] = {};
+  template <typename F>
+  int get(F&& init, const T** out, const char* who) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= CN_MAX_DEVICES) {
+      set_error("%s: no current HIP device (%s)", who, hipGetErrorString(e));
+      return CN_ERR_LAUNCH;
+    }
+    std::call_once(once[dev], [&] { err[dev] = init(dev, value[dev]); });
+    if (err[dev] != hipSuccess) {
+      set_error("%s: one-time kernel setup failed on device %d: %s", who, dev, hipGetErrorString(err[dev]));
+      return CN_ERR_LAUNCH;
+    }
+    if (out) *out = &value[dev];
+    return CN_OK;
+  }
+};
+
 inline unsigned grid_for(long long n, int block, long long cap = 1 << 20) {
   long long g = (n + block - 1) / block;
   if (g < 1) g = 1;
@@ -45,22 +73,94 @@ inline unsigned grid_for(long long n, int block, long long cap = 1 << 20) {
 // device helpers
 // ---------------------------------------------------------------------------------------------
 
+#define CN_P1 2654435761u
+#define CN_P2 805459861u
+
+// One level of a grid as the kernels see it.  entry = off + ((hx ^ hy ^ hz) & mask) with hx = ix (+1), hy = iy * m1 (+ m1),
+// hz = iz * m2 (+ m2): for a hashed level m1, m2 are the hash primes and mask = T - 1; for a dense level of the tcnn layout
+// m1 = 2^b, m2 = 2^2b, mask = 2^3b - 1 (disjoint bit fields: the xor IS the sum) -- one expression, no per-level branch.
+struct Lvl {
+  unsigned off, mask, m1, m2;
+  float scale;
+};
+
 struct GridDev {  // by-value kernel argument
-  const float* table;
+  const void* table;
   int num_levels;
-  unsigned mask;      // T-1
-  unsigned level_stride;  // T
+  int half;          // entries are half2 (CN_TABLE_F16) instead of float2
+  float pos_offset;  // cell = floor(x * scale + pos_offset): 0 (nerfstudio torch HashEncoding) or 0.5 (tcnn)
+  unsigned off[CN_MAX_LEVELS], mask[CN_MAX_LEVELS], m1[CN_MAX_LEVELS], m2[CN_MAX_LEVELS];
   float scale[CN_MAX_LEVELS];
+  __host__ __device__ __forceinline__ Lvl level(int l) const {  // l wave-uniform (scalar loads from the kernarg segment)
+    Lvl v;
+    v.off = off[l];
+    v.mask = mask[l];
+    v.m1 = m1[l];
+    v.m2 = m2[l];
+    v.scale = scale[l];
+    return v;
+  }
+  __host__ __device__ __forceinline__ const float* table_f32() const { return static_cast<const float*>(table); }
 };
 
 inline GridDev make_grid_dev(const cn_grid& g) {
   GridDev d;
   d.table = g.table;
   d.num_levels = g.num_levels;
-  d.level_stride = 1u << g.log2_table_size;
-  d.mask = d.level_stride - 1u;
-  for (int i = 0; i < CN_MAX_LEVELS; ++i) d.scale[i] = i < g.num_levels ? g.scalings[i] : 0.f;
+  d.half = g.table_dtype == CN_TABLE_F16;
+  d.pos_offset = g.layout == CN_GRID_TCNN ? 0.5f : 0.f;
+  const unsigned T = 1u << g.log2_table_size;
+  for (int i = 0; i < CN_MAX_LEVELS; ++i) {
+    const bool live = i < g.num_levels;
+    d.scale[i] = live ? g.scalings[i] : 0.f;
+    const int b = (live && g.layout == CN_GRID_TCNN) ? g.level_bits[i] : 0;
+    d.off[i] = !live ? 0u : (g.layout == CN_GRID_TCNN ? g.level_offset[i] : (unsigned)i * T);
+    d.m1[i] = b ? 1u << b : CN_P1;
+    d.m2[i] = b ? 1u << (2 * b) : CN_P2;
+    d.mask[i] = b ? (1u << (3 * b)) - 1u : T - 1u;
+  }
   return d;
+}
+
+// Host-side validation shared by every entry point that takes a cn_grid.  need_f32: kernels that write gradients or
+// were not built for half tables.
+inline int check_grid(const cn_grid& g, bool need_f32, const char* who) {
+  CN_REQUIRE(g.table, CN_ERR_INVALID, "%s: null hash table", who);
+  CN_REQUIRE(g.num_levels >= 1 && g.num_levels <= CN_MAX_LEVELS, CN_ERR_UNSUPPORTED, "%s: %d grid levels", who,
+             g.num_levels);
+  CN_REQUIRE(g.layout == CN_GRID_TORCH || g.layout == CN_GRID_TCNN, CN_ERR_INVALID, "%s: grid layout %d", who, g.layout);
+  CN_REQUIRE(g.table_dtype == CN_TABLE_F32 || g.table_dtype == CN_TABLE_F16, CN_ERR_INVALID, "%s: table dtype %d", who,
+             g.table_dtype);
+  CN_REQUIRE(!need_f32 || g.table_dtype == CN_TABLE_F32, CN_ERR_UNSUPPORTED,
+             "%s: needs an fp32 hash table (half tables are inference-only)", who);
+  CN_REQUIRE(g.log2_table_size >= 1 && g.log2_table_size <= 24, CN_ERR_UNSUPPORTED, "%s: log2 table size %d", who,
+             g.log2_table_size);
+  // every gather address is a 32-bit byte offset from the table base
+  unsigned long long entries = (unsigned long long)g.num_levels << g.log2_table_size;
+  if (g.layout == CN_GRID_TCNN) {
+    entries = 0;
+    for (int l = 0; l < g.num_levels; ++l) {
+      const int b = g.level_bits[l];
+      CN_REQUIRE(b <= 9, CN_ERR_UNSUPPORTED, "%s: dense level %d with %d bits per axis", who, l, b);
+      const unsigned long long end = (unsigned long long)g.level_offset[l] + (b ? 1ull << (3 * b) : 1ull << g.log2_table_size);
+      if (end > entries) entries = end;
+    }
+  }
+  CN_REQUIRE(entries * 8ull <= (1ull << 31), CN_ERR_UNSUPPORTED, "%s: hash table larger than 2 GiB", who);
+  return CN_OK;
+}
+
+// Backward entry points: the gradient table mirrors the parameter table entry for entry, both fp32.
+inline int check_grad_grid(const cn_grid& p, const cn_grid& g, const char* who) {
+  int rc = check_grid(p, true, who);
+  if (rc) return rc;
+  if ((rc = check_grid(g, true, who))) return rc;
+  bool same = p.layout == g.layout && p.num_levels == g.num_levels && p.log2_table_size == g.log2_table_size;
+  if (same && p.layout == CN_GRID_TCNN)
+    for (int l = 0; l < p.num_levels; ++l)
+      same = same && p.level_offset[l] == g.level_offset[l] && p.level_bits[l] == g.level_bits[l];
+  CN_REQUIRE(same, CN_ERR_INVALID, "%s: the gradient table's geometry differs from the parameter table's", who);
+  return CN_OK;
 }
 
 struct SceneDev {
@@ -78,9 +178,6 @@ inline SceneDev make_scene_dev(const cn_scene& s) {
   d.contraction = s.contraction;
   return d;
 }
-
-#define CN_P1 2654435761u
-#define CN_P2 805459861u
 
 // Normalised position + selector (fruit_field.py:171-180).  Returns selector; p is zeroed when deselected.
 // Select-only (no divergent branches): the contraction scale uses one v_rcp_f32 and the AABB normalisation a
@@ -106,33 +203,59 @@ __device__ __forceinline__ bool normalize_position(const SceneDev& sc, float& x,
   return sel;
 }
 
-// One level of the hash grid (HashEncoding.pytorch_fwd): 8 corner gathers of float2 + trilinear blend in the
-// reference's order (x toward the ceil corner, then y, then z).
-// `table` is the wave-uniform base of the whole [L*T,2] table and `level_off` = l*T the (possibly per-lane) level
-// offset in entries: every gather address is base + 32-bit byte offset (global_load saddr+voffset form), so a gather
-// costs one address VGPR and no 64-bit adds.  L*T*8 B <= 2^31 is checked on the host.
-__device__ __forceinline__ float2 hash_gather(const float* __restrict__ table, unsigned entry) {
-  return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(table) + (size_t)(entry << 3));
+// One level of the hash grid: 8 corner gathers of two features + trilinear blend in the order of
+// HashEncoding.pytorch_fwd (x toward the upper corner, then y, then z).  tcnn's kernel_grid sums the same eight
+// weight * value products corner by corner; the results differ in fp32 rounding only.
+// `table` is the wave-uniform base of the whole table and lv.off the (possibly per-lane) level offset in entries: every
+// gather address is base + 32-bit byte offset (global_load saddr+voffset form), so a gather costs one address VGPR and
+// no 64-bit adds.  entries * 8 B <= 2^31 is checked on the host (check_grid).
+template <bool HALF = false>
+__device__ __forceinline__ float2 hash_gather(const void* __restrict__ table, unsigned entry) {
+  if constexpr (HALF) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 v = *reinterpret_cast<const h2*>(reinterpret_cast<const char*>(table) + (size_t)(entry << 2));
+    return make_float2((float)v.x, (float)v.y);
+  } else {
+    return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(table) + (size_t)(entry << 3));
+  }
 }
 
-__device__ __forceinline__ float2 hash_level(const float* __restrict__ table, unsigned level_off, unsigned mask,
-                                             float scale, float px, float py, float pz) {
-  float sx = px * scale, sy = py * scale, sz = pz * scale;
-  float fx = floorf(sx), fy = floorf(sy), fz = floorf(sz);
-  float ox = sx - fx, oy = sy - fy, oz = sz - fz;
-  unsigned ix = (unsigned)(int)fx, iy = (unsigned)(int)fy, iz = (unsigned)(int)fz;
-  // ceil corner: ceil(s) == floor(s)+1 unless s is integral, where its weight (offset) is 0.
-  unsigned hx0 = ix, hx1 = ix + 1u;
-  unsigned hy0 = iy * CN_P1, hy1 = hy0 + CN_P1;
-  unsigned hz0 = iz * CN_P2, hz1 = hz0 + CN_P2;
-  float2 ccc = hash_gather(table, ((hx1 ^ hy1 ^ hz1) & mask) + level_off);  // f_0
-  float2 cfc = hash_gather(table, ((hx1 ^ hy0 ^ hz1) & mask) + level_off);  // f_1
-  float2 ffc = hash_gather(table, ((hx0 ^ hy0 ^ hz1) & mask) + level_off);  // f_2
-  float2 fcc = hash_gather(table, ((hx0 ^ hy1 ^ hz1) & mask) + level_off);  // f_3
-  float2 ccf = hash_gather(table, ((hx1 ^ hy1 ^ hz0) & mask) + level_off);  // f_4
-  float2 cff = hash_gather(table, ((hx1 ^ hy0 ^ hz0) & mask) + level_off);  // f_5
-  float2 fff = hash_gather(table, ((hx0 ^ hy0 ^ hz0) & mask) + level_off);  // f_6
-  float2 fcf = hash_gather(table, ((hx0 ^ hy1 ^ hz0) & mask) + level_off);  // f_7
+// cell coordinates / in-cell offsets / the per-axis index terms of the 8 corners (upper corner = lower + 1: identical to
+// the ceil corner of the torch fallback unless the coordinate is integral, where that corner's weight is 0)
+struct Cell {
+  float ox, oy, oz;
+  unsigned hx0, hx1, hy0, hy1, hz0, hz1;
+};
+__device__ __forceinline__ Cell hash_cell(const Lvl& lv, float pos_offset, float px, float py, float pz) {
+  const float sx = fmaf(px, lv.scale, pos_offset), sy = fmaf(py, lv.scale, pos_offset), sz = fmaf(pz, lv.scale, pos_offset);
+  const float fx = floorf(sx), fy = floorf(sy), fz = floorf(sz);
+  Cell c;
+  c.ox = sx - fx;
+  c.oy = sy - fy;
+  c.oz = sz - fz;
+  const unsigned ix = (unsigned)(int)fx, iy = (unsigned)(int)fy, iz = (unsigned)(int)fz;
+  c.hx0 = ix;
+  c.hx1 = ix + 1u;
+  c.hy0 = iy * lv.m1;
+  c.hy1 = c.hy0 + lv.m1;
+  c.hz0 = iz * lv.m2;
+  c.hz1 = c.hz0 + lv.m2;
+  return c;
+}
+
+template <bool HALF = false>
+__device__ __forceinline__ float2 hash_level(const void* __restrict__ table, const Lvl& lv, float pos_offset, float px,
+                                             float py, float pz) {
+  const Cell k = hash_cell(lv, pos_offset, px, py, pz);
+  const float ox = k.ox, oy = k.oy, oz = k.oz;
+  float2 ccc = hash_gather<HALF>(table, ((k.hx1 ^ k.hy1 ^ k.hz1) & lv.mask) + lv.off);  // f_0
+  float2 cfc = hash_gather<HALF>(table, ((k.hx1 ^ k.hy0 ^ k.hz1) & lv.mask) + lv.off);  // f_1
+  float2 ffc = hash_gather<HALF>(table, ((k.hx0 ^ k.hy0 ^ k.hz1) & lv.mask) + lv.off);  // f_2
+  float2 fcc = hash_gather<HALF>(table, ((k.hx0 ^ k.hy1 ^ k.hz1) & lv.mask) + lv.off);  // f_3
+  float2 ccf = hash_gather<HALF>(table, ((k.hx1 ^ k.hy1 ^ k.hz0) & lv.mask) + lv.off);  // f_4
+  float2 cff = hash_gather<HALF>(table, ((k.hx1 ^ k.hy0 ^ k.hz0) & lv.mask) + lv.off);  // f_5
+  float2 fff = hash_gather<HALF>(table, ((k.hx0 ^ k.hy0 ^ k.hz0) & lv.mask) + lv.off);  // f_6
+  float2 fcf = hash_gather<HALF>(table, ((k.hx0 ^ k.hy1 ^ k.hz0) & lv.mask) + lv.off);  // f_7
   float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
   // The two features of a corner sit in one register pair: blending them as 2-vectors with scalar weights maps onto
   // v_pk_mul_f32 / v_pk_fma_f32 with the weight broadcast by op_sel, with no register shuffling (written per component,
@@ -154,30 +277,72 @@ __device__ __forceinline__ float2 hash_level(const float* __restrict__ table, un
   return r;
 }
 
+// per-lane level record by static selects (a per-lane index into the kernarg arrays would go to scratch)
+__device__ __forceinline__ Lvl lane_level(const GridDev& g, int l) {
+  Lvl v = g.level(0);
+#pragma unroll
+  for (int k = 1; k < CN_MAX_LEVELS; ++k) {
+    const Lvl w = g.level(k);
+    v.off = l == k ? w.off : v.off;
+    v.mask = l == k ? w.mask : v.mask;
+    v.m1 = l == k ? w.m1 : v.m1;
+    v.m2 = l == k ? w.m2 : v.m2;
+    v.scale = l == k ? w.scale : v.scale;
+  }
+  return v;
+}
+
+// level records staged in LDS by a kernel's prologue: rec[0..16) scales, then [16][4] unsigned {off, mask, m1, m2}
+constexpr int LVL_REC_FLOATS = 16 + 64;
+__device__ __forceinline__ void lds_level_fill(float* rec, const GridDev& g, int tid) {
+  if (tid < CN_MAX_LEVELS) {
+    const Lvl v = lane_level(g, tid);
+    rec[tid] = v.scale;
+    unsigned* u = reinterpret_cast<unsigned*>(rec + 16 + 4 * tid);
+    u[0] = v.off;
+    u[1] = v.mask;
+    u[2] = v.m1;
+    u[3] = v.m2;
+  }
+}
+__device__ __forceinline__ Lvl lds_level_rec(const float* rec, int l) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 r = *reinterpret_cast<const u32x4*>(rec + 16 + 4 * l);
+  Lvl lv;
+  lv.off = r.x;
+  lv.mask = r.y;
+  lv.m1 = r.z;
+  lv.m2 = r.w;
+  lv.scale = rec[l];
+  return lv;
+}
+
+// grid dispatching on the table type (wave-uniform branch per level; the hot kernels are templated on it instead)
+__device__ __forceinline__ float2 hash_level_any(const GridDev& g, int l, float px, float py, float pz) {
+  const Lvl lv = g.level(l);
+  return g.half ? hash_level<true>(g.table, lv, g.pos_offset, px, py, pz)
+                : hash_level<false>(g.table, lv, g.pos_offset, px, py, pz);
+}
+
 // The same with the blend written per component.  hipcc then SLP-packs across corners (~18 extra v_mov per level and
 // sample) but also interleaves each level's 8 gathers with the previous level's blend, waiting for them a few at a
 // time -- in the render kernels' gather waves that schedule measures FASTER than the leaner code above (4.9 vs 4.4
 // Gsamples/s at C2; hand-pipelining 16-32 gathers in flight per wave is slower still: 4.2; issuing a unit's 8 gathers
 // together and blending them with the packed form, i.e. the same pacing with fewer instructions: 4.57 vs 4.84), so they
 // keep this form.
-__device__ __forceinline__ float2 hash_level_sc(const float* __restrict__ table, unsigned level_off, unsigned mask,
-                                             float scale, float px, float py, float pz) {
-  float sx = px * scale, sy = py * scale, sz = pz * scale;
-  float fx = floorf(sx), fy = floorf(sy), fz = floorf(sz);
-  float ox = sx - fx, oy = sy - fy, oz = sz - fz;
-  unsigned ix = (unsigned)(int)fx, iy = (unsigned)(int)fy, iz = (unsigned)(int)fz;
-  // ceil corner: ceil(s) == floor(s)+1 unless s is integral, where its weight (offset) is 0.
-  unsigned hx0 = ix, hx1 = ix + 1u;
-  unsigned hy0 = iy * CN_P1, hy1 = hy0 + CN_P1;
-  unsigned hz0 = iz * CN_P2, hz1 = hz0 + CN_P2;
-  float2 ccc = hash_gather(table, ((hx1 ^ hy1 ^ hz1) & mask) + level_off);  // f_0
-  float2 cfc = hash_gather(table, ((hx1 ^ hy0 ^ hz1) & mask) + level_off);  // f_1
-  float2 ffc = hash_gather(table, ((hx0 ^ hy0 ^ hz1) & mask) + level_off);  // f_2
-  float2 fcc = hash_gather(table, ((hx0 ^ hy1 ^ hz1) & mask) + level_off);  // f_3
-  float2 ccf = hash_gather(table, ((hx1 ^ hy1 ^ hz0) & mask) + level_off);  // f_4
-  float2 cff = hash_gather(table, ((hx1 ^ hy0 ^ hz0) & mask) + level_off);  // f_5
-  float2 fff = hash_gather(table, ((hx0 ^ hy0 ^ hz0) & mask) + level_off);  // f_6
-  float2 fcf = hash_gather(table, ((hx0 ^ hy1 ^ hz0) & mask) + level_off);  // f_7
+template <bool HALF = false>
+__device__ __forceinline__ float2 hash_level_sc(const void* __restrict__ table, const Lvl& lv, float pos_offset, float px,
+                                                float py, float pz) {
+  const Cell k = hash_cell(lv, pos_offset, px, py, pz);
+  const float ox = k.ox, oy = k.oy, oz = k.oz;
+  float2 ccc = hash_gather<HALF>(table, ((k.hx1 ^ k.hy1 ^ k.hz1) & lv.mask) + lv.off);  // f_0
+  float2 cfc = hash_gather<HALF>(table, ((k.hx1 ^ k.hy0 ^ k.hz1) & lv.mask) + lv.off);  // f_1
+  float2 ffc = hash_gather<HALF>(table, ((k.hx0 ^ k.hy0 ^ k.hz1) & lv.mask) + lv.off);  // f_2
+  float2 fcc = hash_gather<HALF>(table, ((k.hx0 ^ k.hy1 ^ k.hz1) & lv.mask) + lv.off);  // f_3
+  float2 ccf = hash_gather<HALF>(table, ((k.hx1 ^ k.hy1 ^ k.hz0) & lv.mask) + lv.off);  // f_4
+  float2 cff = hash_gather<HALF>(table, ((k.hx1 ^ k.hy0 ^ k.hz0) & lv.mask) + lv.off);  // f_5
+  float2 fff = hash_gather<HALF>(table, ((k.hx0 ^ k.hy0 ^ k.hz0) & lv.mask) + lv.off);  // f_6
+  float2 fcf = hash_gather<HALF>(table, ((k.hx0 ^ k.hy1 ^ k.hz0) & lv.mask) + lv.off);  // f_7
   float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
   float2 r;
   {

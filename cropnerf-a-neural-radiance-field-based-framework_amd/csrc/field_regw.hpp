@@ -149,7 +149,7 @@ field_eval_regw_kernel(FieldDev fp, SceneDev sc, int app_mode, int sh_unit, cons
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int l = grp + NW * h;
-      const float2 f = hash_level(fp.grid.table, (unsigned)l * fp.grid.level_stride, fp.grid.mask, scl[l], px, py, pz);
+      const float2 f = hash_level_any(fp.grid, l, px, py, pz);
       ENC[(2 * l) * LDA + s] = f.x;
       ENC[(2 * l + 1) * LDA + s] = f.y;
     }

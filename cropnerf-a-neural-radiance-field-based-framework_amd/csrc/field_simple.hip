@@ -73,7 +73,7 @@ __device__ __forceinline__ float* run_mlp(const MlpDev& m, const float* in, floa
 
 __device__ __forceinline__ void encode_grid(const GridDev& g, float px, float py, float pz, float* out, int lane) {
   for (int l = 0; l < g.num_levels; ++l) {
-    float2 f = hash_level(g.table, (unsigned)l * g.level_stride, g.mask, g.scale[l], px, py, pz);
+    float2 f = hash_level_any(g, l, px, py, pz);
     out[(2 * l) * 64 + lane] = f.x;
     out[(2 * l + 1) * 64 + lane] = f.y;
   }
@@ -234,17 +234,7 @@ static int validate_mlp(const cn_mlp& m, const char* name, int in_dim, int out_d
   return CN_OK;
 }
 
-int validate_grid(const cn_grid& g, const char* name) {
-  CN_REQUIRE(g.table, CN_ERR_INVALID, "%s: null hash table", name);
-  CN_REQUIRE(g.num_levels >= 1 && g.num_levels <= CN_MAX_LEVELS, CN_ERR_UNSUPPORTED, "%s: %d levels", name,
-             g.num_levels);
-  CN_REQUIRE(g.log2_table_size >= 1 && g.log2_table_size <= 24, CN_ERR_UNSUPPORTED, "%s: log2_table_size %d", name,
-             g.log2_table_size);
-  // gathers use 32-bit byte offsets from the table base
-  CN_REQUIRE(((unsigned long long)g.num_levels << g.log2_table_size) * 8ull <= (1ull << 31), CN_ERR_UNSUPPORTED,
-             "%s: table larger than 2 GiB", name);
-  return CN_OK;
-}
+int validate_grid(const cn_grid& g, const char* name) { return check_grid(g, false, name); }
 
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -364,7 +354,7 @@ field_eval_mfma_kernel(FieldDev fp, SceneDev sc, int app_mode, int sh_unit, cons
     const bool sel = normalize_position(sc, px, py, pz);
     __syncthreads();  // the previous tile's readers of bufA / bufC are done
     for (int l = grp; l < fp.grid.num_levels && !(debug_skip & 64); l += NW) {
-      const float2 f = hash_level(fp.grid.table, (unsigned)l * fp.grid.level_stride, fp.grid.mask, fp.grid.scale[l], px, py, pz);
+      const float2 f = hash_level_any(fp.grid, l, px, py, pz);
       bufA[(2 * l) * LDA + s] = f.x;
       bufA[(2 * l + 1) * LDA + s] = f.y;
     }
@@ -496,13 +486,24 @@ extern "C" int cn_field_eval(const cn_field_params* params, const cn_scene* scen
   if (num_rays <= 0) return CN_OK;
   size_t lds = (size_t)(cn::GMAX + 2 * cn::KMAX) * 64 * sizeof(float) + 256 * sizeof(float);
   const size_t lds_mfma = cn::gm::LDS_FLOATS * sizeof(float);
-  static std::once_flag attr_once;  // one-time kernel attributes (the entry points are re-entrant)
-  std::call_once(attr_once, [&] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::field_eval_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::gm::field_eval_mfma_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma);
-  });
+  // one-time kernel attributes, per device (the entry points are re-entrant)
+  static cn::PerDevice<int> attrs;
+  rc = attrs.get(
+      [&](int, int&) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cn::field_eval_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(cn::gm::field_eval_mfma_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mfma);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(cn::rw::field_eval_regw_kernel<15, 2, 64>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)cn::rw::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(cn::rw::field_eval_regw_kernel<30, 3, 128>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)cn::rw::LDS_BYTES);
+      },
+      nullptr, "cn_field_eval");
+  if (rc) return rc;
   // Implementations, fastest first (CN_FIELD_EVAL_IMPL = regw | mfma | scalar forces one; the tests compare them):
   //   regw   weights resident in registers, the two field shapes of the reference's configs (field_regw.hpp)
   //   mfma   any widths <= 128, weights staged through LDS per tile
@@ -512,13 +513,6 @@ extern "C" int cn_field_eval(const cn_field_params* params, const cn_scene* scen
   if (!want || std::strcmp(impl, "regw") == 0) {
     const bool def = cn::rw::regw_shape_matches<15, 2, 64>(*params), big = cn::rw::regw_shape_matches<30, 3, 128>(*params);
     if (def || big) {
-      static std::once_flag regw_once;
-      std::call_once(regw_once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::rw::field_eval_regw_kernel<15, 2, 64>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)cn::rw::LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::rw::field_eval_regw_kernel<30, 3, 128>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)cn::rw::LDS_BYTES);
-      });
       const long long ntiles = (num_rays * (long long)num_samples + cn::rw::TS - 1) / cn::rw::TS;
       const dim3 grid(cn::grid_for(ntiles, 1, 256)), block(cn::rw::NT);
       if (def)

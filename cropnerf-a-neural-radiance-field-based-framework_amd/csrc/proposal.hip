@@ -39,13 +39,13 @@ struct PropArgs {
   float* out_depth;  // [num_levels][R]
 };
 
-template <int L, int H>
+template <int L, int H, bool HALF>
 __device__ __forceinline__ float prop_density(const PropNet& n, const SceneDev& sc, float px, float py, float pz) {
   bool sel = normalize_position(sc, px, py, pz);
   float enc[2 * L];
 #pragma unroll
   for (int l = 0; l < L; ++l) {
-    float2 f = hash_level(n.grid.table, (unsigned)l * n.grid.level_stride, n.grid.mask, n.grid.scale[l], px, py, pz);
+    float2 f = hash_level<HALF>(n.grid.table, n.grid.level(l), n.grid.pos_offset, px, py, pz);
     enc[2 * l] = f.x;
     enc[2 * l + 1] = f.y;
   }
@@ -60,12 +60,15 @@ __device__ __forceinline__ float prop_density(const PropNet& n, const SceneDev& 
   return expf(out) * (sel ? 1.f : 0.f);
 }
 
+template <bool HALF>
 __device__ __forceinline__ float prop_density_dispatch(const PropNet& n, const SceneDev& sc, float px, float py,
                                                        float pz) {
-  if (n.grid.num_levels == 5) return prop_density<5, 16>(n, sc, px, py, pz);
-  return prop_density<7, 16>(n, sc, px, py, pz);
+  if (n.grid.num_levels == 5) return prop_density<5, 16, HALF>(n, sc, px, py, pz);
+  return prop_density<7, 16, HALF>(n, sc, px, py, pz);
 }
 
+// HALF: the proposal nets' hash tables hold half2 entries (CN_TABLE_F16)
+template <bool HALF>
 __global__ void __launch_bounds__(256) proposal_sample_kernel(PropArgs A) {
   extern __shared__ __align__(16) float lds[];
   const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -100,7 +103,7 @@ __global__ void __launch_bounds__(256) proposal_sample_kernel(PropArgs A) {
         const float t0 = spacing_to_euclid(CN_SPACING_PIECEWISE, cur[ic], sn, sf);
         const float t1 = spacing_to_euclid(CN_SPACING_PIECEWISE, cur[ic + 1], sn, sf);
         const float mid = (t0 + t1) / 2.f;
-        const float den = prop_density_dispatch(net, A.scene, ox + dx * mid, oy + dy * mid, oz + dz * mid);
+        const float den = prop_density_dispatch<HALF>(net, A.scene, ox + dx * mid, oy + dy * mid, oz + dz * mid);
         const float w = composite_chunk(st, valid, i == S - 1, t1 - t0, den, mid, 0.f, 0.f, 0.f, 0.f, false);
         if (valid) wts[i] = w;
       }
@@ -162,6 +165,8 @@ extern "C" int cn_proposal_sample(const cn_density_params* const* props, int32_t
     CN_REQUIRE(p.mlp.weight[0] && p.mlp.bias[0] && p.mlp.weight[1] && p.mlp.bias[1], CN_ERR_INVALID,
                "cn_proposal_sample: null MLP parameter in net %d", l);
     A.net[l].grid = cn::make_grid_dev(p.grid);
+    CN_REQUIRE(A.net[l].grid.half == A.net[0].grid.half, CN_ERR_UNSUPPORTED,
+               "cn_proposal_sample: the proposal nets' hash tables must share one dtype");
     A.net[l].w0 = p.mlp.weight[0];
     A.net[l].b0 = p.mlp.bias[0];
     A.net[l].w1 = p.mlp.weight[1];
@@ -183,7 +188,11 @@ extern "C" int cn_proposal_sample(const cn_density_params* const* props, int32_t
   A.out_sp = spacing_bins;
   A.out_depth = prop_depth;
   size_t lds = (size_t)4 * (4 * A.smax + 4) * sizeof(float);
-  hipLaunchKernelGGL(cn::proposal_sample_kernel, dim3(cn::grid_for(num_rays, 4, 256 * 8)), dim3(256), lds,
-                     cn::as_stream(stream), A);
+  if (A.net[0].grid.half)
+    hipLaunchKernelGGL(cn::proposal_sample_kernel<true>, dim3(cn::grid_for(num_rays, 4, 256 * 8)), dim3(256), lds,
+                       cn::as_stream(stream), A);
+  else
+    hipLaunchKernelGGL(cn::proposal_sample_kernel<false>, dim3(cn::grid_for(num_rays, 4, 256 * 8)), dim3(256), lds,
+                       cn::as_stream(stream), A);
   return cn::check_launch("cn_proposal_sample");
 }

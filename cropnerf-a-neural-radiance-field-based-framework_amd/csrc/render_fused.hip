@@ -40,7 +40,8 @@ constexpr int OFF_WRGB = 9488;  // [3][64]
 constexpr int OFF_MISC = 9680;  // [0] folded semantic bias, [1..3] rgb bias
 constexpr int OFF_WSH = 9688;   // [64][16] Wc0[:, 0:16]
 constexpr int OFF_SCALE = 10712;  // [16] hash-grid level scalings (lane group g reads [4g, 4g+4))
-constexpr int BLOB_FLOATS = 10712 + 16;
+constexpr int OFF_LVL = 10728;    // [16][4] unsigned: per-level {first entry, index mask, y multiplier, z multiplier} (cn::Lvl)
+constexpr int BLOB_FLOATS = 10728 + 64;
 static_assert(BLOB_FLOATS % 4 == 0, "blob is copied as float4");
 static_assert(OFF_A0 == 0 && OFF_B0 == 18 * 512, "the split-bf16 images reuse the fp32 A-operand region block for block");
 constexpr int WAVE_SCRATCH = 200;  // floats of per-wave LDS scratch: colour bias [64] | 2 x 66 chunk bin edges
@@ -77,7 +78,7 @@ struct PrepArgs {
   int num_images;
   int app_mode;
   int app_rows;
-  float scale[CN_MAX_LEVELS];
+  GridDev grid;  // per-level records of the blob
   int bf16;     // 1: the A-operand region holds split-bf16 images for v_mfma_f32_16x16x32_bf16 (render_split_kernel<.,true>)
   float* ext;   // [BF16_EXT_FLOATS] the four image blocks that do not fit the fp32 region
 };
@@ -191,11 +192,20 @@ __global__ void __launch_bounds__(256) prep_kernel(PrepArgs p, float* __restrict
     } else if (i < OFF_SCALE) {
       int q = i - OFF_WSH;
       v = p.wc0[(q >> 4) * 63 + (q & 15)];
-    } else if (i < BLOB_FLOATS) {
+    } else if (i < OFF_LVL) {
       int q = i - OFF_SCALE;  // static selects: a dynamically indexed kernarg array would go to scratch
-      v = p.scale[0];
+      v = p.grid.scale[0];
 #pragma unroll
-      for (int k = 1; k < CN_MAX_LEVELS; ++k) v = q == k ? p.scale[k] : v;
+      for (int k = 1; k < CN_MAX_LEVELS; ++k) v = q == k ? p.grid.scale[k] : v;
+    } else if (i < BLOB_FLOATS) {
+      const int q = (i - OFF_LVL) >> 2, f = (i - OFF_LVL) & 3;
+      unsigned u = 0u;
+#pragma unroll
+      for (int k = 0; k < CN_MAX_LEVELS; ++k) {
+        const unsigned w = f == 0 ? p.grid.off[k] : (f == 1 ? p.grid.mask[k] : (f == 2 ? p.grid.m1[k] : p.grid.m2[k]));
+        u = q == k ? w : u;
+      }
+      v = __builtin_bit_cast(float, u);
     } else {
       int q = i - BLOB_FLOATS;
       int row = q >> 6, n = q & 63;
@@ -278,7 +288,21 @@ __device__ __forceinline__ float pick4(int g, float a, float b, float c, float d
   return g == 0 ? a : (g == 1 ? b : (g == 2 ? c : d));
 }
 
-template <bool PER_SAMPLE, bool DENSITY_ONLY>
+// per-lane level record from the LDS blob (lane group g owns levels 4g..4g+3)
+__device__ __forceinline__ Lvl lds_level(const float* lds, int level, float scale) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 r = *reinterpret_cast<const u32x4*>(lds + OFF_LVL + 4 * level);
+  Lvl lv;
+  lv.off = r.x;
+  lv.mask = r.y;
+  lv.m1 = r.z;
+  lv.m2 = r.w;
+  lv.scale = scale;
+  return lv;
+}
+
+// HALF: the hash table holds half2 entries (CN_TABLE_F16: 4-byte gathers, 512 algorithmic bytes per sample)
+template <bool PER_SAMPLE, bool DENSITY_ONLY, bool HALF = false>
 __global__ void __launch_bounds__(FUSED_THREADS, CN_FUSED_MIN_WAVES_PER_SIMD) render_fused_kernel(FusedArgs A) {
   __shared__ __align__(16) float lds[BLOB_FLOATS + FUSED_WAVES * WAVE_SCRATCH];
   {
@@ -397,14 +421,13 @@ __global__ void __launch_bounds__(FUSED_THREADS, CN_FUSED_MIN_WAVES_PER_SIMD) re
           const f32x4 lvl_scale = *reinterpret_cast<const f32x4*>(lds + OFF_SCALE + 4 * g);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const unsigned level_off = (unsigned)(4 * g + q) * A.grid.level_stride;
-            const float scale = lvl_scale[q];
+            const Lvl lv = lds_level(lds, 4 * g + q, lvl_scale[q]);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
 #if CN_ABLATE_GATHER  // timing-only build: no table reads (positions still feed the MLP so nothing is dead code)
-              float2 f = make_float2(px[c] * scale, py[c] + pz[c]);
+              float2 f = make_float2(px[c] * lv.scale, py[c] + pz[c]);
 #else
-              float2 f = hash_level_sc(A.grid.table, level_off, A.grid.mask, scale, px[c], py[c], pz[c]);
+              float2 f = hash_level_sc<HALF>(A.grid.table, lv, A.grid.pos_offset, px[c], py[c], pz[c]);
 #endif
               if (q == 0) { feat[c][0].x = f.x; feat[c][0].y = f.y; }
               if (q == 1) { feat[c][0].z = f.x; feat[c][0].w = f.y; }
@@ -626,17 +649,58 @@ static size_t fused_workspace_bytes(const cn_field_params* p) {
   return (size_t)(BLOB_FLOATS + rows * 64 + 32 + BF16_EXT_FLOATS) * sizeof(float);
 }
 
-// Resident blocks of a kernel variant on this device (rounded down to a multiple of 8 = one group per XCD).  A grid
-// larger than the residency would leave a tail running at a fraction of the occupancy.
+// Per-device launch geometry of the render kernels, and the dynamic-LDS attribute of the producer/consumer variants.
+struct FusedDevice {
+  int split_resident;  // workgroups of render_split_kernel the device holds at once (a multiple of 8 = XCD teams)
+  int res_sample, res_density, res_full;  // resident blocks of the render_fused_kernel variants
+};
+
 template <typename K>
-static int resident_blocks(K kernel) {
-  int dev = 0, cus = 256, per_cu = 2;
-  if (hipGetDevice(&dev) != hipSuccess) return 512;
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, FUSED_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 2;
-  int n = cus * per_cu;
-  return n >= 8 ? (n / 8) * 8 : 8;
+static hipError_t resident_blocks(K kernel, int cus, int* out) {
+  // Resident blocks of a kernel variant (rounded down to a multiple of 8 = one group per XCD).  A grid larger than the
+  // residency would leave a tail running at a fraction of the occupancy.
+  int per_cu = 0;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, FUSED_THREADS, 0);
+  if (e != hipSuccess) return e;
+  if (per_cu < 1) per_cu = 1;
+  const int n = cus * per_cu;
+  *out = n >= 8 ? (n / 8) * 8 : 8;
+  return hipSuccess;
 }
+
+template <bool PS, bool BF, bool H>
+static hipError_t split_attr() {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<PS, BF, H>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BF ? SPLIT_LDS_BYTES_BF16 : SPLIT_LDS_BYTES));
+}
+
+static hipError_t fused_device_init(int dev, FusedDevice& d) {
+  int cus = 256;
+  hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (e != hipSuccess) return e;
+#define CN_TRY(x) if ((e = (x)) != hipSuccess) return e
+  CN_TRY((split_attr<false, false, false>()));
+  CN_TRY((split_attr<true, false, false>()));
+  CN_TRY((split_attr<false, true, false>()));
+  CN_TRY((split_attr<true, true, false>()));
+  CN_TRY((split_attr<false, false, true>()));
+  CN_TRY((split_attr<true, false, true>()));
+  CN_TRY((split_attr<false, true, true>()));
+  CN_TRY((split_attr<true, true, true>()));
+  int per_cu = 0;
+  CN_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_split_kernel<false, false, false>, SPLIT_THREADS,
+                                                      SPLIT_LDS_BYTES));
+  if (per_cu < 1) per_cu = 1;
+  const int r = cus * per_cu;
+  d.split_resident = r >= 8 ? (r / 8) * 8 : 8;
+  CN_TRY(resident_blocks(render_fused_kernel<true, false, false>, cus, &d.res_sample));
+  CN_TRY(resident_blocks(render_fused_kernel<false, true, false>, cus, &d.res_density));
+  CN_TRY(resident_blocks(render_fused_kernel<false, false, false>, cus, &d.res_full));
+#undef CN_TRY
+  return hipSuccess;
+}
+
+static PerDevice<FusedDevice> g_fused_devices;
 
 template <bool PER_SAMPLE>
 static int launch_fused(const cn_field_params* params, const cn_scene* scene, const cn_render_opts* opts,
@@ -659,12 +723,16 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
              "%s: matrix_precision %d", who, opts->matrix_precision);
   int rc = check_fused_shape(*params);
   if (rc) return rc;
+  rc = check_grid(params->grid, false, who);
+  if (rc) return rc;
   CN_REQUIRE(workspace && workspace_bytes >= fused_workspace_bytes(params), CN_ERR_WORKSPACE,
              "%s: workspace %zu B < %zu B", who, workspace_bytes, fused_workspace_bytes(params));
   CN_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, CN_ERR_INVALID, "%s: workspace must be 16-B aligned",
              who);
-  if (num_rays <= 0) return CN_OK;
   CN_REQUIRE(num_rays < (1LL << 31), CN_ERR_INVALID, "%s: at most 2^31-1 rays per call", who);
+  const FusedDevice* dev = nullptr;
+  rc = g_fused_devices.get(fused_device_init, &dev, who);
+  if (rc) return rc;
   hipStream_t s = as_stream(stream);
   float* blob = static_cast<float*>(workspace);
   float* app_bias = blob + BLOB_FLOATS;
@@ -680,24 +748,7 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   // scenes (a mix of rays that hit a surface and rays that cross empty space) better -- so it is the default there and
   // CN_FUSED_SPLIT=2 forces the split kernel.
   if (!opts->density_only && split_mode && (PER_SAMPLE || early_stop == 0.f || split_mode > 1)) {
-    // workgroups the device holds at once (a multiple of 8 = XCD teams); computed once, thread-safely
-    static const int resident = [] {
-      int dev = 0, cus = 256, per_cu = 1;
-      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<false, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS_BYTES);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<true, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS_BYTES);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<false, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS_BYTES_BF16);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<true, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS_BYTES_BF16);
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_split_kernel<false, false>, SPLIT_THREADS,
-                                                       SPLIT_LDS_BYTES) != hipSuccess || per_cu < 1)
-        per_cu = 1;
-      const int r = cus * per_cu;
-      return r >= 8 ? (r / 8) * 8 : 8;
-    }();
+    const int resident = dev->split_resident;
     const long long work = PER_SAMPLE ? num_rays * ((opts->num_samples + 63) / 64) : num_rays;  // (ray, chunk) items
     const long long want_s = (((work + SPLIT_PAIRS - 1) / SPLIT_PAIRS) + 7) / 8 * 8;
     // one workgroup per CU carries 8 rays at a time: with fewer rays than that fills the device (the exporters' 512-ray
@@ -706,6 +757,8 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   }
   // split-bf16 matrix products: an option of the producer/consumer kernel only; elsewhere the products stay fp32
   const bool bf16 = opts->matrix_precision == CN_MATRIX_SPLIT_BF16 && split_blocks > 0;
+  A.grid = make_grid_dev(params->grid);
+  const bool half = A.grid.half != 0;
   PrepArgs P;
   P.bf16 = bf16 ? 1 : 0;
   P.ext = blob + BLOB_FLOATS + (size_t)(params->num_images > 0 ? params->num_images : 1) * 64 + 32;
@@ -733,12 +786,11 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   P.emb_mean = emb_mean;
   if (opts->app_mode == CN_APP_MEAN)
     hipLaunchKernelGGL(prep_mean_kernel, dim3(1), dim3(256), 0, s, params->appearance, params->num_images, emb_mean);
-  for (int i = 0; i < CN_MAX_LEVELS; ++i) P.scale[i] = params->grid.scalings[i];
+  P.grid = A.grid;
   hipLaunchKernelGGL(prep_kernel, dim3(48), dim3(256), 0, s, P, blob, app_bias);
   rc = check_launch("cn_render prep");
   if (rc) return rc;
 
-  A.grid = make_grid_dev(params->grid);
   A.scene = make_scene_dev(*scene);
   A.blob = blob;
   A.blob_ext = P.ext;
@@ -768,28 +820,29 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   if (A.stripes_per_xcd < 1) A.stripes_per_xcd = 1;
   A.pixel_start = opts->pixel_start;
   // persistent grid: exactly the resident block count (a multiple of 8 = XCD groups), never more waves than rays
-  static const int res_sample = resident_blocks(render_fused_kernel<true, false>);
-  static const int res_density = resident_blocks(render_fused_kernel<false, true>);
-  static const int res_full = resident_blocks(render_fused_kernel<false, false>);
-  const long long cap = PER_SAMPLE ? res_sample : (opts->density_only ? res_density : res_full);
+  const long long cap = PER_SAMPLE ? dev->res_sample : (opts->density_only ? dev->res_density : dev->res_full);
   const long long want = (((num_rays + FUSED_WAVES - 1) / FUSED_WAVES) + 7) / 8 * 8;
   const unsigned blocks = (unsigned)(want < cap ? want : cap);
   if (split_blocks) {
-    if (bf16)
-      hipLaunchKernelGGL((render_split_kernel<PER_SAMPLE, true>), dim3(split_blocks), dim3(SPLIT_THREADS),
-                         SPLIT_LDS_BYTES_BF16, s, A);
-    else
-      hipLaunchKernelGGL((render_split_kernel<PER_SAMPLE, false>), dim3(split_blocks), dim3(SPLIT_THREADS), SPLIT_LDS_BYTES,
-                         s, A);
+    const size_t lds_bytes = bf16 ? SPLIT_LDS_BYTES_BF16 : SPLIT_LDS_BYTES;
+#define CN_SPLIT_LAUNCH(BF, H) \
+  hipLaunchKernelGGL((render_split_kernel<PER_SAMPLE, BF, H>), dim3(split_blocks), dim3(SPLIT_THREADS), lds_bytes, s, A)
+    if (bf16 && half) CN_SPLIT_LAUNCH(true, true);
+    else if (bf16) CN_SPLIT_LAUNCH(true, false);
+    else if (half) CN_SPLIT_LAUNCH(false, true);
+    else CN_SPLIT_LAUNCH(false, false);
+#undef CN_SPLIT_LAUNCH
     return check_launch(who);
   }
-  if (PER_SAMPLE) {
-    hipLaunchKernelGGL((render_fused_kernel<true, false>), dim3(blocks), dim3(FUSED_THREADS), 0, s, A);
-  } else if (opts->density_only) {
-    hipLaunchKernelGGL((render_fused_kernel<false, true>), dim3(blocks), dim3(FUSED_THREADS), 0, s, A);
-  } else {
-    hipLaunchKernelGGL((render_fused_kernel<false, false>), dim3(blocks), dim3(FUSED_THREADS), 0, s, A);
-  }
+#define CN_FUSED_LAUNCH(PS, DO) \
+  do {                                                                                                         \
+    if (half) hipLaunchKernelGGL((render_fused_kernel<PS, DO, true>), dim3(blocks), dim3(FUSED_THREADS), 0, s, A);  \
+    else hipLaunchKernelGGL((render_fused_kernel<PS, DO, false>), dim3(blocks), dim3(FUSED_THREADS), 0, s, A);      \
+  } while (0)
+  if (PER_SAMPLE) CN_FUSED_LAUNCH(true, false);
+  else if (opts->density_only) CN_FUSED_LAUNCH(false, true);
+  else CN_FUSED_LAUNCH(false, false);
+#undef CN_FUSED_LAUNCH
   return check_launch(who);
 }
 

@@ -152,21 +152,19 @@ __device__ __forceinline__ bool row_run_reduce(unsigned key, float& v0, float& v
 // the camera pose refinement).
 template <bool POS>
 __device__ __forceinline__ void hash_level_backward(float* __restrict__ gtab, const float* __restrict__ table,
-                                                    unsigned level_off, unsigned mask, float scale, float px, float py,
-                                                    float pz, float g0, float g1, int lane, float& dpx, float& dpy,
-                                                    float& dpz) {
-  float sx = px * scale, sy = py * scale, sz = pz * scale;
-  float fx = floorf(sx), fy = floorf(sy), fz = floorf(sz);
-  float ox = sx - fx, oy = sy - fy, oz = sz - fz;
-  unsigned ix = (unsigned)(int)fx, iy = (unsigned)(int)fy, iz = (unsigned)(int)fz;
-  unsigned hx[2] = {ix, ix + 1u};
-  unsigned hy[2] = {iy * CN_P1, iy * CN_P1 + CN_P1};
-  unsigned hz[2] = {iz * CN_P2, iz * CN_P2 + CN_P2};
+                                                    const Lvl& lv, float pos_offset, float px, float py, float pz,
+                                                    float g0, float g1, int lane, float& dpx, float& dpy, float& dpz) {
+  const Cell cell = hash_cell(lv, pos_offset, px, py, pz);
+  const float ox = cell.ox, oy = cell.oy, oz = cell.oz, scale = lv.scale;
+  const unsigned mask = lv.mask, level_off = lv.off;
+  unsigned hx[2] = {cell.hx0, cell.hx1};
+  unsigned hy[2] = {cell.hy0, cell.hy1};
+  unsigned hz[2] = {cell.hz0, cell.hz1};
   float wx[2] = {1.f - ox, ox}, wy[2] = {1.f - oy, oy}, wz[2] = {1.f - oz, oz};  // index 1 = ceil corner
   const int row_lane = lane & 15;
   float ax = 0.f, ay = 0.f, az = 0.f;
-  // The hash xors ix into the low bits, so the two corners of an x-edge lie in one aligned 64-byte segment of the table
-  // unless ix = 7 (mod 8) -- and the memory pipe takes everything ONE instruction sends to one 64-byte segment as ONE
+  // The index xors ix into the low bits (hashed and dense levels alike), so the two corners of an x-edge lie in one
+  // aligned 64-byte segment of the table unless ix = 7 (mod 8) -- and the memory pipe takes everything ONE instruction sends to one 64-byte segment as ONE
   // atomic request, whatever the lanes (tools/atomic_microbench.hip: 21e9 requests/s, the bound of this kernel).  Each
   // atomic instruction therefore serves ONE x-edge of one source lane from FOUR adjacent lanes (entry = lane & 2 ? x1
   // corner : x0 corner, feature = lane & 1); the four source lanes of a quad take turns: 4 requests per sample and
@@ -281,8 +279,7 @@ struct FieldGrads {
 struct FieldBwdArgs {
   FieldPtrs p;
   FieldGrads g;
-  unsigned mask, level_stride;
-  float scale[CN_MAX_LEVELS];
+  GridDev grid;  // geometry of p.table / g.table (fp32 tables)
   SceneDev scene;
   int sh_unit;
   int app_per_camera;
@@ -382,7 +379,7 @@ __global__ void __launch_bounds__(TB) field_backward_kernel(FieldBwdArgs A) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int l = 4 * wave + q;
-        float2 f = hash_level(A.p.table, (unsigned)l * A.level_stride, A.mask, A.scale[l], px, py, pz);
+        float2 f = hash_level(A.p.table, A.grid.level(l), A.grid.pos_offset, px, py, pz);
         enc[(2 * l) * LD + lane] = f.x;
         enc[(2 * l + 1) * LD + lane] = f.y;
       }
@@ -470,7 +467,7 @@ __global__ void __launch_bounds__(TB) field_backward_kernel(FieldBwdArgs A) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int l = 4 * wave + q;
-          hash_level_backward<true>(A.g.table, A.p.table, (unsigned)l * A.level_stride, A.mask, A.scale[l], px, py, pz,
+          hash_level_backward<true>(A.g.table, A.p.table, A.grid.level(l), A.grid.pos_offset, px, py, pz,
                                     valid ? dA[(2 * l) * LD + lane] : 0.f, valid ? dA[(2 * l + 1) * LD + lane] : 0.f,
                                     lane, gpx, gpy, gpz);
         }
@@ -481,7 +478,7 @@ __global__ void __launch_bounds__(TB) field_backward_kernel(FieldBwdArgs A) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int l = 4 * wave + q;
-          hash_level_backward<false>(A.g.table, A.p.table, (unsigned)l * A.level_stride, A.mask, A.scale[l], px, py, pz,
+          hash_level_backward<false>(A.g.table, A.p.table, A.grid.level(l), A.grid.pos_offset, px, py, pz,
                                      valid ? dA[(2 * l) * LD + lane] : 0.f, valid ? dA[(2 * l + 1) * LD + lane] : 0.f,
                                      lane, gpx, gpy, gpz);
         }
@@ -545,8 +542,7 @@ struct PropBwdArgs {
   const float* table;
   const float *w0, *b0, *w1, *b1;
   float *g_table, *g_w0, *g_b0, *g_w1, *g_b1;
-  unsigned mask, level_stride;
-  float scale[CN_MAX_LEVELS];
+  GridDev grid;
   SceneDev scene;
   const float *origins, *directions, *starts, *ends, *d_density;
   float* d_pos;  // optional [R*S,3]
@@ -596,7 +592,7 @@ __global__ void __launch_bounds__(TB) proposal_backward_kernel(PropBwdArgs A) {
     }
     __syncthreads();
     for (int l = wave; l < L; l += 4) {
-      float2 f = hash_level(A.table, (unsigned)l * A.level_stride, A.mask, A.scale[l], misc[lane], misc[LD + lane],
+      float2 f = hash_level(A.table, A.grid.level(l), A.grid.pos_offset, misc[lane], misc[LD + lane],
                             misc[2 * LD + lane]);
       enc[(2 * l) * LD + lane] = f.x;
       enc[(2 * l + 1) * LD + lane] = f.y;
@@ -630,11 +626,11 @@ __global__ void __launch_bounds__(TB) proposal_backward_kernel(PropBwdArgs A) {
       }
       if (A.debug_skip & 8) continue;
       if (A.d_pos)
-        hash_level_backward<true>(A.g_table, A.table, (unsigned)l * A.level_stride, A.mask, A.scale[l], misc[lane],
+        hash_level_backward<true>(A.g_table, A.table, A.grid.level(l), A.grid.pos_offset, misc[lane],
                                   misc[LD + lane], misc[2 * LD + lane], valid ? g0 : 0.f, valid ? g1 : 0.f, lane, gpx,
                                   gpy, gpz);
       else
-        hash_level_backward<false>(A.g_table, A.table, (unsigned)l * A.level_stride, A.mask, A.scale[l], misc[lane],
+        hash_level_backward<false>(A.g_table, A.table, A.grid.level(l), A.grid.pos_offset, misc[lane],
                                    misc[LD + lane], misc[2 * LD + lane], valid ? g0 : 0.f, valid ? g1 : 0.f, lane, gpx,
                                    gpy, gpz);
     }
@@ -694,8 +690,7 @@ extern "C" int cn_field_backward(const cn_field_params* params, const cn_field_p
   if ((rc = cn::validate_field(*grads))) return rc;
   CN_REQUIRE(cn::is_default_field_shape(*params) && cn::is_default_field_shape(*grads), CN_ERR_UNSUPPORTED,
              "cn_field_backward is built for the default fruit_nerf_method field shape");
-  CN_REQUIRE(grads->grid.log2_table_size == params->grid.log2_table_size, CN_ERR_INVALID,
-             "cn_field_backward: gradient table size differs");
+  if ((rc = cn::check_grad_grid(params->grid, grads->grid, "cn_field_backward"))) return rc;
   if (num_rays <= 0) return CN_OK;
   cn::FieldBwdArgs A{};
   auto fill = [](auto& dst, const cn_field_params& s) {
@@ -720,9 +715,7 @@ extern "C" int cn_field_backward(const cn_field_params* params, const cn_field_p
   };
   fill(A.p, *params);
   fill(A.g, *grads);
-  A.level_stride = 1u << params->grid.log2_table_size;
-  A.mask = A.level_stride - 1u;
-  for (int i = 0; i < CN_MAX_LEVELS; ++i) A.scale[i] = params->grid.scalings[i];
+  A.grid = cn::make_grid_dev(params->grid);
   A.scene = cn::make_scene_dev(*scene);
   A.sh_unit = sh_unit_dir;
   A.app_per_camera = app_mode == CN_APP_PER_CAMERA;
@@ -747,14 +740,18 @@ extern "C" int cn_field_backward(const cn_field_params* params, const cn_field_p
   // kept as an independent device implementation for cross-checks
   const char* impl_env = getenv("CN_FIELD_BACKWARD_IMPL");  // read per call: one process can compare both
   const bool use_scalar = impl_env && std::strcmp(impl_env, "scalar") == 0;
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::field_backward_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)((size_t)cn::FIELD_ROWS * cn::LD * sizeof(float)));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::mf::field_backward_mfma_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)cn::mf::LDS_BYTES);
-  });
+  static cn::PerDevice<int> attrs;  // one-time kernel attributes, per device
+  rc = attrs.get(
+      [](int, int&) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cn::field_backward_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)((size_t)cn::FIELD_ROWS * cn::LD * sizeof(float)));
+        if (e != hipSuccess) return e;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(cn::mf::field_backward_mfma_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)cn::mf::LDS_BYTES);
+      },
+      nullptr, "cn_field_backward");
+  if (rc) return rc;
   const long long nsamp = num_rays * (long long)num_samples;
   if (use_scalar) {
     size_t lds = (size_t)cn::FIELD_ROWS * cn::LD * sizeof(float);
@@ -775,7 +772,7 @@ extern "C" int cn_proposal_backward(const cn_density_params* params, const cn_de
                                     int32_t num_samples, float* d_positions, cn_stream_t stream) {
   CN_REQUIRE(params && grads && scene && origins && directions && starts && ends && d_density, CN_ERR_INVALID,
              "cn_proposal_backward: null argument");
-  int rc = cn::validate_grid(params->grid, "proposal grid");
+  int rc = cn::check_grad_grid(params->grid, grads->grid, "cn_proposal_backward");
   if (rc) return rc;
   const int L = params->grid.num_levels;
   bool ok = (L == 5 || L == 7) && params->mlp.num_layers == 2 && params->mlp.dims[0] == 2 * L &&
@@ -787,19 +784,17 @@ extern "C" int cn_proposal_backward(const cn_density_params* params, const cn_de
              CN_ERR_INVALID, "cn_proposal_backward: null gradient buffer");
   if (num_rays <= 0) return CN_OK;
   cn::PropBwdArgs A{};
-  A.table = params->grid.table;
+  A.table = static_cast<const float*>(params->grid.table);
   A.w0 = params->mlp.weight[0];
   A.b0 = params->mlp.bias[0];
   A.w1 = params->mlp.weight[1];
   A.b1 = params->mlp.bias[1];
-  A.g_table = const_cast<float*>(grads->grid.table);
+  A.g_table = static_cast<float*>(const_cast<void*>(grads->grid.table));
   A.g_w0 = const_cast<float*>(grads->mlp.weight[0]);
   A.g_b0 = const_cast<float*>(grads->mlp.bias[0]);
   A.g_w1 = const_cast<float*>(grads->mlp.weight[1]);
   A.g_b1 = const_cast<float*>(grads->mlp.bias[1]);
-  A.level_stride = 1u << params->grid.log2_table_size;
-  A.mask = A.level_stride - 1u;
-  for (int i = 0; i < CN_MAX_LEVELS; ++i) A.scale[i] = params->grid.scalings[i];
+  A.grid = cn::make_grid_dev(params->grid);
   A.scene = cn::make_scene_dev(*scene);
   A.origins = origins;
   A.directions = directions;
@@ -871,8 +866,7 @@ extern "C" int cn_field_backward_general(const cn_field_params* params, const cn
   if ((rc = cn::validate_field(*grads))) return rc;
   CN_REQUIRE(cn::general_family_ok(*params), CN_ERR_UNSUPPORTED,
              "cn_field_backward_general: base 2 layers, semantics 2-3 layers, colour 3 layers, widths <= 128");
-  CN_REQUIRE(grads->grid.log2_table_size == params->grid.log2_table_size, CN_ERR_INVALID,
-             "cn_field_backward_general: gradient table size differs");
+  if ((rc = cn::check_grad_grid(params->grid, grads->grid, "cn_field_backward_general"))) return rc;
   if (num_rays <= 0) return CN_OK;
   const int nblk = cn::general_blocks();
   const int ppb = (cn::general_param_count(*params) + 3) / 4 * 4;
@@ -934,22 +928,20 @@ extern "C" int cn_field_backward_general(const cn_field_params* params, const cn
   A.r_drgb = take(16);
   A.r_dsem = take(16);
   A.rows = rows;
-  const size_t lds = ((size_t)rows * cn::gb::LDG + 16) * sizeof(float);
+  const size_t lds = ((size_t)rows * cn::gb::LDG + cn::LVL_REC_FLOATS) * sizeof(float);
   CN_REQUIRE(lds <= 160 * 1024, CN_ERR_UNSUPPORTED,
              "cn_field_backward_general: the activations of one 32-sample tile need %zu B of LDS (max 163840)", lds);
-  A.table = params->grid.table;
-  A.g_table = const_cast<float*>(grads->grid.table);
+  A.table = static_cast<const float*>(params->grid.table);
+  A.g_table = static_cast<float*>(const_cast<void*>(grads->grid.table));
   A.emb = params->appearance;
   A.g_emb = const_cast<float*>(grads->appearance);
   A.app_mean = app_mode == CN_APP_MEAN ? app_mean : nullptr;
-  A.level_stride = 1u << params->grid.log2_table_size;
-  A.mask = A.level_stride - 1u;
+  A.grid = cn::make_grid_dev(params->grid);
   A.num_levels = params->grid.num_levels;
   A.geo = params->geo_feat_dim;
   A.app_dim = params->app_dim;
   A.app_per_camera = app_mode == CN_APP_PER_CAMERA;
   A.sh_unit = sh_unit_dir;
-  for (int i = 0; i < CN_MAX_LEVELS; ++i) A.scale[i] = params->grid.scalings[i];
   A.scene = cn::make_scene_dev(*scene);
   A.origins = origins;
   A.directions = directions;
@@ -964,8 +956,10 @@ extern "C" int cn_field_backward_general(const cn_field_params* params, const cn
   A.R = num_rays;
   A.S = num_samples;
   CN_REQUIRE(A.g_table && (!A.app_per_camera || A.g_emb), CN_ERR_INVALID, "cn_field_backward_general: null gradient buffer");
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(cn::gb::field_backward_general_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // (the LDS need depends on the field shape, so the attribute is set per call: cheap, and correct on every device)
+  CN_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(cn::gb::field_backward_general_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+             CN_ERR_LAUNCH, "cn_field_backward_general: hipFuncSetAttribute(MaxDynamicSharedMemorySize, %zu) failed", lds);
   CN_REQUIRE(hipMemsetAsync(workspace, 0, (size_t)nblk * ppb * sizeof(float), s) == hipSuccess, CN_ERR_LAUNCH,
              "cn_field_backward_general: hipMemsetAsync failed");
   const long long ntiles = (num_rays * (long long)num_samples + cn::gb::TSG - 1) / cn::gb::TSG;

@@ -40,9 +40,8 @@ struct GenArgs {
   const float* emb;
   float* g_emb;
   const float* app_mean;
-  unsigned mask, level_stride;
+  GridDev grid;
   int num_levels, geo, app_dim, app_per_camera, sh_unit;
-  float scale[CN_MAX_LEVELS];
   SceneDev scene;
   const float *origins, *directions, *starts, *ends;
   const int64_t* cam_idx;
@@ -166,8 +165,8 @@ __global__ void __launch_bounds__(NTG) field_backward_general_kernel(GenArgs A) 
   extern __shared__ __align__(16) float lds[];
   const int tid = threadIdx.x;
   for (int e = tid; e < A.rows * LDG; e += NTG) lds[e] = 0.f;
-  float* SCL = lds + A.rows * LDG;  // level scales (a per-lane index into the kernarg array would go to scratch)
-  if (tid < CN_MAX_LEVELS) SCL[tid] = A.scale[tid];
+  float* SCL = lds + A.rows * LDG;  // level records (a per-lane index into the kernarg arrays would go to scratch)
+  lds_level_fill(SCL, A.grid, tid);
   __syncthreads();
   float* ENC = lds + A.r_enc * LDG;
   float* H1 = lds + A.r_h1 * LDG;
@@ -202,7 +201,7 @@ __global__ void __launch_bounds__(NTG) field_backward_general_kernel(GenArgs A) 
     const float self = normalize_position(A.scene, px, py, pz) ? 1.f : 0.f;
     // ---- inputs ---------------------------------------------------------------------------------------------------------
     for (int l = grp; l < A.num_levels; l += 16) {
-      const float2 f = hash_level(A.table, (unsigned)l * A.level_stride, A.mask, SCL[l], px, py, pz);
+      const float2 f = hash_level(A.table, lds_level_rec(SCL, l), A.grid.pos_offset, px, py, pz);
       ENC[(2 * l) * LDG + s] = f.x;
       ENC[(2 * l + 1) * LDG + s] = f.y;
     }
@@ -350,10 +349,10 @@ __global__ void __launch_bounds__(NTG) field_backward_general_kernel(GenArgs A) 
       const int lc = on ? l : 0;
       const float g0 = on && valid ? DB[(2 * lc) * LDG + s] : 0.f, g1 = on && valid ? DB[(2 * lc + 1) * LDG + s] : 0.f;
       if (A.d_pos)
-        hash_level_backward<true>(A.g_table, A.table, (unsigned)lc * A.level_stride, A.mask, SCL[lc], px, py, pz, g0, g1,
+        hash_level_backward<true>(A.g_table, A.table, lds_level_rec(SCL, lc), A.grid.pos_offset, px, py, pz, g0, g1,
                                   lane, gpx, gpy, gpz);
       else
-        hash_level_backward<false>(A.g_table, A.table, (unsigned)lc * A.level_stride, A.mask, SCL[lc], px, py, pz, g0,
+        hash_level_backward<false>(A.g_table, A.table, lds_level_rec(SCL, lc), A.grid.pos_offset, px, py, pz, g0,
                                    g1, lane, gpx, gpy, gpz);
     }
     if (A.d_pos) {  // per-group partials -> LDS (DA is dead by now) -> one thread per sample sums the 16 groups

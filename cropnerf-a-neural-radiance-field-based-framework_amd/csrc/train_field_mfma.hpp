@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
     lds[B_C0 + e] = A.p.bc0[e];
     lds[B_C1 + e] = A.p.bc1[e];
     if (e < 16) lds[B_1 + e] = A.p.b1[e];
-    if (e < 16) lds[T_SCALE + e] = A.scale[e];
+    if (e < 16) lds[T_SCALE + e] = A.grid.scale[e];
     if (e < 3) lds[B_RGB + e] = A.p.bc2[e];
   }
   __syncthreads();
@@ -238,6 +238,7 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
   float b_o16 = 0.f, b_rgb[3] = {0.f, 0.f, 0.f}, b_sem = 0.f;
 
   const int s = tid & 31, lvl = tid >> 5;  // gather / scatter role: one (sample, level) per thread
+  const Lvl my_lv = lane_level(A.grid, lvl);
   const long long total = A.R * (long long)A.S;
   const long long ntiles = (total + TSM - 1) / TSM;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -253,7 +254,7 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
     float px = wx, py = wy, pz = wz;
     const float self = normalize_position(A.scene, px, py, pz) ? 1.f : 0.f;
     {
-      const float2 f = hash_level(A.p.table, (unsigned)lvl * A.level_stride, A.mask, lds[T_SCALE + lvl], px, py, pz);
+      const float2 f = hash_level(A.p.table, my_lv, A.grid.pos_offset, px, py, pz);
       ENC[(2 * lvl) * LDA + s] = f.x;
       ENC[(2 * lvl + 1) * LDA + s] = f.y;
     }
@@ -435,11 +436,11 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
     if (!(A.debug_skip & 1)) {
       const float g0 = valid ? D1[(2 * lvl) * LDA + s] : 0.f, g1 = valid ? D1[(2 * lvl + 1) * LDA + s] : 0.f;
       if (A.d_pos)
-        hash_level_backward<true>(A.g.table, A.p.table, (unsigned)lvl * A.level_stride, A.mask, lds[T_SCALE + lvl], px, py, pz,
+        hash_level_backward<true>(A.g.table, A.p.table, my_lv, A.grid.pos_offset, px, py, pz,
                                   g0, g1, lane, gpx, gpy, gpz);
       else
-        hash_level_backward<false>(A.g.table, A.p.table, (unsigned)lvl * A.level_stride, A.mask, lds[T_SCALE + lvl], px, py,
-                                   pz, g0, g1, lane, gpx, gpy, gpz);
+        hash_level_backward<false>(A.g.table, A.p.table, my_lv, A.grid.pos_offset, px, py, pz, g0, g1, lane, gpx,
+                                   gpy, gpz);
     }
     if (A.d_pos) {
       // per-level partials -> LDS (the branch buffers are dead by now) -> one thread per sample sums the 16 levels

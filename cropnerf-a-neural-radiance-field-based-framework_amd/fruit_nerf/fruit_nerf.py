@@ -104,13 +104,24 @@ class FruitModel:
         self.field_spec = cfg.field_spec(self.num_train_data)
         self.proposal_specs = cfg.proposal_specs()
         shapes = param_shapes(self.field_spec, self.proposal_specs)
+        table_dtype = {"float32": torch.float32, "float16": torch.float16}[cfg.hash_table_dtype]
         if self._given_params is not None:
-            params = {k: v.to(self.device, torch.float32).contiguous() for k, v in self._given_params.items()}
+            # hash tables keep a half dtype (the values tcnn computes with); everything else is float32
+            params = {k: v.to(self.device, v.dtype if k.endswith("hash_table") and v.dtype == torch.float16
+                              else torch.float32).contiguous() for k, v in self._given_params.items()}
             for k, shp in shapes.items():
                 if tuple(params[k].shape) != tuple(shp):
                     raise ValueError(f"parameter {k}: shape {tuple(params[k].shape)} != {tuple(shp)}")
         else:
             params = init_params(self.field_spec, self.proposal_specs, seed=self._seed, device=self.device)
+            if cfg.implementation == "tcnn":  # several table entries stand for one tcnn parameter: make them agree
+                ops.tcnn_grid_tie_parameters(self.field_spec.grid, params["field.mlp_base_grid.hash_table"])
+                for i, ps in enumerate(self.proposal_specs):
+                    ops.tcnn_grid_tie_parameters(ps.grid, params[f"proposal_networks.{i}.encoding.hash_table"])
+            if table_dtype != torch.float32:
+                for k in list(params):
+                    if k.endswith("hash_table"):
+                        params[k] = params[k].to(table_dtype)
         self.params = params
         self.field = ops.FieldHandle(params, self.field_spec)
         self.proposal_networks = [ops.DensityHandle(params, i, ps) for i, ps in enumerate(self.proposal_specs)]

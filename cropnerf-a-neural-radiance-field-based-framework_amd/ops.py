@@ -54,18 +54,62 @@ def _farr(vals: Sequence[float]):
 # parameter handles
 # --------------------------------------------------------------------------------------------------------------
 
+def _table_dtype(table: Tensor, name: str = "hash_table") -> int:
+    if not table.is_cuda or not table.is_contiguous() or table.dtype not in (torch.float32, torch.float16):
+        raise TypeError(f"{name}: expected a contiguous float32 / float16 device tensor, got {table.dtype} {table.device}")
+    return L.TABLE_F32 if table.dtype == torch.float32 else L.TABLE_F16
+
+
 def _grid_struct(table: Tensor, spec: GridSpec) -> L.Grid:
-    _f32(table, "hash_table")
-    if tuple(table.shape) != (spec.table_size * spec.num_levels, 2):
-        raise ValueError(f"hash table shape {tuple(table.shape)} != {(spec.table_size * spec.num_levels, 2)}")
+    dtype = _table_dtype(table)
+    if tuple(table.shape) != (spec.num_entries, 2):
+        raise ValueError(f"hash table shape {tuple(table.shape)} != {(spec.num_entries, 2)} (layout {spec.layout})")
     g = L.Grid()
+    if spec.layout == "tcnn":
+        plan = spec.plan()
+        L.check(L.load().cn_tcnn_grid_describe(C.byref(plan), C.c_void_p(table.data_ptr()), dtype, C.byref(g)))
+        return g
     g.table = table.data_ptr()
     g.num_levels = spec.num_levels
     g.log2_table_size = spec.log2_hashmap_size
+    g.layout = L.GRID_TORCH
+    g.table_dtype = dtype
     sc = spec.scalings()
     for i in range(L.CN_MAX_LEVELS):
         g.scalings[i] = sc[i] if i < len(sc) else 0.0
     return g
+
+
+def tcnn_grid_pack(spec: GridSpec, packed: Tensor, table_dtype: torch.dtype = torch.float16) -> Tensor:
+    """tcnn's parameter vector of one grid (``[n_params]``, float32 master copy or float16) -> this library's table."""
+    plan = spec.plan()
+    pd = _table_dtype(packed, "packed tcnn parameters")
+    if packed.numel() != 2 * spec.num_packed_entries:
+        raise ValueError(f"tcnn grid parameter count {packed.numel()} != {2 * spec.num_packed_entries}")
+    table = torch.empty(spec.num_entries, 2, dtype=table_dtype, device=packed.device)
+    L.check(L.load().cn_tcnn_grid_pack(C.byref(plan), _p(packed), pd, _p(table), _table_dtype(table), _stream(packed)))
+    return table
+
+
+def tcnn_grid_unpack(spec: GridSpec, table: Tensor, packed_dtype: torch.dtype = torch.float32) -> Tensor:
+    plan = spec.plan()
+    if tuple(table.shape) != (spec.num_entries, 2):
+        raise ValueError(f"hash table shape {tuple(table.shape)} != {(spec.num_entries, 2)}")
+    packed = torch.empty(2 * spec.num_packed_entries, dtype=packed_dtype, device=table.device)
+    L.check(L.load().cn_tcnn_grid_unpack(C.byref(plan), _p(table), _table_dtype(table), _p(packed),
+                                         _table_dtype(packed, "packed"), _stream(table)))
+    return packed
+
+
+def tcnn_grid_tie_gradients(spec: GridSpec, grad_table: Tensor) -> None:
+    """Fold the gradients of alias entries into the entries that own the tcnn parameter (in place)."""
+    L.check(L.load().cn_tcnn_grid_tie_gradients(C.byref(spec.plan()), _p(_f32(grad_table, "grad_table")),
+                                                _stream(grad_table)))
+
+
+def tcnn_grid_tie_parameters(spec: GridSpec, table: Tensor) -> None:
+    """Copy every tcnn parameter of the dense levels into its alias entries (in place, after an optimiser step)."""
+    L.check(L.load().cn_tcnn_grid_tie_parameters(C.byref(spec.plan()), _p(_f32(table, "table")), _stream(table)))
 
 
 def _mlp_struct(params: Dict[str, Tensor], prefix: str, num_layers: int) -> L.Mlp:

@@ -17,8 +17,8 @@
  *   - `stream` is a hipStream_t passed as void*; work is enqueued, never synchronised.
  *   - re-entrant; no global mutable state.  One process per GPU for multi-GPU use.
  *   - layouts: rays SoA [R,3]/[R,1] row-major; samples [R,S]; weights of Linear layers in
- *     torch.nn.Linear layout [out,in]; hash tables in nerfstudio torch HashEncoding layout
- *     [num_levels * 2^log2_T, 2], level-major.
+ *     torch.nn.Linear layout [out,in]; hash tables [entries, 2] in one of the two layouts of cn_grid (nerfstudio torch
+ *     HashEncoding: [num_levels * 2^log2_T, 2] level-major; or the tcnn-compatible layout of cn_tcnn_grid_plan).
  */
 #ifndef CROPNERF_HIP_H
 #define CROPNERF_HIP_H
@@ -59,13 +59,49 @@ typedef void* cn_stream_t; /* hipStream_t */
 #define CN_BG_LAST_SAMPLE 0
 #define CN_BG_COLOR 1
 
-/* One multiresolution hash grid: nerfstudio torch HashEncoding (fruit_nerf/fruit_field.py:125-132). */
+/* Hash-grid layouts.  The reference builds FruitField with implementation="tcnn" by default (fruit_nerf/fruit_field.py:95,
+ * 125-132) and falls back to nerfstudio's torch HashEncoding with implementation="torch"; the two differ in indexing.
+ *   CN_GRID_TORCH  nerfstudio torch HashEncoding: every level hashed into 2^log2_table_size entries, level l at entry
+ *                  l << log2_table_size, cell = floor(x * scalings[l]), scalings = floor(min_res * growth^l).
+ *   CN_GRID_TCNN   tiny-cuda-nn GridEncoding (encodings/grid.h): cell = floor(x * scalings[l] + 0.5) with
+ *                  scalings[l] = exp2(l * log2(per_level_scale)) * base_resolution - 1; a level whose resolution^3 fits the
+ *                  table is DENSE, the others are hashed (same primes).  This library keeps a dense level with
+ *                  power-of-two strides -- entry = level_offset[l] + (x | y << b | z << 2b), b = level_bits[l] -- so that one
+ *                  index expression (xor of three per-axis terms) serves hashed and dense levels alike; cn_tcnn_grid_pack /
+ *                  cn_tcnn_grid_unpack convert from / to tcnn's packed parameter vector (x + y*res + z*res^2, levels
+ *                  back to back), including the wrap-around entries tcnn reads when a corner index reaches `res`. */
+#define CN_GRID_TORCH 0
+#define CN_GRID_TCNN 1
+/* element type of a hash table: two features per entry, as float2 (8 B) or half2 (4 B, what tcnn computes with) */
+#define CN_TABLE_F32 0
+#define CN_TABLE_F16 1
+
+/* One multiresolution hash grid (fruit_nerf/fruit_field.py:125-132; proposal nets fruit_nerf/fruit_nerf.py:133-142).
+ * A zero-initialised tail (layout .. level_bits) is the torch layout with an fp32 table. */
 typedef struct cn_grid {
-  const float* table;             /* [num_levels << log2_table_size, 2]                   */
-  int32_t num_levels;             /* <= CN_MAX_LEVELS                                      */
-  int32_t log2_table_size;        /* 2^k entries per level                                 */
-  float scalings[CN_MAX_LEVELS];  /* host values: floor(min_res * growth^l)                */
+  const void* table;              /* [entries, 2] float (CN_TABLE_F32) or _Float16 (CN_TABLE_F16)                */
+  int32_t num_levels;             /* <= CN_MAX_LEVELS                                                             */
+  int32_t log2_table_size;        /* 2^k entries per hashed level                                                 */
+  float scalings[CN_MAX_LEVELS];  /* host values, see the layouts above                                           */
+  int32_t layout;                 /* CN_GRID_*                                                                    */
+  int32_t table_dtype;            /* CN_TABLE_*                                                                   */
+  uint32_t level_offset[CN_MAX_LEVELS]; /* CN_GRID_TCNN: first entry of level l                                  */
+  uint8_t level_bits[CN_MAX_LEVELS];    /* CN_GRID_TCNN: 0 = hashed level, b > 0 = dense level with b bits per axis */
 } cn_grid;
+
+/* tiny-cuda-nn grid geometry for (n_levels, log2_hashmap_size, base_resolution, per_level_scale) -- what nerfstudio's
+ * HashEncoding(implementation="tcnn") passes to tcnn.Encoding -- and this library's table layout for it. host struct. */
+typedef struct cn_tcnn_grid_plan {
+  int32_t num_levels;
+  int32_t log2_table_size;
+  int32_t base_resolution;
+  float per_level_scale;
+  float scalings[CN_MAX_LEVELS];               /* grid.h grid_scale(l)                                  */
+  uint32_t resolution[CN_MAX_LEVELS];          /* grid.h grid_resolution(scale) = ceil(scale) + 1       */
+  uint32_t packed_offset[CN_MAX_LEVELS + 1];   /* tcnn's offset table, in entries                       */
+  uint32_t level_offset[CN_MAX_LEVELS + 1];    /* this library's table, in entries; [num_levels] = total */
+  uint8_t level_bits[CN_MAX_LEVELS];
+} cn_tcnn_grid_plan;
 
 /* A nerfstudio torch MLP: Linear(+ReLU) x (num_layers-1), Linear. dims[0]=in, dims[num_layers]=out. */
 typedef struct cn_mlp {
@@ -132,6 +168,34 @@ typedef struct cn_render_opts {
 
 const char* cn_last_error(void);
 int cn_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * tcnn-compatible hash grids: what a reference-trained checkpoint holds (FruitField's default implementation="tcnn",
+ * fruit_nerf/fruit_field.py:95,125-132; loaded by scripts/exporter.py:87, scripts/semantic_projection.py:139-143).
+ * ------------------------------------------------------------------------------------------- */
+
+/* host only: fill `plan` for a tcnn HashGrid encoding (linear interpolation, 2 features per level, 3-D input). */
+int cn_tcnn_grid_plan_init(int32_t num_levels, int32_t log2_table_size, int32_t base_resolution, float per_level_scale,
+                           cn_tcnn_grid_plan* plan);
+
+/* host only: the cn_grid that describes `table` (plan->level_offset[num_levels] entries of table_dtype). */
+int cn_tcnn_grid_describe(const cn_tcnn_grid_plan* plan, const void* table, int32_t table_dtype, cn_grid* grid);
+
+/* tcnn parameter vector (packed_offset[num_levels] entries x 2 values, dtype packed_dtype: the fp32 master copy of a
+ * checkpoint or its fp16 cast) -> this library's table; every entry of `table` is written (unreachable ones with 0). */
+int cn_tcnn_grid_pack(const cn_tcnn_grid_plan* plan, const void* packed, int32_t packed_dtype, void* table,
+                      int32_t table_dtype, cn_stream_t stream);
+
+/* the inverse: `packed` receives the value of every tcnn parameter (the padding entries of dense levels included). */
+int cn_tcnn_grid_unpack(const cn_tcnn_grid_plan* plan, const void* table, int32_t table_dtype, void* packed,
+                        int32_t packed_dtype, cn_stream_t stream);
+
+/* Training on a tcnn-layout table: a corner index that reaches `res` on a dense level wraps into a neighbouring row of
+ * tcnn's x + y*res + z*res^2 array, i.e. several entries of this library's table stand for ONE tcnn parameter.
+ * cn_tcnn_grid_tie_gradients folds the gradient of every such alias into its parameter's own entry (and zeroes the
+ * alias); cn_tcnn_grid_tie_parameters copies the parameter back into its aliases after the optimiser step. fp32 tables. */
+int cn_tcnn_grid_tie_gradients(const cn_tcnn_grid_plan* plan, float* grad_table, cn_stream_t stream);
+int cn_tcnn_grid_tie_parameters(const cn_tcnn_grid_plan* plan, float* table, cn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Ray generation

@@ -66,6 +66,10 @@ class FieldSpec:
     num_images: int = 100
     use_average_appearance_embedding: bool = True
     sh_input: str = "unit"  # "unit": SH of the unit direction (tcnn semantics); "shifted": SH of (d+1)/2
+    # which of FruitField's two implementations (fruit_field.py:95): "torch" = nerfstudio's torch modules (this file),
+    # "tcnn" = tiny-cuda-nn's grid / fully-fused MLPs / SH (oracle/tcnn.py; parameter names *.tcnn_encoding.params)
+    implementation: str = "torch"
+    tcnn_half_activations: bool = False  # diagnostic: round activations to fp16 as tcnn's kernels do
 
 
 @dataclass
@@ -74,6 +78,8 @@ class ProposalSpec:
 
     grid: GridSpec
     hidden_dim: int = 16
+    implementation: str = "torch"
+    tcnn_half_activations: bool = False
 
 
 def default_proposal_specs() -> List[ProposalSpec]:
@@ -189,8 +195,17 @@ def field_density(positions: Tensor, params: Dict[str, Tensor], spec: FieldSpec,
                   contraction: bool) -> Tuple[Tensor, Tensor]:
     """``FruitField.get_density`` (``fruit_field.py:169-194``) -> density [...,1], geo features [...,geo]."""
     p, selector = normalized_positions(positions, aabb, contraction)
-    enc = hash_grid(p.reshape(-1, 3), params["field.mlp_base_grid.hash_table"], spec.grid)
-    h = mlp(enc, params, "field.mlp_base_mlp", 2).view(*positions.shape[:-1], -1)
+    if spec.implementation == "tcnn":
+        from . import tcnn as TC
+
+        g = TC.grid_spec_of(spec.grid)
+        ha = spec.tcnn_half_activations
+        enc = TC.hash_grid(p.reshape(-1, 3), params["field.mlp_base_grid.tcnn_encoding.params"], g, half_activations=ha)
+        h = TC.network(enc, params["field.mlp_base_mlp.tcnn_encoding.params"], g.out_dim, 1 + spec.geo_feat_dim,
+                       spec.hidden_dim, 1, half_activations=ha).view(*positions.shape[:-1], -1)
+    else:
+        enc = hash_grid(p.reshape(-1, 3), params["field.mlp_base_grid.hash_table"], spec.grid)
+        h = mlp(enc, params, "field.mlp_base_mlp", 2).view(*positions.shape[:-1], -1)
     dba, geo = torch.split(h, [1, spec.geo_feat_dim], dim=-1)
     density = torch.exp(dba) * selector[..., None]  # trunc_exp forward = exp
     return density, geo
@@ -213,8 +228,14 @@ def field_forward(
 
     d = directions[:, None, :].expand(R, S, 3)
     shifted = (d + 1.0) / 2.0  # shift_directions_for_tcnn (fruit_field.py:209,244)
-    sh_in = shifted * 2.0 - 1.0 if spec.sh_input == "unit" else shifted
-    sh = sh_deg4(sh_in.reshape(-1, 3))
+    tcnn_impl = spec.implementation == "tcnn"
+    if tcnn_impl:
+        from . import tcnn as TC
+
+        sh = TC.sh_deg4(shifted.reshape(-1, 3))  # tcnn maps its [0,1] input back to [-1,1] itself
+    else:
+        sh_in = shifted * 2.0 - 1.0 if spec.sh_input == "unit" else shifted
+        sh = sh_deg4(sh_in.reshape(-1, 3))
 
     emb = params["field.embedding_appearance.embedding.weight"]
     if test_mode in ("inference", "export"):
@@ -231,6 +252,18 @@ def field_forward(
         app = torch.zeros(R * S, spec.appearance_embedding_dim)
 
     geo_flat = geo.reshape(-1, spec.geo_feat_dim)
+    if tcnn_impl:
+        ha = spec.tcnn_half_activations
+        x = TC.network(geo_flat, params["field.mlp_semantics.tcnn_encoding.params"], spec.geo_feat_dim,
+                       spec.hidden_dim_transient, spec.hidden_dim_semantics, spec.num_layers_semantic - 1,
+                       half_activations=ha)
+        sem = torch.nn.functional.linear(
+            x, params["field.field_head_semantics.net.weight"], params["field.field_head_semantics.net.bias"]
+        ).view(R, S, -1)
+        h = torch.cat([sh, geo_flat, app], dim=-1)
+        rgb = TC.network(h, params["field.mlp_head.tcnn_encoding.params"], h.shape[-1], 3, spec.hidden_dim_color,
+                         spec.num_layers_color - 1, "sigmoid", half_activations=ha).view(R, S, 3)
+        return {"density": density, "rgb": rgb, "semantics": sem}
     x = mlp(geo_flat, params, "field.mlp_semantics", spec.num_layers_semantic)
     sem = torch.nn.functional.linear(
         x, params["field.field_head_semantics.net.weight"], params["field.field_head_semantics.net.bias"]
@@ -245,6 +278,13 @@ def proposal_density(positions: Tensor, params: Dict[str, Tensor], level: int, s
                      contraction: bool = True) -> Tensor:
     """Upstream ``HashMLPDensityField.density_fn`` as built at ``fruit_nerf.py:133-142`` -> [R,S,1]."""
     p, selector = normalized_positions(positions, aabb, contraction)
+    if spec.implementation == "tcnn":
+        from . import tcnn as TC
+
+        dba = TC.network_with_grid(p.reshape(-1, 3), params[f"proposal_networks.{level}.mlp_base.tcnn_encoding.params"],
+                                   TC.grid_spec_of(spec.grid), 1, spec.hidden_dim, 1,
+                                   half_activations=spec.tcnn_half_activations).view(*positions.shape[:-1], -1)
+        return torch.exp(dba) * selector[..., None]
     pre = f"proposal_networks.{level}"
     enc = hash_grid(p.reshape(-1, 3), params[f"{pre}.encoding.hash_table"], spec.grid)
     dba = mlp(enc, params, f"{pre}.mlp", 2).view(*positions.shape[:-1], -1)

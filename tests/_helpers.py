@@ -39,6 +39,24 @@ def make_scene(seed: int = 0, log2_T: int = 19, num_images: int = 6, height: int
     return Scene(params, fspec, pspecs, aabb, c2w, intr, height, width)
 
 
+def make_tcnn_scene(seed: int = 0, log2_T: int = 19, num_images: int = 6, height: int = 40, width: int = 40,
+                    focal: float = 55.0, grid_scale: float = 0.1, prop_log2_T: int = 17) -> Scene:
+    """The same scene shape with the reference's default implementation: tcnn modules, parameters under nerfstudio's
+    tcnn state-dict names (fp32 master values, as a checkpoint holds them)."""
+    from cropnerf_amd import synthetic
+    from oracle import tcnn as TC
+
+    fspec = OF.FieldSpec(grid=OF.GridSpec(log2_hashmap_size=log2_T), num_images=num_images, implementation="tcnn")
+    pspecs = [OF.ProposalSpec(OF.GridSpec(5, 16, 128, prop_log2_T), implementation="tcnn"),
+              OF.ProposalSpec(OF.GridSpec(5, 16, 256, prop_log2_T), implementation="tcnn")]
+    params = TC.random_params(fspec, pspecs, seed=seed, grid_scale=grid_scale)
+    g = torch.Generator().manual_seed(seed + 99)
+    params["camera_optimizer.pose_adjustment"] = (torch.rand(num_images, 6, generator=g) - 0.5) * 0.02
+    c2w, intr = synthetic.orbit_cameras(num_images, height=height, width=width, focal=focal)
+    aabb = torch.tensor(synthetic.SCENE_AABB, dtype=torch.float32)
+    return Scene(params, fspec, pspecs, aabb, c2w, intr, height, width)
+
+
 def oracle_model(sc: Scene, test_mode: str = "test", **cfg) -> OM.OracleModel:
     config = OM.ModelConfig(field=sc.fspec, proposals=sc.pspecs, **cfg)
     return OM.OracleModel(sc.params, config, sc.aabb, test_mode=test_mode)
@@ -50,7 +68,15 @@ def to_dev(t, device="cuda"):
     return t.to(device).contiguous()
 
 
-def dev_params(sc: Scene, device="cuda"):
+def dev_params(sc: Scene, device="cuda", table_dtype=None):
+    """Device parameters of the product.  A tcnn scene goes through the importer (tcnn state dict -> nn.Linear-shaped
+    weights + packed hash tables, fp16 by default: the values tcnn computes with)."""
+    if sc.fspec.implementation == "tcnn":
+        from cropnerf_amd.fruit_nerf import tcnn_params
+
+        fspec, pspecs = product_specs(sc)
+        return tcnn_params.from_tcnn_state_dict(sc.params, fspec, pspecs, device,
+                                                table_dtype or torch.float16)
     return {k: v.to(device).contiguous() for k, v in sc.params.items()}
 
 
@@ -59,12 +85,13 @@ def product_specs(sc: Scene):
     from cropnerf_amd import config as PC
 
     g = sc.fspec.grid
-    fspec = PC.FieldSpec(grid=PC.GridSpec(g.num_levels, g.min_res, g.max_res, g.log2_hashmap_size, 2),
+    layout = sc.fspec.implementation
+    fspec = PC.FieldSpec(grid=PC.GridSpec(g.num_levels, g.min_res, g.max_res, g.log2_hashmap_size, 2, layout),
                          geo_feat_dim=sc.fspec.geo_feat_dim, num_layers_semantic=sc.fspec.num_layers_semantic,
                          hidden_dim_semantics=sc.fspec.hidden_dim_semantics, num_images=sc.fspec.num_images,
                          sh_input=sc.fspec.sh_input)
     pspecs = [PC.ProposalSpec(PC.GridSpec(p.grid.num_levels, p.grid.min_res, p.grid.max_res,
-                                          p.grid.log2_hashmap_size, 2), p.hidden_dim) for p in sc.pspecs]
+                                          p.grid.log2_hashmap_size, 2, layout), p.hidden_dim) for p in sc.pspecs]
     return fspec, pspecs
 
 

@@ -1,0 +1,315 @@
+"""GPU parity tests of the tcnn-compatible field: the reference's default ``implementation="tcnn"``
+(``fruit_nerf/fruit_field.py:95,116-167``) -- tcnn grid geometry (dense coarse levels, +0.5 offset), fp16 parameter
+values, bias-free padded MLPs, tcnn's SH sign convention -- imported from a nerfstudio-style state dict
+(``cropnerf_amd.fruit_nerf.tcnn_params``) and evaluated by the same HIP kernels, against ``oracle/tcnn.py``.
+
+Tolerance: the oracle and the kernels compute in fp32 on the SAME fp16-rounded parameter values, so the fp32 bars of
+``test_gpu_parity.py`` apply (rtol 2e-4, atol 2e-5).
+"""
+
+import math
+
+import pytest
+import torch
+
+from _helpers import assert_close, dev_params, make_tcnn_scene, oracle_model, product_specs, rays_with_box, to_dev
+from oracle import field as OF
+from oracle import rays as ORY
+from oracle import samplers as OSM
+from oracle import tcnn as TC
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 2e-4, 2e-5
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    from cropnerf_amd import ops as _ops
+
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def scene():
+    return make_tcnn_scene(seed=3)
+
+
+# ------------------------------------------------------------------------------------------------ layout conversion
+def test_pack_unpack_round_trip_and_alias_entries(scene, ops):
+    fspec, pspecs = product_specs(scene)
+    for spec in (fspec.grid, pspecs[0].grid, pspecs[1].grid):
+        plan = spec.plan()
+        n = 2 * spec.num_packed_entries
+        g = torch.Generator().manual_seed(11)
+        packed = torch.randn(n, generator=g).cuda()
+        table = ops.tcnn_grid_pack(spec, packed, torch.float32)
+        assert table.shape == (spec.num_entries, 2)
+        back = ops.tcnn_grid_unpack(spec, table)
+        assert torch.equal(back, packed)  # every tcnn parameter (padding entries included) survives bit for bit
+        # half tables: exactly the fp16 cast of the master copy
+        th = ops.tcnn_grid_pack(spec, packed, torch.float16)
+        assert torch.equal(th, table.to(torch.float16))
+        assert torch.equal(ops.tcnn_grid_pack(spec, packed.to(torch.float16), torch.float16), th)
+        # entry by entry against the oracle's index arithmetic on the dense levels (x | y << b | z << 2b), corner
+        # index `res` included: the entry holds the parameter tcnn's grid_index gives for that corner
+        import numpy as np
+
+        o = TC.TcnnGridSpec(spec.num_levels, spec.min_res, spec.max_res, spec.log2_hashmap_size)
+        offs, ress = o.offset_table(), o.resolutions()
+        tcpu, pcpu = table.cpu(), packed.cpu().view(-1, 2)
+        for l in range(spec.num_levels):
+            b = int(plan.level_bits[l])
+            res, size = ress[l], offs[l + 1] - offs[l]
+            lo = int(plan.level_offset[l])
+            if b == 0:
+                assert torch.equal(tcpu[lo:lo + size], pcpu[offs[l]:offs[l + 1]])
+                continue
+            rng = np.random.default_rng(l)
+            c = rng.integers(0, res + 1, size=(4000, 3)).astype(np.uint32)
+            c[:200] = res  # corners on the upper faces / edges / the far corner
+            c[:200, rng.integers(0, 3, 200)] = rng.integers(0, res + 1, 200).astype(np.uint32)
+            idx = TC.grid_index(c, res, size) + offs[l]
+            mine = lo + (c[:, 0].astype(np.int64) | (c[:, 1].astype(np.int64) << b) | (c[:, 2].astype(np.int64) << (2 * b)))
+            assert torch.equal(tcpu[torch.from_numpy(mine)], pcpu[torch.from_numpy(idx)]), f"level {l}"
+        # tying: parameters already agree after a pack; a gradient placed on an alias moves to the owner
+        t2 = table.clone()
+        ops.tcnn_grid_tie_parameters(spec, t2)
+        assert torch.equal(t2, table)
+        b0, res0 = int(plan.level_bits[0]), int(plan.resolution[0])
+        grad = torch.zeros_like(table)
+        alias = res0 | (3 << b0) | (5 << (2 * b0))  # (res, 3, 5) stands for (0, 4, 5)
+        owner = 0 | (4 << b0) | (5 << (2 * b0))
+        grad[alias] = torch.tensor([1.5, -2.0]).cuda()
+        grad[owner] = torch.tensor([0.25, 0.5]).cuda()
+        ops.tcnn_grid_tie_gradients(spec, grad)
+        assert grad[alias].abs().sum().item() == 0
+        assert torch.equal(grad[owner].cpu(), torch.tensor([1.75, -1.5]))
+        assert abs(grad.sum().item() - 0.25) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ field kernels
+@pytest.fixture(scope="module")
+def rounded_scene():
+    """A tcnn scene whose grid parameters are fp16-representable: fp32 and fp16 device tables then hold the same values
+    and one oracle evaluation serves both."""
+    sc = make_tcnn_scene(seed=3)
+    for k, v in sc.params.items():
+        if k.endswith("tcnn_encoding.params"):
+            sc.params[k] = v.to(torch.float16).to(torch.float32)
+    return sc
+
+
+@pytest.fixture(scope="module", params=["float16", "float32"])
+def rhandles(request, rounded_scene, ops):
+    dtype = getattr(torch, request.param)
+    fspec, pspecs = product_specs(rounded_scene)
+    dp = dev_params(rounded_scene, table_dtype=dtype)
+    fh = ops.FieldHandle(dp, fspec)
+    dh = [ops.DensityHandle(dp, i, ps) for i, ps in enumerate(pspecs)]
+    assert dp["field.mlp_base_grid.hash_table"].dtype == dtype
+    return dp, fh, dh
+
+
+@pytest.mark.parametrize("contraction", [True, False])
+def test_proposal_density(rounded_scene, ops, rhandles, contraction):
+    scene = rounded_scene
+    dp, fh, dh = rhandles
+    rb = rays_with_box(scene, 1, 300)
+    rs = OSM.spaced_sampler(rb, 40, "uniform")
+    sc = ops.scene_struct(scene.aabb, contraction)
+    for lvl in range(2):
+        ref = OF.proposal_density(rs.positions(), scene.params, lvl, scene.pspecs[lvl], scene.aabb, contraction)
+        out = ops.proposal_density(dh[lvl], sc, to_dev(rb.origins), to_dev(rb.directions), to_dev(rs.starts[..., 0]),
+                                   to_dev(rs.ends[..., 0]))
+        assert_close(out, ref[..., 0], RTOL, ATOL, f"proposal density {lvl}")
+
+
+@pytest.mark.parametrize("contraction,mode", [(True, "test"), (False, "inference"), (True, "train_app")])
+@pytest.mark.parametrize("impl", ["regw", "mfma", "scalar"])
+def test_field_eval(rounded_scene, ops, rhandles, contraction, mode, impl, monkeypatch):
+    from cropnerf_amd import _lib as L
+
+    monkeypatch.setenv("CN_FIELD_EVAL_IMPL", impl)
+    scene = rounded_scene
+    dp, fh, dh = rhandles
+    rb = rays_with_box(scene, 2, 150)
+    g = torch.Generator().manual_seed(7)
+    rb.camera_indices = torch.randint(0, scene.c2w.shape[0], (len(rb), 1), generator=g)
+    rs = OSM.spaced_sampler(rb, 33, "uniform")
+    training = mode == "train_app"
+    ref = OF.field_forward(rs.positions(), rb.directions, rb.camera_indices, scene.params, scene.fspec, scene.aabb,
+                           contraction, "inference" if mode == "inference" else "test", training=training)
+    sc = ops.scene_struct(scene.aabb, contraction)
+    out = ops.field_eval(fh, sc, to_dev(rb.origins), to_dev(rb.directions), to_dev(rb.camera_indices[:, 0]),
+                         to_dev(rs.starts[..., 0]), to_dev(rs.ends[..., 0]),
+                         app_mode=L.APP_PER_CAMERA if training else L.APP_MEAN)
+    assert_close(out["density"], ref["density"][..., 0], RTOL, ATOL, "density")
+    assert_close(out["semantics"], ref["semantics"][..., 0], RTOL, ATOL, "semantics")
+    assert_close(out["rgb"], ref["rgb"], RTOL, ATOL, "rgb")
+
+
+def test_samples_in_the_outer_half_cell_read_the_wrapped_entries(rounded_scene, ops, rhandles):
+    """Positions within half a coarse cell of the upper box faces have the corner index `res` on the dense levels --
+    tcnn wraps into the next row of its linear array; the packed table reproduces that (alias entries)."""
+    scene = rounded_scene
+    dp, fh, dh = rhandles
+    g = torch.Generator().manual_seed(21)
+    R, S = 256, 8
+    # AABB-normalised coordinates in (0.97, 1): level 0 (scale 15) has pos in (15.05, 15.5) -> corner 16 = res
+    target = 0.97 + 0.0299 * torch.rand(R, S, 3, generator=g)
+    lo, hi = scene.aabb[0], scene.aabb[1]
+    world = lo + target * (hi - lo)
+    # one ray per row through its first sample; samples are placed by (start + end) / 2 = t
+    origins = world[:, 0, :].clone()
+    directions = torch.nn.functional.normalize(torch.tensor([[1e-3, 2e-3, 1e-3]]).expand(R, 3), dim=-1).contiguous()
+    starts = (torch.arange(S, dtype=torch.float32) * 1e-3).expand(R, S).contiguous()
+    ends = starts + 1e-3
+    pos = origins[:, None, :] + directions[:, None, :] * ((starts + ends) / 2)[..., None]
+    q, sel = OF.normalized_positions(pos, scene.aabb, False)
+    assert bool(sel.all()) and float(q.min()) > 0.96
+    ref = OF.field_forward(pos, directions, None, scene.params, scene.fspec, scene.aabb, False, "inference")
+    sc = ops.scene_struct(scene.aabb, False)
+    out = ops.field_eval(fh, sc, to_dev(origins), to_dev(directions), None, to_dev(starts), to_dev(ends))
+    assert_close(out["density"], ref["density"][..., 0], RTOL, ATOL, "density at the upper faces")
+    assert_close(out["rgb"], ref["rgb"], RTOL, ATOL, "rgb at the upper faces")
+    for lvl in range(2):
+        refd = OF.proposal_density(pos, scene.params, lvl, scene.pspecs[lvl], scene.aabb, False)
+        outd = ops.proposal_density(dh[lvl], sc, to_dev(origins), to_dev(directions), to_dev(starts), to_dev(ends))
+        assert_close(outd, refd[..., 0], RTOL, ATOL, f"proposal density {lvl} at the upper faces")
+
+
+# ------------------------------------------------------------------------------------------------ fused renderers
+def _fused_vs_oracle(scene, ops, fh, S, contraction, n_rays, cam, **opt_kw):
+    rb = rays_with_box(scene, cam, n_rays)
+    m = oracle_model(scene, "inference", disable_scene_contraction=not contraction)
+    m.uniform_samples = S
+    ref = m.forward(rb)
+    sc = ops.scene_struct(scene.aabb, contraction)
+    opts = ops.render_opts(S, **opt_kw)
+    out = ops.render_rays(fh, sc, opts, to_dev(rb.origins), to_dev(rb.directions), to_dev(rb.nears), to_dev(rb.fars),
+                          want_weights=True)
+    return ref, out
+
+
+def _depth_match(dev_depth, ref_depth, frac=0.995):
+    ok = (dev_depth.cpu() - ref_depth).abs() <= 1e-5 + 1e-5 * ref_depth.abs()
+    assert ok.float().mean().item() >= frac
+
+
+@pytest.mark.parametrize("split", ["0", "2"])  # single-wave kernel / producer-consumer kernel
+@pytest.mark.parametrize("S,contraction", [(192, False), (64, True), (100, False)])
+def test_render_rays(rounded_scene, ops, rhandles, S, contraction, split, monkeypatch):
+    monkeypatch.setenv("CN_FUSED_SPLIT", split)
+    dp, fh, dh = rhandles
+    ref, out = _fused_vs_oracle(rounded_scene, ops, fh, S, contraction, 600, 0)
+    assert_close(out["weights"], ref["_weights"][..., 0], RTOL, 1e-6, "weights")
+    assert_close(out["accumulation"], ref["accumulation"], RTOL, ATOL, "accumulation")
+    assert_close(out["rgb"], ref["rgb"], RTOL, ATOL, "rgb")
+    assert_close(out["semantics"], ref["semantics"], RTOL, 5e-5, "semantics")
+    _depth_match(out["depth"], ref["depth"])
+
+
+def test_render_rays_split_bf16_option(rounded_scene, ops, rhandles, monkeypatch):
+    from cropnerf_amd import _lib as L
+
+    monkeypatch.setenv("CN_FUSED_SPLIT", "2")
+    dp, fh, dh = rhandles
+    ref, out = _fused_vs_oracle(rounded_scene, ops, fh, 96, False, 600, 1, matrix_precision=L.MATRIX_SPLIT_BF16)
+    assert_close(out["rgb"], ref["rgb"], RTOL, ATOL, "rgb (split bf16)")
+    assert_close(out["accumulation"], ref["accumulation"], RTOL, ATOL, "accumulation (split bf16)")
+
+
+@pytest.mark.parametrize("split", ["0", "2"])
+def test_render_samples_export_mode(rounded_scene, ops, rhandles, split, monkeypatch):
+    monkeypatch.setenv("CN_FUSED_SPLIT", split)
+    scene = rounded_scene
+    dp, fh, dh = rhandles
+    aabb = torch.tensor([[-1.0, -1.0, -0.682], [1.0, 1.0, 1.318]])
+    pts, plane = ORY.surface_points(ORY.corners_of_aabb(aabb), 12)
+    rb = ORY.ortho_rays(pts, plane, 100, 1)
+    S = 150
+    m = oracle_model(scene, "export")
+    m.setup_inference(True, S)
+    ref = m.forward(rb)
+    sc = ops.scene_struct(scene.aabb, False)
+    o, d, n, f = (to_dev(x) for x in (rb.origins, rb.directions, rb.nears, rb.fars))
+    out = ops.render_samples(fh, sc, ops.render_opts(S), o, d, n, f)
+    assert_close(out["density"], ref["density"], RTOL, ATOL, "density")
+    assert_close(out["semantics"], ref["semantics"], RTOL, ATOL, "semantics")
+    assert_close(out["rgb"], ref["rgb"], RTOL, ATOL, "rgb")
+    clear = (ref["semantics"] - math.log(9.0)).abs() > 1e-3
+    assert torch.equal(out["semantics_colormap"].cpu()[clear], ref["semantics_colormap"][clear])
+
+
+def test_proposal_sample_and_full_forward(rounded_scene, ops, rhandles):
+    scene = rounded_scene
+    dp, fh, dh = rhandles
+    rb = ORY.image_rays(scene.c2w, scene.intr, 5, scene.height, scene.width).slice(0, 500)
+    m = oracle_model(scene, "test")
+    ref = m.forward(rb)
+    o, d = to_dev(rb.origins).clone(), to_dev(rb.directions).clone()
+    ops.apply_pose_adjustment(dp["camera_optimizer.pose_adjustment"], to_dev(rb.camera_indices[:, 0]), o, d)
+    R = len(rb)
+    nears = torch.zeros(R, 1, device="cuda")
+    fars = torch.full((R, 1), 1000.0, device="cuda")
+    sc = ops.scene_struct(scene.aabb, True)
+    ps = ops.proposal_sample(dh, sc, o, d, nears, fars, (256, 96), 48)
+    ref_bins = torch.cat([ref["_starts"][..., 0], ref["_ends"][:, -1:, 0]], -1)
+    assert_close(ps["euclidean_bins"], ref_bins, 2e-3, 1e-4, "final euclidean bins", frac_ok=0.999)
+    opts = ops.render_opts(48)
+    out2 = ops.render_rays(fh, sc, opts, o, d, nears, fars, bins=to_dev(ref_bins), want_weights=True)
+    assert_close(out2["weights"], ref["_weights"][..., 0], RTOL, 1e-6, "weights (oracle bins)")
+    assert_close(out2["rgb"], ref["rgb"], RTOL, ATOL, "rgb (oracle bins)")
+    assert_close(out2["semantics"], ref["semantics"], RTOL, 5e-5, "semantics (oracle bins)")
+
+
+def test_unrounded_master_copy_in_fp16_tables_matches_the_oracle(scene, ops):
+    """The real import path: fp32 master values (not fp16-representable) -> fp16 tables; the oracle rounds the same
+    way (tcnn casts its parameters to half for every forward)."""
+    fspec, pspecs = product_specs(scene)
+    dp = dev_params(scene)  # fp16 tables by default
+    assert dp["field.mlp_base_grid.hash_table"].dtype == torch.float16
+    fh = ops.FieldHandle(dp, fspec)
+    ref, out = _fused_vs_oracle(scene, ops, fh, 128, False, 500, 2)
+    assert_close(out["rgb"], ref["rgb"], RTOL, ATOL, "rgb")
+    assert_close(out["accumulation"], ref["accumulation"], RTOL, ATOL, "accumulation")
+    assert_close(out["semantics"], ref["semantics"], RTOL, 5e-5, "semantics")
+
+
+def test_torch_layout_with_half_table(ops):
+    """The table dtype is independent of the layout: a torch-layout grid stored as half2 entries."""
+    from _helpers import make_scene
+
+    sc_ = make_scene(seed=5, log2_T=15, prop_log2_T=12)
+    sc_.params["field.mlp_base_grid.hash_table"] = sc_.params["field.mlp_base_grid.hash_table"].to(torch.float16).to(torch.float32)
+    fspec, _ = product_specs(sc_)
+    dp = dev_params(sc_)
+    dp["field.mlp_base_grid.hash_table"] = dp["field.mlp_base_grid.hash_table"].to(torch.float16)
+    fh = ops.FieldHandle(dp, fspec)
+    rb = rays_with_box(sc_, 0, 400)
+    m = oracle_model(sc_, "inference", disable_scene_contraction=True)
+    m.uniform_samples = 96
+    ref = m.forward(rb)
+    out = ops.render_rays(fh, ops.scene_struct(sc_.aabb, False), ops.render_opts(96), to_dev(rb.origins),
+                          to_dev(rb.directions), to_dev(rb.nears), to_dev(rb.fars))
+    assert_close(out["rgb"], ref["rgb"], RTOL, ATOL, "rgb (torch layout, half table)")
+    assert_close(out["accumulation"], ref["accumulation"], RTOL, ATOL, "accumulation")
+
+
+def test_backward_rejects_half_tables(rounded_scene, ops):
+    from cropnerf_amd._lib import CropNerfHipError
+
+    scene = rounded_scene
+    fspec, pspecs = product_specs(scene)
+    dp = dev_params(scene, table_dtype=torch.float16)
+    dh = ops.DensityHandle(dp, 0, pspecs[0])
+    grads = {k: torch.zeros_like(v) for k, v in dp.items()}
+    gh = ops.DensityHandle(grads, 0, pspecs[0])
+    rb = rays_with_box(scene, 0, 64)
+    rs = OSM.spaced_sampler(rb, 16, "uniform")
+    with pytest.raises(CropNerfHipError, match="fp32 hash table"):
+        ops.proposal_backward(dh, gh, ops.scene_struct(scene.aabb, True), to_dev(rb.origins), to_dev(rb.directions),
+                              to_dev(rs.starts[..., 0]), to_dev(rs.ends[..., 0]),
+                              torch.ones(64, 16, device="cuda"))
