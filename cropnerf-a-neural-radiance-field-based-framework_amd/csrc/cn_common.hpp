@@ -226,8 +226,13 @@ struct Cell {
   float ox, oy, oz;
   unsigned hx0, hx1, hy0, hy1, hz0, hz1;
 };
+// OFFSET = false: pos_offset is known to be 0 (torch layout in the kernels specialised for it): plain products, which
+// hipcc contracts with the subtraction below exactly as the round-1 kernels did.
+template <bool OFFSET = true>
 __device__ __forceinline__ Cell hash_cell(const Lvl& lv, float pos_offset, float px, float py, float pz) {
-  const float sx = fmaf(px, lv.scale, pos_offset), sy = fmaf(py, lv.scale, pos_offset), sz = fmaf(pz, lv.scale, pos_offset);
+  const float sx = OFFSET ? fmaf(px, lv.scale, pos_offset) : px * lv.scale;
+  const float sy = OFFSET ? fmaf(py, lv.scale, pos_offset) : py * lv.scale;
+  const float sz = OFFSET ? fmaf(pz, lv.scale, pos_offset) : pz * lv.scale;
   const float fx = floorf(sx), fy = floorf(sy), fz = floorf(sz);
   Cell c;
   c.ox = sx - fx;
@@ -330,10 +335,10 @@ __device__ __forceinline__ float2 hash_level_any(const GridDev& g, int l, float 
 // Gsamples/s at C2; hand-pipelining 16-32 gathers in flight per wave is slower still: 4.2; issuing a unit's 8 gathers
 // together and blending them with the packed form, i.e. the same pacing with fewer instructions: 4.57 vs 4.84), so they
 // keep this form.
-template <bool HALF = false>
+template <bool HALF = false, bool OFFSET = true>
 __device__ __forceinline__ float2 hash_level_sc(const void* __restrict__ table, const Lvl& lv, float pos_offset, float px,
                                                 float py, float pz) {
-  const Cell k = hash_cell(lv, pos_offset, px, py, pz);
+  const Cell k = hash_cell<OFFSET>(lv, pos_offset, px, py, pz);
   const float ox = k.ox, oy = k.oy, oz = k.oz;
   float2 ccc = hash_gather<HALF>(table, ((k.hx1 ^ k.hy1 ^ k.hz1) & lv.mask) + lv.off);  // f_0
   float2 cfc = hash_gather<HALF>(table, ((k.hx1 ^ k.hy0 ^ k.hz1) & lv.mask) + lv.off);  // f_1

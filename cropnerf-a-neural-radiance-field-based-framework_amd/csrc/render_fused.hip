@@ -288,21 +288,31 @@ __device__ __forceinline__ float pick4(int g, float a, float b, float c, float d
   return g == 0 ? a : (g == 1 ? b : (g == 2 ? c : d));
 }
 
-// per-lane level record from the LDS blob (lane group g owns levels 4g..4g+3)
-__device__ __forceinline__ Lvl lds_level(const float* lds, int level, float scale) {
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  const u32x4 r = *reinterpret_cast<const u32x4*>(lds + OFF_LVL + 4 * level);
+// Level record of a lane (lane group g owns levels 4g..4g+3).  GENERIC = false (nerfstudio torch layout: every level
+// hashed with the same primes and mask, level l at l * T): compile-time multipliers, scalar mask -- the code of the
+// round-1 kernels.  GENERIC = true (tcnn layout: dense and hashed levels mixed): the record comes from the LDS blob.
+template <bool GENERIC>
+__device__ __forceinline__ Lvl lane_level_rec(const float* lds, const GridDev& grid, int level, float scale) {
   Lvl lv;
-  lv.off = r.x;
-  lv.mask = r.y;
-  lv.m1 = r.z;
-  lv.m2 = r.w;
+  if constexpr (GENERIC) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 r = *reinterpret_cast<const u32x4*>(lds + OFF_LVL + 4 * level);
+    lv.off = r.x;
+    lv.mask = r.y;
+    lv.m1 = r.z;
+    lv.m2 = r.w;
+  } else {
+    lv.mask = grid.mask[0];
+    lv.off = (unsigned)level * (grid.mask[0] + 1u);
+    lv.m1 = CN_P1;
+    lv.m2 = CN_P2;
+  }
   lv.scale = scale;
   return lv;
 }
 
 // HALF: the hash table holds half2 entries (CN_TABLE_F16: 4-byte gathers, 512 algorithmic bytes per sample)
-template <bool PER_SAMPLE, bool DENSITY_ONLY, bool HALF = false>
+template <bool PER_SAMPLE, bool DENSITY_ONLY, bool HALF = false, bool GENERIC = false>
 __global__ void __launch_bounds__(FUSED_THREADS, CN_FUSED_MIN_WAVES_PER_SIMD) render_fused_kernel(FusedArgs A) {
   __shared__ __align__(16) float lds[BLOB_FLOATS + FUSED_WAVES * WAVE_SCRATCH];
   {
@@ -421,13 +431,14 @@ __global__ void __launch_bounds__(FUSED_THREADS, CN_FUSED_MIN_WAVES_PER_SIMD) re
           const f32x4 lvl_scale = *reinterpret_cast<const f32x4*>(lds + OFF_SCALE + 4 * g);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const Lvl lv = lds_level(lds, 4 * g + q, lvl_scale[q]);
+            const Lvl lv = lane_level_rec<GENERIC>(lds, A.grid, 4 * g + q, lvl_scale[q]);
+            const float pos_off = GENERIC ? A.grid.pos_offset : 0.f;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
 #if CN_ABLATE_GATHER  // timing-only build: no table reads (positions still feed the MLP so nothing is dead code)
               float2 f = make_float2(px[c] * lv.scale, py[c] + pz[c]);
 #else
-              float2 f = hash_level_sc<HALF>(A.grid.table, lv, A.grid.pos_offset, px[c], py[c], pz[c]);
+              float2 f = hash_level_sc<HALF, GENERIC>(A.grid.table, lv, pos_off, px[c], py[c], pz[c]);
 #endif
               if (q == 0) { feat[c][0].x = f.x; feat[c][0].y = f.y; }
               if (q == 1) { feat[c][0].z = f.x; feat[c][0].w = f.y; }
@@ -670,7 +681,11 @@ static hipError_t resident_blocks(K kernel, int cus, int* out) {
 
 template <bool PS, bool BF, bool H>
 static hipError_t split_attr() {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<PS, BF, H>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<PS, BF, H, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(BF ? SPLIT_LDS_BYTES_BF16 : SPLIT_LDS_BYTES));
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<PS, BF, H, true>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BF ? SPLIT_LDS_BYTES_BF16 : SPLIT_LDS_BYTES));
 }
 
@@ -688,14 +703,14 @@ static hipError_t fused_device_init(int dev, FusedDevice& d) {
   CN_TRY((split_attr<false, true, true>()));
   CN_TRY((split_attr<true, true, true>()));
   int per_cu = 0;
-  CN_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_split_kernel<false, false, false>, SPLIT_THREADS,
-                                                      SPLIT_LDS_BYTES));
+  CN_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_split_kernel<false, false, false, false>,
+                                                      SPLIT_THREADS, SPLIT_LDS_BYTES));
   if (per_cu < 1) per_cu = 1;
   const int r = cus * per_cu;
   d.split_resident = r >= 8 ? (r / 8) * 8 : 8;
-  CN_TRY(resident_blocks(render_fused_kernel<true, false, false>, cus, &d.res_sample));
-  CN_TRY(resident_blocks(render_fused_kernel<false, true, false>, cus, &d.res_density));
-  CN_TRY(resident_blocks(render_fused_kernel<false, false, false>, cus, &d.res_full));
+  CN_TRY(resident_blocks(render_fused_kernel<true, false, false, false>, cus, &d.res_sample));
+  CN_TRY(resident_blocks(render_fused_kernel<false, true, false, false>, cus, &d.res_density));
+  CN_TRY(resident_blocks(render_fused_kernel<false, false, false, false>, cus, &d.res_full));
 #undef CN_TRY
   return hipSuccess;
 }
@@ -759,6 +774,7 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   const bool bf16 = opts->matrix_precision == CN_MATRIX_SPLIT_BF16 && split_blocks > 0;
   A.grid = make_grid_dev(params->grid);
   const bool half = A.grid.half != 0;
+  const bool generic = params->grid.layout != CN_GRID_TORCH;
   PrepArgs P;
   P.bf16 = bf16 ? 1 : 0;
   P.ext = blob + BLOB_FLOATS + (size_t)(params->num_images > 0 ? params->num_images : 1) * 64 + 32;
@@ -825,8 +841,15 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   const unsigned blocks = (unsigned)(want < cap ? want : cap);
   if (split_blocks) {
     const size_t lds_bytes = bf16 ? SPLIT_LDS_BYTES_BF16 : SPLIT_LDS_BYTES;
-#define CN_SPLIT_LAUNCH(BF, H) \
-  hipLaunchKernelGGL((render_split_kernel<PER_SAMPLE, BF, H>), dim3(split_blocks), dim3(SPLIT_THREADS), lds_bytes, s, A)
+#define CN_SPLIT_LAUNCH(BF, H)                                                                                       \
+  do {                                                                                                               \
+    if (generic)                                                                                                     \
+      hipLaunchKernelGGL((render_split_kernel<PER_SAMPLE, BF, H, true>), dim3(split_blocks), dim3(SPLIT_THREADS),    \
+                         lds_bytes, s, A);                                                                           \
+    else                                                                                                             \
+      hipLaunchKernelGGL((render_split_kernel<PER_SAMPLE, BF, H, false>), dim3(split_blocks), dim3(SPLIT_THREADS),   \
+                         lds_bytes, s, A);                                                                           \
+  } while (0)
     if (bf16 && half) CN_SPLIT_LAUNCH(true, true);
     else if (bf16) CN_SPLIT_LAUNCH(true, false);
     else if (half) CN_SPLIT_LAUNCH(false, true);
@@ -834,15 +857,21 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
 #undef CN_SPLIT_LAUNCH
     return check_launch(who);
   }
-#define CN_FUSED_LAUNCH(PS, DO) \
-  do {                                                                                                         \
-    if (half) hipLaunchKernelGGL((render_fused_kernel<PS, DO, true>), dim3(blocks), dim3(FUSED_THREADS), 0, s, A);  \
-    else hipLaunchKernelGGL((render_fused_kernel<PS, DO, false>), dim3(blocks), dim3(FUSED_THREADS), 0, s, A);      \
+#define CN_FUSED_LAUNCH1(PS, DO, H)                                                                                \
+  do {                                                                                                             \
+    if (generic) hipLaunchKernelGGL((render_fused_kernel<PS, DO, H, true>), dim3(blocks), dim3(FUSED_THREADS), 0, s, A);  \
+    else hipLaunchKernelGGL((render_fused_kernel<PS, DO, H, false>), dim3(blocks), dim3(FUSED_THREADS), 0, s, A);         \
+  } while (0)
+#define CN_FUSED_LAUNCH(PS, DO)           \
+  do {                                    \
+    if (half) CN_FUSED_LAUNCH1(PS, DO, true);  \
+    else CN_FUSED_LAUNCH1(PS, DO, false);      \
   } while (0)
   if (PER_SAMPLE) CN_FUSED_LAUNCH(true, false);
   else if (opts->density_only) CN_FUSED_LAUNCH(false, true);
   else CN_FUSED_LAUNCH(false, false);
 #undef CN_FUSED_LAUNCH
+#undef CN_FUSED_LAUNCH1
   return check_launch(who);
 }
 

@@ -130,8 +130,8 @@ __device__ __forceinline__ void split_fill_edges(const FusedArgs& A, const Split
 
 // BF16: the matrix waves run the MLPs on split-bf16 products (cn_render_opts.matrix_precision = 1; the weight images in the
 // blob are then the bf16 ones of prep_kernel, four more blocks of them behind the pair scratch).
-// HALF: half2 table entries (CN_TABLE_F16).
-template <bool PER_SAMPLE, bool BF16 = false, bool HALF = false>
+// HALF: half2 table entries (CN_TABLE_F16).  GENERIC: per-level index records (tcnn layout), see lane_level_rec.
+template <bool PER_SAMPLE, bool BF16 = false, bool HALF = false, bool GENERIC = false>
 __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A) {
   extern __shared__ __align__(16) float lds[];
   constexpr int OFF_EXT = BLOB_FLOATS + SPLIT_PAIRS * PAIR_SCRATCH;  // BF16 only
@@ -235,13 +235,14 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
             const f32x4 lvl_scale = *reinterpret_cast<const f32x4*>(lds + OFF_SCALE + 4 * g);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const Lvl lv = lds_level(lds, 4 * g + q, lvl_scale[q]);
+              const Lvl lv = lane_level_rec<GENERIC>(lds, A.grid, 4 * g + q, lvl_scale[q]);
+              const float pos_off = GENERIC ? A.grid.pos_offset : 0.f;
 #pragma unroll
               for (int c = 0; c < 2; ++c) {
 #if CN_ABLATE_GATHER  // timing-only build: no table reads
                 const float2 f = make_float2(px[c] * lv.scale, py[c] + pz[c]);
 #else
-                const float2 f = hash_level_sc<HALF>(A.grid.table, lv, A.grid.pos_offset, px[c], py[c], pz[c]);
+                const float2 f = hash_level_sc<HALF, GENERIC>(A.grid.table, lv, pos_off, px[c], py[c], pz[c]);
 #endif
                 if (q == 0) { feat[c][0].x = f.x; feat[c][0].y = f.y; }
                 if (q == 1) { feat[c][0].z = f.x; feat[c][0].w = f.y; }

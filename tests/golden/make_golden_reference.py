@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""Golden vectors produced by EXECUTING the reference's own functions (build container only).
+
+    python tests/golden/make_golden_reference.py      ->  tests/golden/reference_functions.npz
+
+Most of the reference cannot be imported here (its modules import nerfstudio / open3d / cv2 at the top, and
+``depth_based_semantic_projection.py`` runs a hard-coded job at import time).  A handful of its functions on or next to
+the hot path are nevertheless pure numpy / torch / networkx code.  This script reads the reference's source files with
+``ast``, takes the *definitions* of exactly those functions out of the module, executes them unchanged in a namespace
+that holds only the libraries they use, and runs them on seeded inputs:
+
+    fruit_nerf/scripts/depth_based_semantic_projection.py   get_projection_mat :31-43, get_projection :45-49,
+                                                            update_buffer :84-105
+    fruit_nerf/data/fruit_datamanager.py                    get_corners_of_aabb :42-69, sample_surface_points :71-121
+    segmentation/merger.py                                  get_component :26-74, calc_affinity :335-355
+                                                            (with segmentation/lpa.py, which imports as is)
+
+Nothing of the reference is copied into the repository: the fixture holds inputs and outputs only.  The oracle
+(``oracle/zbuffer.py``, ``oracle/rays.py``), the host mirrors (``cropnerf_amd/segmentation/merger.py``,
+``fruit_nerf/data/fruit_datamanager.py``) and the HIP kernels (``cn_depth_project``, ``cn_zbuffer_update*``,
+``cn_surface_grid``) are tested against it (``tests/test_reference_golden.py``).
+"""
+
+import ast
+import os
+import random
+import sys
+
+import networkx as nx
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/crop_nerf"
+
+
+def extract(path, names, namespace):
+    """exec the FunctionDef nodes `names` of the module at `path` (and nothing else of it) inside `namespace`."""
+    with open(path, encoding="utf-8") as f:
+        tree = ast.parse(f.read(), filename=path)
+    found = []
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            mod = ast.Module(body=[node], type_ignores=[])
+            exec(compile(mod, path, "exec"), namespace)
+            found.append(node.name)
+    missing = set(names) - set(found)
+    if missing:
+        raise RuntimeError(f"{path}: functions not found: {sorted(missing)}")
+    return namespace
+
+
+def orbit_c2w(rng):
+    """A camera-to-world matrix looking roughly at the origin from a random direction (float64, like the reference's)."""
+    d = rng.normal(size=3)
+    eye = d / np.linalg.norm(d) * rng.uniform(0.6, 1.2)
+    z = eye / np.linalg.norm(eye)  # camera looks down -z
+    up = np.array([0.0, 0.0, 1.0])
+    x = np.cross(up, z)
+    x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    c2w = np.eye(4)
+    c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = x, y, z, eye
+    return c2w
+
+
+def sparse(img):
+    idx = np.argwhere(img != 0)
+    return idx.astype(np.int32), img[img != 0]
+
+
+def projection_cases(out):
+    ns = extract(f"{REF}/fruit_nerf/scripts/depth_based_semantic_projection.py",
+                 {"get_projection_mat", "get_projection", "update_buffer"}, {"np": np})
+    rng = np.random.default_rng(20)
+    fx = fy = 1442.4757
+    cx, cy = 961.9397, 723.2478  # fruit_nerf/utils/transforms.json
+    for case in range(3):
+        c2w = orbit_c2w(rng)
+        P = ns["get_projection_mat"](fx, fy, cx, cy, c2w)
+        # three clouds: a wide "tree" (large=True splat), then two compact clusters tested against it (large=False)
+        # (coordinates on a 2^-12 lattice: exactly representable, and the fixture compresses)
+        q = lambda a: np.round(a * 4096.0) / 4096.0
+        tree = q(rng.normal(size=(2500, 3)) * 0.25)
+        c1 = q(rng.normal(size=(600, 3)) * 0.03 + rng.normal(size=3) * 0.15)
+        c2 = q(rng.normal(size=(600, 3)) * 0.03 + rng.normal(size=3) * 0.15)
+        z_buffer = np.ones((1440, 1920), dtype=np.float32) * 1e10
+        img = np.zeros((1440, 1920), dtype=np.uint8)
+        k = f"proj{case}"
+        out[f"{k}/c2w"], out[f"{k}/intrinsics"], out[f"{k}/P"] = c2w, np.array([fx, fy, cx, cy]), P
+        for name, pts, label, large in (("tree", tree, 60, True), ("c1", c1, 120, False), ("c2", c2, 200, False)):
+            im = ns["get_projection"](P, pts)
+            z_buffer, img, (vx, vy) = ns["update_buffer"](z_buffer, im, img, label, large)
+            out[f"{k}/{name}/points"], out[f"{k}/{name}/im"] = pts, im
+            out[f"{k}/{name}/label"], out[f"{k}/{name}/large"] = np.array(label), np.array(large)
+            out[f"{k}/{name}/visible_xs"], out[f"{k}/{name}/visible_ys"] = np.asarray(vx), np.asarray(vy)
+            idx, val = sparse(img)
+            out[f"{k}/{name}/img_idx"], out[f"{k}/{name}/img_val"] = idx, val
+            zi = np.argwhere(z_buffer < 1e9).astype(np.int32)
+            out[f"{k}/{name}/z_idx"], out[f"{k}/{name}/z_val"] = zi, z_buffer[z_buffer < 1e9]
+    out["num_proj"] = np.array(3)
+
+
+def datamanager_cases(out):
+    ns = extract(f"{REF}/fruit_nerf/data/fruit_datamanager.py", {"get_corners_of_aabb", "sample_surface_points"},
+                 {"torch": torch})
+    cases = [
+        (torch.tensor([[-1.0, -1.0, -0.682], [1.0, 1.0, 1.318]]), 4),  # SURVEY 8(c) KAT 11
+        (torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]]), 7),
+        (torch.tensor([[-0.5, -0.75, -0.25], [0.5, 0.25, 0.75]]), 6),
+        (torch.tensor([[-0.3, -0.2, 0.1], [0.4, 0.6, 0.9]]), 9),
+    ]
+    for i, (aabb, n) in enumerate(cases):
+        corners = ns["get_corners_of_aabb"](aabb, "cpu")
+        pts, plane = ns["sample_surface_points"](corners, n, "cpu")
+        out[f"dm{i}/aabb"], out[f"dm{i}/n"] = aabb.numpy(), np.array(n)
+        out[f"dm{i}/corners"], out[f"dm{i}/points"], out[f"dm{i}/plane"] = corners.numpy(), pts.numpy(), plane.numpy()
+    out["num_dm"] = np.array(len(cases))
+
+
+def merger_cases(out):
+    import matplotlib
+
+    matplotlib.use("Agg")
+    from matplotlib import cm
+
+    sys.path.insert(0, f"{REF}/segmentation")
+    import lpa  # the reference's own module (networkx only)
+
+    cmap = matplotlib.colors.ListedColormap(cm.tab20.colors + cm.tab20c.colors, name="tab40")  # merger.py:20
+    ns = extract(f"{REF}/segmentation/merger.py", {"get_component", "calc_affinity"},
+                 {"np": np, "nx": nx, "lpa": lpa, "cmap": cmap, "plt": None})
+    rng = np.random.default_rng(21)
+    case = 0
+    for n_clusters in (2, 3, 4, 6, 9):
+        for n_cams in (5, 24):
+            prop = {}
+            for i in range(n_clusters):
+                label = rng.integers(0, 4, size=n_cams)  # 0 = not seen
+                reliability = rng.uniform(0, 1, size=n_cams) * (label != 0)
+                prop[i] = {"label": label, "reliability": reliability}
+            aff = ns["calc_affinity"](prop)
+            out[f"mg{case}/labels"] = np.stack([prop[i]["label"] for i in range(n_clusters)])
+            out[f"mg{case}/reliability"] = np.stack([prop[i]["reliability"] for i in range(n_clusters)])
+            out[f"mg{case}/affinity"] = aff
+            for algo in ("clique", "bridge", "community"):
+                random.seed(35)  # merger.py:23 graph_seed; lpa draws from `random`
+                count, labels = ns["get_component"](aff.copy(), algo)
+                out[f"mg{case}/{algo}/count"], out[f"mg{case}/{algo}/labels"] = np.array(count), np.asarray(labels)
+            case += 1
+    out["num_mg"] = np.array(case)
+
+
+def main():
+    out = {}
+    projection_cases(out)
+    datamanager_cases(out)
+    merger_cases(out)
+    path = os.path.join(HERE, "reference_functions.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()

@@ -158,14 +158,14 @@ def test_samples_in_the_outer_half_cell_read_the_wrapped_entries(rounded_scene, 
     g = torch.Generator().manual_seed(21)
     R, S = 256, 8
     # AABB-normalised coordinates in (0.97, 1): level 0 (scale 15) has pos in (15.05, 15.5) -> corner 16 = res
-    target = 0.97 + 0.0299 * torch.rand(R, S, 3, generator=g)
+    target = 0.97 + 0.02 * torch.rand(R, S, 3, generator=g)
     lo, hi = scene.aabb[0], scene.aabb[1]
     world = lo + target * (hi - lo)
     # one ray per row through its first sample; samples are placed by (start + end) / 2 = t
     origins = world[:, 0, :].clone()
     directions = torch.nn.functional.normalize(torch.tensor([[1e-3, 2e-3, 1e-3]]).expand(R, 3), dim=-1).contiguous()
-    starts = (torch.arange(S, dtype=torch.float32) * 1e-3).expand(R, S).contiguous()
-    ends = starts + 1e-3
+    starts = (torch.arange(S, dtype=torch.float32) * 1e-4).expand(R, S).contiguous()
+    ends = starts + 1e-4
     pos = origins[:, None, :] + directions[:, None, :] * ((starts + ends) / 2)[..., None]
     q, sel = OF.normalized_positions(pos, scene.aabb, False)
     assert bool(sel.all()) and float(q.min()) > 0.96
