@@ -1,9 +1,13 @@
 """Plugin surface -- mirror of ``crop_nerf/fruit_nerf/fruit_nerf_config.py:29-172``: the three method specs
 ``fruit_nerf_method``, ``fruit_nerf_method_big``, ``fruit_nerf_method_huge`` under the same attribute names, so
 ``NERFSTUDIO_METHOD_CONFIGS=fruit_nerf=fruit_nerf.fruit_nerf_config:fruit_nerf_method`` (``README.md:79``) resolves
-here when this directory is on PYTHONPATH.  With nerfstudio importable the objects are real ``MethodSpecification``s
-whose pipeline config targets this package; without it (this image) they are same-shaped dataclasses consumed by this
-repo's own CLIs."""
+here when this directory is on PYTHONPATH.
+
+When ``import nerfstudio`` succeeds the three attributes ARE ``nerfstudio.plugins.types.MethodSpecification`` objects
+built from nerfstudio's own config types, with ``Model`` / ``VanillaPipeline`` / ``VanillaDataManager`` subclasses around
+the HIP model as their targets (``nerfstudio_adapter.py``; wiring tested against ``tests/fakes/nerfstudio``).  Without it
+(this image has no nerfstudio) they are the same-shaped dataclasses below, which this repo's own CLIs consume in either
+case (``native_method``)."""
 
 from __future__ import annotations
 
@@ -55,7 +59,7 @@ def _optim(field_opt: str, lr_final=1e-4, max_steps=200000, prop_sched=True):
     }
 
 
-fruit_nerf_method = MethodSpecification(
+_native_fruit_nerf_method = MethodSpecification(
     config=TrainerConfig(
         method_name="fruit_nerf", steps_per_eval_batch=500, steps_per_save=2000, max_num_iterations=40000,
         mixed_precision=True,
@@ -69,7 +73,7 @@ fruit_nerf_method = MethodSpecification(
     description="Base config for LERF",  # sic (fruit_nerf_config.py:64)
 )
 
-fruit_nerf_method_big = MethodSpecification(
+_native_fruit_nerf_method_big = MethodSpecification(
     config=TrainerConfig(
         method_name="fruit_nerf_big", max_num_iterations=100000,
         pipeline=FruitPipelineConfig(
@@ -86,7 +90,7 @@ fruit_nerf_method_big = MethodSpecification(
     description="Base config for FruitNeRF-Big",
 )
 
-fruit_nerf_method_huge = MethodSpecification(
+_native_fruit_nerf_method_huge = MethodSpecification(
     config=TrainerConfig(
         method_name="fruit_nerf_huge", max_num_iterations=100000,
         pipeline=FruitPipelineConfig(
@@ -108,10 +112,32 @@ fruit_nerf_method_huge = MethodSpecification(
 )
 
 
-def as_nerfstudio_method(spec: MethodSpecification):
-    """When nerfstudio is installed, wrap ``spec`` in the real plugin types (same field values)."""
-    from nerfstudio.plugins.types import MethodSpecification as NSMethod  # ImportError without nerfstudio
+NATIVE_METHODS = {"fruit_nerf": _native_fruit_nerf_method, "fruit_nerf_big": _native_fruit_nerf_method_big,
+                  "fruit_nerf_huge": _native_fruit_nerf_method_huge}
 
-    raise NotImplementedError(
-        "nerfstudio adapter: subclass nerfstudio Model/Pipeline around cropnerf_amd.fruit_nerf.FruitModel "
-        "(see INTEGRATION.md); not exercisable in an image without nerfstudio") from None
+
+def native_method(name: str) -> MethodSpecification:
+    """The method specification in this package's own dataclasses (what ``scripts/train.py`` runs), whatever the public
+    attributes below are."""
+    return NATIVE_METHODS[name]
+
+
+def _nerfstudio_available() -> bool:
+    try:
+        import nerfstudio.plugins.types  # noqa: F401
+    except ImportError:
+        return False
+    return True
+
+
+HAVE_NERFSTUDIO = _nerfstudio_available()
+if HAVE_NERFSTUDIO:
+    from . import nerfstudio_adapter as _adapter
+
+    fruit_nerf_method = _adapter.method_specification(_native_fruit_nerf_method)
+    fruit_nerf_method_big = _adapter.method_specification(_native_fruit_nerf_method_big)
+    fruit_nerf_method_huge = _adapter.method_specification(_native_fruit_nerf_method_huge)
+else:
+    fruit_nerf_method = _native_fruit_nerf_method
+    fruit_nerf_method_big = _native_fruit_nerf_method_big
+    fruit_nerf_method_huge = _native_fruit_nerf_method_huge

@@ -2,9 +2,11 @@
 ``fruit_nerf_config.py`` (``fruit_nerf``, ``fruit_nerf_big``, ``fruit_nerf_huge``) on a nerfstudio-format capture with a
 ``semantics/`` mask folder (``data/cotton_nerf_dataparser.py``) and writes the run directory the exporters read:
 
-    outputs/<experiment>/<method>/<timestamp>/config.json
+    outputs/<experiment>/<method>/<timestamp>/config.yml                    (nerfstudio's TrainerConfig dump)
                                               dataparser_transforms.json
-                                              nerfstudio_models/step-000001999.pt
+                                              cameras.json
+                                              nerfstudio_models/step-000001999.ckpt
+                                                  {"step", "pipeline": {"_model.<name>": tensor}, "optimizers", ...}
 
     python cropnerf-a-neural-radiance-field-based-framework_amd/fruit_nerf/scripts/train.py fruit_nerf --data plant_1 \\
         [--output-dir outputs] [--max-num-iterations 40000] [--steps-per-save 2000] [--downscale-factor 2]
@@ -32,7 +34,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
 
 def train(method: str, data: Path, output_dir: Path = Path("outputs"), max_num_iterations=None, steps_per_save=None,
           downscale_factor=None, experiment_name=None, timestamp=None, seed: int = 0, log_every: int = 100,
-          train_split_fraction=None, device: str = "cuda", quiet: bool = False, load_dir=None):
+          train_split_fraction=None, device: str = "cuda", quiet: bool = False, load_dir=None, implementation=None):
     from cropnerf_amd.fruit_nerf import fruit_nerf_config as FC
     from cropnerf_amd.fruit_nerf.checkpoint import save_run
     from cropnerf_amd.fruit_nerf.data.cotton_dataset import FruitDataset
@@ -41,11 +43,14 @@ def train(method: str, data: Path, output_dir: Path = Path("outputs"), max_num_i
     from cropnerf_amd.fruit_nerf.fruit_nerf import FruitModel
     from cropnerf_amd.fruit_nerf.trainer import FruitTrainer, groups_from_spec
 
-    specs = {"fruit_nerf": FC.fruit_nerf_method, "fruit_nerf_big": FC.fruit_nerf_method_big,
-             "fruit_nerf_huge": FC.fruit_nerf_method_huge}
+    specs = FC.NATIVE_METHODS  # this package's own dataclasses (FC.fruit_nerf_method may be nerfstudio's type)
     if method not in specs:
         raise SystemExit(f"unknown method {method!r}; choose from {sorted(specs)}")
-    tc = specs[method].config
+    import copy as _copy
+
+    tc = _copy.deepcopy(specs[method].config)
+    if implementation is not None:  # "tcnn" (the reference's default module implementation) or "torch"
+        tc.pipeline.model.implementation = implementation
     iters = max_num_iterations if max_num_iterations is not None else tc.max_num_iterations
     save_every = steps_per_save if steps_per_save is not None else tc.steps_per_save
     from cropnerf_amd.distributed import init_from_env
@@ -78,36 +83,64 @@ def train(method: str, data: Path, output_dir: Path = Path("outputs"), max_num_i
 
     start = 0
     if load_dir is not None:  # ns-train --load-dir: parameters, optimiser moments, schedules and sampling state
-        ckpts = sorted(Path(load_dir).glob("step-*.pt"))
-        if not ckpts:
-            raise FileNotFoundError(f"no checkpoint under {load_dir}")
-        state = torch.load(ckpts[-1], map_location="cpu", weights_only=False)
-        for k, v in state["params"].items():
-            model.params[k].copy_(v)
-        if "optimizers" in state:
-            trainer.load_state_dict(state["optimizers"])
-            dm._gen.set_state(state["optimizers"]["datamanager_generator"])
-            dm.train_count = int(state["optimizers"]["train_count"])
-        start = int(state["step"]) + 1
-        say(f"[resume] {ckpts[-1]} -> continuing at step {start}")
+        from cropnerf_amd.fruit_nerf import nerfstudio_io as NIO
+        from cropnerf_amd.fruit_nerf.tcnn_params import from_tcnn_state_dict, is_tcnn_state_dict
+
+        ck = NIO.latest_checkpoint(load_dir)
+        step0, state, loaded = NIO.load_checkpoint(ck)
+        if is_tcnn_state_dict(state) != (model.config.implementation == "tcnn"):
+            raise ValueError(f"{ck} holds a {'tcnn' if is_tcnn_state_dict(state) else 'torch'}-implementation model, the "
+                             f"method is configured for {model.config.implementation!r}")
+        if is_tcnn_state_dict(state):  # fp32 tables: the master values, not their half cast
+            state = from_tcnn_state_dict(state, model.field_spec, model.proposal_specs, device, torch.float32)
+        for k in model.params:
+            model.params[k].copy_(state[k].to(device))
+        opt = loaded.get("optimizers") or {}
+        if "exp_avg" in opt:
+            # every rank has its own random streams (jitter, pixel sampler): restore THIS rank's; a checkpoint written
+            # by a different number of ranks gives new streams derived from (seed, rank, step) instead of duplicates
+            ranks = opt.get("rank_states") or []
+            mine = ranks[rank] if len(ranks) == world else None
+            trainer.load_state_dict(opt, load_generator=False)
+            if mine is not None:
+                trainer._gen.set_state(mine["generator"])
+                dm._gen.set_state(mine["datamanager_generator"])
+                dm.train_count = int(mine["train_count"])
+            else:
+                trainer._gen.manual_seed(seed + rank + 7919 * (step0 + 1))
+                dm._gen.manual_seed(seed + 1000 * rank + 104729 * (step0 + 1))
+                dm.train_count = step0 + 1
+        start = step0 + 1
+        say(f"[resume] {ck} -> continuing at step {start}")
 
     run_dir = Path(output_dir) / (experiment_name or Path(data).name) / tc.method_name / (
         timestamp or datetime.now().strftime("%Y-%m-%d_%H%M%S"))
 
     def checkpoint(step: int) -> Path:
+        # the random streams of EVERY rank go into the checkpoint (rank 0 writes it)
+        mine = {"generator": trainer._gen.get_state(), "datamanager_generator": dm._gen.get_state(),
+                "train_count": dm.train_count}
+        rank_states = [mine]
+        if world > 1:
+            rank_states = [None] * world if rank == 0 else None
+            dist.gather_object(mine, rank_states, dst=0)
         if rank != 0:
-            return run_dir / "config.json"
+            return run_dir / "config.yml"
+        dp = {k: (str(v) if isinstance(v, Path) else v) for k, v in vars(pc).items()
+              if isinstance(v, (int, float, str, bool, Path, type(None)))}
+        dp["__class__"] = f"fruit_nerf.data.{type(pc).__module__.rsplit('.', 1)[-1]}.{type(pc).__name__}"
         cfg_path = save_run(run_dir, model.config, dm.cameras.to("cpu"), train_out.scene_box, model.params, step=step,
                             transform=train_out.dataparser_transform.tolist(), scale=train_out.dataparser_scale,
-                            method_name=tc.method_name,
-                            optimizers=dict(trainer.state_dict(), datamanager_generator=dm._gen.get_state(),
-                                            train_count=dm.train_count))
-        for old in sorted((run_dir / "nerfstudio_models").glob("step-*.pt"))[:-1]:
+                            method_name=tc.method_name, data=str(Path(data).resolve()), dataparser=dp, trainer_config=tc,
+                            optimizers=dict(trainer.state_dict(), rank_states=rank_states),
+                            schedulers={g: {"last_epoch": trainer.step, "lr": grp.lr_at(trainer.step)}
+                                        for g, grp in trainer.groups.items()})
+        for old in sorted((run_dir / "nerfstudio_models").glob("step-*.ckpt"))[:-1]:
             old.unlink()  # nerfstudio's save_only_latest_checkpoint
         return cfg_path
 
     t0 = time.perf_counter()
-    t_log, cfg_path = t0, run_dir / "config.json"
+    t_log, cfg_path = t0, run_dir / "config.yml"
     for step in range(start, iters):
         ray_bundle, batch = dm.next_train(step)
         out = trainer.train_iteration(ray_bundle, batch)  # averages the gradients over the ranks when there are several
@@ -172,9 +205,14 @@ def entrypoint(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--log-every", type=int, default=100)
     ap.add_argument("--load-dir", type=Path, default=None, help="a run's nerfstudio_models directory to resume from")
+    ap.add_argument("--implementation", choices=["tcnn", "torch"], default=None,
+                    help="module implementation of the field / proposal networks (nerfacto's `implementation`): tcnn = "
+                         "tiny-cuda-nn's grid geometry and bias-free MLPs, the reference's default; torch = nerfstudio's "
+                         "torch modules.  Default: the method specification's")
     a = ap.parse_args(argv)
     return train(a.method, a.data, a.output_dir, a.max_num_iterations, a.steps_per_save, a.downscale_factor,
-                 a.experiment_name, a.timestamp, a.seed, a.log_every, a.train_split_fraction, load_dir=a.load_dir)
+                 a.experiment_name, a.timestamp, a.seed, a.log_every, a.train_split_fraction, load_dir=a.load_dir,
+                 implementation=a.implementation)
 
 
 if __name__ == "__main__":

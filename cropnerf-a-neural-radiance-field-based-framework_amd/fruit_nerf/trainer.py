@@ -12,6 +12,16 @@ them per ray and ``cn_pose_adjustment_backward`` chains through exp_map_SO3xR3; 
 (``fruit_nerf.py:614``) is added by ``cn_pose_regularizer``.  The proposal networks follow the reference's update
 schedule (``fruit_nerf.py:144-149``): evaluated without gradient unless ``steps_since_update > update_sched(step) or
 step < 10``.  No GradScaler / autocast (everything is fp32).
+
+An optimiser group is stepped only when the iteration produced a gradient for it: on the iterations where the proposal
+networks are evaluated under ``no_grad`` their parameters have ``grad is None`` in the reference, ``torch.optim.Adam``
+skips them (moments, per-parameter step count and weights untouched) -- the learning-rate schedules advance every
+iteration regardless (nerfstudio steps all schedulers).  ``group_steps`` holds the per-group Adam step counts.
+
+tcnn-layout models (``FruitNerfModelConfig.implementation == "tcnn"``, fp32 tables): several table entries of a dense
+level can stand for one tcnn parameter (``cn_tcnn_grid_plan``), so their gradients are folded into the owning entry before
+the step and the parameter is copied back into its aliases after it; the biases a tcnn module cannot hold stay zero
+(``tcnn_params.frozen_parameter_names``).  The trained model exports to tcnn's own parameter vectors.
 """
 
 from __future__ import annotations
@@ -65,6 +75,19 @@ class FruitTrainer:
         self.train_pose = "camera_opt" in self.groups
         self.trans_l2_penalty, self.rot_l2_penalty = 1e-2, 1e-3  # CameraOptimizerConfig defaults
         self.trainable = [k for k in model.params if self.train_pose or not k.startswith("camera_optimizer.")]
+        for k, v in model.params.items():
+            if v.dtype != torch.float32:
+                raise TypeError(f"{k} is {v.dtype}: training needs float32 parameters (half hash tables are inference-only; "
+                                "load the run with hash_table_dtype='float32')")
+        self.tcnn = model.config.implementation == "tcnn"
+        self._tcnn_tables = []
+        self._frozen: List[str] = []
+        if self.tcnn:
+            from .tcnn_params import frozen_parameter_names
+
+            self._tcnn_tables = [(model.field_spec.grid, "field.mlp_base_grid.hash_table")] + [
+                (ps.grid, f"proposal_networks.{i}.encoding.hash_table") for i, ps in enumerate(model.proposal_specs)]
+            self._frozen = frozen_parameter_names(model.field_spec, model.proposal_specs)
         # Parameters, gradients and both Adam moments live in four flat buffers with per-tensor views, ordered by
         # optimiser group: data-parallel training all-reduces the gradients in ONE collective (the reference's DDP,
         # fruit_pipeline.py:119-121, made explicit; 78 MB per step for the default field) and the optimiser step is one
@@ -102,6 +125,7 @@ class FruitTrainer:
         self.grad_field = ops.FieldHandle(self.grads, model.field_spec)
         self.grad_props = [ops.DensityHandle(self.grads, i, ps) for i, ps in enumerate(model.proposal_specs)]
         self.step = 0
+        self.group_steps = {g: 0 for g in self.group_range}  # Adam's per-parameter step count, per group
         self._steps_since_update = 0  # ProposalNetworkSampler state (_steps_since_update, _step)
         self._sampler_step = 0
         self._gen = torch.Generator(device="cpu").manual_seed(seed)
@@ -217,32 +241,49 @@ class FruitTrainer:
 
         self.flat_grads.copy_(all_reduce_mean(self.flat_grads, group))
 
-    def optimizer_step(self) -> None:
+    def optimizer_step(self, proposals_updated: bool = True) -> None:
+        """One optimiser step of every group that has a gradient.  ``proposals_updated`` False: the proposal networks
+        were evaluated without gradient this iteration (``grad is None`` in the reference): their group is not stepped."""
         self.step += 1
+        if self.tcnn:
+            for spec, key in self._tcnn_tables:
+                ops.tcnn_grid_tie_gradients(spec, self.grads[key])
+            for k in self._frozen:
+                self.grads[k].zero_()
         for g, (lo, hi) in self.group_range.items():
-            if g not in self.groups:  # frozen group: its gradient is dropped
-                self.flat_grads[lo:hi].zero_()
+            if g not in self.groups or (g == "proposal_networks" and not proposals_updated):
+                self.flat_grads[lo:hi].zero_()  # frozen group / no gradient this iteration: nothing moves
                 continue
             grp = self.groups[g]
+            self.group_steps[g] += 1
             step_fn = {"adam": ops.adam_step, "radam": ops.radam_step}[grp.optimizer]
             step_fn(self.flat_params[lo:hi], self.flat_grads[lo:hi], self.flat_exp_avg[lo:hi],
-                    self.flat_exp_avg_sq[lo:hi], self.step, grp.lr_at(self.step - 1), eps=grp.eps, zero_grad=True)
+                    self.flat_exp_avg_sq[lo:hi], self.group_steps[g], grp.lr_at(self.step - 1), eps=grp.eps,
+                    zero_grad=True)
+        if self.tcnn:
+            for spec, key in self._tcnn_tables:
+                ops.tcnn_grid_tie_parameters(spec, self.model.params[key])
 
     def state_dict(self) -> Dict[str, object]:
         """What a resumed run needs beside the parameters (nerfstudio checkpoints carry "optimizers" too): the Adam
-        moments in flat-buffer order, the step, the proposal sampler's schedule state and the jitter generator."""
-        return {"step": self.step, "exp_avg": self.flat_exp_avg.detach().cpu(), "exp_avg_sq": self.flat_exp_avg_sq.detach().cpu(),
+        moments in flat-buffer order, the global and per-group step counts, the proposal sampler's schedule state and the
+        jitter generator (this rank's; ``scripts/train.py`` stores one per rank)."""
+        return {"step": self.step, "group_steps": dict(self.group_steps),
+                "exp_avg": self.flat_exp_avg.detach().cpu(), "exp_avg_sq": self.flat_exp_avg_sq.detach().cpu(),
                 "steps_since_update": self._steps_since_update, "sampler_step": self._sampler_step,
                 "generator": self._gen.get_state()}
 
-    def load_state_dict(self, state: Dict[str, object]) -> None:
+    def load_state_dict(self, state: Dict[str, object], load_generator: bool = True) -> None:
         if tuple(state["exp_avg"].shape) != tuple(self.flat_exp_avg.shape):
             raise ValueError("optimizer state of a different model / trainer configuration")
         self.step = int(state["step"])
+        gs = state.get("group_steps") or {}
+        self.group_steps = {g: int(gs.get(g, self.step)) for g in self.group_range}
         self.flat_exp_avg.copy_(state["exp_avg"])
         self.flat_exp_avg_sq.copy_(state["exp_avg_sq"])
         self._steps_since_update, self._sampler_step = int(state["steps_since_update"]), int(state["sampler_step"])
-        self._gen.set_state(state["generator"])
+        if load_generator:
+            self._gen.set_state(state["generator"])
 
     def train_iteration(self, ray_bundle: RayBundle, batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
         self.set_anneal(self.step)
@@ -255,7 +296,7 @@ class FruitTrainer:
 
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             self.all_reduce_gradients()
-        self.optimizer_step()
+        self.optimizer_step(proposals_updated=updated)
         self._sampler_step = it  # step_cb, an AFTER_TRAIN_ITERATION callback
         self._steps_since_update += 1
         out["metrics_dict"] = self.get_metrics_dict(out)

@@ -131,8 +131,13 @@ def test_train_cli_then_export_cli(tmp_path):
     cfg = Path(res["config"])
     assert cfg.exists() and cfg.parent == tmp_path / "outputs" / "plant" / "fruit_nerf" / "t0"
     assert (cfg.parent / "dataparser_transforms.json").exists()
-    ckpts = sorted((cfg.parent / "nerfstudio_models").glob("step-*.pt"))
-    assert [c.name for c in ckpts] == ["step-000000059.pt"]
+    assert cfg.name == "config.yml"  # nerfstudio's run layout: TrainerConfig dump + step-*.ckpt
+    ckpts = sorted((cfg.parent / "nerfstudio_models").glob("step-*.ckpt"))
+    assert [c.name for c in ckpts] == ["step-000000059.ckpt"]
+    loaded = torch.load(ckpts[0], map_location="cpu", weights_only=False)
+    assert set(loaded) >= {"step", "pipeline", "optimizers", "schedulers", "scalers"} and loaded["step"] == 59
+    assert "_model.field.mlp_base_grid.hash_table" in loaded["pipeline"] and "_model.field.aabb" in loaded["pipeline"]
+    assert "_model.proposal_networks.0.mlp_base.model.0.hash_table" in loaded["pipeline"]
     assert math.isfinite(res["eval_psnr"]) and res["eval_psnr"] > 5.0
     exporter.entrypoint(["semantic-pointcloud", "--load-config", str(cfg), "--output-dir", str(tmp_path / "pcd"),
                          "--num-points-per-side", "40", "--num-rays-per-batch", "512"])
@@ -165,14 +170,31 @@ def test_train_cli_two_ranks_rehearsal(tmp_path):
     res = json.loads(last)
     assert res["ranks"] == 2 and math.isfinite(res["eval_psnr"])
     run = tmp_path / "out" / "plant" / "fruit_nerf" / "t"
-    assert (run / "nerfstudio_models" / "step-000000029.pt").exists()
+    ck = run / "nerfstudio_models" / "step-000000029.ckpt"
+    assert ck.exists()
+    # the random streams of BOTH ranks are in the checkpoint (rank 0 wrote it), and they differ
+    rs = torch.load(ck, map_location="cpu", weights_only=False)["optimizers"]["rank_states"]
+    assert len(rs) == 2 and not torch.equal(rs[0]["generator"], rs[1]["generator"])
+    assert not torch.equal(rs[0]["datamanager_generator"], rs[1]["datamanager_generator"])
     # ... and the exporter CLI under the same launcher: batches dealt over the ranks, rank 0 writes the gathered clouds
     exp = root / "cropnerf-a-neural-radiance-field-based-framework_amd" / "fruit_nerf" / "scripts" / "exporter.py"
-    cmd = cmd[:10] + [str(exp), "semantic-pointcloud", "--load-config", str(run / "config.json"), "--output-dir",
+    cmd = cmd[:10] + [str(exp), "semantic-pointcloud", "--load-config", str(run / "config.yml"), "--output-dir",
                       str(tmp_path / "pcd"), "--num-points-per-side", "30", "--num-rays-per-batch", "128"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert (tmp_path / "pcd" / "fruit_nerf" / "density.ply").exists() and p.stdout.count("Saving Point Cloud: done") == 1
+    # two-rank RESUME: every rank continues its own random streams -- the two ranks keep drawing different pixels
+    cmd = cmd[:10] + [str(script), "fruit_nerf", "--data", cap, "--output-dir", str(tmp_path / "out2"),
+                      "--max-num-iterations", "40", "--log-every", "10", "--timestamp", "t", "--train-split-fraction", "0.8",
+                      "--load-dir", str(run / "nerfstudio_models")]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    res2 = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res2["resumed_at"] == 30 and res2["ranks"] == 2
+    rs2 = torch.load(tmp_path / "out2" / "plant" / "fruit_nerf" / "t" / "nerfstudio_models" / "step-000000039.ckpt",
+                     map_location="cpu", weights_only=False)["optimizers"]["rank_states"]
+    assert not torch.equal(rs2[0]["datamanager_generator"], rs2[1]["datamanager_generator"])
+    assert rs2[0]["train_count"] == rs2[1]["train_count"] == 40
 
 
 def test_fruitnerf_dataparser_variant_and_method_dataparsers(capture, tmp_path):
@@ -219,18 +241,25 @@ def test_train_cli_resume_continues_the_same_run(tmp_path):
     assert resumed["resumed_at"] == 13 and full["resumed_at"] == 0
 
     def params(res):
-        ck = sorted((Path(res["config"]).parent / "nerfstudio_models").glob("step-*.pt"))[-1]
-        assert ck.name == "step-000000023.pt"
+        ck = sorted((Path(res["config"]).parent / "nerfstudio_models").glob("step-*.ckpt"))[-1]
+        assert ck.name == "step-000000023.ckpt"
         return torch.load(ck, map_location="cpu", weights_only=False)
 
     a, c = params(full), params(resumed)
     assert "optimizers" in a and a["optimizers"]["step"] == 24
-    for k in a["params"]:
-        ref = a["params"][k]
-        rel = (c["params"][k] - ref).norm().item() / (ref.norm().item() + 1e-12)
+    # the proposal networks are stepped only on the iterations that gave them a gradient (all of the first 10, then by
+    # the update schedule): their Adam step count is below the global one, and it survives the resume
+    gs = a["optimizers"]["group_steps"]
+    assert gs["fields"] == 24 and 10 <= gs["proposal_networks"] < 24 and c["optimizers"]["group_steps"] == gs
+    skip = ("_model.field.aabb", "_model.field.max_res", "_model.field.num_levels", "_model.field.log2_hashmap_size")
+    for k in a["pipeline"]:
+        if k in skip:
+            continue
+        ref = a["pipeline"][k]
+        rel = (c["pipeline"][k] - ref).norm().item() / (ref.norm().item() + 1e-12)
         # two uninterrupted runs differ by up to ~2e-2 here (hash tables, pose: Adam's normalisation amplifies the noise
         # of the atomic sums on rarely-hit entries); a resume that lost the moments or a schedule is off by far more
-        assert rel < (0.25 if k.startswith("camera_optimizer") else 5e-2), (k, rel)  # the 12 x 6 pose tweaks are ~1e-4: noisiest
+        assert rel < (0.25 if "camera_optimizer" in k else 5e-2), (k, rel)  # the 12 x 6 pose tweaks are ~1e-4: noisiest
     assert abs(resumed["eval_psnr"] - full["eval_psnr"]) < 1.0
 
 

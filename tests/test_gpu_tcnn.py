@@ -313,3 +313,83 @@ def test_backward_rejects_half_tables(rounded_scene, ops):
         ops.proposal_backward(dh, gh, ops.scene_struct(scene.aabb, True), to_dev(rb.origins), to_dev(rb.directions),
                               to_dev(rs.starts[..., 0]), to_dev(rs.ends[..., 0]),
                               torch.ones(64, 16, device="cuda"))
+
+
+# ------------------------------------------------------------------------------------------------ run directories
+def _write_reference_style_run(tmp_path, sc):
+    """A run directory as the reference's ``ns-train fruit_nerf`` leaves it: config.yml (TrainerConfig dump) and a
+    checkpoint whose ``pipeline`` holds the tcnn-packed tensors under ``_model.``; plus the camera side file (there is no
+    capture on disk to re-parse)."""
+    import json
+
+    from cropnerf_amd.config import FruitNerfModelConfig
+    from cropnerf_amd.fruit_nerf import nerfstudio_io as NIO
+    from cropnerf_amd.fruit_nerf.checkpoint import _cameras_dict
+    from cropnerf_amd.rays import Cameras
+
+    run = tmp_path / "outputs" / "plant_1" / "fruit_nerf" / "2024-05-01_120000"
+    (run / "nerfstudio_models").mkdir(parents=True)
+    pl = [{"hidden_dim": 16, "log2_hashmap_size": p.grid.log2_hashmap_size, "num_levels": 5, "max_res": p.grid.max_res,
+           "use_linear": False} for p in sc.pspecs]
+    mc = FruitNerfModelConfig(log2_hashmap_size=sc.fspec.grid.log2_hashmap_size, proposal_net_args_list=pl)
+    NIO.write_config_yml(run / "config.yml", method_name="fruit_nerf", model_config=mc, data=None,
+                         output_dir=str(tmp_path / "outputs"), experiment_name="plant_1", timestamp=run.name,
+                         max_num_iterations=30000, steps_per_save=2000, mixed_precision=True,
+                         train_num_rays_per_batch=4096, eval_num_rays_per_batch=4096)
+    state = dict(sc.params)
+    state["lpips.net.scaling_layer.shift"] = torch.zeros(1, 3, 1, 1)  # a module without a counterpart here: ignored
+    NIO.save_checkpoint(run / "nerfstudio_models" / "step-000029999.ckpt", 29999, state,
+                        buffers=NIO.field_buffers(mc, sc.aabb))
+    cams = Cameras(sc.c2w, sc.intr[:, 0], sc.intr[:, 1], sc.intr[:, 2], sc.intr[:, 3], sc.height, sc.width)
+    (run / "cameras.json").write_text(json.dumps(_cameras_dict(cams)))
+    (run / "dataparser_transforms.json").write_text(json.dumps(
+        {"transform": [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], "scale": 0.5}))
+    return run
+
+
+def test_eval_setup_and_exporter_cli_load_a_tcnn_run_directory(tmp_path, ops):
+    """scripts/exporter.py:87 / scripts/semantic_projection.py:139-143: ``eval_setup`` on a reference-style run whose
+    checkpoint is tcnn-packed -> the model renders what the tcnn oracle renders; the exporter CLI runs on it; and
+    ``save_run`` writes the same tcnn vectors back."""
+    from cropnerf_amd.fruit_nerf import nerfstudio_io as NIO
+    from cropnerf_amd.fruit_nerf.checkpoint import eval_setup, save_run
+    from cropnerf_amd.fruit_nerf.scripts import exporter
+
+    sc = make_tcnn_scene(seed=4, log2_T=16, num_images=3, height=20, width=20, focal=28.0, prop_log2_T=13, grid_scale=0.5)
+    run = _write_reference_style_run(tmp_path, sc)
+    cfg, pipe, ck, step = eval_setup(run / "config.yml", test_mode="inference")
+    m = pipe.model
+    assert step == 29999 and ck.name == "step-000029999.ckpt"
+    assert m.config.implementation == "tcnn" and m.params["field.mlp_base_grid.hash_table"].dtype == torch.float16
+    assert m.field_spec.grid.layout == "tcnn" and m.num_train_data == 3
+    # full-image render of camera 1 against the tcnn oracle (inference mode: proposal sampler + 48 field samples)
+    rb = ORY.image_rays(sc.c2w, sc.intr, 1, sc.height, sc.width)
+    ref = oracle_model(sc, "inference").render_rays(rb)
+    from cropnerf_amd.rays import RayBundle
+
+    out = m.get_outputs_for_camera_ray_bundle(pipe.datamanager.cameras.to("cuda").generate_rays(1, keep_shape=True))
+    assert_close(out["rgb"].reshape(-1, 3), ref["rgb"], 2e-3, 2e-3, "rgb of a loaded tcnn run", frac_ok=0.99)
+    assert_close(out["accumulation"].reshape(-1, 1), ref["accumulation"], 2e-3, 2e-3, "accumulation", frac_ok=0.99)
+    # the dense exporter CLI on the same run
+    outdir = tmp_path / "export"
+    exporter.entrypoint(["semantic-pointcloud", "--load-config", str(run / "config.yml"), "--output-dir", str(outdir),
+                         "--num-points-per-side", "12", "--num-rays-per-batch", "50"])
+    assert sorted(p.name for p in outdir.rglob("*.ply")) == ["density.ply", "semantic.ply", "semantic_colormap.ply"]
+    # and back: a run written from this model holds the (fp16-rounded) tcnn vectors the checkpoint had
+    cfg2 = save_run(tmp_path / "o2" / "plant_1" / "fruit_nerf" / "t", m.config, pipe.datamanager.cameras.to("cpu"),
+                    m.scene_box, m.params, step=5)
+    _, state2, loaded2 = NIO.load_checkpoint(NIO.latest_checkpoint(cfg2.parent / "nerfstudio_models"))
+    assert set(loaded2) >= {"step", "pipeline", "optimizers", "schedulers", "scalers"}
+    for k in ("field.mlp_base_grid.tcnn_encoding.params", "field.mlp_base_mlp.tcnn_encoding.params",
+              "proposal_networks.1.mlp_base.tcnn_encoding.params"):
+        want = sc.params[k].to(torch.float16).to(torch.float32)
+        assert state2[k].shape == want.shape
+        if "grid" in k:
+            assert torch.equal(state2[k], want), k
+    # MLP vectors: every value tcnn reads is back (padded output rows are written as zeros)
+    base = TC.mlp_matrices(state2["field.mlp_base_mlp.tcnn_encoding.params"], 32, 16, 64, 1)
+    base0 = TC.mlp_matrices(sc.params["field.mlp_base_mlp.tcnn_encoding.params"].to(torch.float16).to(torch.float32), 32, 16, 64, 1)
+    assert torch.equal(base[0], base0[0]) and torch.equal(base[1], base0[1])
+    head = TC.mlp_matrices(state2["field.mlp_head.tcnn_encoding.params"], 63, 3, 64, 2)
+    head0 = TC.mlp_matrices(sc.params["field.mlp_head.tcnn_encoding.params"].to(torch.float16).to(torch.float32), 63, 3, 64, 2)
+    assert torch.equal(head[0], head0[0]) and torch.equal(head[2][:3], head0[2][:3])
