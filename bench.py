@@ -38,8 +38,18 @@ R = 65536
 NUM_CAMERAS = 100
 DISTINCT_BATCHES = 10  # ~ one 800x800 view (640 000 rays) worth of different batches, cycled
 BYTES_PER_SAMPLE = 16 * 8 * 2 * 4  # 16 levels x 8 corners x 2 features x fp32 = 1024 B of table reads
+BYTES_PER_SAMPLE_F16 = 16 * 8 * 2 * 2  # the same gathers from a half table (tcnn's parameter type): 512 B
+BYTES_PER_PROPOSAL_SAMPLE = 5 * 8 * 2 * 4  # 5 levels x 8 corners x 2 features x fp32 = 320 B
 BYTES_PER_RAY_IO = (3 + 3 + 1 + 1) * 4 + (3 + 1 + 1 + 1 + 3) * 4  # o,d,near,far in; rgb,acc,depth,sem,cmap out
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_FP32_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32: 64 FLOP/clk/SIMD x 4 SIMD x 256 CU x 2.4 GHz (dense)
+MLP_MAC_PER_SAMPLE = 9216  # the folded field MLPs as the render kernels evaluate them
+ATOMIC_REQUESTS_PER_SEC = 21.07e9  # float-atomic requests the memory side takes (tools/atomic_microbench.hip)
+# float-atomic requests per iteration, MEASURED (profiles/r01_v7_pmc_train_atomics.json, TCC_ATOMIC == TCC_EA0_ATOMIC, default
+# method, 4096 random rays): field backward 72.94 per field sample (4.56 per sample and level: the floor of the x-edge
+# scatter is 4.5), each proposal backward 5.372e6 per launch (coarse grids: the run-length pre-reduction merges most)
+ATOMIC_REQUESTS_PER_FIELD_SAMPLE = 72.94
+ATOMIC_REQUESTS_PER_PROPOSAL_LAUNCH_PER_RAY = 5.372e6 / 4096
 
 
 def parse_args():
@@ -56,7 +66,8 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true",
                     help="headline workload only (use under rocprofv3 so per-kernel averages are not mixed with the "
                          "proposal-mode and training launches)")
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-baseline-chunks", type=int, default=12,
+                    help="timed chunks of the CPU baseline (after 3 warm-ups; the median chunk time is reported)")
     return ap.parse_args()
 
 
@@ -138,6 +149,7 @@ def main():
         gather_bufs = [torch.empty(world * R, 6, device=device) for _ in range(2)]
         gather_buf = gather_bufs[0]
     pending = []
+    last = {}  # the last step's packed outputs and the buffer they were gathered into (checked after the timed region)
 
     def step(i: int):
         o, d, n, f, cam, start = batches[i % DISTINCT_BATCHES]
@@ -152,10 +164,12 @@ def main():
                 host = torch.empty(gather_buf.shape)
                 dist.all_gather_into_tensor(host, packed.cpu())
                 gather_buf.copy_(host)
+                last["packed"], last["buf"] = packed, gather_buf
             else:
                 if len(pending) == 2:
                     pending.pop(0).wait()  # stream-side wait: the buffer about to be reused has been filled
                 pending.append(dist.all_gather_into_tensor(gather_bufs[i % 2], packed, async_op=True))
+                last["packed"], last["buf"] = packed, gather_bufs[i % 2]
         return out
 
     def barrier():
@@ -179,33 +193,48 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- roofline of the dominant kernel (render_fused_kernel), measured live with HIP events on the launch stream
+    # ---- N > 1: the gathered buffer of the last step holds every rank's rows, in rank order (outside the timed region) ---
+    gather_check = None
+    if world > 1:
+        mine = last["packed"].double().sum(dim=0).cpu()  # [6] column sums of this rank's per-ray outputs
+        sums = [None] * world
+        dist.all_gather_object(sums, mine)
+        got = last["buf"].view(world, R, 6).double().sum(dim=1).cpu()
+        ok = all(torch.allclose(got[r], sums[r], rtol=1e-9, atol=1e-6) for r in range(world))
+        distinct = len({tuple(round(float(v), 3) for v in s_) for s_ in sums}) == world  # ranks rendered different batches
+        if not ok:
+            raise SystemExit(f"rank {rank}: the all-gathered buffer does not hold the ranks' outputs in rank order")
+        gather_check = {"ranks_in_buffer": world, "rows_per_rank": R, "bytes_per_rank": R * 6 * 4, "distinct_batches": distinct}
+
+    # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream -------------------------------
     roofline = None
     extra = {}
     if rank == 0:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        durs = []
-        for i in range(min(args.steps, 20)):
-            o, d, n, f, cam, start = batches[i % DISTINCT_BATCHES]
-            ev0.record()
-            ops.render_rays(fh, scene_u, opts_for(start), o, d, n, f)
-            ev1.record()
-            ev1.synchronize()
-            durs.append(ev0.elapsed_time(ev1) * 1e-3)
-        avg = sum(durs) / len(durs)
+        avg = launch_time(lambda i: ops.render_rays(fh, scene_u, opts_for(batches[i % DISTINCT_BATCHES][5]),
+                                                    *batches[i % DISTINCT_BATCHES][:4]), min(args.steps, 20))
         alg_bytes = R * (S * BYTES_PER_SAMPLE + BYTES_PER_RAY_IO)
         achieved = alg_bytes / avg / 1e9
-        traffic, traffic_note = pmc_traffic()
+        pmc = pmc_summary()
         kernel_name = ("render_fused_kernel<false,false>" if os.environ.get("CN_FUSED_SPLIT", "1") == "0"
                        else "render_split_kernel")
+        mlp_tflops = R * S * 2 * MLP_MAC_PER_SAMPLE / avg / 1e12
+        # `frac` = ALGORITHMIC bytes (1024 B per field sample + 68 B per ray) / launch time / HBM peak, the
+        # figure the target is stated in.  The kernel is not limited by HBM: the 64 MB table is cache-resident (measured
+        # traffic below is a small fraction of the algorithmic bytes).  What limits it is SIMD issue: the fp32 MFMA passes
+        # of the MLPs and the VALU instructions of hashing / blending / compositing do not overlap on a SIMD, their cycles
+        # add -- `limited_by` says so and `roofline_mfma` prices the matrix half of it.
         roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                    "traffic": traffic, "traffic_note": traffic_note, "algorithmic_bytes_per_launch": alg_bytes,
-                    "avg_launch_ms": round(avg * 1e3, 4),
-                    # second bound, reported beside the first: the folded MLP (9216 MAC per sample) on the fp32 matrix
-                    # pipe (v_mfma_f32_16x16x4_f32: 64 FLOP/clk/SIMD = 157.3 TFLOP/s dense at 2.4 GHz)
-                    "mlp_tflops_fp32": round(R * S * 2 * 9216 / avg / 1e12, 2), "mfma_peak_tflops_fp32": 157.3,
-                    "mfma_frac": round(R * S * 2 * 9216 / avg / 1e12 / 157.3, 4)}
+                    "traffic": pmc.get("traffic"), "traffic_source": pmc.get("source"),
+                    "hbm_measured_frac": (round(pmc["traffic"] / avg / 1e9 / HBM_PEAK_GBPS, 4) if pmc.get("traffic") else None),
+                    "limited_by": "SIMD issue: fp32 MFMA cycles + VALU cycles (they add on a SIMD); not HBM",
+                    "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_sample": BYTES_PER_SAMPLE,
+                    "avg_launch_ms": round(avg * 1e3, 4), "mfma_frac": round(mlp_tflops / MFMA_FP32_PEAK_TFLOPS, 4)}
+        extra["roofline_mfma"] = {"bound": "mfma", "kernel": kernel_name, "achieved": round(mlp_tflops, 2),
+                                  "peak": MFMA_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(mlp_tflops / MFMA_FP32_PEAK_TFLOPS, 4), "traffic": None,
+                                  "flops_per_sample": 2 * MLP_MAC_PER_SAMPLE,
+                                  "note": "exact-fp32 matrix products (v_mfma_f32_16x16x4_f32); dense fp32 matrix peak"}
         extra["uniform_samples_per_sec_single_launch"] = R * S / avg
 
     # ---- CPU baseline (rank 0, N=1): the oracle ("port") on a bounded sample of the same workload ---------------
@@ -242,30 +271,51 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }
+        if gather_check is not None:
+            line["gather_check"] = gather_check
         line.update(extra)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def pmc_traffic():
-    """Memory-side bytes per launch of render_fused_kernel from the committed rocprofv3 PMC passes of this same
-    command (profiles/*_pmc_render_fused.json: FETCH_SIZE and WRITE_SIZE, KiB, separate passes).  No 2x FETCH_SIZE
-    correction is applied: the guide calibrates that factor for 16-B-per-lane streaming reads only, these are 8-B
-    gathers; the TCC miss count (x64 B) of the same run agrees with the raw value.  Infinity-Cache hits are included,
-    so this is an upper bound on HBM bytes (the 64 MB table is cache-resident)."""
+def launch_time(fn, n: int) -> float:
+    """Average seconds per call of ``fn(i)``: HIP events on the current stream (the stream the kernels are launched on)."""
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    durs = []
+    fn(0)
+    torch.cuda.synchronize()
+    for i in range(n):
+        ev0.record()
+        fn(i)
+        ev1.record()
+        ev1.synchronize()
+        durs.append(ev0.elapsed_time(ev1) * 1e-3)
+    return sum(durs) / len(durs)
+
+
+def pmc_summary() -> dict:
+    """Memory-side bytes per launch of the render kernel from the committed rocprofv3 PMC passes of this same command
+    (``profiles/r*_pmc_render*.json``, written by tools/collect_pmc.sh + tools/summarise_pmc.py: FETCH_SIZE and WRITE_SIZE,
+    KiB, separate passes; the summary records the commit it was measured on).  Counters cannot be read from inside this
+    process, so the figure is labelled with its source instead of passing as a live measurement.  No 2x FETCH_SIZE
+    correction: the guide calibrates that factor for 16-B streaming reads, these are 8-B gathers, and TCC_MISS x 64 B of
+    the same run agrees with the raw value.  Infinity-Cache hits are included (an upper bound on HBM bytes)."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_render_fused.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_render*.json")))
     if not files:
-        return None, "no PMC summary under profiles/"
+        return {"traffic": None, "source": "no PMC summary under profiles/"}
     try:
         with open(files[-1]) as fh_:
             d = json.load(fh_)
         val = lambda k: d[k]["avg_per_launch"] if isinstance(d[k], dict) else d[k]
-        return int((val("FETCH_SIZE") + val("WRITE_SIZE")) * 1024), f"from {os.path.basename(files[-1])} (measured on the kernel version named there)"
+        src = f"profiles/{os.path.basename(files[-1])}"
+        if d.get("commit"):
+            src += f" @ {d['commit']}"
+        return {"traffic": int((val("FETCH_SIZE") + val("WRITE_SIZE")) * 1024), "source": src}
     except Exception as e:  # noqa: BLE001
-        return None, f"unreadable PMC summary: {e}"
+        return {"traffic": None, "source": f"unreadable PMC summary: {e}"}
 
 
 def secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, opts):
@@ -312,9 +362,46 @@ def secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, o
         "psnr_vs_fp32_render_db": round(-10.0 * math.log10(max(mse, 1e-30)), 1),
         "note": "optional arithmetic (operands split into bf16 hi + lo, fp32 accumulation); the headline value is exact fp32"}
 
+    # ---- the reference's default module implementation: tcnn grid geometry, half2 table entries (512 B per sample) ------
+    from cropnerf_amd import config as _PC
+
+    tcfg_t = _PC.FruitNerfModelConfig(num_nerf_samples_per_ray=S, implementation="tcnn")
+    tspec = tcfg_t.field_spec(num_images=NUM_CAMERAS)
+    gq = torch.Generator(device="cpu").manual_seed(0)
+    packed = ((torch.rand(2 * tspec.grid.num_packed_entries, generator=gq) * 2 - 1) * 0.1).to(batches[0][0].device)
+    pt = dict(params)
+    pt["field.mlp_base_grid.hash_table"] = ops.tcnn_grid_pack(tspec.grid, packed, torch.float16)
+    fht = ops.FieldHandle(pt, tspec)
+
+    def tcnn_half(i):
+        o, d, n, f, cam, start = batches[i % DISTINCT_BATCHES]
+        o_ = ops.render_opts(S, **({} if args.no_image_hint else {"image_width": W, "pixel_start": start}))
+        return ops.render_rays(fht, scene_u, o_, o, d, n, f)
+
+    t = timed(tcnn_half, 20)
+    alg = R * (S * BYTES_PER_SAMPLE_F16 + BYTES_PER_RAY_IO)
+    out["uniform_mode_tcnn_f16_table"] = {
+        "ms_per_batch": round(t * 1e3, 3), "samples_per_sec": R * S / t, "rays_per_sec": R / t,
+        "roofline": {"bound": "hbm", "kernel": "render_split_kernel<.,.,half,generic>", "achieved": round(alg / t / 1e9, 1),
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(alg / t / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "bytes_per_sample": BYTES_PER_SAMPLE_F16, "mfma_frac": round(R * S * 2 * MLP_MAC_PER_SAMPLE / t / 1e12 / MFMA_FP32_PEAK_TFLOPS, 4)},
+        "note": "tcnn-compatible layout (dense coarse levels, +0.5 offset) with fp16 table entries -- what a reference-trained "
+                "checkpoint imports to; arithmetic stays fp32; the headline is the fp32 torch-layout table"}
+
     t = timed(prop, 10)
     out["proposal_mode"] = {"ms_per_batch": round(t * 1e3, 3), "rays_per_sec": R / t, "field_samples_per_sec": R * S / t,
                             "network_evals_per_sec": R * (S + sum(cfg.num_proposal_samples_per_ray)) / t}
+    # the sampler kernel on its own: SURVEY.md 8(d) prices a proposal sample at 320 B of table reads
+    n_prop = sum(cfg.num_proposal_samples_per_ray)
+    tp = launch_time(lambda i: ops.proposal_sample(dh, scene_c, *batches[i % DISTINCT_BATCHES][:4],
+                                                   cfg.num_proposal_samples_per_ray, S), 10)
+    alg = R * n_prop * BYTES_PER_PROPOSAL_SAMPLE
+    out["proposal_mode"]["roofline"] = {
+        "bound": "hbm", "kernel": "proposal_sample_kernel", "achieved": round(alg / tp / 1e9, 1), "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s", "frac": round(alg / tp / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+        "algorithmic_bytes_per_launch": alg, "bytes_per_sample": BYTES_PER_PROPOSAL_SAMPLE, "avg_launch_ms": round(tp * 1e3, 4),
+        "limited_by": "VALU issue (hashing, 10->16->1 MLP on scalar-operand FMAs, inverse-cdf search); the two 10 MB tables "
+                      "are L2-resident, so the algorithmic rate can exceed what HBM could deliver"}
     if not args.no_train:
         from cropnerf_amd import config as PC
         from cropnerf_amd.fruit_nerf.fruit_nerf import FruitModel, Semantics
@@ -342,13 +429,32 @@ def secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, o
             batch = {k: v.to(batches[0][0].device) for k, v in batch.items()}
             t = timed(lambda i: tr.train_iteration(rb, batch), 5)
             train[str(nrays)] = {"ms_per_iter": round(t * 1e3, 3), "rays_per_sec": nrays / t}
+            # The iteration's bound is the rate at which the memory side takes float-atomic requests (hash-grid gradient
+            # scatter), not HBM bytes or MFMA: requests per iteration = rays x (48 field samples x 72.94 + 2
+            # proposal launches x 1311.5), the per-ray counts measured with the TCC atomic counters.  Proposal networks
+            # take part in one iteration out of `proposal_update_every` after warm-up; the timed iterations are early ones
+            # (every iteration updates them), i.e. the expensive case.
+            req = nrays * (tcfg.num_nerf_samples_per_ray * ATOMIC_REQUESTS_PER_FIELD_SAMPLE
+                           + len(tcfg.num_proposal_samples_per_ray) * ATOMIC_REQUESTS_PER_PROPOSAL_LAUNCH_PER_RAY)
+            train[str(nrays)]["roofline"] = {
+                "bound": "hbm", "kernel": "train_iteration (field_backward_mfma_kernel + 2 x proposal_backward_kernel scatter)",
+                "achieved": round(req / t / 1e9, 3), "peak": round(ATOMIC_REQUESTS_PER_SEC / 1e9, 2),
+                "unit": "G atomic requests/s (memory side; 64-byte read-modify-writes)", "frac": round(req / t / ATOMIC_REQUESTS_PER_SEC, 4),
+                "traffic": None, "atomic_requests_per_iteration": int(req),
+                "requests_source": "profiles/r01_v7_pmc_train_atomics.json (TCC_ATOMIC per launch, 4096 rays)",
+                "hbm_equivalent_GBps": round(req * 64 / t / 1e9, 1)}
         out["train_iteration"] = train
     return out
 
 
 def run_cpu_baseline(args, params, fspec, pspecs, batches, ops, fh, scene_u, opts):
-    """Time the CPU oracle (kind "port": this repo's op-for-op PyTorch restatement; the reference itself needs
-    nerfstudio and cannot run) on a bounded sample of batch 0, all host cores; also PSNR of the GPU render vs it."""
+    """the CPU oracle (kind "port": this repo's op-for-op PyTorch restatement of the reference's
+    path -- the reference itself needs nerfstudio and cannot run) on a bounded sample of the same workload, all host cores
+    of this GPU's share: 3 warm-up chunks, then a FIXED number of timed chunks, MEDIAN chunk time.  C2 (800x800 camera,
+    192 samples/ray) in 4096-ray chunks -- the number `value` compares with -- and C1 (400x400, 64 samples/ray, 1024-ray
+    chunks: BASELINE.json configs[0]).  Also PSNR of the GPU render against the oracle on the C2 sample."""
+    import statistics
+
     from oracle import field as OF
     from oracle import model as OM
     from oracle import rays as ORY
@@ -365,32 +471,59 @@ def run_cpu_baseline(args, params, fspec, pspecs, batches, ops, fh, scene_u, opt
     ofs = OF.FieldSpec(grid=OF.GridSpec(g.num_levels, g.min_res, g.max_res, g.log2_hashmap_size), num_images=fspec.num_images)
     ops_ = [OF.ProposalSpec(OF.GridSpec(p.grid.num_levels, p.grid.min_res, p.grid.max_res, p.grid.log2_hashmap_size))
             for p in pspecs]
-    model = OM.OracleModel(cpu_params, OM.ModelConfig(field=ofs, proposals=ops_, disable_scene_contraction=True),
-                           torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), test_mode="inference")
+    aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+
+    def timed_chunks(model, rays_cpu, chunk, n_timed):
+        o, d, n, f = rays_cpu
+        total = o.shape[0]
+
+        def bundle(k):
+            sel = (torch.arange(chunk) * (total // chunk) + k) % total  # spread over the batch, shifted per chunk
+            return ORY.RayBundle(o[sel], d[sel], torch.zeros(chunk, 1), None, n[sel], f[sel]), sel
+
+        times = []
+        with torch.no_grad():
+            for k in range(3):
+                model.forward(bundle(k)[0])
+            for k in range(n_timed):
+                rb, _ = bundle(3 + k)
+                t0 = time.perf_counter()
+                model.forward(rb)
+                times.append(time.perf_counter() - t0)
+            rb0, sel0 = bundle(0)
+            ref = model.forward(rb0)
+        return statistics.median(times), sum(times), ref, sel0
+
+    # ---- C2: the bench workload -------------------------------------------------------------------------------------------
+    model = OM.OracleModel(cpu_params, OM.ModelConfig(field=ofs, proposals=ops_, disable_scene_contraction=True), aabb,
+                           test_mode="inference")
     model.uniform_samples = S
-    o, d, n, f, cam = (t.detach().cpu() for t in batches[0][:5])
-    chunk = 1024
-    idx = torch.arange(0, R, R // chunk)[:chunk]  # spread over the batch
-
-    def bundle(sel):
-        return ORY.RayBundle(o[sel], d[sel], torch.zeros(len(sel), 1), None, n[sel], f[sel])
-
-    with torch.no_grad():
-        ref = model.forward(bundle(idx))  # warm-up + PSNR reference
-        t0 = time.perf_counter()
-        done = 0
-        k = 0
-        while time.perf_counter() - t0 < args.cpu_baseline_seconds:
-            sel = (idx + 1 + k) % R
-            model.forward(bundle(sel))
-            done += chunk
-            k += 1
-        dt = time.perf_counter() - t0
-    gpu = ops.render_rays(fh, scene_u, opts, *(t[idx.to(t.device)].contiguous() for t in batches[0][:4]))
+    rays2 = tuple(t.detach().cpu() for t in batches[0][:4])
+    chunk2, n2 = 4096, max(10, args.cpu_baseline_chunks)
+    med2, tot2, ref, sel = timed_chunks(model, rays2, chunk2, n2)
+    gpu = ops.render_rays(fh, scene_u, opts, *(t[sel.to(t.device)].contiguous() for t in batches[0][:4]))
     mse = torch.mean((gpu["rgb"].cpu() - ref["rgb"]) ** 2).item()
     psnr = 10.0 * math.log10(1.0 / max(mse, 1e-20))
-    base = {"value": done * S / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{done} rays x {S} samples of batch 0 in {chunk}-ray chunks, {dt:.1f} s, torch {torch.get_num_threads()} threads"}
+    # ---- C1: 400 x 400, 64 samples per ray, 1024-ray chunks -------------------------------------------------------------------
+    from cropnerf_amd import synthetic
+
+    dev = batches[0][0].device
+    c2w1, intr1 = synthetic.orbit_cameras(1, height=400, width=400, focal=555.6)
+    r1 = ops.raygen_pinhole(c2w1.to(dev), intr1.to(dev), cam=0, height=400, width=400, pixel_start=0, num_rays=400 * 400)
+    n1_, f1_ = ops.intersect_aabb(r1["origins"], r1["directions"], [-1.0, -1.0, -1.0, 1.0, 1.0, 1.0])
+    rays1 = tuple(t.detach().cpu() for t in (r1["origins"], r1["directions"], n1_, f1_))
+    model1 = OM.OracleModel(cpu_params, OM.ModelConfig(field=ofs, proposals=ops_, disable_scene_contraction=True), aabb,
+                            test_mode="inference")
+    model1.uniform_samples = 64
+    chunk1, n1 = 1024, 20
+    med1, tot1, _, _ = timed_chunks(model1, rays1, chunk1, n1)
+    base = {"value": chunk2 * S / med2, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"C2: {n2} timed chunks of {chunk2} rays x {S} samples of batch 0 after 3 warm-ups, median chunk time "
+                      f"{med2 * 1e3:.1f} ms ({tot2:.1f} s timed), torch {torch.get_num_threads()} threads, fp32, eval mode",
+            "rays_per_sec": chunk2 / med2,
+            "c1": {"value": chunk1 * 64 / med1, "unit": "samples/s", "rays_per_sec": chunk1 / med1,
+                   "sample": f"C1 (BASELINE.json configs[0]): 400x400 camera, 64 samples/ray, {n1} timed chunks of {chunk1} rays "
+                             f"after 3 warm-ups, median chunk time {med1 * 1e3:.1f} ms ({tot1:.1f} s timed)"}}
     return base, round(psnr, 2)
 
 

@@ -92,7 +92,7 @@ def train(method: str, data: Path, output_dir: Path = Path("outputs"), max_num_i
             raise ValueError(f"{ck} holds a {'tcnn' if is_tcnn_state_dict(state) else 'torch'}-implementation model, the "
                              f"method is configured for {model.config.implementation!r}")
         if is_tcnn_state_dict(state):  # fp32 tables: the master values, not their half cast
-            state = from_tcnn_state_dict(state, model.field_spec, model.proposal_specs, device, torch.float32)
+            state = from_tcnn_state_dict(state, model.field_spec, model.proposal_specs, device, torch.float32)  # unrounded
         for k in model.params:
             model.params[k].copy_(state[k].to(device))
         opt = loaded.get("optimizers") or {}

@@ -118,11 +118,18 @@ def _field_dims(fs: FieldSpec):
 
 
 def from_tcnn_state_dict(state: Dict[str, Tensor], field_spec: FieldSpec, prop_specs: Sequence[ProposalSpec],
-                         device, table_dtype: torch.dtype = torch.float16) -> Dict[str, Tensor]:
+                         device, table_dtype: torch.dtype = torch.float16, round_to_half: Optional[bool] = None
+                         ) -> Dict[str, Tensor]:
     """nerfstudio state dict of a tcnn-built ``FruitModel`` (keys without the ``_model.`` prefix) -> the parameter dict
     ``FruitModel`` / ``ops.FieldHandle`` take (``config.param_shapes`` names, specs with ``grid.layout == "tcnn"``).
-    Hash tables are packed on the device; ``table_dtype`` float16 keeps exactly the values tcnn's kernels read."""
+    Hash tables are packed on the device.  ``round_to_half`` (default: exactly when the tables are float16, i.e. for
+    inference): every tcnn parameter is rounded to fp16 first -- the values tcnn's kernels compute with; False keeps the
+    float32 master values (resuming training)."""
     from .. import ops
+
+    if round_to_half is None:
+        round_to_half = table_dtype == torch.float16
+    half = bool(round_to_half)
 
     if field_spec.grid.layout != "tcnn" or any(p.grid.layout != "tcnn" for p in prop_specs):
         raise ValueError("from_tcnn_state_dict needs specs with grid.layout == 'tcnn'")
@@ -136,17 +143,20 @@ def from_tcnn_state_dict(state: Dict[str, Tensor], field_spec: FieldSpec, prop_s
             out[f"{prefix}.layers.{i}.bias"] = b.to(device).contiguous()
 
     def packed(t: Tensor) -> Tensor:
-        return t.detach().to(device=device, dtype=torch.float32).contiguous()
+        t = t.detach().to(device=device, dtype=torch.float32)
+        if half:
+            t = t.to(torch.float16).to(torch.float32)
+        return t.contiguous()
 
     out["field.mlp_base_grid.hash_table"] = ops.tcnn_grid_pack(
         fs.grid, packed(state["field.mlp_base_grid.tcnn_encoding.params"]), table_dtype)
     put_mlp("field.mlp_base_mlp", mlp_to_linear(state["field.mlp_base_mlp.tcnn_encoding.params"], enc,
-                                                1 + fs.geo_feat_dim, fs.hidden_dim, 1))
+                                                1 + fs.geo_feat_dim, fs.hidden_dim, 1, half=half))
     put_mlp("field.mlp_semantics", mlp_to_linear(state["field.mlp_semantics.tcnn_encoding.params"], fs.geo_feat_dim,
                                                  fs.hidden_dim_transient, fs.hidden_dim_semantics,
-                                                 fs.num_layers_semantic - 1))
+                                                 fs.num_layers_semantic - 1, half=half))
     head = mlp_to_linear(state["field.mlp_head.tcnn_encoding.params"], head_in, 3, fs.hidden_dim_color,
-                         fs.num_layers_color - 1)
+                         fs.num_layers_color - 1, half=half)
     w0 = head[0][0].clone()
     w0[:, list(SH_FLIPPED)] *= -1.0  # tcnn SH sign convention -> the kernels' (nerfstudio torch) convention
     head[0] = (w0, head[0][1])
@@ -158,7 +168,8 @@ def from_tcnn_state_dict(state: Dict[str, Tensor], field_spec: FieldSpec, prop_s
         p = state[f"proposal_networks.{i}.mlp_base.tcnn_encoding.params"]
         pin = ps.grid.num_levels * ps.grid.features_per_level
         n_mlp = mlp_param_count(pin, 1, ps.hidden_dim, 1)
-        put_mlp(f"proposal_networks.{i}.mlp", mlp_to_linear(p[:n_mlp], pin, 1, ps.hidden_dim, 1, input_pad_value=0.0))
+        put_mlp(f"proposal_networks.{i}.mlp", mlp_to_linear(p[:n_mlp], pin, 1, ps.hidden_dim, 1, input_pad_value=0.0,
+                                                            half=half))
         out[f"proposal_networks.{i}.encoding.hash_table"] = ops.tcnn_grid_pack(ps.grid, packed(p[n_mlp:]), table_dtype)
     pose = state.get("camera_optimizer.pose_adjustment")
     out["camera_optimizer.pose_adjustment"] = (

@@ -191,6 +191,20 @@ def normalized_positions(positions: Tensor, aabb: Tensor, contraction: bool) -> 
 # FruitField
 # ----------------------------------------------------------------------------------------------
 
+def semantics_from_geo(geo_flat: Tensor, params: Dict[str, Tensor], spec: "FieldSpec") -> Tensor:
+    """``mlp_semantics`` -> ``field_head_semantics`` (``fruit_field.py:146-157,264-269``) on [N, geo] -> [N, 1]."""
+    if spec.implementation == "tcnn":
+        from . import tcnn as TC
+
+        x = TC.network(geo_flat, params["field.mlp_semantics.tcnn_encoding.params"], spec.geo_feat_dim,
+                       spec.hidden_dim_transient, spec.hidden_dim_semantics, spec.num_layers_semantic - 1,
+                       half_activations=spec.tcnn_half_activations)
+    else:
+        x = mlp(geo_flat, params, "field.mlp_semantics", spec.num_layers_semantic)
+    return torch.nn.functional.linear(x, params["field.field_head_semantics.net.weight"],
+                                      params["field.field_head_semantics.net.bias"])
+
+
 def field_density(positions: Tensor, params: Dict[str, Tensor], spec: FieldSpec, aabb: Tensor,
                   contraction: bool) -> Tuple[Tensor, Tensor]:
     """``FruitField.get_density`` (``fruit_field.py:169-194``) -> density [...,1], geo features [...,geo]."""
@@ -254,20 +268,12 @@ def field_forward(
     geo_flat = geo.reshape(-1, spec.geo_feat_dim)
     if tcnn_impl:
         ha = spec.tcnn_half_activations
-        x = TC.network(geo_flat, params["field.mlp_semantics.tcnn_encoding.params"], spec.geo_feat_dim,
-                       spec.hidden_dim_transient, spec.hidden_dim_semantics, spec.num_layers_semantic - 1,
-                       half_activations=ha)
-        sem = torch.nn.functional.linear(
-            x, params["field.field_head_semantics.net.weight"], params["field.field_head_semantics.net.bias"]
-        ).view(R, S, -1)
+        sem = semantics_from_geo(geo_flat, params, spec).view(R, S, -1)
         h = torch.cat([sh, geo_flat, app], dim=-1)
         rgb = TC.network(h, params["field.mlp_head.tcnn_encoding.params"], h.shape[-1], 3, spec.hidden_dim_color,
                          spec.num_layers_color - 1, "sigmoid", half_activations=ha).view(R, S, 3)
         return {"density": density, "rgb": rgb, "semantics": sem}
-    x = mlp(geo_flat, params, "field.mlp_semantics", spec.num_layers_semantic)
-    sem = torch.nn.functional.linear(
-        x, params["field.field_head_semantics.net.weight"], params["field.field_head_semantics.net.bias"]
-    ).view(R, S, -1)
+    sem = semantics_from_geo(geo_flat, params, spec).view(R, S, -1)
 
     h = torch.cat([sh, geo_flat, app], dim=-1)
     rgb = mlp(h, params, "field.mlp_head", spec.num_layers_color, out_activation="sigmoid").view(R, S, 3)

@@ -4,8 +4,8 @@ TEST INFRASTRUCTURE (see ``oracle/__init__.py``).  Restates ``FruitModel.get_los
 (``fruit_nerf/fruit_nerf.py:601-615``): ``MSELoss(image[:, :3], rgb)``, ``semantic_loss_weight *
 BCEWithLogitsLoss(semantics, fruit_mask)`` and, in training, ``interlevel_loss_mult * interlevel_loss(weights_list,
 ray_samples_list)`` (upstream nerfstudio ``losses.interlevel_loss`` / ``lossfun_outer`` / ``outer``, SURVEY.md A.8);
-``get_metrics_dict`` (``:639-645``): PSNR and the distortion metric.  The camera-optimizer regulariser is left out
-(pose refinement is not trained in this round).
+``get_metrics_dict`` (``:639-645``): PSNR and the distortion metric; ``camera_opt_regularizer`` below.  Works for
+both implementations of the field (``FieldSpec.implementation``: parameters under the torch or the tcnn names).
 """
 
 from __future__ import annotations
@@ -94,9 +94,7 @@ def train_forward(
     # the semantic MLP sees detached geo features and the renderer detached weights (fruit_field.py:264-266,
     # fruit_nerf.py:586-591): gradients of the semantic loss reach only mlp_semantics and its head
     geo = F.field_density(rs.positions(), params, fspec, aabb, True)[1].detach()
-    x = F.mlp(geo.reshape(-1, fspec.geo_feat_dim), params, "field.mlp_semantics", fspec.num_layers_semantic)
-    sem_s = torch.nn.functional.linear(x, params["field.field_head_semantics.net.weight"],
-                                       params["field.field_head_semantics.net.bias"]).view(*weights.shape[:2], 1)
+    sem_s = F.semantics_from_geo(geo.reshape(-1, fspec.geo_feat_dim), params, fspec).view(*weights.shape[:2], 1)
     sem = RD.render_semantics(sem_s, weights.detach())
     return {"rgb": rgb, "semantics": sem, "accumulation": RD.render_accumulation(weights),
             "weights_list": weights_list, "ray_samples_list": samples_list, "_field": fo}

@@ -166,3 +166,36 @@ def test_sharded_exporters_two_ranks_rehearsal():
            "--master-port", str(_free_port()), worker]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "sharded export ok" in p.stdout, p.stdout[-1500:] + p.stderr[-2500:]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal():
+    """``bench.py --gpus 2`` launched exactly as the driver launches it (``torch.distributed.run``, fresh child processes),
+    rehearsed on this box's single GPU (``BENCH_REHEARSE_ON_ONE_GPU=1``: both ranks on cuda:0, exchange over gloo; on a
+    multi-GPU node the same code path runs one rank per GPU over RCCL): one JSON line from rank 0, n_gpus 2, the sharding
+    string, weak scaling (twice the work per step), and the gathered buffer holds both ranks' rows."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BENCH_REHEARSE_ON_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert "all-gather" in d["config"]["sharding"] and d["cpu_baseline"] is None  # the CPU baseline is an N = 1 item
+    g = d["gather_check"]
+    assert g["ranks_in_buffer"] == 2 and g["rows_per_rank"] == 65536 and g["distinct_batches"] is True
+    # value = the samples BOTH ranks rendered per step / the slowest rank's time
+    assert abs(d["ms_per_step"] * 1e-3 * d["value"] - 2 * 65536 * 192) / (2 * 65536 * 192) < 1e-6
+    assert d["roofline"]["kernel"].startswith("render_")

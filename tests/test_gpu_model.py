@@ -355,13 +355,13 @@ def test_model_matrix_precision_option(scene):
 
 def test_bench_line_contract():
     """bench.py prints ONE JSON line with the driver's keys plus ``roofline`` and ``cpu_baseline`` (a short run here: few
-    steps, 3 s of CPU baseline, no secondary timings)."""
+    steps, the minimum CPU-baseline chunk count, no secondary timings)."""
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-secondary",
-                        "--cpu-baseline-seconds", "3"], capture_output=True, text=True, timeout=600, cwd=root)
+                        "--cpu-baseline-chunks", "10"], capture_output=True, text=True, timeout=600, cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
@@ -374,6 +374,10 @@ def test_bench_line_contract():
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and 0 < r["frac"] <= 1.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["peak"] == 8000.0
+    assert "limited_by" in r and "traffic_source" in r and r["bytes_per_sample"] == 1024
+    m = d["roofline_mfma"]
+    assert m["bound"] == "mfma" and m["unit"] == "TFLOP/s" and abs(m["frac"] - m["achieved"] / m["peak"]) < 1e-3
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
+    assert "median" in c["sample"] and c["c1"]["value"] > 0 and "400x400" in c["c1"]["sample"]
     assert d["value"] > 1e9 and abs(d["ms_per_step"] * 1e-3 * d["value"] - 65536 * 192) / (65536 * 192) < 1e-6

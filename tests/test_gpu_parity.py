@@ -534,10 +534,28 @@ def test_image_width_hint_changes_schedule_not_results(scene, ops, handles, widt
     o, d, n, f = (to_dev(t[idx]) for t in (rb.origins, rb.directions, rb.nears, rb.fars))
     sc = ops.scene_struct(scene.aabb, True)
     base = ops.render_rays(fh, sc, ops.render_opts(48), o, d, n, f)
-    poison = {k: torch.full_like(v, float("nan")) for k, v in base.items()}
     hinted = ops.render_rays(fh, sc, ops.render_opts(48, image_width=width, pixel_start=start), o, d, n, f)
     for k in base:
         assert torch.equal(base[k], hinted[k]), k
+    # "every ray exactly once": call the C ABI on output buffers pre-filled with NaN -- a ray the striped schedule
+    # skipped would keep its poison, and since the launch only ever writes (no accumulation into the outputs), a ray
+    # rendered twice could not differ from the baseline either; no NaN left + bit-equality = each row written
+    import ctypes as C
+
+    from cropnerf_amd import _lib as L
+
+    poison = {k: torch.full_like(base[k], float("nan")) for k in ("rgb", "accumulation", "depth", "semantics", "semantics_colormap")}
+    opts = ops.render_opts(48, image_width=width, pixel_start=start)
+    ws = fh.workspace()
+    L.check(L.load().cn_render_rays(C.byref(fh.struct), C.byref(sc), C.byref(opts), o.data_ptr(), d.data_ptr(), n.data_ptr(),
+                                    f.data_ptr(), None, None, R, poison["rgb"].data_ptr(), poison["accumulation"].data_ptr(),
+                                    poison["depth"].data_ptr(), poison["semantics"].data_ptr(),
+                                    poison["semantics_colormap"].data_ptr(), None, ws.data_ptr(), ws.numel(),
+                                    torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    for k, v in poison.items():
+        assert not torch.isnan(v).any(), f"{k}: rows never written under the striped schedule"
+        assert torch.equal(v, base[k]), k
 
 
 @pytest.mark.parametrize("split", ["0", "2"])  # single-wave kernel / producer-consumer kernel (forced for a small batch)
