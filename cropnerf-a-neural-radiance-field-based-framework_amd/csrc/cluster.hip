@@ -235,3 +235,74 @@ extern "C" int cn_dbscan(const float* points_sorted, const int64_t* cell_keys, c
                      root);
   return cn::check_launch("cn_dbscan");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// K-means sub-clustering of one super-cluster (segmentation/segmenter.py:28-45,153-181: sklearn KMeans(init="k-means++",
+// n_clusters=k, n_init="auto", random_state=0)).  The k-means++ seeding (a handful of weighted random draws) stays on the
+// host with scikit-learn's own routine and random stream; this is ONE Lloyd iteration of sklearn's _kmeans_single_lloyd in
+// float64 like sklearn: label every point with its nearest centre (first minimum, as np.argmin), accumulate per-cluster
+// coordinate sums and counts, and flag whether any label changed (sklearn's strict-convergence test).  The host divides
+// the sums and applies the stopping rules (two scalars read back per iteration; a super-cluster converges in ~10-30).
+// ---------------------------------------------------------------------------------------------------------------
+namespace cn {
+
+constexpr int KM_MAX_K = 32;
+
+__global__ void __launch_bounds__(256)
+kmeans_step_kernel(const double* __restrict__ pts, long long n, const double* __restrict__ centers, int k,
+                   int* __restrict__ labels, double* __restrict__ sums /*[k,3]*/, long long* __restrict__ counts /*[k]*/,
+                   int* __restrict__ changed, int accumulate) {
+  __shared__ double c[KM_MAX_K * 3];
+  __shared__ double bs[KM_MAX_K * 3];
+  __shared__ unsigned long long bc[KM_MAX_K];
+  for (int i = threadIdx.x; i < 3 * k; i += blockDim.x) {
+    c[i] = centers[i];
+    bs[i] = 0.0;
+  }
+  for (int i = threadIdx.x; i < k; i += blockDim.x) bc[i] = 0ull;
+  __syncthreads();
+  int any = 0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    int best = 0;
+    double bd = 0.0;
+    for (int j = 0; j < k; ++j) {
+      const double dx = x - c[3 * j], dy = y - c[3 * j + 1], dz = z - c[3 * j + 2];
+      const double d = dx * dx + dy * dy + dz * dz;
+      if (j == 0 || d < bd) {  // strict <: the first minimum wins
+        bd = d;
+        best = j;
+      }
+    }
+    any |= labels[i] != best;
+    labels[i] = best;
+    if (accumulate) {
+      atomicAdd(&bs[3 * best], x);
+      atomicAdd(&bs[3 * best + 1], y);
+      atomicAdd(&bs[3 * best + 2], z);
+      atomicAdd(&bc[best], 1ull);
+    }
+  }
+  if (any) atomicOr(changed, 1);
+  __syncthreads();
+  if (accumulate) {
+    for (int i = threadIdx.x; i < 3 * k; i += blockDim.x)
+      if (bs[i] != 0.0) atomicAdd(&sums[i], bs[i]);
+    for (int i = threadIdx.x; i < k; i += blockDim.x)
+      if (bc[i]) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[i]), bc[i]);
+  }
+}
+
+}  // namespace cn
+
+extern "C" int cn_kmeans_step(const double* points, int64_t num_points, const double* centers, int32_t k, int32_t* labels,
+                              double* sums, int64_t* counts, int32_t* changed, int32_t accumulate, cn_stream_t stream) {
+  CN_REQUIRE(points && centers && labels && changed, CN_ERR_INVALID, "cn_kmeans_step: null argument");
+  CN_REQUIRE(!accumulate || (sums && counts), CN_ERR_INVALID, "cn_kmeans_step: sums / counts required when accumulating");
+  CN_REQUIRE(k >= 1 && k <= cn::KM_MAX_K, CN_ERR_UNSUPPORTED, "cn_kmeans_step: k = %d (1..%d)", k, cn::KM_MAX_K);
+  if (num_points <= 0) return CN_OK;
+  hipLaunchKernelGGL(cn::kmeans_step_kernel, dim3(cn::grid_for(num_points, 256, 1024)), dim3(256), 0, cn::as_stream(stream),
+                     points, (long long)num_points, centers, k, labels, sums, reinterpret_cast<long long*>(counts), changed,
+                     accumulate);
+  return cn::check_launch("cn_kmeans_step");
+}

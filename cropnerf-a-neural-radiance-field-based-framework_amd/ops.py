@@ -813,6 +813,61 @@ def dbscan(points: Tensor, eps: float, min_points: int) -> Tuple[Tensor, Tensor]
     return labels, core
 
 
+def kmeans(points: Tensor, k: int, max_iter: int = 300, tol: float = 1e-4, random_state: int = 0) -> Tensor:
+    """``sklearn.cluster.KMeans(init="k-means++", n_clusters=k, n_init="auto", random_state=0).fit(points).labels_``
+    (``segmentation/segmenter.py:41-43``) with the Lloyd iterations on the device (``cn_kmeans_step``, float64 as sklearn).
+    Seeding is scikit-learn's own ``kmeans_plusplus`` on the host with the same random stream (a few weighted draws over
+    the points); centring, the scaled tolerance and the two stopping rules follow ``_kmeans_single_lloyd``.  Returns
+    labels [N] int64 on the device."""
+    import numpy as np
+    from sklearn.cluster import kmeans_plusplus
+
+    lib = L.load()
+    if points.dtype not in (torch.float32, torch.float64) or not points.is_cuda:
+        raise TypeError("kmeans: expected a float device tensor [N,3]")
+    n = points.shape[0]
+    if n < k:
+        raise ValueError(f"n_samples={n} should be >= n_clusters={k}.")  # sklearn's message
+    x = points.to(torch.float64)
+    x = (x - x.mean(dim=0)).contiguous()  # KMeans.fit centres the data before anything else
+    xh = x.cpu().numpy()
+    tol_ = float(np.mean(np.var(xh, axis=0)) * tol)  # _tolerance
+    centers_h, _ = kmeans_plusplus(xh, k, random_state=np.random.RandomState(random_state))
+    centers = torch.from_numpy(np.ascontiguousarray(centers_h)).to(x.device)
+    labels = torch.full((n,), -1, dtype=torch.int32, device=x.device)
+    sums = torch.empty(k, 3, dtype=torch.float64, device=x.device)
+    counts = torch.empty(k, dtype=torch.int64, device=x.device)
+    changed = torch.empty(1, dtype=torch.int32, device=x.device)
+    strict = False
+    for it in range(max_iter):
+        sums.zero_(), counts.zero_(), changed.zero_()
+        L.check(lib.cn_kmeans_step(_p(x), n, _p(centers), k, _p(labels), _p(sums), _p(counts), _p(changed), 1, _stream(x)))
+        if bool((counts == 0).any()):
+            # _relocate_empty_clusters: an empty cluster takes the point farthest from its own centre (rare)
+            lab = labels.to(torch.int64)
+            d = ((x - centers[lab]) ** 2).sum(dim=1)
+            empty = (counts == 0).nonzero().squeeze(1)
+            far = torch.argsort(d, descending=True)[: empty.numel()]
+            for e, f in zip(empty.tolist(), far.tolist()):
+                old = int(lab[f])
+                sums[old] -= x[f]
+                counts[old] -= 1
+                sums[e] = x[f]
+                counts[e] = 1
+        new = sums / counts.to(torch.float64)[:, None]
+        shift = float(((new - centers) ** 2).sum())
+        centers = new.contiguous()
+        if it > 0 and int(changed.item()) == 0:
+            strict = True  # labels equal to the previous iteration's: sklearn's strict convergence
+            break
+        if shift <= tol_:
+            break
+    if not strict:  # rerun the E-step so that the labels match the final centres
+        changed.zero_()
+        L.check(lib.cn_kmeans_step(_p(x), n, _p(centers), k, _p(labels), None, None, _p(changed), 0, _stream(x)))
+    return labels.to(torch.int64)
+
+
 def get_super_clusters(points: Tensor, vx_size: float = 10e-5, colors: Optional[Tensor] = None):
     """``segmentation/segmenter.py:69-86``: voxel down-sample, DBSCAN(eps = 20 voxels, min_points = 30), drop the noise,
     statistical outlier removal (20 neighbours, std_ratio 2).  Returns (points, labels)."""

@@ -3,9 +3,9 @@ projections: it turns the exported semantic point
 ``all_super_cluster_info*.npy`` list that ``FruitModel.get_outputs_for_projections`` and the depth-based projection read.
 
 ``get_super_clusters`` (``:69-86``: voxel down-sampling, DBSCAN, noise removal, statistical outlier removal) runs on the HIP
-kernels (``csrc/cluster.hip``, ``csrc/knn.hip``) with the cloud resident on the device.  ``cluster_kmeans`` (``:28-45``) is
-the same scikit-learn call as the reference's (k-means++ with ``random_state=0`` on the few thousand points of one
-super-cluster: CPU, as there).  open3d point-cloud objects are replaced by [N,3] arrays / tensors; the visualisation helpers
+kernels (``csrc/cluster.hip``, ``csrc/knn.hip``) with the cloud resident on the device.  ``cluster_kmeans`` (``:28-45``) runs
+its Lloyd iterations on the device too (``cn_kmeans_step``, float64); only the k-means++ seeding -- a few weighted draws --
+stays with scikit-learn's own routine and random stream on the host, so the labels are scikit-learn's.  open3d point-cloud objects are replaced by [N,3] arrays / tensors; the visualisation helpers
 are not mirrored.
 """
 
@@ -21,12 +21,11 @@ from torch import Tensor
 from .. import ops
 
 
-def cluster_kmeans(points, k: int = 10) -> np.ndarray:
-    """``:28-45`` without the normals option: KMeans(init="k-means++", n_clusters=k, n_init="auto", random_state=0)."""
-    from sklearn.cluster import KMeans
-
-    feats = points.detach().cpu().numpy() if isinstance(points, Tensor) else np.asarray(points)
-    return KMeans(init="k-means++", n_clusters=k, n_init="auto", random_state=0).fit(feats).labels_
+def cluster_kmeans(points, k: int = 10, device="cuda") -> np.ndarray:
+    """``:28-45`` without the normals option: KMeans(init="k-means++", n_clusters=k, n_init="auto", random_state=0) --
+    ``ops.kmeans`` (Lloyd iterations on the device, scikit-learn's seeding on the host)."""
+    pts = points if isinstance(points, Tensor) else torch.as_tensor(np.asarray(points))
+    return ops.kmeans(pts.to(device), k).cpu().numpy()
 
 
 def get_super_clusters(points, vx_size: float = 10e-5, device="cuda") -> Tuple[Tensor, Tensor]:

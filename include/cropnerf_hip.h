@@ -509,6 +509,15 @@ int cn_dbscan(const float* points_sorted, const int64_t* cell_keys, const int32_
               int32_t min_points, const int64_t* order, int64_t num_points, int32_t* neighbour_count, int32_t* parent,
               int32_t* root, void* workspace, size_t workspace_bytes, cn_stream_t stream);
 
+/* K-means sub-clustering of one super-cluster (segmentation/segmenter.py:28-45: sklearn KMeans(init="k-means++",
+ * n_clusters=k, n_init="auto", random_state=0), called per super-cluster at :153-181).  ONE Lloyd iteration in float64, as
+ * sklearn's _kmeans_single_lloyd: labels[i] <- index of the nearest of the k centres [k,3] (first minimum); *changed |= 1
+ * when any label differs from its previous value; with accumulate != 0 the coordinate sums [k,3] and counts [k] of the new
+ * assignment are ADDED to `sums` / `counts` (caller zeroes them).  The k-means++ seeding and the stopping rules stay on
+ * the host. points [N,3] float64 (centred as sklearn does), k <= 32. */
+int cn_kmeans_step(const double* points, int64_t num_points, const double* centers, int32_t k, int32_t* labels,
+                   double* sums, int64_t* counts, int32_t* changed, int32_t accumulate, cn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

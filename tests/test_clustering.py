@@ -158,3 +158,30 @@ def test_segmenter_process_for_pipeline(tmp_path):
     out = SG.process_for_pipeline(str(tmp_path), "semantics_pc.ply", k=2, vx_size=0.002)
     info = np.load(out, allow_pickle=True)
     assert out.endswith("all_super_cluster_info_nsub_2.npy") and len(info) >= 4 and info[0]["aabb"].shape == (2, 2, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [2, 3, 5, 10])
+def test_device_kmeans_labels_are_scikit_learns(k):
+    """segmentation/segmenter.py:28-45: the sub-cluster labels of ``ops.kmeans`` (Lloyd iterations in ``cn_kmeans_step``,
+    scikit-learn's k-means++ seeding with random_state=0 on the host) against
+    ``KMeans(init="k-means++", n_clusters=k, n_init="auto", random_state=0)`` itself -- identical, point for point."""
+    from sklearn.cluster import KMeans
+
+    from cropnerf_amd import ops
+    from cropnerf_amd.segmentation import segmenter
+
+    rng = np.random.default_rng(100 + k)
+    for n, spread in ((400, 0.02), (6000, 0.05), (50000, 0.03)):
+        # a fruit-sized super-cluster: a few overlapping lumps (float32 coordinates, as the exporter writes them)
+        centres = rng.normal(size=(max(k, 3), 3)) * 0.05
+        pts = (centres[rng.integers(0, len(centres), n)] + rng.normal(size=(n, 3)) * spread).astype(np.float32)
+        ref = KMeans(init="k-means++", n_clusters=k, n_init="auto", random_state=0).fit(pts.astype(np.float64)).labels_
+        got = ops.kmeans(torch.from_numpy(pts).cuda(), k).cpu().numpy()
+        assert got.shape == ref.shape and set(got.tolist()) == set(range(k))
+        same = (got == ref).mean()
+        assert same == 1.0, f"k={k} n={n}: {100 * same:.3f} % of the labels agree"
+        # through the mirror's entry point (what process_and_save_all calls), from float64 input as there
+        assert np.array_equal(segmenter.cluster_kmeans(pts.astype(np.float64), k), ref)
+    with pytest.raises(ValueError):
+        ops.kmeans(torch.zeros(3, 3).cuda(), 5)
