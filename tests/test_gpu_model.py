@@ -381,3 +381,64 @@ def test_bench_line_contract():
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
     assert "median" in c["sample"] and c["c1"]["value"] > 0 and "400x400" in c["c1"]["sample"]
     assert d["value"] > 1e9 and abs(d["ms_per_step"] * 1e-3 * d["value"] - 65536 * 192) / (65536 * 192) < 1e-6
+
+
+def test_pointcloud_export_at_c4_size():
+    """BASELINE.json configs[3]: ``ns-export pointcloud --num-points 10000000`` on the full-size default field at
+    800 x 800 (export/exporter_utils_nerfacto.py:125-183: 2048-ray calls until 10 M semantic points are kept), with a
+    runtime bound -- the whole export is a few seconds on the device (the reference's loop syncs the host per call)."""
+    import time
+
+    from cropnerf_amd import config as PC
+    from cropnerf_amd import synthetic
+    from cropnerf_amd.fruit_nerf.data.fruit_datamanager import FruitDataManagerConfig
+    from cropnerf_amd.fruit_nerf.export.exporter_utils_nerfacto import generate_point_cloud
+    from cropnerf_amd.fruit_nerf.fruit_pipeline import FruitPipeline, FruitPipelineConfig
+    from cropnerf_amd.rays import Cameras, SceneBox
+
+    cfg = PC.FruitNerfModelConfig()
+    params = synthetic.p_rand(cfg.field_spec(100), cfg.proposal_specs(), seed=0, device="cuda")
+    params["field.mlp_base_mlp.layers.1.bias"][0] += 4.0   # density and fruit probability high enough to keep points
+    params["field.field_head_semantics.net.bias"] += 3.0
+    c2w, intr = synthetic.orbit_cameras(100, height=800, width=800)
+    cams = Cameras(c2w, intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], 800, 800)
+    pipe = FruitPipeline(FruitPipelineConfig(FruitDataManagerConfig(2048, 2048), cfg), "cuda", cams,
+                         SceneBox(torch.tensor([[-1.0, -1, -1], [1, 1, 1]])), test_mode="test", params=params)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pcd = generate_point_cloud(pipe, num_points=10_000_000, remove_outliers=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n = pcd["points"].shape[0]
+    # the loop stops at the first 2048-ray call that reaches the target: at most one call's worth beyond it
+    assert 10_000_000 <= n < 10_000_000 + 2048, n
+    assert pcd["colors"].shape == (n, 3) and np.isfinite(pcd["points"]).all()
+    assert pcd["colors"].min() >= 0 and pcd["colors"].max() <= 1
+    assert np.abs(pcd["points"]).max() < 1e4
+    assert dt < 60.0, f"10 M-point export took {dt:.1f} s"
+
+
+def test_pipeline_replicas_one_plant_per_rank():
+    """BASELINE.json configs[4]: the full train -> export -> segmenter -> projection pipeline as independent REPLICAS, one
+    plant per GPU (``tools/pipeline.py`` under ``torch.distributed.run``; the path does not shard across plants, so there is
+    no collective and no process group).  Two replicas rehearsed on this box's one GPU at a small size."""
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CROPNERF_REHEARSE_ON_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tools", "pipeline.py"), "--iters", "300", "--res", "64",
+           "--side", "160", "--views", "2", "--plant", "3"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert sorted(d["plant"] for d in lines) == [3, 4] and all(d["replicas"] == 2 for d in lines)
+    for d in lines:
+        for k in ("train_s", "export_s", "segment_s", "projection_s", "depth_projection_s", "fruit_count", "export_kept"):
+            assert k in d, k
+        assert d["export_samples"] == 160 ** 3

@@ -4,6 +4,14 @@ depth-based projection.  Reports the seconds of each stage and the fruit count (
 bolls of the closed-form plant.
 
     python tools/pipeline.py [--iters 2000] [--res 200] [--side 800] [--views 8]
+
+BASELINE.json configs[4] proper -- all plants concurrently, one per GPU -- is N independent REPLICAS of this pipeline
+(the path does not shard across plants: no collective, no process group):
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/pipeline.py [...]
+
+Every rank binds to GPU LOCAL_RANK, takes plant ``--plant + RANK`` (its own training seed / batches) and prints its own
+JSON line; nothing is exchanged.  ``CROPNERF_REHEARSE_ON_ONE_GPU=1`` puts every replica on cuda:0 (tests on a one-GPU box).
 """
 import argparse, json, os, sys, tempfile, time
 import numpy as np, torch
@@ -25,9 +33,13 @@ def clock():
 
 
 def main(a):
-    out = {}
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = 0 if os.environ.get("CROPNERF_REHEARSE_ON_ONE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)  # replicas: one plant per GPU, no process group is ever created
+    plant = a.plant + rank
+    out = {"plant": plant, "replica": rank, "replicas": world, "device": f"cuda:{local}"}
     t = clock()
-    fit, pipe, (cams_all, images, masks, held) = fit_scene.fit(a.iters, a.res)
+    fit, pipe, (cams_all, images, masks, held) = fit_scene.fit(a.iters, a.res, seed=plant, device=f"cuda:{local}")
     out["train_s"] = round(clock() - t, 2)
     out["held_out_psnr"], out["held_out_fruit_iou"] = fit["held_out_psnr_mean"], fit["held_out_fruit_iou_mean"]
     model, dm = pipe.model, pipe.datamanager
@@ -59,7 +71,7 @@ def main(a):
     SG.get_super_clusters(fruit, vx)
     out["super_clusters_s"] = round(clock() - t, 3)  # voxel down-sample + DBSCAN + outlier removal (device)
     t = clock()
-    info = SG.process_and_save_all(fruit, k=2, vx_size=vx)  # the same again + k-means per super-cluster (scikit-learn, host)
+    info = SG.process_and_save_all(fruit, k=2, vx_size=vx)  # the same again + k-means per super-cluster (Lloyd iterations on the device)
     out["segment_s"] = round(clock() - t, 3)
     out["fruit_count"], out["bolls"] = len(info), len(synthetic.BOLLS)
     centres = [np.concatenate(list(sc["pcd"].values())).mean(0) for sc in info]
@@ -109,4 +121,5 @@ if __name__ == "__main__":
     ap.add_argument("--sem-thresh", type=float, default=3.0)
     ap.add_argument("--den-thresh", type=float, default=70.0)
     ap.add_argument("--matrix-precision", choices=["fp32", "split_bf16"], default="fp32")
+    ap.add_argument("--plant", type=int, default=0, help="first plant id (rank r of a replicated launch takes plant + r)")
     main(ap.parse_args())
