@@ -29,6 +29,13 @@ if stats:
 if "TCC_HIT_sum" in out and "TCC_MISS_sum" in out:
     h, m = out["TCC_HIT_sum"]["avg_per_launch"], out["TCC_MISS_sum"]["avg_per_launch"]
     out["l2_hit_rate"] = h / max(h + m, 1.0)
+import subprocess
+
+try:  # the commit the counters were measured on (bench.py prints it next to `traffic`)
+    out["commit"] = os.environ.get("CN_PROFILE_COMMIT") or subprocess.run(
+        ["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+except Exception:  # noqa: BLE001
+    out["commit"] = os.environ.get("CN_PROFILE_COMMIT")
 out["note"] = ("per-launch averages over the launches of the named kernel in `bench.py --steps 3 --warmup 1 "
                "--no-cpu-baseline --no-secondary`, one rocprofv3 --pmc pass per counter group; FETCH_SIZE / WRITE_SIZE in KiB")
 with open(os.path.join(root, "profiles", f"{tag}_pmc_render_fused.json"), "w") as fh:

@@ -9,7 +9,8 @@ for R in 4096 65536; do
   mkdir -p $O
   TRAIN_RAYS=$R rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 $ROOT/tools/train_probe.py > $O/run.log 2>&1
   f=$(find $O -name "*kernel_stats.csv" | head -1)
-  echo "== $R rays: $(tail -1 $O/run.log)"
+  cp "$f" $ROOT/gpurun_out/${TAG}_train_${R}_kernel_stats.csv
+  echo "== $R rays: $(grep ms/iter $O/run.log | tail -1)"
   python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
