@@ -132,6 +132,8 @@ SIGNATURES = {
     "cn_segment_mean": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "cn_dbscan_workspace_bytes": (C.c_size_t, [_I64]),
     "cn_dbscan": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _F, _I32, _P, _I64, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cn_contour_workspace_bytes": (C.c_size_t, [_I32, _I32, _I32]),
+    "cn_contour_largest": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
     "cn_kmeans_step": (C.c_int, [_P, _I64, _P, _I32, _P, _P, _P, _P, _I32, _P]),
     "cn_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _I32, C.c_double, C.c_double, C.c_double, C.c_double, _I32, _P]),
     "cn_radam_step": (C.c_int, [_P, _P, _P, _P, _I64, _I32, C.c_double, C.c_double, C.c_double, C.c_double, _I32, _P]),

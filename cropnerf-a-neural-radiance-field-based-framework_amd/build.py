@@ -22,7 +22,7 @@ BUILD = HERE / "build"
 ARCH = "gfx950"
 
 SOURCES = ["api_common.cpp", "raygen.hip", "sampler.hip", "field_simple.hip", "composite.hip", "render_fused.hip",
-           "proposal.hip", "export.hip", "train_render.hip", "train_field.hip", "zbuffer.hip", "knn.hip", "cluster.hip", "tcnn_grid.hip"]
+           "proposal.hip", "export.hip", "train_render.hip", "train_field.hip", "zbuffer.hip", "knn.hip", "cluster.hip", "tcnn_grid.hip", "contour.hip"]
 HEADERS = ["cn_common.hpp", "wave_ops.hpp", "sampler_dev.hpp", "composite_dev.hpp", "train_field_mfma.hpp", "train_field_general.hpp", "render_split.hpp", "field_regw.hpp",
            "../../include/cropnerf_hip.h"]
 

@@ -813,6 +813,42 @@ def dbscan(points: Tensor, eps: float, min_points: int) -> Tuple[Tensor, Tensor]
     return labels, core
 
 
+def contour_largest(gray: Tensor, thresh: int, roi: Optional[Tensor] = None, labels: Optional[Tensor] = None,
+                    label_index: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """``cn_contour_largest`` on a stack of gray images [J,H,W] uint8 (device): per image the OpenCV contour of largest
+    area inside ``roi`` [J,4] int32 (x0, y0, x1, y1) -> ``area`` [J], ``bbox`` [J,4] (x, y, w, h), ``start`` [J]; with
+    ``labels`` [C,H,W] uint8 (+ ``label_index`` [J] int32) also ``vertex_count``, ``label``, ``label_count`` [J]."""
+    lib = L.load()
+    if gray.dtype != torch.uint8 or not gray.is_cuda or not gray.is_contiguous() or gray.dim() != 3:
+        raise TypeError("contour_largest: expected a contiguous uint8 device tensor [J,H,W]")
+    J, H, W = gray.shape
+    dev = gray.device
+    out = {"area": torch.empty(J, device=dev), "bbox": torch.empty(J, 4, dtype=torch.int32, device=dev),
+           "start": torch.empty(J, dtype=torch.int32, device=dev)}
+    if roi is not None:
+        roi = _dev(roi, torch.int32, "roi")
+        if tuple(roi.shape) != (J, 4):
+            raise ValueError(f"roi shape {tuple(roi.shape)} != {(J, 4)}")
+    if labels is not None:
+        labels = _dev(labels, torch.uint8, "labels")
+        if labels.dim() != 3 or tuple(labels.shape[1:]) != (H, W):
+            raise ValueError("labels: expected [C,H,W] uint8 frames of the image size")
+        if label_index is None:
+            if labels.shape[0] != J:
+                raise ValueError("label_index is required when the label stack is not one frame per image")
+        else:
+            label_index = _dev(label_index, torch.int32, "label_index")
+            if J and (int(label_index.min()) < 0 or int(label_index.max()) >= labels.shape[0]):
+                raise ValueError("label_index out of range")
+        for k_ in ("vertex_count", "label", "label_count"):
+            out[k_] = torch.empty(J, dtype=torch.int32, device=dev)
+    ws = torch.empty(int(lib.cn_contour_workspace_bytes(J, H, W)) + 8, dtype=torch.uint8, device=dev)
+    L.check(lib.cn_contour_largest(_p(gray), _p(roi), J, H, W, int(thresh), _p(labels), _p(label_index), _p(out["area"]),
+                                   _p(out["bbox"]), _p(out["start"]), _p(out.get("vertex_count")), _p(out.get("label")),
+                                   _p(out.get("label_count")), _p(ws), ws.numel(), _stream(gray)))
+    return out
+
+
 def kmeans(points: Tensor, k: int, max_iter: int = 300, tol: float = 1e-4, random_state: int = 0) -> Tensor:
     """``sklearn.cluster.KMeans(init="k-means++", n_clusters=k, n_init="auto", random_state=0).fit(points).labels_``
     (``segmentation/segmenter.py:41-43``) with the Lloyd iterations on the device (``cn_kmeans_step``, float64 as sklearn).

@@ -509,6 +509,25 @@ int cn_dbscan(const float* points_sorted, const int64_t* cell_keys, const int32_
               int32_t min_points, const int64_t* order, int64_t num_points, int32_t* neighbour_count, int32_t* parent,
               int32_t* root, void* workspace, size_t workspace_bytes, cn_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Image stage of the merger (segmentation/merger.py:219-271) on a stack of gray images [num_images, height, width]
+ * (the projections of a15, quantised as save_image does).  Per image, inside roi (x0, y0, x1, y1; NULL = whole image):
+ * foreground = gray > thresh; the contour of largest area as cv2.findContours(RETR_TREE, CHAIN_APPROX_SIMPLE) +
+ * max(key=cv2.contourArea) select it (always an outer border; ties to the component found last in raster order):
+ *   area [J]        cv2.contourArea of it (0 when the image has no foreground)          -- get_wo_occlusion_projection_area
+ *   bbox [J,4]      cv2.boundingRect: x, y, w, h in full-image coordinates
+ *   start [J]       linear index of the contour's first pixel, -1 when none (optional)
+ * and, when `labels` ([*, height, width] uint8 instance-label frames, image j uses labels[label_index[j]]) is given
+ * -- get_visible_projection_area, whose drawContours(mask, cnt, -1, 255, -1) call with a BARE contour draws its vertices only:
+ *   vertex_count [J] number of distinct vertex pixels of the compressed contour ("area" of the visible projection)
+ *   label [J], label_count [J]  the label under most of those pixels (ties to the larger label) and that count.
+ * ------------------------------------------------------------------------------------------- */
+size_t cn_contour_workspace_bytes(int32_t num_images, int32_t height, int32_t width);
+int cn_contour_largest(const uint8_t* gray, const int32_t* roi, int32_t num_images, int32_t height, int32_t width,
+                       int32_t thresh, const uint8_t* labels, const int32_t* label_index, float* area, int32_t* bbox,
+                       int32_t* start, int32_t* vertex_count, int32_t* label, int32_t* label_count, void* workspace,
+                       size_t workspace_bytes, cn_stream_t stream);
+
 /* K-means sub-clustering of one super-cluster (segmentation/segmenter.py:28-45: sklearn KMeans(init="k-means++",
  * n_clusters=k, n_init="auto", random_state=0), called per super-cluster at :153-181).  ONE Lloyd iteration in float64, as
  * sklearn's _kmeans_single_lloyd: labels[i] <- index of the nearest of the k centres [k,3] (first minimum); *changed |= 1
