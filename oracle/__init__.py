@@ -34,7 +34,8 @@ build container and stores inputs / outputs in ``tests/golden/reference_function
 ``rays.surface_points``; ``calc_affinity`` / ``get_component`` (``segmentation/merger.py:26-74,335-355``) and
 ``segmentation/lpa.py`` (imports as is; ``tests/golden/merger_small.npz``) pin the merger's graph stage
 (``tests/test_reference_golden.py``, ``tests/test_merger.py``).  ``outliers.py`` and ``clustering.py`` restate open3d's
-published algorithms with scipy / scikit-learn -- open3d is absent, so they are unpinned.
+published algorithms with scipy / scikit-learn, ``contours.py`` OpenCV's ``findContours`` / ``contourArea`` / ``boundingRect`` /
+``drawContours`` for the merger's image stage -- open3d and OpenCV are absent, so they are unpinned (known-answer tests).
 """
 
 from . import field, model, rays, render, samplers  # noqa: F401

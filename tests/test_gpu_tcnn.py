@@ -522,3 +522,138 @@ def test_tcnn_training_keeps_the_model_expressible_as_tcnn_modules(tmp_path):
     back = TP.from_tcnn_state_dict(state, model.field_spec, model.proposal_specs, "cuda", torch.float32)
     for k, v in model.params.items():
         assert torch.equal(back[k], v), k
+
+
+# ------------------------------------------------------------------------------------------------ other field shapes
+@pytest.mark.parametrize("max_res", [4096, 8192])
+def test_big_shapes_in_the_tcnn_layout_forward_and_backward(max_res, monkeypatch):
+    """fruit_nerf_method_big / _huge field shapes (geo 30, 3 x 128 semantic layers, max_res 4096 / 8192:
+    fruit_nerf_config.py:66-172) with tcnn modules: the three implementations of cn_field_eval and
+    cn_field_backward_general against ``oracle/tcnn.py`` (forward values, autograd gradients of every tcnn vector)."""
+    from cropnerf_amd import config as PC
+    from cropnerf_amd import ops as O
+    from cropnerf_amd.fruit_nerf import tcnn_params as TP
+    from _helpers import make_scene
+    import oracle.tcnn as TCM
+
+    n_img, R, S = 5, 41, 13
+    ospec = OF.FieldSpec(grid=OF.GridSpec(16, 16, max_res, 12, 2), geo_feat_dim=30, num_layers_semantic=3,
+                         hidden_dim_semantics=128, num_images=n_img, implementation="tcnn")
+    state = {k: v for k, v in TC.random_params(ospec, [], seed=22, grid_scale=0.1).items() if k.startswith("field.")}
+    state["field.mlp_head.tcnn_encoding.params"] = state["field.mlp_head.tcnn_encoding.params"] * 4.0  # see _tcnn_train_setup
+    pspec = PC.FieldSpec(grid=PC.GridSpec(16, 16, max_res, 12, 2, "tcnn"), geo_feat_dim=30, num_layers_semantic=3,
+                         hidden_dim_semantics=128, num_images=n_img)
+    sc = make_scene(seed=2, log2_T=12, num_images=n_img, height=12, width=12, focal=16.0, prop_log2_T=10)
+    rb = ORY.with_aabb_near_far(ORY.image_rays(sc.c2w, sc.intr, 1, 12, 12), sc.aabb.reshape(-1)).slice(0, R)
+    g = torch.Generator().manual_seed(4)
+    cam = torch.randint(0, n_img, (R, 1), generator=g)
+    rs = OSM.spaced_sampler(rb, S, "uniform")
+    gd, grgb, gsem = (torch.randn(R, S, generator=g), torch.randn(R, S, 3, generator=g), torch.randn(R, S, generator=g))
+    # ---- oracle at the fp32 master values + autograd ----------------------------------------------------------------------
+    real = TCM._as_compute
+    TCM._as_compute = lambda q, half: q.to(torch.float32)
+    try:
+        pos = rs.positions()
+        # Conditioning.  At max_res 4096+ one ulp of a position moves the finest levels' interpolation weights by 2e-4 and the
+        # base MLP's hidden pre-activations by ~1e-5; a hidden unit that close to zero has its ReLU gate decided by the order
+        # of the position arithmetic, and ONE flipped gate among the 34k moves the base MLP's and the grid's gradient by
+        # 1e-3..1e-2 of its norm (measured per sample; the oracle shows the same on itself when its positions are moved by one
+        # ulp: 7e-3).  So the samples holding such a unit get no upstream gradient (a few per cent of them), and the rest
+        # is held to the tolerance of the well-conditioned default shape.
+        x01, _ = OF.normalized_positions(pos, sc.aabb, True)
+        enc = TC.hash_grid(x01.reshape(-1, 3), state["field.mlp_base_grid.tcnn_encoding.params"], TC.grid_spec_of(ospec.grid),
+                           half_params=False)
+        pre = enc @ TC.mlp_matrices(state["field.mlp_base_mlp.tcnn_encoding.params"], 32, 31, 64, 1)[0][:, :32].t()
+        keep = (pre.abs().min(dim=1).values > 5e-4 * pre.abs().max()).view(R, S)
+        assert 0.8 < float(keep.float().mean()) < 1.0, float(keep.float().mean())
+        gd, grgb, gsem = gd * keep, grgb * keep[..., None], gsem * keep
+        p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+        fo = OF.field_forward(pos, rb.directions, cam, p, ospec, sc.aabb, True, "val", training=True)
+        geo = OF.field_density(pos, p, ospec, sc.aabb, True)[1].detach()
+        sem = OF.semantics_from_geo(geo.reshape(-1, 30), p, ospec).view(R, S)
+        ((fo["density"][..., 0] * gd).sum() + (fo["rgb"] * grgb).sum() + (sem * gsem).sum()).backward()
+    finally:
+        TCM._as_compute = real
+    # ---- HIP: forward through every implementation that takes this shape ------------------------------------------------------
+    full = dict(state)
+    full["camera_optimizer.pose_adjustment"] = torch.zeros(n_img, 6)
+    # (no proposal networks in this test: convert the field part only)
+    dp = TP.from_tcnn_state_dict({**full}, pspec, [], "cuda", torch.float32)
+    fh = O.FieldHandle(dp, pspec)
+    scene = O.scene_struct(sc.aabb, True)
+    from cropnerf_amd import _lib as L
+
+    for impl in ("regw", "mfma", "scalar"):
+        monkeypatch.setenv("CN_FIELD_EVAL_IMPL", impl)
+        out = O.field_eval(fh, scene, to_dev(rb.origins), to_dev(rb.directions), to_dev(cam[:, 0]), to_dev(rs.starts[..., 0]),
+                           to_dev(rs.ends[..., 0]), app_mode=L.APP_PER_CAMERA)
+        assert_close(out["density"], fo["density"][..., 0].detach(), RTOL, ATOL, f"density ({impl})")
+        assert_close(out["rgb"], fo["rgb"].detach(), RTOL, ATOL, f"rgb ({impl})")
+        assert_close(out["semantics"], sem.detach(), RTOL, 5e-5, f"semantics ({impl})")
+    monkeypatch.delenv("CN_FIELD_EVAL_IMPL")
+    # ---- HIP: backward ------------------------------------------------------------------------------------------------------------
+    grads = {k: torch.zeros_like(v) for k, v in dp.items()}
+    O.field_backward_general(fh, O.FieldHandle(grads, pspec), scene, to_dev(rb.origins), to_dev(rb.directions), to_dev(cam[:, 0]),
+                             to_dev(rs.starts[..., 0]), to_dev(rs.ends[..., 0]), to_dev(gd), to_dev(grgb), to_dev(gsem))
+    O.tcnn_grid_tie_gradients(pspec.grid, grads["field.mlp_base_grid.hash_table"])
+    for name in TP.frozen_parameter_names(pspec, []):
+        grads[name].zero_()
+    got = TP.to_tcnn_state_dict(grads, pspec, [])
+    dims = {"field.mlp_base_mlp": (32, 31, 64, 1), "field.mlp_semantics": (30, 64, 128, 2), "field.mlp_head": (16 + 30 + 32, 3, 64, 2)}
+    worst = {}
+    for k, v in p.items():
+        assert v.grad is not None and v.grad.abs().sum() > 0, k
+        a, b = got[k], v.grad
+        if k[: -len(".tcnn_encoding.params")] in dims:
+            # compare what is a free parameter on both sides: tcnn's gradient is the same in EVERY padded (constant one)
+            # input column, here the first padded column is the bias and the others are frozen at zero
+            n_in, n_out, width, n_hidden = dims[k[: -len(".tcnn_encoding.params")]]
+            ma, mb = TC.mlp_matrices(a, n_in, n_out, width, n_hidden), TC.mlp_matrices(b, n_in, n_out, width, n_hidden)
+            ma[0], mb[0] = ma[0][:, : n_in + 1], mb[0][:, : n_in + 1]
+            a, b = torch.cat([m.reshape(-1) for m in ma]), torch.cat([m.reshape(-1) for m in mb])
+        worst[k] = float((a - b).norm() / (b.norm() + 1e-12))
+    bad = {k: e for k, e in worst.items() if e > 1e-3}
+    assert not bad, f"{bad} (all: {worst})"
+
+
+def test_seven_level_proposal_net_in_the_tcnn_layout(ops):
+    """The _huge method's second proposal network has 7 levels up to 2048 (fruit_nerf_config.py:143-146): fused sampler and
+    density kernel in the tcnn layout (dense levels 0-2, hashed above)."""
+    from cropnerf_amd import config as PC
+    from cropnerf_amd.fruit_nerf import tcnn_params as TP
+    from _helpers import make_scene
+
+    sc = make_scene(seed=6, log2_T=12, num_images=3, height=16, width=16, focal=20.0, prop_log2_T=12)
+    og = [OF.ProposalSpec(OF.GridSpec(5, 16, 512, 12), implementation="tcnn"),
+          OF.ProposalSpec(OF.GridSpec(7, 16, 2048, 12), implementation="tcnn")]
+    ofs = OF.FieldSpec(grid=OF.GridSpec(log2_hashmap_size=12), num_images=3, implementation="tcnn")
+    state = TC.random_params(ofs, og, seed=8, grid_scale=0.3)
+    for k in list(state):
+        if k.endswith("tcnn_encoding.params"):
+            state[k] = state[k].to(torch.float16).to(torch.float32)
+    fs = PC.FieldSpec(grid=PC.GridSpec(16, 16, 2048, 12, 2, "tcnn"), num_images=3)
+    ps = [PC.ProposalSpec(PC.GridSpec(5, 16, 512, 12, 2, "tcnn")), PC.ProposalSpec(PC.GridSpec(7, 16, 2048, 12, 2, "tcnn"))]
+    dp = TP.from_tcnn_state_dict(state, fs, ps, "cuda", torch.float16)
+    dh = [ops.DensityHandle(dp, i, s) for i, s in enumerate(ps)]
+    rb = rays_with_box(sc, 1, 200)
+    rs = OSM.spaced_sampler(rb, 24, "uniform")
+    scene = ops.scene_struct(sc.aabb, True)
+    for lvl in range(2):
+        ref = OF.proposal_density(rs.positions(), state, lvl, og[lvl], sc.aabb, True)
+        out = ops.proposal_density(dh[lvl], scene, to_dev(rb.origins), to_dev(rb.directions), to_dev(rs.starts[..., 0]),
+                                   to_dev(rs.ends[..., 0]))
+        assert_close(out, ref[..., 0], RTOL, ATOL, f"{og[lvl].grid.num_levels}-level proposal density")
+    # fused sampler (5- and 7-level nets) against the unfused composition on the device
+    from cropnerf_amd import _lib as L
+
+    o, d, n, f = (to_dev(x) for x in (rb.origins, rb.directions, rb.nears + 0.01, rb.fars))
+    fused = ops.proposal_sample(dh, scene, o, d, n, f, (64, 32), 16)
+    sm = ops.sample_spaced(n, f, 64, L.SPACING_PIECEWISE)
+    bins = torch.cat([sm["spacing_starts"], sm["spacing_ends"][:, -1:]], -1).contiguous()
+    starts, ends = sm["starts"], sm["ends"]
+    for lvl, s_next in ((0, 32), (1, 16)):
+        den = ops.proposal_density(dh[lvl], scene, o, d, starts, ends)
+        w = ops.composite(starts, ends, den, want_weights=True)["weights"]
+        bins, eu = ops.sample_pdf(bins, w, n, f, s_next)
+        starts, ends = eu[:, :-1].contiguous(), eu[:, 1:].contiguous()
+    assert_close(eu, fused["euclidean_bins"].cpu(), 1e-5, 1e-6, "fused vs composed bins (7-level net, tcnn layout)")
