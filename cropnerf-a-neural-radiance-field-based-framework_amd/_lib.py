@@ -62,6 +62,11 @@ class DensityParams(C.Structure):
     _fields_ = [("grid", Grid), ("mlp", Mlp)]
 
 
+class ProposalLevelOut(C.Structure):
+    """``cn_proposal_level_out``"""
+    _fields_ = [("spacing_bins", C.c_void_p), ("starts", C.c_void_p), ("ends", C.c_void_p), ("density", C.c_void_p)]
+
+
 class Scene(C.Structure):
     _fields_ = [("aabb", C.c_float * 6), ("contraction", C.c_int32)]
 
@@ -107,6 +112,8 @@ SIGNATURES = {
     "cn_proposal_sample_workspace_bytes": (C.c_size_t, [_I64, C.POINTER(_I32), _I32, _I32]),
     "cn_proposal_sample": (C.c_int, [C.POINTER(C.POINTER(DensityParams)), _I32, C.POINTER(Scene), _P, _P, _P, _P, _I64,
                                      C.POINTER(_I32), _I32, _F, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cn_proposal_sample_train": (C.c_int, [C.POINTER(C.POINTER(DensityParams)), _I32, C.POINTER(Scene), _P, _P, _P, _P,
+                                           _I64, C.POINTER(_I32), _I32, _F, _P, C.POINTER(ProposalLevelOut), _P, _P, _P]),
     "cn_export_compact": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _I64, C.POINTER(_P), C.POINTER(_P), _P, _P]),
     "cn_pointcloud_compact": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
     "cn_embedding_mean": (C.c_int, [_P, _I32, _I32, _P, _P]),

@@ -37,6 +37,13 @@ struct PropArgs {
   float* out_eu;
   float* out_sp;
   float* out_depth;  // [num_levels][R]
+  // training (TRAIN = true): one uniform random per ray and resampling step, and what the interlevel loss and the
+  // proposal backward need of every level
+  const float* jitter;                 // [num_levels + 1][R]
+  float* lv_sp[PROP_MAX_LEVELS];       // [R, S_l + 1] spacing bins
+  float* lv_starts[PROP_MAX_LEVELS];   // [R, S_l]
+  float* lv_ends[PROP_MAX_LEVELS];     // [R, S_l]
+  float* lv_density[PROP_MAX_LEVELS];  // [R, S_l]
 };
 
 template <int L, int H, bool HALF>
@@ -67,8 +74,10 @@ __device__ __forceinline__ float prop_density_dispatch(const PropNet& n, const S
   return prop_density<7, 16, HALF>(n, sc, px, py, pz);
 }
 
-// HALF: the proposal nets' hash tables hold half2 entries (CN_TABLE_F16)
-template <bool HALF>
+// HALF: the proposal nets' hash tables hold half2 entries (CN_TABLE_F16).  TRAIN: the training forward of
+// ProposalNetworkSampler (fruit_nerf.py:549 under model.train()): stratified single-jitter level-0 bins
+// (ray_samplers.py:84-87), PDF resampling at u + rand / nb, and every level's bins / intervals / densities written out.
+template <bool HALF, bool TRAIN>
 __global__ void __launch_bounds__(256) proposal_sample_kernel(PropArgs A) {
   extern __shared__ __align__(16) float lds[];
   const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -88,7 +97,17 @@ __global__ void __launch_bounds__(256) proposal_sample_kernel(PropArgs A) {
     // level 0 bins: linspace(0,1,S0+1) in the spacing domain
     {
       const int s0 = A.s_prop[0];
-      for (int e = lane; e <= s0; e += 64) cur[e] = linspace01(e, s0 + 1);
+      if constexpr (TRAIN) {
+        const float t = A.jitter[r];
+        for (int e = lane; e <= s0; e += 64) {
+          const float be = linspace01(e, s0 + 1);
+          const float lo = e == 0 ? be : (be + linspace01(e - 1, s0 + 1)) / 2.f;
+          const float hi = e == s0 ? be : (linspace01(e + 1, s0 + 1) + be) / 2.f;
+          cur[e] = lo + (hi - lo) * t;
+        }
+      } else {
+        for (int e = lane; e <= s0; e += 64) cur[e] = linspace01(e, s0 + 1);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -106,6 +125,17 @@ __global__ void __launch_bounds__(256) proposal_sample_kernel(PropArgs A) {
         const float den = prop_density_dispatch<HALF>(net, A.scene, ox + dx * mid, oy + dy * mid, oz + dz * mid);
         const float w = composite_chunk(st, valid, i == S - 1, t1 - t0, den, mid, 0.f, 0.f, 0.f, 0.f, false);
         if (valid) wts[i] = w;
+        if constexpr (TRAIN) {
+          if (valid) {
+            const long long o = r * S + i;
+            A.lv_starts[lvl][o] = t0;
+            A.lv_ends[lvl][o] = t1;
+            A.lv_density[lvl][o] = den;
+          }
+        }
+      }
+      if constexpr (TRAIN) {
+        for (int e = lane; e <= S; e += 64) A.lv_sp[lvl][r * (S + 1) + e] = cur[e];
       }
       if (A.out_depth && lane == 0) A.out_depth[lvl * A.num_rays + r] = st.found ? st.depth : st.last_mid;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -115,7 +145,7 @@ __global__ void __launch_bounds__(256) proposal_sample_kernel(PropArgs A) {
       const int nb = s_next + 1;
       const bool last = lvl + 1 == A.num_levels;
       for (int b = lane; b < nb; b += 64) {
-        float bin = pdf_invert(cdf, cur, S, pdf_u(b, nb, nullptr, 0));
+        float bin = pdf_invert(cdf, cur, S, pdf_u(b, nb, TRAIN ? A.jitter + (lvl + 1) * A.num_rays + r : nullptr, 1));
         nxt[b] = bin;
         if (last) {
           if (A.out_sp) A.out_sp[r * nb + b] = bin;
@@ -137,48 +167,59 @@ int validate_grid(const cn_grid& g, const char* name);  // field_simple.hip
 
 extern "C" size_t cn_proposal_sample_workspace_bytes(int64_t, const int32_t*, int32_t, int32_t) { return 0; }
 
-extern "C" int cn_proposal_sample(const cn_density_params* const* props, int32_t num_levels, const cn_scene* scene,
-                                  const float* origins, const float* directions, const float* nears, const float* fars,
-                                  int64_t num_rays, const int32_t* s_prop, int32_t s_final, float anneal,
-                                  float* euclidean_bins, float* spacing_bins, float* prop_depth, void*, size_t,
-                                  cn_stream_t stream) {
+namespace cn {
+static int proposal_sample_launch(const char* who, const cn_density_params* const* props, int32_t num_levels,
+                                  const cn_scene* scene, const float* origins, const float* directions,
+                                  const float* nears, const float* fars, int64_t num_rays, const int32_t* s_prop,
+                                  int32_t s_final, float anneal, const float* jitter,
+                                  const cn_proposal_level_out* levels, float* euclidean_bins, float* spacing_bins,
+                                  float* prop_depth, cn_stream_t stream) {
   CN_REQUIRE(props && scene && origins && directions && nears && fars && s_prop && euclidean_bins, CN_ERR_INVALID,
-             "cn_proposal_sample: null argument");
-  CN_REQUIRE(num_levels >= 1 && num_levels <= cn::PROP_MAX_LEVELS, CN_ERR_UNSUPPORTED,
-             "cn_proposal_sample: %d proposal iterations (max %d)", num_levels, cn::PROP_MAX_LEVELS);
-  CN_REQUIRE(s_final >= 1 && s_final <= cn::PROP_MAX_SAMPLES, CN_ERR_UNSUPPORTED, "cn_proposal_sample: s_final %d",
-             s_final);
-  CN_REQUIRE(num_rays < (1LL << 31), CN_ERR_INVALID, "cn_proposal_sample: at most 2^31-1 rays per call");
-  cn::PropArgs A{};
+             "%s: null argument", who);
+  CN_REQUIRE(num_levels >= 1 && num_levels <= PROP_MAX_LEVELS, CN_ERR_UNSUPPORTED,
+             "%s: %d proposal iterations (max %d)", who, num_levels, PROP_MAX_LEVELS);
+  CN_REQUIRE(s_final >= 1 && s_final <= PROP_MAX_SAMPLES, CN_ERR_UNSUPPORTED, "%s: s_final %d", who, s_final);
+  CN_REQUIRE(num_rays < (1LL << 31), CN_ERR_INVALID, "%s: at most 2^31-1 rays per call", who);
+  const bool train = jitter != nullptr;
+  CN_REQUIRE(!train || levels, CN_ERR_INVALID, "%s: null level outputs", who);
+  PropArgs A{};
   A.smax = s_final;
   for (int l = 0; l < num_levels; ++l) {
-    CN_REQUIRE(props[l], CN_ERR_INVALID, "cn_proposal_sample: null proposal net %d", l);
-    CN_REQUIRE(s_prop[l] >= 1 && s_prop[l] <= cn::PROP_MAX_SAMPLES, CN_ERR_UNSUPPORTED,
-               "cn_proposal_sample: %d samples at level %d (max %d)", s_prop[l], l, cn::PROP_MAX_SAMPLES);
+    CN_REQUIRE(props[l], CN_ERR_INVALID, "%s: null proposal net %d", who, l);
+    CN_REQUIRE(s_prop[l] >= 1 && s_prop[l] <= PROP_MAX_SAMPLES, CN_ERR_UNSUPPORTED,
+               "%s: %d samples at level %d (max %d)", who, s_prop[l], l, PROP_MAX_SAMPLES);
     const cn_density_params& p = *props[l];
-    int rc = cn::validate_grid(p.grid, "proposal grid");
+    int rc = validate_grid(p.grid, "proposal grid");
     if (rc) return rc;
     bool ok = (p.grid.num_levels == 5 || p.grid.num_levels == 7) && p.mlp.num_layers == 2 &&
               p.mlp.dims[0] == 2 * p.grid.num_levels && p.mlp.dims[1] == 16 && p.mlp.dims[2] == 1;
-    CN_REQUIRE(ok, CN_ERR_UNSUPPORTED,
-               "cn_proposal_sample: proposal net %d is not {5|7 levels, 2L->16->1}; compose the unfused calls", l);
+    CN_REQUIRE(ok, CN_ERR_UNSUPPORTED, "%s: proposal net %d is not {5|7 levels, 2L->16->1}; compose the unfused calls",
+               who, l);
     CN_REQUIRE(p.mlp.weight[0] && p.mlp.bias[0] && p.mlp.weight[1] && p.mlp.bias[1], CN_ERR_INVALID,
-               "cn_proposal_sample: null MLP parameter in net %d", l);
-    A.net[l].grid = cn::make_grid_dev(p.grid);
+               "%s: null MLP parameter in net %d", who, l);
+    A.net[l].grid = make_grid_dev(p.grid);
     CN_REQUIRE(A.net[l].grid.half == A.net[0].grid.half, CN_ERR_UNSUPPORTED,
-               "cn_proposal_sample: the proposal nets' hash tables must share one dtype");
+               "%s: the proposal nets' hash tables must share one dtype", who);
     A.net[l].w0 = p.mlp.weight[0];
     A.net[l].b0 = p.mlp.bias[0];
     A.net[l].w1 = p.mlp.weight[1];
     A.net[l].b1 = p.mlp.bias[1];
     A.s_prop[l] = s_prop[l];
     if (s_prop[l] > A.smax) A.smax = s_prop[l];
+    if (train) {
+      const cn_proposal_level_out& o = levels[l];
+      CN_REQUIRE(o.spacing_bins && o.starts && o.ends && o.density, CN_ERR_INVALID, "%s: null output of level %d", who, l);
+      A.lv_sp[l] = o.spacing_bins;
+      A.lv_starts[l] = o.starts;
+      A.lv_ends[l] = o.ends;
+      A.lv_density[l] = o.density;
+    }
   }
   if (num_rays <= 0) return CN_OK;
   A.num_levels = num_levels;
   A.s_final = s_final;
   A.anneal = anneal;
-  A.scene = cn::make_scene_dev(*scene);
+  A.scene = make_scene_dev(*scene);
   A.origins = origins;
   A.directions = directions;
   A.nears = nears;
@@ -187,12 +228,39 @@ extern "C" int cn_proposal_sample(const cn_density_params* const* props, int32_t
   A.out_eu = euclidean_bins;
   A.out_sp = spacing_bins;
   A.out_depth = prop_depth;
-  size_t lds = (size_t)4 * (4 * A.smax + 4) * sizeof(float);
-  if (A.net[0].grid.half)
-    hipLaunchKernelGGL(cn::proposal_sample_kernel<true>, dim3(cn::grid_for(num_rays, 4, 256 * 8)), dim3(256), lds,
-                       cn::as_stream(stream), A);
-  else
-    hipLaunchKernelGGL(cn::proposal_sample_kernel<false>, dim3(cn::grid_for(num_rays, 4, 256 * 8)), dim3(256), lds,
-                       cn::as_stream(stream), A);
-  return cn::check_launch("cn_proposal_sample");
+  A.jitter = jitter;
+  const size_t lds = (size_t)4 * (4 * A.smax + 4) * sizeof(float);
+  const dim3 grid(grid_for(num_rays, 4, 256 * 8)), block(256);
+  const bool half = A.net[0].grid.half;
+#define CN_PROP_LAUNCH(H, T) hipLaunchKernelGGL((proposal_sample_kernel<H, T>), grid, block, lds, as_stream(stream), A)
+  if (train) {
+    if (half) CN_PROP_LAUNCH(true, true); else CN_PROP_LAUNCH(false, true);
+  } else {
+    if (half) CN_PROP_LAUNCH(true, false); else CN_PROP_LAUNCH(false, false);
+  }
+#undef CN_PROP_LAUNCH
+  return check_launch(who);
+}
+}  // namespace cn
+
+extern "C" int cn_proposal_sample(const cn_density_params* const* props, int32_t num_levels, const cn_scene* scene,
+                                  const float* origins, const float* directions, const float* nears, const float* fars,
+                                  int64_t num_rays, const int32_t* s_prop, int32_t s_final, float anneal,
+                                  float* euclidean_bins, float* spacing_bins, float* prop_depth, void*, size_t,
+                                  cn_stream_t stream) {
+  return cn::proposal_sample_launch("cn_proposal_sample", props, num_levels, scene, origins, directions, nears, fars,
+                                    num_rays, s_prop, s_final, anneal, nullptr, nullptr, euclidean_bins, spacing_bins,
+                                    prop_depth, stream);
+}
+
+extern "C" int cn_proposal_sample_train(const cn_density_params* const* props, int32_t num_levels,
+                                        const cn_scene* scene, const float* origins, const float* directions,
+                                        const float* nears, const float* fars, int64_t num_rays, const int32_t* s_prop,
+                                        int32_t s_final, float anneal, const float* jitter,
+                                        const cn_proposal_level_out* levels, float* euclidean_bins, float* spacing_bins,
+                                        cn_stream_t stream) {
+  CN_REQUIRE(jitter, CN_ERR_INVALID, "cn_proposal_sample_train: null jitter");
+  return cn::proposal_sample_launch("cn_proposal_sample_train", props, num_levels, scene, origins, directions, nears,
+                                    fars, num_rays, s_prop, s_final, anneal, jitter, levels, euclidean_bins,
+                                    spacing_bins, nullptr, stream);
 }

@@ -26,6 +26,8 @@ the step and the parameter is copied back into its aliases after it; the biases 
 
 from __future__ import annotations
 
+import os
+
 import math
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
@@ -67,6 +69,9 @@ class FruitTrainer:
         # fruit_nerf_method_big / _huge field shapes train through the shape-generic kernels (cn_field_eval +
         # cn_field_backward_general)
         self.general = not model._fused_shape
+        # the proposal sampler of the training forward as ONE launch (cn_proposal_sample_train) when the proposal networks
+        # have the shapes it is built for; CN_TRAIN_FUSED_SAMPLER=0 composes the materialising calls instead (A/B, tests)
+        self.fused_sampler = os.environ.get("CN_TRAIN_FUSED_SAMPLER", "1") != "0"
         self.groups = groups or {"proposal_networks": OptimGroup(), "fields": OptimGroup(),
                                  "camera_opt": OptimGroup(1e-3, 1e-15, 1e-4, 5000)}
         self._general_ws = None
@@ -173,18 +178,29 @@ class FruitTrainer:
             jitter = [torch.rand(R, 1, generator=self._gen) for _ in range(n_lvl + 1)]
         jitter = [j.to(dev).contiguous() for j in jitter]
         scene = m._scene(True)
-        # ---- proposal sampler, level by level (weights and bins are kept for the interlevel loss) ---------------
-        levels = []
-        sm = ops.sample_spaced(nears, fars, cfg.num_proposal_samples_per_ray[0], L.SPACING_PIECEWISE, jitter[0])
-        bins = torch.cat([sm["spacing_starts"], sm["spacing_ends"][:, -1:]], -1).contiguous()
-        starts, ends = sm["starts"], sm["ends"]
-        for lvl in range(n_lvl):
-            den = ops.proposal_density(m.proposal_networks[lvl], scene, o, d, starts, ends)
-            w = ops.composite(starts, ends, den, want_weights=True, eval_clamp=False)["weights"]
-            levels.append({"bins": bins, "starts": starts, "ends": ends, "density": den})
-            s_next = cfg.num_proposal_samples_per_ray[lvl + 1] if lvl + 1 < n_lvl else cfg.num_nerf_samples_per_ray
-            bins, eu = ops.sample_pdf(bins, w, nears, fars, s_next, anneal=m._anneal, u_rand=jitter[lvl + 1])
+        # ---- proposal sampler (bins, intervals and densities of every level are kept for the interlevel loss) --------
+        s_prop = [int(v) for v in cfg.num_proposal_samples_per_ray[:n_lvl]]
+        if self.fused_sampler and ops.proposal_sample_fused_supported(m.proposal_networks, s_prop, cfg.num_nerf_samples_per_ray):
+            # one launch: cn_proposal_sample_train
+            ps = ops.proposal_sample_train(m.proposal_networks, scene, o, d, nears, fars, s_prop,
+                                           cfg.num_nerf_samples_per_ray, m._anneal,
+                                           torch.cat([j.reshape(1, R) for j in jitter], 0).contiguous())
+            levels = ps["levels"]
+            bins, eu = ps["spacing_bins"], ps["euclidean_bins"]
             starts, ends = eu[:, :-1].contiguous(), eu[:, 1:].contiguous()
+        else:
+            # the same, level by level through the materialising calls (any proposal shape)
+            levels = []
+            sm = ops.sample_spaced(nears, fars, s_prop[0], L.SPACING_PIECEWISE, jitter[0])
+            bins = torch.cat([sm["spacing_starts"], sm["spacing_ends"][:, -1:]], -1).contiguous()
+            starts, ends = sm["starts"], sm["ends"]
+            for lvl in range(n_lvl):
+                den = ops.proposal_density(m.proposal_networks[lvl], scene, o, d, starts, ends)
+                w = ops.composite(starts, ends, den, want_weights=True, eval_clamp=False)["weights"]
+                levels.append({"bins": bins, "starts": starts, "ends": ends, "density": den})
+                s_next = s_prop[lvl + 1] if lvl + 1 < n_lvl else cfg.num_nerf_samples_per_ray
+                bins, eu = ops.sample_pdf(bins, w, nears, fars, s_next, anneal=m._anneal, u_rand=jitter[lvl + 1])
+                starts, ends = eu[:, :-1].contiguous(), eu[:, 1:].contiguous()
         # ---- field forward (fused kernel, per-sample outputs) --------------------------------------------------------
         S = cfg.num_nerf_samples_per_ray
         if self.general:

@@ -322,6 +322,39 @@ def proposal_sample(props: Sequence[DensityHandle], scene: L.Scene, origins: Ten
     return {"euclidean_bins": eu, "spacing_bins": sp, "prop_depth": depth}
 
 
+def proposal_sample_fused_supported(props: Sequence[DensityHandle], s_prop: Sequence[int], s_final: int) -> bool:
+    """The shapes ``cn_proposal_sample`` / ``cn_proposal_sample_train`` are built for (others compose the unfused calls)."""
+    return (1 <= len(props) <= 3 and max(list(s_prop) + [s_final]) <= 512 and
+            all(p.spec.grid.num_levels in (5, 7) and p.spec.hidden_dim == 16 for p in props))
+
+
+def proposal_sample_train(props: Sequence[DensityHandle], scene: L.Scene, origins: Tensor, directions: Tensor,
+                          nears: Tensor, fars: Tensor, s_prop: Sequence[int], s_final: int, anneal: float,
+                          jitter: Tensor) -> Dict[str, object]:
+    """``cn_proposal_sample_train``: the proposal sampler of the training forward in one launch.  ``jitter`` [n + 1, R].
+    Returns the final bins and, per level, what the interlevel loss and the proposal backward read."""
+    lib = L.load()
+    R = origins.shape[0]
+    dev = origins.device
+    n = len(props)
+    if tuple(jitter.shape) != (n + 1, R):
+        raise ValueError(f"jitter must be [{n + 1}, {R}], got {tuple(jitter.shape)}")
+    arr = (C.POINTER(L.DensityParams) * n)(*[C.pointer(p.struct) for p in props])
+    sp_arr = (C.c_int32 * n)(*[int(s) for s in s_prop])
+    eu = torch.empty(R, s_final + 1, device=dev)
+    sp = torch.empty(R, s_final + 1, device=dev)
+    levels = [{"bins": torch.empty(R, int(s) + 1, device=dev), "starts": torch.empty(R, int(s), device=dev),
+               "ends": torch.empty(R, int(s), device=dev), "density": torch.empty(R, int(s), device=dev)} for s in s_prop]
+    outs = (L.ProposalLevelOut * n)(*[L.ProposalLevelOut(lv["bins"].data_ptr(), lv["starts"].data_ptr(),
+                                                         lv["ends"].data_ptr(), lv["density"].data_ptr())
+                                      for lv in levels])
+    L.check(lib.cn_proposal_sample_train(arr, n, C.byref(scene), _p(_f32(origins, "origins")),
+                                         _p(_f32(directions, "directions")), _p(_f32(nears, "nears")),
+                                         _p(_f32(fars, "fars")), R, sp_arr, s_final, anneal, _p(_f32(jitter, "jitter")),
+                                         outs, _p(eu), _p(sp), _stream(origins)))
+    return {"euclidean_bins": eu, "spacing_bins": sp, "levels": levels}
+
+
 # --------------------------------------------------------------------------------------------------------------
 # field / compositing
 # --------------------------------------------------------------------------------------------------------------

@@ -327,6 +327,25 @@ int cn_proposal_sample(const cn_density_params* const* props_host, int32_t num_l
                        float* euclidean_bins, float* spacing_bins, float* prop_depth, void* workspace,
                        size_t workspace_bytes, cn_stream_t stream);
 
+/* The same sampler under model.train() (fruit_nerf/fruit_nerf.py:549 -> ProposalNetworkSampler.generate_ray_samples with
+ * the samplers' train_stratified / single_jitter defaults, components/ray_samplers.py:84-87): level-0 bins jittered by ONE
+ * uniform random per ray, every PDF resampling at u + rand / nb with one random per ray, and every level's spacing bins,
+ * euclidean intervals and densities written out -- what interlevel_loss (fruit_nerf.py:608-611) and the proposal
+ * backward read.  jitter: device [num_levels + 1][R] uniforms in [0, 1) (row l + 1 = the resampling after level l).
+ * Replaces the composed cn_sample_spaced / cn_proposal_density / cn_composite / cn_sample_pdf chain of the training
+ * forward (same arithmetic per step; tested against it and against oracle/losses.py). */
+typedef struct cn_proposal_level_out {
+  float* spacing_bins; /* [R, S_l + 1] */
+  float* starts;       /* [R, S_l] euclidean */
+  float* ends;         /* [R, S_l] */
+  float* density;      /* [R, S_l] */
+} cn_proposal_level_out;
+int cn_proposal_sample_train(const cn_density_params* const* props_host, int32_t num_levels, const cn_scene* scene,
+                             const float* origins, const float* directions, const float* nears, const float* fars,
+                             int64_t num_rays, const int32_t* s_prop_host, int32_t s_final, float anneal,
+                             const float* jitter, const cn_proposal_level_out* levels_host, float* euclidean_bins,
+                             float* spacing_bins, cn_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Exporters
  * ------------------------------------------------------------------------------------------- */

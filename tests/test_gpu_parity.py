@@ -382,6 +382,41 @@ def test_unfused_proposal_chain_matches_fused(scene, ops, handles):
     assert_close(eu, fused["euclidean_bins"].cpu(), 1e-5, 1e-6, "fused vs composed bins")
 
 
+def test_training_sampler_in_one_launch_matches_the_composed_chain(scene, ops, handles):
+    """cn_proposal_sample_train (stratified single-jitter bins, PDF resampling at u + rand / nb, every level's bins /
+    intervals / densities written out) == cn_sample_spaced + cn_proposal_density + cn_composite + cn_sample_pdf with the same
+    randoms (fruit_nerf.py:549 under model.train()).  Against the oracle: tests/test_gpu_train.py, whose training
+    iterations run through this launch and are compared with oracle/losses.py loss by loss and gradient by gradient."""
+    from cropnerf_amd import _lib as L
+
+    dp, fh, dh = handles
+    rb = rays_with_box(scene, 1, 300)
+    R = rb.origins.shape[0]
+    g = torch.Generator().manual_seed(31)
+    jitter = [torch.rand(R, 1, generator=g) for _ in range(3)]
+    o, d, n, f = (to_dev(x) for x in (rb.origins, rb.directions, rb.nears + 0.01, rb.fars))
+    sc = ops.scene_struct(scene.aabb, True)
+    s_prop, s_final, anneal = (128, 70), 33, 0.7  # ragged against the 64-lane chunks on purpose
+    assert ops.proposal_sample_fused_supported(dh, s_prop, s_final)
+    fused = ops.proposal_sample_train(dh, sc, o, d, n, f, s_prop, s_final, anneal,
+                                      to_dev(torch.cat([j.reshape(1, R) for j in jitter], 0)))
+    sm = ops.sample_spaced(n, f, s_prop[0], L.SPACING_PIECEWISE, to_dev(jitter[0]))
+    bins = torch.cat([sm["spacing_starts"], sm["spacing_ends"][:, -1:]], -1).contiguous()
+    starts, ends = sm["starts"], sm["ends"]
+    for lvl, s_next in ((0, s_prop[1]), (1, s_final)):
+        den = ops.proposal_density(dh[lvl], sc, o, d, starts, ends)
+        lv = fused["levels"][lvl]
+        assert_close(lv["bins"].cpu(), bins.cpu(), 1e-5, 1e-6, f"level {lvl} spacing bins")
+        assert_close(lv["starts"].cpu(), starts.cpu(), 1e-5, 1e-6, f"level {lvl} starts")
+        assert_close(lv["ends"].cpu(), ends.cpu(), 1e-5, 1e-6, f"level {lvl} ends")
+        assert_close(lv["density"].cpu(), den.cpu(), 2e-4, 1e-6, f"level {lvl} density")
+        w = ops.composite(starts, ends, den, want_weights=True, eval_clamp=False)["weights"]
+        bins, eu = ops.sample_pdf(bins, w, n, f, s_next, anneal=anneal, u_rand=to_dev(jitter[lvl + 1]))
+        starts, ends = eu[:, :-1].contiguous(), eu[:, 1:].contiguous()
+    assert_close(fused["euclidean_bins"].cpu(), eu.cpu(), 1e-5, 2e-6, "final euclidean bins")
+    assert_close(fused["spacing_bins"].cpu(), bins.cpu(), 1e-5, 2e-6, "final spacing bins")
+
+
 # ------------------------------------------------------------------------------------------------ exporters
 def _sort_rows(t):
     """Lexicographic row order on the three position columns (positions are copied bit-exactly)."""
