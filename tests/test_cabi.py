@@ -31,7 +31,7 @@ def test_header_declares_the_expected_surface():
     names = _declared()
     for must in ("cn_raygen_pinhole", "cn_intersect_aabb", "cn_raygen_ortho", "cn_sample_spaced", "cn_sample_pdf",
                  "cn_proposal_density", "cn_field_eval", "cn_composite", "cn_render_rays", "cn_render_samples",
-                 "cn_proposal_sample", "cn_export_compact", "cn_pointcloud_compact", "cn_last_error"):
+                 "cn_proposal_sample", "cn_proposal_sample_train", "cn_export_compact", "cn_pointcloud_compact", "cn_last_error"):
         assert must in names
 
 
