@@ -318,19 +318,18 @@ __global__ void __launch_bounds__(NTG) field_backward_general_kernel(GenArgs A) 
       A.d_dir[3 * ismp + 2] = gz * chain;
     }
     if (A.app_per_camera) {
-      // the 32 samples of a tile are almost always one ray (one camera row): sum them in the wave first, otherwise the
-      // same 32 addresses take 32-way conflicting atomics from every tile of every workgroup
-      const long long i_first = tile * TSG, i_last = (i_first + TSG - 1 < total ? i_first + TSG - 1 : total - 1);
-      const bool one_ray = (i_first / A.S) == (i_last / A.S);  // workgroup-uniform
-      for (int k0 = 0; k0 < A.app_dim; k0 += 16) {             // uniform trip count: every lane runs the DPP ops
-        const int k = k0 + grp;
-        float gsum = (valid && k < A.app_dim) ? DCIN[(16 + A.geo + k) * LDG + s] : 0.f;
-        if (one_ray) {
-          gsum = cn::mf::row16_sum(gsum);
-          const float other = __shfl_up(gsum, 16, 32);
-          if (s == 31 && k < A.app_dim) atomicAdd(A.g_emb + A.cam_idx[r] * (long long)A.app_dim + k, gsum + other);
-        } else if (valid && k < A.app_dim) {
-          atomicAdd(A.g_emb + A.cam_idx[r] * (long long)A.app_dim + k, gsum);
+      // a tile's samples belong to one ray or to a few consecutive ones (one camera row each): sum the runs of equal ray
+      // inside every 16-lane row first; the last lane of a run adds the sums (per-sample atomics would be up to 32-way
+      // conflicting requests on the same addresses from every tile of every workgroup)
+      for (int k0 = 0; k0 < A.app_dim; k0 += 32) {  // uniform trip count: every lane runs the DPP ops
+        const int ka = k0 + grp, kb = k0 + 16 + grp;
+        float ga = (valid && ka < A.app_dim) ? DCIN[(16 + A.geo + ka) * LDG + s] : 0.f;
+        float gb = (valid && kb < A.app_dim) ? DCIN[(16 + A.geo + kb) * LDG + s] : 0.f;
+        const bool last = row_run_reduce(valid ? (unsigned)r : 0xffffffffu, ga, gb, tid & 15);
+        if (last && valid) {
+          float* ge = A.g_emb + A.cam_idx[r] * (long long)A.app_dim;
+          if (ka < A.app_dim && ga != 0.f) atomicAdd(ge + ka, ga);
+          if (kb < A.app_dim && gb != 0.f) atomicAdd(ge + kb, gb);
         }
       }
     }
