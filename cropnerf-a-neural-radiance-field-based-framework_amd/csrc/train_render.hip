@@ -31,6 +31,7 @@ train_render_backward_kernel(const float* __restrict__ starts, const float* __re
   float* pbuf = wbuf + S;
   const long long waves = (long long)gridDim.x * 4;
   const float inv_3r = 1.f / (3.f * (float)R), inv_r = 1.f / (float)R;
+  float mse_sum = 0.f, bce_sum = 0.f;  // this wave's rays (lane 0): one atomic per wave at the end, not one per ray on one address
   for (long long r = blockIdx.x * 4LL + wave; r < R; r += waves) {
     const long long base = r * (long long)S;
     // ---- forward: weights, rgb / accumulation / semantics ------------------------------------------------------
@@ -74,8 +75,8 @@ train_render_backward_kernel(const float* __restrict__ starts, const float* __re
       }
       if (out_sem) out_sem[r] = so;
       if (out_acc) out_acc[r] = acc;
-      atomicAdd(loss_sums + 0, e0 * e0 + e1 * e1 + e2 * e2);
-      atomicAdd(loss_sums + 1, fmaxf(so, 0.f) - so * y + log1pf(expf(-fabsf(so))));
+      mse_sum += e0 * e0 + e1 * e1 + e2 * e2;
+      bce_sum += fmaxf(so, 0.f) - so * y + log1pf(expf(-fabsf(so)));
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -105,6 +106,10 @@ train_render_backward_kernel(const float* __restrict__ starts, const float* __re
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if (lane == 0 && (mse_sum != 0.f || bce_sum != 0.f)) {
+    atomicAdd(loss_sums + 0, mse_sum);
+    atomicAdd(loss_sums + 1, bce_sum);
+  }
 }
 
 // first index in [0,n) with a[idx] > v   (torch.searchsorted side="right")
@@ -133,6 +138,7 @@ interlevel_backward_kernel(const float* __restrict__ c_bins, const float* __rest
   float* diff = cy + Sp + 1;
   const long long waves = (long long)gridDim.x * 4;
   const float eps = 1.0e-7f;
+  float loss_acc = 0.f;  // this wave's rays: one atomic per wave
   for (long long r = blockIdx.x * 4LL + wave; r < R; r += waves) {
     const long long bp = r * (long long)Sp, bf = r * (long long)Sf;
     for (int e = lane; e <= Sp; e += 64) {
@@ -179,8 +185,7 @@ interlevel_backward_kernel(const float* __restrict__ c_bins, const float* __rest
         atomicAdd(diff + hi + 1, -g);
       }
     }
-    lsum = wave_sum(lsum);
-    if (lane == 0) atomicAdd(loss_sum, lsum);
+    loss_acc += wave_sum(lsum);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // gw[m] = prefix(diff)[m]  (in place, chunked scan)
@@ -213,6 +218,7 @@ interlevel_backward_kernel(const float* __restrict__ c_bins, const float* __rest
     }
     __builtin_amdgcn_wave_barrier();
   }
+  if (lane == 0 && loss_acc != 0.f) atomicAdd(loss_sum, loss_acc);
 }
 
 // nerfstudio distortion_loss on the final level (a metric in the reference, fruit_nerf.py:643):
@@ -226,6 +232,7 @@ distortion_kernel(const float* __restrict__ bins, const float* __restrict__ weig
   float* w = lds + wave * 2 * S;
   float* u = w + S;
   const long long waves = (long long)gridDim.x * 4;
+  float acc_total = 0.f;  // this wave's rays: one atomic per wave
   for (long long r = blockIdx.x * 4LL + wave; r < R; r += waves) {
     float intra = 0.f;
     for (int i = lane; i < S; i += 64) {
@@ -244,10 +251,10 @@ distortion_kernel(const float* __restrict__ bins, const float* __restrict__ weig
       for (int j = 0; j < S; ++j) s += w[j] * fabsf(ui - u[j]);
       inter += w[i] * s;
     }
-    const float total = wave_sum(inter + intra / 3.f);
-    if (lane == 0) atomicAdd(sum_out, total);
+    acc_total += wave_sum(inter + intra / 3.f);
     __builtin_amdgcn_wave_barrier();
   }
+  if (lane == 0 && acc_total != 0.f) atomicAdd(sum_out, acc_total);
 }
 
 // Camera pose refinement, backward.  Sample positions are o + d * mid with constant mid (the sampler's bins are
