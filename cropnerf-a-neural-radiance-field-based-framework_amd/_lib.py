@@ -37,7 +37,8 @@ TABLE_F32, TABLE_F16 = 0, 1  # cn_grid.table_dtype
 class Grid(C.Structure):
     _fields_ = [("table", C.c_void_p), ("num_levels", C.c_int32), ("log2_table_size", C.c_int32),
                 ("scalings", C.c_float * CN_MAX_LEVELS), ("layout", C.c_int32), ("table_dtype", C.c_int32),
-                ("level_offset", C.c_uint32 * CN_MAX_LEVELS), ("level_bits", C.c_uint8 * CN_MAX_LEVELS)]
+                ("level_offset", C.c_uint32 * CN_MAX_LEVELS), ("level_bits", C.c_uint8 * CN_MAX_LEVELS),
+                ("scatter_scratch", C.c_void_p), ("scatter_scratch_bytes", C.c_uint64)]
 
 
 class TcnnGridPlan(C.Structure):
@@ -112,6 +113,7 @@ SIGNATURES = {
     "cn_proposal_sample_workspace_bytes": (C.c_size_t, [_I64, C.POINTER(_I32), _I32, _I32]),
     "cn_proposal_sample": (C.c_int, [C.POINTER(C.POINTER(DensityParams)), _I32, C.POINTER(Scene), _P, _P, _P, _P, _I64,
                                      C.POINTER(_I32), _I32, _F, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cn_grid_scatter_scratch_bytes": (C.c_size_t, [C.POINTER(Grid)]),
     "cn_proposal_sample_train": (C.c_int, [C.POINTER(C.POINTER(DensityParams)), _I32, C.POINTER(Scene), _P, _P, _P, _P,
                                            _I64, C.POINTER(_I32), _I32, _F, _P, C.POINTER(ProposalLevelOut), _P, _P, _P]),
     "cn_export_compact": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _I64, C.POINTER(_P), C.POINTER(_P), _P, _P]),

@@ -282,6 +282,33 @@ __device__ __forceinline__ float2 hash_level(const void* __restrict__ table, con
   return r;
 }
 
+// Private accumulation of the coarsest level's gradient (cn_grid.scatter_scratch): `copies` dense [n1^3][2] arrays,
+// vertex (x, y, z) at x + n1 * (y + n1 * z); a workgroup adds to copy blockIdx.x % copies.  base == nullptr: off.
+struct CoarseScatter {
+  float* base;
+  unsigned n1, copies;
+};
+constexpr unsigned COARSE_COPIES = 64, COARSE_MIN_COPIES = 8, COARSE_MAX_N1 = 40;
+// vertices per axis that level 0 can address for positions in [0, 1]: floor(scale + offset) is the largest cell index
+inline unsigned coarse_n1(const cn_grid& g) {
+  const float off = g.layout == CN_GRID_TCNN ? 0.5f : 0.f;
+  return (unsigned)floorf(g.scalings[0] + off) + 2u;
+}
+inline CoarseScatter make_coarse_scatter(const cn_grid& grads_grid) {
+  CoarseScatter c{nullptr, 0u, 0u};
+  if (!grads_grid.scatter_scratch || grads_grid.num_levels < 1) return c;
+  const unsigned n1 = coarse_n1(grads_grid);
+  if (n1 > COARSE_MAX_N1) return c;
+  const size_t per_copy = (size_t)n1 * n1 * n1 * 2 * sizeof(float);
+  size_t copies = grads_grid.scatter_scratch_bytes / per_copy;
+  if (copies > COARSE_COPIES) copies = COARSE_COPIES;
+  if (copies < COARSE_MIN_COPIES) return c;
+  c.base = static_cast<float*>(grads_grid.scatter_scratch);
+  c.n1 = n1;
+  c.copies = (unsigned)copies;
+  return c;
+}
+
 // per-lane level record by static selects (a per-lane index into the kernarg arrays would go to scratch)
 __device__ __forceinline__ Lvl lane_level(const GridDev& g, int l) {
   Lvl v = g.level(0);

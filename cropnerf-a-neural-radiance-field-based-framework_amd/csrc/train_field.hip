@@ -215,6 +215,105 @@ __device__ __forceinline__ void hash_level_backward(float* __restrict__ gtab, co
   }
 }
 
+// The same for the level whose gradient is accumulated in private dense copies (CoarseScatter): the atomics go to
+// `priv` (this workgroup's copy) at the vertex's dense index; lanes whose cell lies outside the copy's n1^3 vertices
+// (positions outside [0, 1]: only without scene contraction) take the table path afterwards.  The position gradient reads
+// the parameter table at the real entries as before.
+template <bool POS>
+__device__ __forceinline__ void hash_level_backward_private(float* __restrict__ priv, unsigned n1,
+                                                            float* __restrict__ gtab, const float* __restrict__ table,
+                                                            const Lvl& lv, float pos_offset, float px, float py, float pz,
+                                                            float g0, float g1, int lane, float& dpx, float& dpy,
+                                                            float& dpz) {
+  const Cell cell = hash_cell(lv, pos_offset, px, py, pz);
+  const float ox = cell.ox, oy = cell.oy, oz = cell.oz, scale = lv.scale;
+  // the integer cell coordinates again (hash_cell keeps their index terms only)
+  const unsigned ix = cell.hx0;
+  const unsigned iy = (unsigned)(int)floorf(fmaf(py, lv.scale, pos_offset));
+  const unsigned iz = (unsigned)(int)floorf(fmaf(pz, lv.scale, pos_offset));
+  const bool inside = ix + 1u < n1 && iy + 1u < n1 && iz + 1u < n1;  // unsigned: negative coordinates are huge
+  const float h0 = inside ? g0 : 0.f, h1 = inside ? g1 : 0.f;
+  unsigned hx[2] = {cell.hx0, cell.hx1};
+  unsigned hy[2] = {cell.hy0, cell.hy1};
+  unsigned hz[2] = {cell.hz0, cell.hz1};
+  float wx[2] = {1.f - ox, ox}, wy[2] = {1.f - oy, oy}, wz[2] = {1.f - oz, oz};
+  const int row_lane = lane & 15;
+  float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+  for (int bd = 0; bd < 4; ++bd) {
+    const int b = bd & 1, d = bd >> 1;
+    unsigned eu[2];
+    float v0[2], v1[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const float w = wx[a] * wy[b] * wz[d];
+      const unsigned e = inside ? (ix + a) + n1 * ((iy + b) + n1 * (iz + d)) : 0xfffffffeu;
+      if constexpr (POS) {
+        const float2 t = hash_gather(table, ((hx[a] ^ hy[b] ^ hz[d]) & lv.mask) + lv.off);
+        const float tg = t.x * h0 + t.y * h1;
+        ax += (a ? tg : -tg) * (wy[b] * wz[d]);
+        ay += (b ? tg : -tg) * (wx[a] * wz[d]);
+        az += (d ? tg : -tg) * (wx[a] * wy[b]);
+      }
+      v0[a] = w * h0;
+      v1[a] = w * h1;
+      const bool issue = row_run_reduce(e, v0[a], v1[a], row_lane);
+      eu[a] = issue && (v0[a] != 0.f || v1[a] != 0.f) ? e : 0xffffffffu;
+    }
+    const int ql = lane & 3;
+#define CN_QUAD_ROUND(CTRL)                                                                          \
+  {                                                                                                  \
+    const unsigned e0 = dpp_u32<CTRL>(eu[0]), e1 = dpp_u32<CTRL>(eu[1]);                             \
+    const float a00 = dpp_f32<CTRL>(v0[0]), a01 = dpp_f32<CTRL>(v1[0]);                              \
+    const float a10 = dpp_f32<CTRL>(v0[1]), a11 = dpp_f32<CTRL>(v1[1]);                              \
+    const unsigned es = (ql & 2) ? e1 : e0;                                                          \
+    const float val = (ql & 2) ? ((ql & 1) ? a11 : a10) : ((ql & 1) ? a01 : a00);                    \
+    if (es != 0xffffffffu) atomicAdd(priv + 2 * (size_t)es + (ql & 1), val);                         \
+  }
+    CN_QUAD_ROUND(0x00)
+    CN_QUAD_ROUND(0x55)
+    CN_QUAD_ROUND(0xAA)
+    CN_QUAD_ROUND(0xFF)
+#undef CN_QUAD_ROUND
+  }
+  if constexpr (POS) {
+    dpx = fmaf(ax, scale, dpx);
+    dpy = fmaf(ay, scale, dpy);
+    dpz = fmaf(az, scale, dpz);
+  }
+  // cells outside the private copy (never with scene contraction): the plain path, for those lanes only
+  if (__builtin_amdgcn_ballot_w64(!inside && (g0 != 0.f || g1 != 0.f)) != 0ull)
+    hash_level_backward<POS>(gtab, table, lv, pos_offset, px, py, pz, inside ? 0.f : g0, inside ? 0.f : g1, lane, dpx, dpy,
+                             dpz);
+}
+
+// fold the private copies into the gradient table and zero them again: one thread per vertex of the dense n1^3 array
+__global__ void __launch_bounds__(256) coarse_scatter_reduce_kernel(CoarseScatter c, Lvl lv, float* __restrict__ gtab) {
+  const unsigned nv = c.n1 * c.n1 * c.n1;
+  const unsigned v = blockIdx.x * 256u + threadIdx.x;
+  if (v >= nv) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (unsigned k = 0; k < c.copies; ++k) {
+    float2* p = reinterpret_cast<float2*>(c.base) + (size_t)k * nv + v;
+    const float2 t = *p;
+    if (t.x != 0.f || t.y != 0.f) {
+      s0 += t.x;
+      s1 += t.y;
+      *p = make_float2(0.f, 0.f);
+    }
+  }
+  if (s0 == 0.f && s1 == 0.f) return;
+  const unsigned x = v % c.n1, y = (v / c.n1) % c.n1, z = v / (c.n1 * c.n1);
+  const unsigned e = ((x ^ (y * lv.m1) ^ (z * lv.m2)) & lv.mask) + lv.off;
+  atomicAdd(gtab + 2 * (size_t)e, s0);
+  atomicAdd(gtab + 2 * (size_t)e + 1, s1);
+}
+inline void launch_coarse_reduce(const CoarseScatter& c, const GridDev& grid, float* gtab, hipStream_t stream) {
+  if (!c.base) return;
+  const unsigned nv = c.n1 * c.n1 * c.n1;
+  hipLaunchKernelGGL(coarse_scatter_reduce_kernel, dim3((nv + 255) / 256), dim3(256), 0, stream, c, grid.level(0), gtab);
+}
+
 // d(loss)/d(normalised position) -> d(loss)/d(world position): the transpose Jacobian of normalize_position
 // (L-inf scene contraction then (c+2)/4, or the AABB normalisation), zero where the selector dropped the sample.
 __device__ __forceinline__ void normalize_position_backward(const SceneDev& sc, float x, float y, float z, float sel,
@@ -291,6 +390,7 @@ struct FieldBwdArgs {
   int S;
   float *d_pos, *d_dir;  // optional [R*S,3] outputs for the camera pose refinement (null: skipped)
   int debug_skip;  // profiling aid (env CN_DEBUG_SKIP): 1 hash atomics, 2 embedding atomics, 4 weight-gradient dots
+  CoarseScatter coarse;  // private copies for level 0's gradient (cn_grid.scatter_scratch of the gradient grid)
 };
 
 // LDS rows (each LD floats)
@@ -549,6 +649,7 @@ struct PropBwdArgs {
   long long R;
   int S;
   int debug_skip;  // CN_DEBUG_SKIP: 8 hash atomics, 16 weight-gradient dots
+  CoarseScatter coarse;
 };
 
 template <int L>
@@ -624,8 +725,18 @@ __global__ void __launch_bounds__(TB) proposal_backward_kernel(PropBwdArgs A) {
         g0 = fmaf(A.w0[n * K + 2 * l], d, g0);
         g1 = fmaf(A.w0[n * K + 2 * l + 1], d, g1);
       }
-      if (A.debug_skip & 8) continue;
-      if (A.d_pos)
+      if ((A.debug_skip & 8) || ((A.debug_skip >> (8 + l)) & 1)) continue;  // bits 8..14: skip the scatter of level l (profiling)
+      if (l == 0 && A.coarse.base) {
+        float* mine = A.coarse.base + (size_t)(blockIdx.x % A.coarse.copies) * (2u * A.coarse.n1 * A.coarse.n1 * A.coarse.n1);
+        if (A.d_pos)
+          hash_level_backward_private<true>(mine, A.coarse.n1, A.g_table, A.table, A.grid.level(0), A.grid.pos_offset,
+                                            misc[lane], misc[LD + lane], misc[2 * LD + lane], valid ? g0 : 0.f,
+                                            valid ? g1 : 0.f, lane, gpx, gpy, gpz);
+        else
+          hash_level_backward_private<false>(mine, A.coarse.n1, A.g_table, A.table, A.grid.level(0), A.grid.pos_offset,
+                                             misc[lane], misc[LD + lane], misc[2 * LD + lane], valid ? g0 : 0.f,
+                                             valid ? g1 : 0.f, lane, gpx, gpy, gpz);
+      } else if (A.d_pos)
         hash_level_backward<true>(A.g_table, A.table, A.grid.level(l), A.grid.pos_offset, misc[lane],
                                   misc[LD + lane], misc[2 * LD + lane], valid ? g0 : 0.f, valid ? g1 : 0.f, lane, gpx,
                                   gpy, gpz);
@@ -760,8 +871,10 @@ extern "C" int cn_field_backward(const cn_field_params* params, const cn_field_p
                        cn::as_stream(stream), A);
   } else {
     long long ntiles = (nsamp + cn::mf::TSM - 1) / cn::mf::TSM;
+    A.coarse = cn::make_coarse_scatter(grads->grid);
     hipLaunchKernelGGL(cn::mf::field_backward_mfma_kernel, dim3(cn::grid_for(ntiles, 1, 256)), dim3(cn::mf::NT),
                        cn::mf::LDS_BYTES, cn::as_stream(stream), A);
+    cn::launch_coarse_reduce(A.coarse, A.grid, A.g.table, cn::as_stream(stream));
   }
   return cn::check_launch("cn_field_backward");
 }
@@ -808,13 +921,22 @@ extern "C" int cn_proposal_backward(const cn_density_params* params, const cn_de
     const char* dbg = getenv("CN_DEBUG_SKIP");
     A.debug_skip = dbg ? atoi(dbg) : 0;
   }
+  A.coarse = cn::make_coarse_scatter(grads->grid);
   long long ntiles = (num_rays * (long long)num_samples + cn::TS - 1) / cn::TS;
   dim3 grid(cn::grid_for(ntiles, 1, 1024));
   if (L == 5)
     hipLaunchKernelGGL(cn::proposal_backward_kernel<5>, grid, dim3(cn::TB), 0, cn::as_stream(stream), A);
   else
     hipLaunchKernelGGL(cn::proposal_backward_kernel<7>, grid, dim3(cn::TB), 0, cn::as_stream(stream), A);
+  cn::launch_coarse_reduce(A.coarse, A.grid, A.g_table, cn::as_stream(stream));
   return cn::check_launch("cn_proposal_backward");
+}
+
+extern "C" size_t cn_grid_scatter_scratch_bytes(const cn_grid* grid) {
+  if (!grid || grid->num_levels < 1) return 0;
+  const unsigned n1 = cn::coarse_n1(*grid);
+  if (n1 > cn::COARSE_MAX_N1) return 0;
+  return (size_t)cn::COARSE_COPIES * n1 * n1 * n1 * 2 * sizeof(float);
 }
 
 // ---- shape-generic field backward ------------------------------------------------------------------------------------------

@@ -432,8 +432,19 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
     gB0 = blk_dw(D2, 16 * (wave >> 1), ENC, 16 * (wave & 1), gB0, lane);                            // dW base0
     float gpx = 0.f, gpy = 0.f, gpz = 0.f;
     if (!(A.debug_skip & 1)) {
-      const float g0 = valid ? D1[(2 * lvl) * LDA + s] : 0.f, g1 = valid ? D1[(2 * lvl + 1) * LDA + s] : 0.f;
-      if (A.d_pos)
+      const bool lvl_off = (A.debug_skip >> (8 + lvl)) & 1;  // bits 8..23: skip the scatter of level l (profiling)
+      const float g0 = valid && !lvl_off ? D1[(2 * lvl) * LDA + s] : 0.f, g1 = valid && !lvl_off ? D1[(2 * lvl + 1) * LDA + s] : 0.f;
+      // (a wave holds two levels, 32 lanes each: the branch below splits it along whole 16-lane rows, which is all the
+      //  DPP run-length reduction and the quad rounds reach across)
+      if (lvl == 0 && A.coarse.base) {
+        float* mine = A.coarse.base + (size_t)(blockIdx.x % A.coarse.copies) * (2u * A.coarse.n1 * A.coarse.n1 * A.coarse.n1);
+        if (A.d_pos)
+          hash_level_backward_private<true>(mine, A.coarse.n1, A.g.table, A.p.table, my_lv, A.grid.pos_offset, px, py, pz,
+                                            g0, g1, lane, gpx, gpy, gpz);
+        else
+          hash_level_backward_private<false>(mine, A.coarse.n1, A.g.table, A.p.table, my_lv, A.grid.pos_offset, px, py,
+                                             pz, g0, g1, lane, gpx, gpy, gpz);
+      } else if (A.d_pos)
         hash_level_backward<true>(A.g.table, A.p.table, my_lv, A.grid.pos_offset, px, py, pz,
                                   g0, g1, lane, gpx, gpy, gpz);
       else

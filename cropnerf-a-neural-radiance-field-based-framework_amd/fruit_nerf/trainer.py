@@ -132,8 +132,9 @@ class FruitTrainer:
             off += pad4(sizes[k])
         model.field = ops.FieldHandle(model.params, model.field_spec)
         model.proposal_networks = [ops.DensityHandle(model.params, i, ps) for i, ps in enumerate(model.proposal_specs)]
-        self.grad_field = ops.FieldHandle(self.grads, model.field_spec)
-        self.grad_props = [ops.DensityHandle(self.grads, i, ps) for i, ps in enumerate(model.proposal_specs)]
+        self.grad_field = ops.FieldHandle(self.grads, model.field_spec).enable_scatter_scratch()
+        self.grad_props = [ops.DensityHandle(self.grads, i, ps).enable_scatter_scratch()
+                           for i, ps in enumerate(model.proposal_specs)]
         self.step = 0
         self.group_steps = {g: 0 for g in self.group_range}  # Adam's per-parameter step count, per group
         self._steps_since_update = 0  # ProposalNetworkSampler state (_steps_since_update, _step)

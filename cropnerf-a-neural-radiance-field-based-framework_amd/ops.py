@@ -8,6 +8,7 @@ tensors on the ROCm device; a missing library or a failed call raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -125,6 +126,18 @@ def _mlp_struct(params: Dict[str, Tensor], prefix: str, num_layers: int) -> L.Ml
     return m
 
 
+def _attach_scatter_scratch(grid: L.Grid, device) -> Optional[Tensor]:
+    """``cn_grid.scatter_scratch`` for a GRADIENT grid: a zeroed buffer of ``cn_grid_scatter_scratch_bytes`` (the backward
+    kernels accumulate the coarsest level's gradient in private copies there and leave it zeroed)."""
+    n = int(L.load().cn_grid_scatter_scratch_bytes(C.byref(grid)))
+    if n <= 0:
+        return None
+    buf = torch.zeros(n // 4, dtype=torch.float32, device=device)
+    grid.scatter_scratch = buf.data_ptr()
+    grid.scatter_scratch_bytes = n
+    return buf
+
+
 class FieldHandle:
     """cn_field_params for a parameter dict (keeps the tensors alive)."""
 
@@ -146,6 +159,13 @@ class FieldHandle:
         self.struct = p
         self.device = emb.device
         self._workspace: Optional[Tensor] = None
+        self._scatter_scratch: Optional[Tensor] = None
+
+    def enable_scatter_scratch(self) -> "FieldHandle":
+        """For a handle over GRADIENT buffers: private copies for the coarsest level's scatter (``cn_grid.scatter_scratch``)."""
+        if self._scatter_scratch is None and os.environ.get("CN_SCATTER_SCRATCH", "1") != "0":
+            self._scatter_scratch = _attach_scatter_scratch(self.struct.grid, self.device)
+        return self
 
     def workspace(self) -> Tensor:
         n = int(L.load().cn_render_workspace_bytes(C.byref(self.struct)))
@@ -162,6 +182,14 @@ class DensityHandle:
         p.grid = _grid_struct(params[f"proposal_networks.{level}.encoding.hash_table"], spec.grid)
         p.mlp = _mlp_struct(params, f"proposal_networks.{level}.mlp", 2)
         self.struct = p
+        self._scatter_scratch: Optional[Tensor] = None
+
+    def enable_scatter_scratch(self) -> "DensityHandle":
+        """For a handle over GRADIENT buffers (see ``FieldHandle.enable_scatter_scratch``)."""
+        if self._scatter_scratch is None and os.environ.get("CN_SCATTER_SCRATCH", "1") != "0":
+            self._scatter_scratch = _attach_scatter_scratch(
+                self.struct.grid, self.params[next(k for k in self.params if k.endswith("hash_table"))].device)
+        return self
 
 
 def scene_struct(aabb: Tensor, contraction: bool) -> L.Scene:

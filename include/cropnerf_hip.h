@@ -77,7 +77,7 @@ typedef void* cn_stream_t; /* hipStream_t */
 #define CN_TABLE_F16 1
 
 /* One multiresolution hash grid (fruit_nerf/fruit_field.py:125-132; proposal nets fruit_nerf/fruit_nerf.py:133-142).
- * A zero-initialised tail (layout .. level_bits) is the torch layout with an fp32 table. */
+ * A zero-initialised tail (layout .. scatter_scratch_bytes) is the torch layout with an fp32 table and no scratch. */
 typedef struct cn_grid {
   const void* table;              /* [entries, 2] float (CN_TABLE_F32) or _Float16 (CN_TABLE_F16)                */
   int32_t num_levels;             /* <= CN_MAX_LEVELS                                                             */
@@ -87,7 +87,15 @@ typedef struct cn_grid {
   int32_t table_dtype;            /* CN_TABLE_*                                                                   */
   uint32_t level_offset[CN_MAX_LEVELS]; /* CN_GRID_TCNN: first entry of level l                                  */
   uint8_t level_bits[CN_MAX_LEVELS];    /* CN_GRID_TCNN: 0 = hashed level, b > 0 = dense level with b bits per axis */
+  /* Only read when the grid is a GRADIENT target (the `grads` argument of the backward entry points): optional scratch
+   * of cn_grid_scatter_scratch_bytes(grid) bytes, zeroed ONCE by the caller; every backward call leaves it zeroed.  With
+   * it the gradient of the coarsest level -- a few thousand vertices that every sample of every ray adds to -- is
+   * accumulated in 64 private dense copies and folded into `table` by one small kernel afterwards, instead of all
+   * workgroups queueing on the same few hundred 64-byte lines.  NULL: every level goes straight to `table`. */
+  void* scatter_scratch;
+  uint64_t scatter_scratch_bytes;
 } cn_grid;
+size_t cn_grid_scatter_scratch_bytes(const cn_grid* grid);
 
 /* tiny-cuda-nn grid geometry for (n_levels, log2_hashmap_size, base_resolution, per_level_scale) -- what nerfstudio's
  * HashEncoding(implementation="tcnn") passes to tcnn.Encoding -- and this library's table layout for it. host struct. */

@@ -6,7 +6,7 @@ import math
 import pytest
 import torch
 
-from _helpers import assert_close, make_scene, to_dev
+from _helpers import assert_close, dev_params, make_scene, product_specs, to_dev
 from oracle import losses as OL
 from oracle import rays as ORY
 
@@ -399,3 +399,60 @@ def test_big_method_trains():
         losses.append(sum(float(v) for v in o2["loss_dict"].values()))
         tr.optimizer_step()
     assert losses[-1] < losses[0], losses
+
+
+def test_private_copies_of_the_coarsest_level_change_nothing(monkeypatch):
+    """cn_grid.scatter_scratch: the coarsest level's gradient accumulated in private dense copies and folded into the table
+    afterwards == the plain scatter (order of additions apart), the scratch is left zeroed, and cells outside the copies
+    (positions outside the box, no scene contraction) take the table path."""
+    from cropnerf_amd import _lib as L
+    from cropnerf_amd import ops
+    from cropnerf_amd.fruit_nerf.trainer import FruitTrainer
+
+    sc, idx, jitter, image, mask = _setup(seed=9, R=128)
+    tables = ["field.mlp_base_grid.hash_table", "proposal_networks.0.encoding.hash_table",
+              "proposal_networks.1.encoding.hash_table", "camera_optimizer.pose_adjustment"]
+    got = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CN_SCATTER_SCRATCH", flag)
+        model = _hip_model(sc)
+        model.training = True
+        tr = FruitTrainer(model)
+        handles = [tr.grad_field] + tr.grad_props
+        assert all((h._scatter_scratch is not None) == (flag == "1") for h in handles)
+        tr.forward_backward(_hip_rays(sc, idx), {"image": image, "fruit_mask": mask}, jitter=jitter)
+        got[flag] = {k: tr.grads[k].clone() for k in tables}
+        if flag == "1":
+            assert all(float(h._scatter_scratch.abs().max()) == 0.0 for h in handles), "scratch not left zeroed"
+    for k in tables:
+        assert float(got["0"][k].abs().sum()) > 0, k
+        err = float((got["1"][k] - got["0"][k]).norm() / got["0"][k].norm())
+        assert err < 2e-6, f"{k}: {err}"
+    # ---- no contraction, half of the samples outside the box: their level-0 cells are not in the private copies ----------
+    fspec, pspecs = product_specs(sc)
+    dp = dev_params(sc)
+    fh = ops.FieldHandle(dp, fspec)
+    R, S = 64, 16
+    g = torch.Generator().manual_seed(3)
+    o = (torch.rand(R, 3, generator=g) - 0.5) * 0.2
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    t = torch.sort(torch.rand(R, S + 1, generator=g) * 2.5, dim=1).values  # the box is +-1: samples beyond t ~ 1 are outside
+    starts, ends = t[:, :-1].contiguous(), t[:, 1:].contiguous()
+    cam = torch.randint(0, sc.c2w.shape[0], (R,), generator=g)
+    gd, grgb, gs = torch.randn(R, S, generator=g), torch.randn(R, S, 3, generator=g), torch.randn(R, S, generator=g)
+    scene = ops.scene_struct(sc.aabb, False)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CN_SCATTER_SCRATCH", flag)
+        grads = {k: torch.zeros_like(v) for k, v in dp.items()}
+        gh = ops.FieldHandle(grads, fspec).enable_scatter_scratch()
+        dpos = torch.zeros(R, S, 3, device="cuda")
+        ops.field_backward(fh, gh, scene, to_dev(o), to_dev(d), to_dev(cam), to_dev(starts), to_dev(ends), to_dev(gd),
+                           to_dev(grgb), to_dev(gs), app_mode=L.APP_PER_CAMERA, d_positions=dpos,
+                           d_directions=torch.zeros(R, S, 3, device="cuda"))
+        res[flag] = (grads["field.mlp_base_grid.hash_table"].clone(), dpos)
+        if flag == "1":
+            assert float(gh._scatter_scratch.abs().max()) == 0.0
+    assert float(res["0"][0].abs().sum()) > 0
+    assert float((res["1"][0] - res["0"][0]).norm() / res["0"][0].norm()) < 2e-6
+    assert float((res["1"][1] - res["0"][1]).norm() / (res["0"][1].norm() + 1e-20)) < 2e-6
