@@ -106,9 +106,20 @@ train_render_backward_kernel(const float* __restrict__ starts, const float* __re
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (lane == 0 && (mse_sum != 0.f || bce_sum != 0.f)) {
-    atomicAdd(loss_sums + 0, mse_sum);
-    atomicAdd(loss_sums + 1, bce_sum);
+  // one atomic pair per workgroup (every ray's own atomic on these two addresses is served one after the other: at
+  // 4096 rays that alone was a third of this kernel)
+  __shared__ float red[4][2];
+  if (lane == 0) {
+    red[wave][0] = mse_sum;
+    red[wave][1] = bce_sum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float a = red[0][0] + red[1][0] + red[2][0] + red[3][0], b = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    if (a != 0.f || b != 0.f) {
+      atomicAdd(loss_sums + 0, a);
+      atomicAdd(loss_sums + 1, b);
+    }
   }
 }
 
@@ -218,7 +229,13 @@ interlevel_backward_kernel(const float* __restrict__ c_bins, const float* __rest
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (lane == 0 && loss_acc != 0.f) atomicAdd(loss_sum, loss_acc);
+  __shared__ float red[4];  // one atomic per workgroup
+  if (lane == 0) red[wave] = loss_acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float a = red[0] + red[1] + red[2] + red[3];
+    if (a != 0.f) atomicAdd(loss_sum, a);
+  }
 }
 
 // nerfstudio distortion_loss on the final level (a metric in the reference, fruit_nerf.py:643):
@@ -254,7 +271,13 @@ distortion_kernel(const float* __restrict__ bins, const float* __restrict__ weig
     acc_total += wave_sum(inter + intra / 3.f);
     __builtin_amdgcn_wave_barrier();
   }
-  if (lane == 0 && acc_total != 0.f) atomicAdd(sum_out, acc_total);
+  __shared__ float red[4];  // one atomic per workgroup
+  if (lane == 0) red[wave] = acc_total;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float a = red[0] + red[1] + red[2] + red[3];
+    if (a != 0.f) atomicAdd(sum_out, a);
+  }
 }
 
 // Camera pose refinement, backward.  Sample positions are o + d * mid with constant mid (the sampler's bins are
