@@ -45,11 +45,30 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_FP32_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32: 64 FLOP/clk/SIMD x 4 SIMD x 256 CU x 2.4 GHz (dense)
 MLP_MAC_PER_SAMPLE = 9216  # the folded field MLPs as the render kernels evaluate them
 ATOMIC_REQUESTS_PER_SEC = 21.07e9  # float-atomic requests the memory side takes (tools/atomic_microbench.hip)
-# float-atomic requests per iteration, MEASURED (profiles/r01_v7_pmc_train_atomics.json, TCC_ATOMIC == TCC_EA0_ATOMIC, default
-# method, 4096 random rays): field backward 72.94 per field sample (4.56 per sample and level: the floor of the x-edge
-# scatter is 4.5), each proposal backward 5.372e6 per launch (coarse grids: the run-length pre-reduction merges most)
-ATOMIC_REQUESTS_PER_FIELD_SAMPLE = 72.94
-ATOMIC_REQUESTS_PER_PROPOSAL_LAUNCH_PER_RAY = 5.372e6 / 4096
+# float-atomic requests per iteration, MEASURED with the TCC atomic counters on tools/train_probe.py (default method, 4096
+# random rays, 48 field samples per ray): read from the newest profiles/r*_pmc_train_atomics.json (TCC_ATOMIC ==
+# TCC_EA0_ATOMIC); the fallbacks are the round-1 figures (72.94 per field sample, 5.372e6 per proposal launch).
+def _measured_atomic_requests():
+    import glob
+    import json as _json
+
+    field, prop, src = 72.94, 5.372e6 / 4096, "profiles/r01_v7_pmc_train_atomics.json (TCC_ATOMIC per launch, 4096 rays)"
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_train_atomics.json")))
+    if files:
+        try:
+            d = _json.load(open(files[-1]))
+            k = d["kernels"]
+            f = next(v for n, v in k.items() if "field_backward_mfma_kernel" in n)["TCC_ATOMIC_sum"]["avg_per_launch"]
+            q = next(v for n, v in k.items() if "proposal_backward_kernel" in n)["TCC_ATOMIC_sum"]["avg_per_launch"]
+            field, prop = f / (4096 * 48), q / 4096
+            src = f"profiles/{os.path.basename(files[-1])} @ {d.get('commit', '?')} (TCC_ATOMIC per launch, 4096 rays)"
+        except (KeyError, StopIteration, ValueError, OSError):
+            pass
+    return field, prop, src
+
+
+ATOMIC_REQUESTS_PER_FIELD_SAMPLE, ATOMIC_REQUESTS_PER_PROPOSAL_LAUNCH_PER_RAY, ATOMIC_REQUESTS_SOURCE = _measured_atomic_requests()
 
 
 def parse_args():
@@ -430,8 +449,8 @@ def secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, o
             t = timed(lambda i: tr.train_iteration(rb, batch), 5)
             train[str(nrays)] = {"ms_per_iter": round(t * 1e3, 3), "rays_per_sec": nrays / t}
             # The iteration's bound is the rate at which the memory side takes float-atomic requests (hash-grid gradient
-            # scatter), not HBM bytes or MFMA: requests per iteration = rays x (48 field samples x 72.94 + 2
-            # proposal launches x 1311.5), the per-ray counts measured with the TCC atomic counters.  Proposal networks
+            # scatter), not HBM bytes or MFMA: requests per iteration = rays x (48 field samples x the measured
+            # requests per field sample + 2 proposal launches x the measured requests per ray and launch).  Proposal networks
             # take part in one iteration out of `proposal_update_every` after warm-up; the timed iterations are early ones
             # (every iteration updates them), i.e. the expensive case.
             req = nrays * (tcfg.num_nerf_samples_per_ray * ATOMIC_REQUESTS_PER_FIELD_SAMPLE
@@ -441,7 +460,7 @@ def secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, o
                 "achieved": round(req / t / 1e9, 3), "peak": round(ATOMIC_REQUESTS_PER_SEC / 1e9, 2),
                 "unit": "G atomic requests/s (memory side; 64-byte read-modify-writes)", "frac": round(req / t / ATOMIC_REQUESTS_PER_SEC, 4),
                 "traffic": None, "atomic_requests_per_iteration": int(req),
-                "requests_source": "profiles/r01_v7_pmc_train_atomics.json (TCC_ATOMIC per launch, 4096 rays)",
+                "requests_source": ATOMIC_REQUESTS_SOURCE,
                 "hbm_equivalent_GBps": round(req * 64 / t / 1e9, 1)}
         out["train_iteration"] = train
     return out

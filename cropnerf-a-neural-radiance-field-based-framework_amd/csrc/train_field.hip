@@ -287,21 +287,30 @@ __device__ __forceinline__ void hash_level_backward_private(float* __restrict__ 
                              dpz);
 }
 
-// fold the private copies into the gradient table and zero them again: one thread per vertex of the dense n1^3 array
+// fold the private copies into the gradient table and zero them again: 64 vertices of the dense n1^3 array per workgroup,
+// the copies shared out over its 4 waves (each load is 64 consecutive float2 of one copy)
 __global__ void __launch_bounds__(256) coarse_scatter_reduce_kernel(CoarseScatter c, Lvl lv, float* __restrict__ gtab) {
+  __shared__ float2 part[4][64];
   const unsigned nv = c.n1 * c.n1 * c.n1;
-  const unsigned v = blockIdx.x * 256u + threadIdx.x;
-  if (v >= nv) return;
+  const unsigned j = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  const unsigned v = blockIdx.x * 64u + j;
   float s0 = 0.f, s1 = 0.f;
-  for (unsigned k = 0; k < c.copies; ++k) {
-    float2* p = reinterpret_cast<float2*>(c.base) + (size_t)k * nv + v;
-    const float2 t = *p;
-    if (t.x != 0.f || t.y != 0.f) {
-      s0 += t.x;
-      s1 += t.y;
-      *p = make_float2(0.f, 0.f);
+  if (v < nv) {
+    for (unsigned k = w; k < c.copies; k += 4) {
+      float2* p = reinterpret_cast<float2*>(c.base) + (size_t)k * nv + v;
+      const float2 t = *p;
+      if (t.x != 0.f || t.y != 0.f) {
+        s0 += t.x;
+        s1 += t.y;
+        *p = make_float2(0.f, 0.f);
+      }
     }
   }
+  part[w][j] = make_float2(s0, s1);
+  __syncthreads();
+  if (w != 0 || v >= nv) return;
+  s0 = part[0][j].x + part[1][j].x + part[2][j].x + part[3][j].x;
+  s1 = part[0][j].y + part[1][j].y + part[2][j].y + part[3][j].y;
   if (s0 == 0.f && s1 == 0.f) return;
   const unsigned x = v % c.n1, y = (v / c.n1) % c.n1, z = v / (c.n1 * c.n1);
   const unsigned e = ((x ^ (y * lv.m1) ^ (z * lv.m2)) & lv.mask) + lv.off;
@@ -311,7 +320,7 @@ __global__ void __launch_bounds__(256) coarse_scatter_reduce_kernel(CoarseScatte
 inline void launch_coarse_reduce(const CoarseScatter& c, const GridDev& grid, float* gtab, hipStream_t stream) {
   if (!c.base) return;
   const unsigned nv = c.n1 * c.n1 * c.n1;
-  hipLaunchKernelGGL(coarse_scatter_reduce_kernel, dim3((nv + 255) / 256), dim3(256), 0, stream, c, grid.level(0), gtab);
+  hipLaunchKernelGGL(coarse_scatter_reduce_kernel, dim3((nv + 63) / 64), dim3(256), 0, stream, c, grid.level(0), gtab);
 }
 
 // d(loss)/d(normalised position) -> d(loss)/d(world position): the transpose Jacobian of normalize_position
