@@ -253,8 +253,10 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
                 wz = A.origins[3 * r + 2] + dirz * mid;
     float px = wx, py = wy, pz = wz;
     const float self = normalize_position(A.scene, px, py, pz) ? 1.f : 0.f;
+    float2 corners[8];  // this (sample, level)'s table entries: read again by the position gradient at the end of the tile
     {
-      const float2 f = hash_level(A.p.table, my_lv, A.grid.pos_offset, px, py, pz);
+      const float2 f = A.d_pos ? hash_level_corners(A.p.table, my_lv, A.grid.pos_offset, px, py, pz, corners)
+                               : hash_level(A.p.table, my_lv, A.grid.pos_offset, px, py, pz);
       ENC[(2 * lvl) * LDA + s] = f.x;
       ENC[(2 * lvl + 1) * LDA + s] = f.y;
     }
@@ -440,13 +442,13 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
         float* mine = A.coarse.base + (size_t)(blockIdx.x % A.coarse.copies) * (2u * A.coarse.n1 * A.coarse.n1 * A.coarse.n1);
         if (A.d_pos)
           hash_level_backward_private<true>(mine, A.coarse.n1, A.g.table, A.p.table, my_lv, A.grid.pos_offset, px, py, pz,
-                                            g0, g1, lane, gpx, gpy, gpz);
+                                            g0, g1, lane, gpx, gpy, gpz, corners);
         else
           hash_level_backward_private<false>(mine, A.coarse.n1, A.g.table, A.p.table, my_lv, A.grid.pos_offset, px, py,
                                              pz, g0, g1, lane, gpx, gpy, gpz);
       } else if (A.d_pos)
         hash_level_backward<true>(A.g.table, A.p.table, my_lv, A.grid.pos_offset, px, py, pz,
-                                  g0, g1, lane, gpx, gpy, gpz);
+                                  g0, g1, lane, gpx, gpy, gpz, corners);
       else
         hash_level_backward<false>(A.g.table, A.p.table, my_lv, A.grid.pos_offset, px, py, pz, g0, g1, lane, gpx,
                                    gpy, gpz);
