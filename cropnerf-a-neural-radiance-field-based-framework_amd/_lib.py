@@ -115,7 +115,8 @@ SIGNATURES = {
                                      C.POINTER(_I32), _I32, _F, _P, _P, _P, _P, C.c_size_t, _P]),
     "cn_grid_scatter_scratch_bytes": (C.c_size_t, [C.POINTER(Grid)]),
     "cn_proposal_sample_train": (C.c_int, [C.POINTER(C.POINTER(DensityParams)), _I32, C.POINTER(Scene), _P, _P, _P, _P,
-                                           _I64, C.POINTER(_I32), _I32, _F, _P, C.POINTER(ProposalLevelOut), _P, _P, _P]),
+                                           _I64, C.POINTER(_I32), _I32, _F, _P, C.POINTER(ProposalLevelOut), _P, _P, _P, _P,
+                                           _P]),
     "cn_export_compact": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _I64, C.POINTER(_P), C.POINTER(_P), _P, _P]),
     "cn_pointcloud_compact": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
     "cn_embedding_mean": (C.c_int, [_P, _I32, _I32, _P, _P]),

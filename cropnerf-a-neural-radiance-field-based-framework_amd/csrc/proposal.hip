@@ -44,6 +44,7 @@ struct PropArgs {
   float* lv_starts[PROP_MAX_LEVELS];   // [R, S_l]
   float* lv_ends[PROP_MAX_LEVELS];     // [R, S_l]
   float* lv_density[PROP_MAX_LEVELS];  // [R, S_l]
+  float *final_starts, *final_ends;    // [R, s_final] (optional): euclidean_bins[:, :-1] / [:, 1:] as contiguous arrays
 };
 
 template <int L, int H, bool HALF>
@@ -149,7 +150,12 @@ __global__ void __launch_bounds__(256) proposal_sample_kernel(PropArgs A) {
         nxt[b] = bin;
         if (last) {
           if (A.out_sp) A.out_sp[r * nb + b] = bin;
-          A.out_eu[r * nb + b] = spacing_to_euclid(CN_SPACING_PIECEWISE, bin, sn, sf);
+          const float eu = spacing_to_euclid(CN_SPACING_PIECEWISE, bin, sn, sf);
+          A.out_eu[r * nb + b] = eu;
+          if constexpr (TRAIN) {
+            if (A.final_starts && b < s_next) A.final_starts[r * s_next + b] = eu;
+            if (A.final_ends && b > 0) A.final_ends[r * s_next + b - 1] = eu;
+          }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -173,7 +179,7 @@ static int proposal_sample_launch(const char* who, const cn_density_params* cons
                                   const float* nears, const float* fars, int64_t num_rays, const int32_t* s_prop,
                                   int32_t s_final, float anneal, const float* jitter,
                                   const cn_proposal_level_out* levels, float* euclidean_bins, float* spacing_bins,
-                                  float* prop_depth, cn_stream_t stream) {
+                                  float* prop_depth, float* final_starts, float* final_ends, cn_stream_t stream) {
   CN_REQUIRE(props && scene && origins && directions && nears && fars && s_prop && euclidean_bins, CN_ERR_INVALID,
              "%s: null argument", who);
   CN_REQUIRE(num_levels >= 1 && num_levels <= PROP_MAX_LEVELS, CN_ERR_UNSUPPORTED,
@@ -229,6 +235,8 @@ static int proposal_sample_launch(const char* who, const cn_density_params* cons
   A.out_sp = spacing_bins;
   A.out_depth = prop_depth;
   A.jitter = jitter;
+  A.final_starts = final_starts;
+  A.final_ends = final_ends;
   const size_t lds = (size_t)4 * (4 * A.smax + 4) * sizeof(float);
   const dim3 grid(grid_for(num_rays, 4, 256 * 8)), block(256);
   const bool half = A.net[0].grid.half;
@@ -250,7 +258,7 @@ extern "C" int cn_proposal_sample(const cn_density_params* const* props, int32_t
                                   cn_stream_t stream) {
   return cn::proposal_sample_launch("cn_proposal_sample", props, num_levels, scene, origins, directions, nears, fars,
                                     num_rays, s_prop, s_final, anneal, nullptr, nullptr, euclidean_bins, spacing_bins,
-                                    prop_depth, stream);
+                                    prop_depth, nullptr, nullptr, stream);
 }
 
 extern "C" int cn_proposal_sample_train(const cn_density_params* const* props, int32_t num_levels,
@@ -258,9 +266,9 @@ extern "C" int cn_proposal_sample_train(const cn_density_params* const* props, i
                                         const float* nears, const float* fars, int64_t num_rays, const int32_t* s_prop,
                                         int32_t s_final, float anneal, const float* jitter,
                                         const cn_proposal_level_out* levels, float* euclidean_bins, float* spacing_bins,
-                                        cn_stream_t stream) {
+                                        float* final_starts, float* final_ends, cn_stream_t stream) {
   CN_REQUIRE(jitter, CN_ERR_INVALID, "cn_proposal_sample_train: null jitter");
   return cn::proposal_sample_launch("cn_proposal_sample_train", props, num_levels, scene, origins, directions, nears,
                                     fars, num_rays, s_prop, s_final, anneal, jitter, levels, euclidean_bins,
-                                    spacing_bins, nullptr, stream);
+                                    spacing_bins, nullptr, final_starts, final_ends, stream);
 }

@@ -727,7 +727,11 @@ __global__ void __launch_bounds__(TB) proposal_backward_kernel(PropBwdArgs A) {
     bias_add<H>(gb0, dh, tid);
     // delta_enc[k] = sum_n W0[n][k] dh[n] -> straight into the table gradient
     float gpx = 0.f, gpy = 0.f, gpz = 0.f;
-    for (int l = wave; l < L; l += 4) {
+    // the finest level costs most (one request per x-edge, no runs to merge) and the coarsest least: the waves take the
+    // levels from the fine end, the second round from the other side (L = 5: {4}, {3}, {2}, {1, 0})
+    for (int round = 0; round < 2; ++round) {
+      const int l = round == 0 ? L - 1 - wave : L - 8 + wave;
+      if (l < 0) continue;
       float g0 = 0.f, g1 = 0.f;
 #pragma unroll
       for (int n = 0; n < H; ++n) {

@@ -180,9 +180,13 @@ class FruitTrainer:
         nears = rb.nears if rb.nears is not None else torch.full((R, 1), float(cfg.near_plane), device=dev)
         fars = rb.fars if rb.fars is not None else torch.full((R, 1), float(cfg.far_plane), device=dev)
         n_lvl = len(m.proposal_networks)
+        jitter_rows = None
         if jitter is None:
-            jitter = [torch.rand(R, 1, generator=self._gen) for _ in range(n_lvl + 1)]
-        jitter = [j.to(dev).contiguous() for j in jitter]
+            # one draw, one host-to-device copy: rows = the samplers' per-ray uniforms, level by level
+            jitter_rows = torch.rand(n_lvl + 1, R, generator=self._gen).to(dev)
+            jitter = [jitter_rows[i].reshape(R, 1) for i in range(n_lvl + 1)]
+        else:
+            jitter = [j.to(dev).contiguous() for j in jitter]
         scene = m._scene(True)
         # ---- proposal sampler (bins, intervals and densities of every level are kept for the interlevel loss) --------
         s_prop = [int(v) for v in cfg.num_proposal_samples_per_ray[:n_lvl]]
@@ -190,10 +194,11 @@ class FruitTrainer:
             # one launch: cn_proposal_sample_train
             ps = ops.proposal_sample_train(m.proposal_networks, scene, o, d, nears, fars, s_prop,
                                            cfg.num_nerf_samples_per_ray, m._anneal,
+                                           jitter_rows if jitter_rows is not None else
                                            torch.cat([j.reshape(1, R) for j in jitter], 0).contiguous())
             levels = ps["levels"]
             bins, eu = ps["spacing_bins"], ps["euclidean_bins"]
-            starts, ends = eu[:, :-1].contiguous(), eu[:, 1:].contiguous()
+            starts, ends = ps["starts"], ps["ends"]
         else:
             # the same, level by level through the materialising calls (any proposal shape)
             levels = []

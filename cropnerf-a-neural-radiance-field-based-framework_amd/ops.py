@@ -376,11 +376,12 @@ def proposal_sample_train(props: Sequence[DensityHandle], scene: L.Scene, origin
     outs = (L.ProposalLevelOut * n)(*[L.ProposalLevelOut(lv["bins"].data_ptr(), lv["starts"].data_ptr(),
                                                          lv["ends"].data_ptr(), lv["density"].data_ptr())
                                       for lv in levels])
+    starts, ends = torch.empty(R, s_final, device=dev), torch.empty(R, s_final, device=dev)
     L.check(lib.cn_proposal_sample_train(arr, n, C.byref(scene), _p(_f32(origins, "origins")),
                                          _p(_f32(directions, "directions")), _p(_f32(nears, "nears")),
                                          _p(_f32(fars, "fars")), R, sp_arr, s_final, anneal, _p(_f32(jitter, "jitter")),
-                                         outs, _p(eu), _p(sp), _stream(origins)))
-    return {"euclidean_bins": eu, "spacing_bins": sp, "levels": levels}
+                                         outs, _p(eu), _p(sp), _p(starts), _p(ends), _stream(origins)))
+    return {"euclidean_bins": eu, "spacing_bins": sp, "starts": starts, "ends": ends, "levels": levels}
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -340,6 +340,7 @@ int cn_proposal_sample(const cn_density_params* const* props_host, int32_t num_l
  * uniform random per ray, every PDF resampling at u + rand / nb with one random per ray, and every level's spacing bins,
  * euclidean intervals and densities written out -- what interlevel_loss (fruit_nerf.py:608-611) and the proposal
  * backward read.  jitter: device [num_levels + 1][R] uniforms in [0, 1) (row l + 1 = the resampling after level l).
+ * final_starts / final_ends: euclidean_bins[:, :-1] / [:, 1:] as contiguous arrays (what the field kernels take).
  * Replaces the composed cn_sample_spaced / cn_proposal_density / cn_composite / cn_sample_pdf chain of the training
  * forward (same arithmetic per step; tested against it and against oracle/losses.py). */
 typedef struct cn_proposal_level_out {
@@ -352,7 +353,8 @@ int cn_proposal_sample_train(const cn_density_params* const* props_host, int32_t
                              const float* origins, const float* directions, const float* nears, const float* fars,
                              int64_t num_rays, const int32_t* s_prop_host, int32_t s_final, float anneal,
                              const float* jitter, const cn_proposal_level_out* levels_host, float* euclidean_bins,
-                             float* spacing_bins, cn_stream_t stream);
+                             float* spacing_bins, float* final_starts /*[R,s_final] or NULL*/,
+                             float* final_ends /*[R,s_final] or NULL*/, cn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Exporters

@@ -414,6 +414,7 @@ def test_training_sampler_in_one_launch_matches_the_composed_chain(scene, ops, h
         bins, eu = ops.sample_pdf(bins, w, n, f, s_next, anneal=anneal, u_rand=to_dev(jitter[lvl + 1]))
         starts, ends = eu[:, :-1].contiguous(), eu[:, 1:].contiguous()
     assert_close(fused["euclidean_bins"].cpu(), eu.cpu(), 1e-5, 2e-6, "final euclidean bins")
+    assert torch.equal(fused["starts"], fused["euclidean_bins"][:, :-1]) and torch.equal(fused["ends"], fused["euclidean_bins"][:, 1:])
     assert_close(fused["spacing_bins"].cpu(), bins.cpu(), 1e-5, 2e-6, "final spacing bins")
 
 
