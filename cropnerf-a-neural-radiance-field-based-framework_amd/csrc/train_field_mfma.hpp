@@ -241,6 +241,58 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
   const Lvl my_lv = lane_level(A.grid, lvl);
   const long long total = A.R * (long long)A.S;
   const long long ntiles = (total + TSM - 1) / TSM;
+  // The hash scatter of a tile is DEFERRED to just after the next tile's gather: a wave's loads and atomics share one
+  // in-order counter (vmcnt), so a gather issued after the atomics waits until every one of them has been acknowledged by
+  // the memory side -- at the end of a tile that round trip was exposed on every CU; issued after the next gather, it
+  // drains under that tile's matrix phases (LDS and MFMA only: the per-tile inputs are all loaded in the gather phase).
+  bool have_prev = false;   // workgroup-uniform
+  float p_px = 0.f, p_py = 0.f, p_pz = 0.f, p_wx = 0.f, p_wy = 0.f, p_wz = 0.f, p_self = 0.f, p_g0 = 0.f, p_g1 = 0.f;
+  long long p_ismp = 0;
+  bool p_valid = false;
+  auto deferred_scatter = [&]() {
+    float gpx = 0.f, gpy = 0.f, gpz = 0.f;
+    if (!(A.debug_skip & 1)) {
+      // (a wave holds two levels, 32 lanes each: the branch below splits it along whole 16-lane rows, which is all the
+      //  DPP run-length reduction and the quad rounds reach across)
+      if (lvl == 0 && A.coarse.base) {
+        float* mine = A.coarse.base + (size_t)(blockIdx.x % A.coarse.copies) * (2u * A.coarse.n1 * A.coarse.n1 * A.coarse.n1);
+        if (A.d_pos)
+          hash_level_backward_private<true>(mine, A.coarse.n1, A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py,
+                                            p_pz, p_g0, p_g1, lane, gpx, gpy, gpz);
+        else
+          hash_level_backward_private<false>(mine, A.coarse.n1, A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py,
+                                             p_pz, p_g0, p_g1, lane, gpx, gpy, gpz);
+      } else if (A.d_pos)
+        hash_level_backward<true>(A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py, p_pz, p_g0, p_g1, lane, gpx,
+                                  gpy, gpz);
+      else
+        hash_level_backward<false>(A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py, p_pz, p_g0, p_g1, lane, gpx,
+                                   gpy, gpz);
+    }
+    if (A.d_pos) {
+      // per-level partials -> LDS (A1 is not written before the s1 phase, two barriers away) -> one thread per sample sums
+      // the 16 levels
+      float* part = A1;
+      part[(3 * lvl + 0) * LDA + s] = gpx;
+      part[(3 * lvl + 1) * LDA + s] = gpy;
+      part[(3 * lvl + 2) * LDA + s] = gpz;
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      if (lvl == 0 && p_valid) {
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) {
+          gx += part[(3 * l + 0) * LDA + s];
+          gy += part[(3 * l + 1) * LDA + s];
+          gz += part[(3 * l + 2) * LDA + s];
+        }
+        normalize_position_backward(A.scene, p_wx, p_wy, p_wz, p_self, gx, gy, gz);
+        A.d_pos[3 * p_ismp] = gx;
+        A.d_pos[3 * p_ismp + 1] = gy;
+        A.d_pos[3 * p_ismp + 2] = gz;
+      }
+    }
+  };
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // ---- gather ------------------------------------------------------------------------------------------------------
     const long long ismp = tile * TSM + s;
@@ -253,12 +305,24 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
                 wz = A.origins[3 * r + 2] + dirz * mid;
     float px = wx, py = wy, pz = wz;
     const float self = normalize_position(A.scene, px, py, pz) ? 1.f : 0.f;
-    float2 corners[8];  // this (sample, level)'s table entries: read again by the position gradient at the end of the tile
     {
-      const float2 f = A.d_pos ? hash_level_corners(A.p.table, my_lv, A.grid.pos_offset, px, py, pz, corners)
-                               : hash_level(A.p.table, my_lv, A.grid.pos_offset, px, py, pz);
+      const float2 f = hash_level(A.p.table, my_lv, A.grid.pos_offset, px, py, pz);
       ENC[(2 * lvl) * LDA + s] = f.x;
       ENC[(2 * lvl + 1) * LDA + s] = f.y;
+    }
+    // every other global input of the tile is read here too, so that nothing between this phase and the next gather waits
+    // on vmcnt (see deferred_scatter): the upstream colour gradients (two waves, 16 lanes each), the density gradient and
+    // the camera row of the sample
+    const long long cam_row = A.app_per_camera ? A.cam_idx[r] : 0;
+    const float dd_in = (lvl == 0 && valid) ? A.d_density[ic] : 0.f;
+    float drgb_in[3] = {0.f, 0.f, 0.f};
+    if (wave < 2 && (lane >> 4) == 0) {
+      const long long io = tile * TSM + 16 * wave + (lane & 15);
+      if (io < total) {
+        drgb_in[0] = A.d_rgb[3 * io];
+        drgb_in[1] = A.d_rgb[3 * io + 1];
+        drgb_in[2] = A.d_rgb[3 * io + 2];
+      }
     }
     if (lvl == 0) {
       const float ds = valid ? A.d_sem[ic] : 0.f;
@@ -277,11 +341,13 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
       for (int k = 0; k < 16; ++k) CIN[k * LDA + s] = sh[k];
     }
     {
-      const float* a = A.app_per_camera ? A.p.emb + A.cam_idx[r] * 32 : A.app_mean;
+      const float* a = A.app_per_camera ? A.p.emb + cam_row * 32 : A.app_mean;
       CIN[(31 + 2 * lvl) * LDA + s] = a ? a[2 * lvl] : 0.f;
       CIN[(32 + 2 * lvl) * LDA + s] = a ? a[2 * lvl + 1] : 0.f;
     }
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    if (have_prev) deferred_scatter();  // the previous tile's hash-table gradient (+ its position gradient)
     __builtin_amdgcn_sched_barrier(0);
     // ---- h1 = relu(W0 enc + b0) -----------------------------------------------------------------------------------------
     store_blk<true>(H1, n0, s0, blk_fwd<32>(Wb0, 36, n0, ENC, s0, bias4(lds + B_0, n0, lane), lane), lane);
@@ -335,12 +401,10 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
       const f32x4 v = blk_fwd<64>(Wrgb, 68, 0, A2, c0, bias4(lds + B_RGB, 0, lane), lane);
       CN_LANE_IQ
       if (q == 0) {
-        const long long io = tile * TSM + c0 + i;
-        const bool ok = io < total;
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr) {
           const float sg = 1.f / (1.f + expf(-v[rr]));
-          const float d = ok ? A.d_rgb[3 * io + rr] * sg * (1.f - sg) : 0.f;
+          const float d = drgb_in[rr] * sg * (1.f - sg);  // (zero past the end of the batch)
           DRGB[rr * LDA + c0 + i] = d;
           b_rgb[rr] += d;
         }
@@ -378,8 +442,7 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
       float v;
       if (row == 0) {
         const float logit = O16[s];
-        const float dd = valid ? A.d_density[ic] : 0.f;
-        v = dd * self * expf(fminf(fmaxf(logit, -15.f), 15.f));
+        v = dd_in * self * expf(fminf(fmaxf(logit, -15.f), 15.f));
       } else {
         v = DCIN[(15 + row) * LDA + s];
       }
@@ -394,7 +457,7 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
         float g1 = valid ? DCIN[(32 + 2 * lvl) * LDA + s] : 0.f;
         const bool last = row_run_reduce(valid ? (unsigned)r : 0xffffffffu, g0, g1, lane & 15);
         if (last && valid) {
-          float* ge = A.g.emb + A.cam_idx[r] * 32 + 2 * lvl;
+          float* ge = A.g.emb + cam_row * 32 + 2 * lvl;
           if (g0 != 0.f) atomicAdd(ge, g0);
           if (g1 != 0.f) atomicAdd(ge + 1, g1);
         }
@@ -432,51 +495,27 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     gB0 = blk_dw(D2, 16 * (wave >> 1), ENC, 16 * (wave & 1), gB0, lane);                            // dW base0
-    float gpx = 0.f, gpy = 0.f, gpz = 0.f;
-    if (!(A.debug_skip & 1)) {
+    {
       const bool lvl_off = (A.debug_skip >> (8 + lvl)) & 1;  // bits 8..23: skip the scatter of level l (profiling)
-      const float g0 = valid && !lvl_off ? D1[(2 * lvl) * LDA + s] : 0.f, g1 = valid && !lvl_off ? D1[(2 * lvl + 1) * LDA + s] : 0.f;
-      // (a wave holds two levels, 32 lanes each: the branch below splits it along whole 16-lane rows, which is all the
-      //  DPP run-length reduction and the quad rounds reach across)
-      if (lvl == 0 && A.coarse.base) {
-        float* mine = A.coarse.base + (size_t)(blockIdx.x % A.coarse.copies) * (2u * A.coarse.n1 * A.coarse.n1 * A.coarse.n1);
-        if (A.d_pos)
-          hash_level_backward_private<true>(mine, A.coarse.n1, A.g.table, A.p.table, my_lv, A.grid.pos_offset, px, py, pz,
-                                            g0, g1, lane, gpx, gpy, gpz, corners);
-        else
-          hash_level_backward_private<false>(mine, A.coarse.n1, A.g.table, A.p.table, my_lv, A.grid.pos_offset, px, py,
-                                             pz, g0, g1, lane, gpx, gpy, gpz);
-      } else if (A.d_pos)
-        hash_level_backward<true>(A.g.table, A.p.table, my_lv, A.grid.pos_offset, px, py, pz,
-                                  g0, g1, lane, gpx, gpy, gpz, corners);
-      else
-        hash_level_backward<false>(A.g.table, A.p.table, my_lv, A.grid.pos_offset, px, py, pz, g0, g1, lane, gpx,
-                                   gpy, gpz);
-    }
-    if (A.d_pos) {
-      // per-level partials -> LDS (the branch buffers are dead by now) -> one thread per sample sums the 16 levels
-      float* part = A1;
-      part[(3 * lvl + 0) * LDA + s] = gpx;
-      part[(3 * lvl + 1) * LDA + s] = gpy;
-      part[(3 * lvl + 2) * LDA + s] = gpz;
-      __syncthreads();
-    __builtin_amdgcn_sched_barrier(0);
-      if (lvl == 0 && valid) {
-        float gx = 0.f, gy = 0.f, gz = 0.f;
-#pragma unroll
-        for (int l = 0; l < 16; ++l) {
-          gx += part[(3 * l + 0) * LDA + s];
-          gy += part[(3 * l + 1) * LDA + s];
-          gz += part[(3 * l + 2) * LDA + s];
-        }
-        normalize_position_backward(A.scene, wx, wy, wz, self, gx, gy, gz);
-        A.d_pos[3 * ismp] = gx;
-        A.d_pos[3 * ismp + 1] = gy;
-        A.d_pos[3 * ismp + 2] = gz;
-      }
+      p_g0 = valid && !lvl_off ? D1[(2 * lvl) * LDA + s] : 0.f;
+      p_g1 = valid && !lvl_off ? D1[(2 * lvl + 1) * LDA + s] : 0.f;
+      p_px = px;
+      p_py = py;
+      p_pz = pz;
+      p_wx = wx;
+      p_wy = wy;
+      p_wz = wz;
+      p_self = self;
+      p_ismp = ismp;
+      p_valid = valid;
+      have_prev = true;
     }
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
+  }
+  if (have_prev) {
+    deferred_scatter();  // the last tile's
+    __syncthreads();
   }
 
   // ---- flush -------------------------------------------------------------------------------------------------------------
