@@ -1100,7 +1100,9 @@ extern "C" int cn_field_backward_general(const cn_field_params* params, const cn
              "cn_field_backward_general: hipMemsetAsync failed");
   const long long ntiles = (num_rays * (long long)num_samples + cn::gb::TSG - 1) / cn::gb::TSG;
   const int grid = (int)std::min<long long>(ntiles, nblk);
+  A.coarse = cn::make_coarse_scatter(grads->grid);
   hipLaunchKernelGGL(cn::gb::field_backward_general_kernel, dim3(grid), dim3(cn::gb::NTG), lds, s, A);
+  cn::launch_coarse_reduce(A.coarse, A.grid, A.g_table, s);
   rc = cn::check_launch("cn_field_backward_general");
   if (rc) return rc;
   for (int i = 0; i < nt; ++i)

@@ -49,6 +49,7 @@ struct GenArgs {
   float *d_pos, *d_dir;  // optional [R*S,3]: gradients w.r.t. the sample position / the ray direction (pose refinement)
   long long R;
   int S;
+  CoarseScatter coarse;  // private copies for level 0's gradient (cn_grid.scatter_scratch of the gradient grid)
 };
 
 __device__ __forceinline__ int opaque_i(int v) {
@@ -347,7 +348,16 @@ __global__ void __launch_bounds__(NTG) field_backward_general_kernel(GenArgs A) 
       const bool on = l < A.num_levels;
       const int lc = on ? l : 0;
       const float g0 = on && valid ? DB[(2 * lc) * LDG + s] : 0.f, g1 = on && valid ? DB[(2 * lc + 1) * LDG + s] : 0.f;
-      if (A.d_pos)
+      // (a wave holds two levels, 32 lanes each; the branch splits it along whole 16-lane rows)
+      if (on && lc == 0 && A.coarse.base) {
+        float* mine = A.coarse.base + (size_t)(blockIdx.x % A.coarse.copies) * (2u * A.coarse.n1 * A.coarse.n1 * A.coarse.n1);
+        if (A.d_pos)
+          hash_level_backward_private<true>(mine, A.coarse.n1, A.g_table, A.table, lds_level_rec(SCL, 0), A.grid.pos_offset,
+                                            px, py, pz, g0, g1, lane, gpx, gpy, gpz);
+        else
+          hash_level_backward_private<false>(mine, A.coarse.n1, A.g_table, A.table, lds_level_rec(SCL, 0), A.grid.pos_offset,
+                                             px, py, pz, g0, g1, lane, gpx, gpy, gpz);
+      } else if (A.d_pos)
         hash_level_backward<true>(A.g_table, A.table, lds_level_rec(SCL, lc), A.grid.pos_offset, px, py, pz, g0, g1,
                                   lane, gpx, gpy, gpz);
       else
