@@ -92,3 +92,25 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.delenv("CROPNERF_HIP_LIB")
     monkeypatch.setattr(_lib, "_lib", None)
     _lib.load()
+
+
+def test_scatter_scratch_size_is_a_host_computation(lib):
+    """cn_grid_scatter_scratch_bytes: 64 private dense copies of level 0, n = floor(scale_0 + offset) + 2 vertices per axis."""
+    import ctypes as C
+
+    from cropnerf_amd import _lib
+    from cropnerf_amd.config import GridSpec
+
+    g = _lib.Grid()
+    g.num_levels = 16
+    g.log2_table_size = 19
+    for i, sc in enumerate(GridSpec().scalings()):
+        g.scalings[i] = sc
+    assert g.scalings[0] == 16.0
+    assert lib.cn_grid_scatter_scratch_bytes(C.byref(g)) == 64 * 18 ** 3 * 2 * 4
+    g.layout = _lib.GRID_TCNN  # tcnn: scale_0 = 15, positions shifted by half a cell -> cells 0..15, vertices 0..16
+    g.scalings[0] = 15.0
+    assert lib.cn_grid_scatter_scratch_bytes(C.byref(g)) == 64 * 17 ** 3 * 2 * 4
+    g.scalings[0] = 1000.0  # a fine "coarsest level": not worth private copies
+    assert lib.cn_grid_scatter_scratch_bytes(C.byref(g)) == 0
+    assert lib.cn_grid_scatter_scratch_bytes(None) == 0
