@@ -663,16 +663,14 @@ struct PropBwdArgs {
 };
 
 template <int L>
-__global__ void __launch_bounds__(TB, 4) proposal_backward_kernel(PropBwdArgs A) {
+__global__ void __launch_bounds__(TB) proposal_backward_kernel(PropBwdArgs A) {
   constexpr int K = 2 * L, H = 16;
-  __shared__ float lds[(K + H + H + 1 + 4 + 3 + 12 + K + 7) * LD];
+  __shared__ float lds[(K + H + H + 1 + 4 + 3 + 12) * LD];
   float* enc = lds;                  // [K]
   float* hid = enc + K * LD;         // [H] post ReLU
   float* dh = hid + H * LD;          // [H] delta hidden
   float* dout = dh + H * LD;         // [1] delta logit
   float* misc = dout + LD;           // normalised pos(3) sel(1) world pos(3) per-wave d(pos)(12)
-  float* pd = misc + 19 * LD;        // [K] delta_enc of the PREVIOUS tile (its scatter is deferred, see below)
-  float* pm = pd + K * LD;           // [7] normalised pos / sel / world pos of the previous tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> weights come through s_load
   WGrad<K, H> gW0;
@@ -682,69 +680,17 @@ __global__ void __launch_bounds__(TB, 4) proposal_backward_kernel(PropBwdArgs A)
   float gb0 = 0.f, gb1 = 0.f;
   const long long total = A.R * (long long)A.S;
   const long long ntiles = (total + TS - 1) / TS;
-  // The hash scatter of a tile is issued after the NEXT tile's gathers (as in field_backward_mfma_kernel): a wave's loads
-  // wait for its earlier atomics to be acknowledged (one in-order counter), so the scatter goes where nothing but LDS and
-  // scalar work follows it.  The finest level costs most (one request per x-edge, no runs to merge) and the coarsest
-  // least: the waves take the levels from the fine end, the second round from the other side (L = 5: {4}, {3}, {2}, {1, 0}).
-  long long prev_tile = -1;
-  auto deferred_scatter = [&]() {
-    const long long i = prev_tile * TS + lane;
-    const bool valid = i < total;
-    float gpx = 0.f, gpy = 0.f, gpz = 0.f;
-    const float px = pm[lane], py = pm[LD + lane], pz = pm[2 * LD + lane];
-    for (int round = 0; round < 2; ++round) {
-      const int l = round == 0 ? L - 1 - wave : L - 8 + wave;
-      if (l < 0) continue;
-      if ((A.debug_skip & 8) || ((A.debug_skip >> (8 + l)) & 1)) continue;  // bits 8..14: skip the scatter of level l (profiling)
-      const float g0 = valid ? pd[(2 * l) * LD + lane] : 0.f, g1 = valid ? pd[(2 * l + 1) * LD + lane] : 0.f;
-      if (l == 0 && A.coarse.base) {
-        float* mine = A.coarse.base + (size_t)(blockIdx.x % A.coarse.copies) * (2u * A.coarse.n1 * A.coarse.n1 * A.coarse.n1);
-        if (A.d_pos)
-          hash_level_backward_private<true>(mine, A.coarse.n1, A.g_table, A.table, A.grid.level(0), A.grid.pos_offset, px, py,
-                                            pz, g0, g1, lane, gpx, gpy, gpz);
-        else
-          hash_level_backward_private<false>(mine, A.coarse.n1, A.g_table, A.table, A.grid.level(0), A.grid.pos_offset, px,
-                                             py, pz, g0, g1, lane, gpx, gpy, gpz);
-      } else if (A.d_pos)
-        hash_level_backward<true>(A.g_table, A.table, A.grid.level(l), A.grid.pos_offset, px, py, pz, g0, g1, lane, gpx, gpy,
-                                  gpz);
-      else
-        hash_level_backward<false>(A.g_table, A.table, A.grid.level(l), A.grid.pos_offset, px, py, pz, g0, g1, lane, gpx, gpy,
-                                   gpz);
-    }
-    if (A.d_pos) {
-      misc[(7 + 3 * wave) * LD + lane] = gpx;
-      misc[(8 + 3 * wave) * LD + lane] = gpy;
-      misc[(9 + 3 * wave) * LD + lane] = gpz;
-      __syncthreads();
-      if (wave == 0 && valid) {
-        float gx = 0.f, gy = 0.f, gz = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          gx += misc[(7 + 3 * w) * LD + lane];
-          gy += misc[(8 + 3 * w) * LD + lane];
-          gz += misc[(9 + 3 * w) * LD + lane];
-        }
-        normalize_position_backward(A.scene, pm[4 * LD + lane], pm[5 * LD + lane], pm[6 * LD + lane], pm[3 * LD + lane], gx,
-                                    gy, gz);
-        A.d_pos[3 * i] = gx;
-        A.d_pos[3 * i + 1] = gy;
-        A.d_pos[3 * i + 2] = gz;
-      }
-    }
-  };
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long long i = tile * TS + lane;
     const bool valid = i < total;
     const long long ic = valid ? i : total - 1;
     const long long r = ic / A.S;
-    float sel_f = 0.f, up = 0.f;
+    float sel_f = 0.f;
     if (wave == 0) {
       const float mid = (A.starts[ic] + A.ends[ic]) / 2.f;
       float px = A.origins[3 * r] + A.directions[3 * r] * mid;
       float py = A.origins[3 * r + 1] + A.directions[3 * r + 1] * mid;
       float pz = A.origins[3 * r + 2] + A.directions[3 * r + 2] * mid;
-      up = valid ? A.d_density[ic] : 0.f;  // every global input of the tile is read here (nothing later waits on vmcnt)
       misc[4 * LD + lane] = px;
       misc[5 * LD + lane] = py;
       misc[6 * LD + lane] = pz;
@@ -763,13 +709,13 @@ __global__ void __launch_bounds__(TB, 4) proposal_backward_kernel(PropBwdArgs A)
       enc[(2 * l + 1) * LD + lane] = f.y;
     }
     __syncthreads();
-    if (prev_tile >= 0) deferred_scatter();  // the previous tile's table gradient (+ its position gradient)
     fwd_rows<K, H, true>(A.w0, A.b0, enc, hid, wave, lane);
     __syncthreads();
     if (wave == 0) {
       float logit = A.b1[0];
 #pragma unroll
       for (int k = 0; k < H; ++k) logit = fmaf(A.w1[k], hid[k * LD + lane], logit);
+      const float up = valid ? A.d_density[ic] : 0.f;
       dout[lane] = up * misc[3 * LD + lane] * expf(fminf(fmaxf(logit, -15.f), 15.f));
     }
     __syncthreads();
@@ -779,18 +725,62 @@ __global__ void __launch_bounds__(TB, 4) proposal_backward_kernel(PropBwdArgs A)
     __syncthreads();
     if (!(A.debug_skip & 16)) gW0.add(dh, enc, tid);
     bias_add<H>(gb0, dh, tid);
-    // delta_enc[k] = sum_n W0[n][k] dh[n], kept in LDS with the tile's positions for the deferred scatter
-    for (int k = wave; k < K; k += 4) {
-      float g = 0.f;
+    // delta_enc[k] = sum_n W0[n][k] dh[n] -> straight into the table gradient
+    float gpx = 0.f, gpy = 0.f, gpz = 0.f;
+    // the finest level costs most (one request per x-edge, no runs to merge) and the coarsest least: the waves take the
+    // levels from the fine end, the second round from the other side (L = 5: {4}, {3}, {2}, {1, 0})
+    for (int round = 0; round < 2; ++round) {
+      const int l = round == 0 ? L - 1 - wave : L - 8 + wave;
+      if (l < 0) continue;
+      float g0 = 0.f, g1 = 0.f;
 #pragma unroll
-      for (int n = 0; n < H; ++n) g = fmaf(A.w0[n * K + k], dh[n * LD + lane], g);
-      pd[k * LD + lane] = g;
+      for (int n = 0; n < H; ++n) {
+        const float d = dh[n * LD + lane];
+        g0 = fmaf(A.w0[n * K + 2 * l], d, g0);
+        g1 = fmaf(A.w0[n * K + 2 * l + 1], d, g1);
+      }
+      if ((A.debug_skip & 8) || ((A.debug_skip >> (8 + l)) & 1)) continue;  // bits 8..14: skip the scatter of level l (profiling)
+      if (l == 0 && A.coarse.base) {
+        float* mine = A.coarse.base + (size_t)(blockIdx.x % A.coarse.copies) * (2u * A.coarse.n1 * A.coarse.n1 * A.coarse.n1);
+        if (A.d_pos)
+          hash_level_backward_private<true>(mine, A.coarse.n1, A.g_table, A.table, A.grid.level(0), A.grid.pos_offset,
+                                            misc[lane], misc[LD + lane], misc[2 * LD + lane], valid ? g0 : 0.f,
+                                            valid ? g1 : 0.f, lane, gpx, gpy, gpz);
+        else
+          hash_level_backward_private<false>(mine, A.coarse.n1, A.g_table, A.table, A.grid.level(0), A.grid.pos_offset,
+                                             misc[lane], misc[LD + lane], misc[2 * LD + lane], valid ? g0 : 0.f,
+                                             valid ? g1 : 0.f, lane, gpx, gpy, gpz);
+      } else if (A.d_pos)
+        hash_level_backward<true>(A.g_table, A.table, A.grid.level(l), A.grid.pos_offset, misc[lane],
+                                  misc[LD + lane], misc[2 * LD + lane], valid ? g0 : 0.f, valid ? g1 : 0.f, lane, gpx,
+                                  gpy, gpz);
+      else
+        hash_level_backward<false>(A.g_table, A.table, A.grid.level(l), A.grid.pos_offset, misc[lane],
+                                   misc[LD + lane], misc[2 * LD + lane], valid ? g0 : 0.f, valid ? g1 : 0.f, lane, gpx,
+                                   gpy, gpz);
     }
-    for (int k = wave; k < 7; k += 4) pm[k * LD + lane] = misc[k * LD + lane];
-    prev_tile = tile;
+    if (A.d_pos) {
+      misc[(7 + 3 * wave) * LD + lane] = gpx;
+      misc[(8 + 3 * wave) * LD + lane] = gpy;
+      misc[(9 + 3 * wave) * LD + lane] = gpz;
+      __syncthreads();
+      if (wave == 0 && valid) {
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          gx += misc[(7 + 3 * w) * LD + lane];
+          gy += misc[(8 + 3 * w) * LD + lane];
+          gz += misc[(9 + 3 * w) * LD + lane];
+        }
+        normalize_position_backward(A.scene, misc[4 * LD + lane], misc[5 * LD + lane], misc[6 * LD + lane],
+                                    misc[3 * LD + lane], gx, gy, gz);
+        A.d_pos[3 * i] = gx;
+        A.d_pos[3 * i + 1] = gy;
+        A.d_pos[3 * i + 2] = gz;
+      }
+    }
     __syncthreads();
   }
-  if (prev_tile >= 0) deferred_scatter();
   gW0.flush(A.g_w0, tid);
   gW1.flush(A.g_w1, tid);
   if (tid < H) atomicAdd(A.g_b0 + tid, gb0);
