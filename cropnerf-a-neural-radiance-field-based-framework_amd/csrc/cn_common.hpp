@@ -309,34 +309,6 @@ inline CoarseScatter make_coarse_scatter(const cn_grid& grads_grid) {
   return c;
 }
 
-// hash_level that also hands back the 8 corner entries, c[a + 2 b + 4 d] = entry of corner (x + a, y + b, z + d): the
-// backward of the same (sample, level) needs them again for the position gradient and keeps them in registers instead of
-// gathering twice (every second gather of a random-ray batch is a request beyond the L2).
-__device__ __forceinline__ float2 hash_level_corners(const void* __restrict__ table, const Lvl& lv, float pos_offset, float px,
-                                                     float py, float pz, float2 (&c)[8]) {
-  const Cell k = hash_cell(lv, pos_offset, px, py, pz);
-  const unsigned hx[2] = {k.hx0, k.hx1}, hy[2] = {k.hy0, k.hy1}, hz[2] = {k.hz0, k.hz1};
-#pragma unroll
-  for (int i = 0; i < 8; ++i) c[i] = hash_gather<false>(table, ((hx[i & 1] ^ hy[(i >> 1) & 1] ^ hz[i >> 2]) & lv.mask) + lv.off);
-  const float ox = k.ox, oy = k.oy, oz = k.oz, mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
-  typedef float v2f __attribute__((ext_vector_type(2)));
-  auto V = [](float2 t) {
-    v2f v;
-    v.x = t.x;
-    v.y = t.y;
-    return v;
-  };
-  // the blend of hash_level, corner by corner: ccc = c[7], cfc = c[5], ffc = c[4], fcc = c[6], ccf = c[3], cff = c[1], fff = c[0], fcf = c[2]
-  const v2f f03 = V(c[7]) * ox + V(c[6]) * mx, f12 = V(c[5]) * ox + V(c[4]) * mx;
-  const v2f f56 = V(c[1]) * ox + V(c[0]) * mx, f47 = V(c[3]) * ox + V(c[2]) * mx;
-  const v2f a = f03 * oy + f12 * my, b = f47 * oy + f56 * my;
-  const v2f rv = a * oz + b * mz;
-  float2 r;
-  r.x = rv.x;
-  r.y = rv.y;
-  return r;
-}
-
 // per-lane level record by static selects (a per-lane index into the kernarg arrays would go to scratch)
 __device__ __forceinline__ Lvl lane_level(const GridDev& g, int l) {
   Lvl v = g.level(0);

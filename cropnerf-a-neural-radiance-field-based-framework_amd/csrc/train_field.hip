@@ -153,8 +153,7 @@ __device__ __forceinline__ bool row_run_reduce(unsigned key, float& v0, float& v
 template <bool POS>
 __device__ __forceinline__ void hash_level_backward(float* __restrict__ gtab, const float* __restrict__ table,
                                                     const Lvl& lv, float pos_offset, float px, float py, float pz,
-                                                    float g0, float g1, int lane, float& dpx, float& dpy, float& dpz,
-                                                    const float2* kept = nullptr /* hash_level_corners' entries */) {
+                                                    float g0, float g1, int lane, float& dpx, float& dpy, float& dpz) {
   const Cell cell = hash_cell(lv, pos_offset, px, py, pz);
   const float ox = cell.ox, oy = cell.oy, oz = cell.oz, scale = lv.scale;
   const unsigned mask = lv.mask, level_off = lv.off;
@@ -180,7 +179,7 @@ __device__ __forceinline__ void hash_level_backward(float* __restrict__ gtab, co
       const float w = wx[a] * wy[b] * wz[d];
       const unsigned e = ((hx[a] ^ hy[b] ^ hz[d]) & mask) + level_off;
       if constexpr (POS) {
-        const float2 t = kept ? kept[a + 2 * b + 4 * d] : hash_gather(table, e);
+        const float2 t = hash_gather(table, e);
         const float tg = t.x * g0 + t.y * g1;
         ax += (a ? tg : -tg) * (wy[b] * wz[d]);
         ay += (b ? tg : -tg) * (wx[a] * wz[d]);
@@ -225,7 +224,7 @@ __device__ __forceinline__ void hash_level_backward_private(float* __restrict__ 
                                                             float* __restrict__ gtab, const float* __restrict__ table,
                                                             const Lvl& lv, float pos_offset, float px, float py, float pz,
                                                             float g0, float g1, int lane, float& dpx, float& dpy,
-                                                            float& dpz, const float2* kept = nullptr) {
+                                                            float& dpz) {
   const Cell cell = hash_cell(lv, pos_offset, px, py, pz);
   const float ox = cell.ox, oy = cell.oy, oz = cell.oz, scale = lv.scale;
   // the integer cell coordinates again (hash_cell keeps their index terms only)
@@ -250,7 +249,7 @@ __device__ __forceinline__ void hash_level_backward_private(float* __restrict__ 
       const float w = wx[a] * wy[b] * wz[d];
       const unsigned e = inside ? (ix + a) + n1 * ((iy + b) + n1 * (iz + d)) : 0xfffffffeu;
       if constexpr (POS) {
-        const float2 t = kept ? kept[a + 2 * b + 4 * d] : hash_gather(table, ((hx[a] ^ hy[b] ^ hz[d]) & lv.mask) + lv.off);
+        const float2 t = hash_gather(table, ((hx[a] ^ hy[b] ^ hz[d]) & lv.mask) + lv.off);
         const float tg = t.x * h0 + t.y * h1;
         ax += (a ? tg : -tg) * (wy[b] * wz[d]);
         ay += (b ? tg : -tg) * (wx[a] * wz[d]);
@@ -285,7 +284,7 @@ __device__ __forceinline__ void hash_level_backward_private(float* __restrict__ 
   // cells outside the private copy (never with scene contraction): the plain path, for those lanes only
   if (__builtin_amdgcn_ballot_w64(!inside && (g0 != 0.f || g1 != 0.f)) != 0ull)
     hash_level_backward<POS>(gtab, table, lv, pos_offset, px, py, pz, inside ? 0.f : g0, inside ? 0.f : g1, lane, dpx, dpy,
-                             dpz, kept);
+                             dpz);
 }
 
 // fold the private copies into the gradient table and zero them again: 64 vertices of the dense n1^3 array per workgroup,
