@@ -309,6 +309,65 @@ inline CoarseScatter make_coarse_scatter(const cn_grid& grads_grid) {
   return c;
 }
 
+// Cell-major gradient records of the coarse levels (cn_grid.scatter_scratch, behind the level-0 vertex copies): level l < num_levels
+// keeps copies[l] arrays of n[l]^3 records of 16 floats -- the 8 corners x 2 features of ONE cell, corner c = a + 2 b + 4 d at
+// floats 2c, 2c + 1 -- so that a sample adds its whole cell in ONE 64-byte request (the hash table takes 4.5: one per x-edge),
+// and consecutive samples of a ray in the same cell merge into one.  A fold kernel adds the touched records to the table and
+// zeroes them.  Worth it where samples outnumber cells: the launch picks the levels by batch size.
+constexpr int CN_CELL_LEVELS = 8;
+constexpr unsigned long long CELL_MAX_CELLS = 2200000ull;  // 129^3 fits
+struct CellScatter {
+  float* base;  // nullptr: off
+  int num_levels;
+  unsigned n[CN_CELL_LEVELS];
+  unsigned copies[CN_CELL_LEVELS];
+  unsigned long long offset[CN_CELL_LEVELS];  // in floats from base
+};
+inline unsigned cell_n(const cn_grid& g, int l) {  // cells per axis that positions in [0, 1] can fall into
+  const float off = g.layout == CN_GRID_TCNN ? 0.5f : 0.f;
+  return (unsigned)floorf(g.scalings[l] + off) + 1u;
+}
+inline unsigned cell_copies(unsigned long long ncells) { return ncells <= 8192 ? 16u : ncells <= 65536 ? 4u : 1u; }
+// bytes of the vertex copies (first part of the scratch)
+inline size_t coarse_scratch_bytes(const cn_grid& g) {
+  if (g.num_levels < 1) return 0;
+  const unsigned n1 = coarse_n1(g);
+  return n1 > COARSE_MAX_N1 ? 0 : (size_t)COARSE_COPIES * n1 * n1 * n1 * 2 * sizeof(float);
+}
+// the consecutive coarse levels that may be kept cell-major, and the bytes they need (second part of the scratch)
+inline size_t cell_scratch_layout(const cn_grid& g, CellScatter* out) {
+  CellScatter c{};
+  unsigned long long floats = 0;
+  for (int l = 0; l < g.num_levels && l < CN_CELL_LEVELS; ++l) {
+    const unsigned n = cell_n(g, l);
+    const unsigned long long cells = (unsigned long long)n * n * n;
+    if (cells > CELL_MAX_CELLS) break;
+    c.n[l] = n;
+    c.copies[l] = cell_copies(cells);
+    c.offset[l] = floats;
+    floats += c.copies[l] * cells * 16ull;
+    c.num_levels = l + 1;
+  }
+  if (out) *out = c;
+  return (size_t)floats * sizeof(float);
+}
+// levels 0 .. k-1 with at most max_cells cells each (the launch passes ~ samples / 2)
+inline CellScatter make_cell_scatter(const cn_grid& grads_grid, unsigned long long max_cells) {
+  CellScatter c{};
+  if (!grads_grid.scatter_scratch) return c;
+  const size_t head = coarse_scratch_bytes(grads_grid);
+  const size_t need = cell_scratch_layout(grads_grid, &c);
+  if (need == 0 || grads_grid.scatter_scratch_bytes < head + need) {
+    c = CellScatter{};
+    return c;
+  }
+  int k = 0;
+  while (k < c.num_levels && (unsigned long long)c.n[k] * c.n[k] * c.n[k] <= max_cells) ++k;
+  c.num_levels = k;
+  c.base = k > 0 ? reinterpret_cast<float*>(static_cast<char*>(grads_grid.scatter_scratch) + head) : nullptr;
+  return c;
+}
+
 // per-lane level record by static selects (a per-lane index into the kernarg arrays would go to scratch)
 __device__ __forceinline__ Lvl lane_level(const GridDev& g, int l) {
   Lvl v = g.level(0);

@@ -287,6 +287,106 @@ __device__ __forceinline__ void hash_level_backward_private(float* __restrict__ 
                              dpz);
 }
 
+// The scatter of one CELL-MAJOR level (CellScatter): every sample adds the 16 weighted values of its cell -- 8 corners x 2
+// features -- to the cell's 64-byte record with ONE request: runs of consecutive samples in the same cell are summed first
+// (the same DPP run-length reduction, keyed by the cell), the 16 sums of a run end go through a wave-private LDS buffer
+// `tb` ([64][17] floats) so that 16 lanes carry one record, and in round k the 16 lanes of every row add the record of the
+// row's k-th sample.  Cells outside the n^3 array (positions outside [0, 1]: only without scene contraction) take the table
+// path afterwards.  All 64 lanes of the wave must call.
+template <bool POS>
+__device__ __forceinline__ void hash_level_backward_cells(float* __restrict__ rec, unsigned n, float* __restrict__ tb,
+                                                          float* __restrict__ gtab, const float* __restrict__ table,
+                                                          const Lvl& lv, float pos_offset, float px, float py, float pz,
+                                                          float g0, float g1, int lane, float& dpx, float& dpy,
+                                                          float& dpz) {
+  const Cell cell = hash_cell(lv, pos_offset, px, py, pz);
+  const float ox = cell.ox, oy = cell.oy, oz = cell.oz;
+  const unsigned ix = cell.hx0;
+  const unsigned iy = (unsigned)(int)floorf(fmaf(py, lv.scale, pos_offset));
+  const unsigned iz = (unsigned)(int)floorf(fmaf(pz, lv.scale, pos_offset));
+  const bool inside = ix < n && iy < n && iz < n;  // unsigned: negative coordinates are huge
+  const float h0 = inside ? g0 : 0.f, h1 = inside ? g1 : 0.f;
+  const unsigned key = inside ? ix + n * (iy + n * iz) : 0xfffffffeu;
+  const float wx[2] = {1.f - ox, ox}, wy[2] = {1.f - oy, oy}, wz[2] = {1.f - oz, oz};
+  const int row_lane = lane & 15;
+  bool last = false, any = false;
+  float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int a = c & 1, b = (c >> 1) & 1, d = c >> 2;
+    const float w = wx[a] * wy[b] * wz[d];
+    if constexpr (POS) {
+      const unsigned hx = a ? cell.hx1 : cell.hx0, hy = b ? cell.hy1 : cell.hy0, hz = d ? cell.hz1 : cell.hz0;
+      const float2 t = hash_gather(table, ((hx ^ hy ^ hz) & lv.mask) + lv.off);
+      const float tg = t.x * h0 + t.y * h1;
+      ax += (a ? tg : -tg) * (wy[b] * wz[d]);
+      ay += (b ? tg : -tg) * (wx[a] * wz[d]);
+      az += (d ? tg : -tg) * (wx[a] * wy[b]);
+    }
+    float v0 = w * h0, v1 = w * h1;
+    last = row_run_reduce(key, v0, v1, row_lane);
+    any = any || v0 != 0.f || v1 != 0.f;
+    tb[lane * 17 + 2 * c] = v0;
+    tb[lane * 17 + 2 * c + 1] = v1;
+  }
+  tb[lane * 17 + 16] = __builtin_bit_cast(float, (last && any && inside) ? key : 0xffffffffu);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int row0 = lane & 48;
+#pragma unroll 4
+  for (int k = 0; k < 16; ++k) {
+    const unsigned cellk = __builtin_bit_cast(unsigned, tb[(row0 + k) * 17 + 16]);
+    if (cellk != 0xffffffffu) atomicAdd(rec + (size_t)cellk * 16 + row_lane, tb[(row0 + k) * 17 + row_lane]);
+  }
+  __builtin_amdgcn_wave_barrier();
+  if constexpr (POS) {
+    dpx = fmaf(ax, lv.scale, dpx);
+    dpy = fmaf(ay, lv.scale, dpy);
+    dpz = fmaf(az, lv.scale, dpz);
+  }
+  if (__builtin_amdgcn_ballot_w64(!inside && (g0 != 0.f || g1 != 0.f)) != 0ull)
+    hash_level_backward<POS>(gtab, table, lv, pos_offset, px, py, pz, inside ? 0.f : g0, inside ? 0.f : g1, lane, dpx, dpy,
+                             dpz);
+}
+
+// fold one cell-major level into the gradient table and zero its touched records: one thread per (copy, cell) record
+__global__ void __launch_bounds__(256) cell_scatter_fold_kernel(float* __restrict__ rec, unsigned n, unsigned copies, Lvl lv,
+                                                               float* __restrict__ gtab) {
+  const unsigned long long cells = (unsigned long long)n * n * n;
+  const unsigned long long i = blockIdx.x * 256ull + threadIdx.x;
+  if (i >= cells * copies) return;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4* p = reinterpret_cast<f32x4*>(rec + i * 16);
+  const f32x4 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
+  const float v[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+  bool any = false;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) any = any || v[j] != 0.f;
+  if (!any) return;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  p[0] = zero;
+  p[1] = zero;
+  p[2] = zero;
+  p[3] = zero;
+  const unsigned long long cidx = i % cells;
+  const unsigned x = (unsigned)(cidx % n), y = (unsigned)((cidx / n) % n), z = (unsigned)(cidx / ((unsigned long long)n * n));
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if (v[2 * c] == 0.f && v[2 * c + 1] == 0.f) continue;
+    const unsigned e = (((x + (c & 1)) ^ ((y + ((c >> 1) & 1)) * lv.m1) ^ ((z + (c >> 2)) * lv.m2)) & lv.mask) + lv.off;
+    atomicAdd(gtab + 2 * (size_t)e, v[2 * c]);
+    atomicAdd(gtab + 2 * (size_t)e + 1, v[2 * c + 1]);
+  }
+}
+inline void launch_cell_fold(const CellScatter& c, const GridDev& grid, float* gtab, hipStream_t stream) {
+  if (!c.base) return;
+  for (int l = 0; l < c.num_levels; ++l) {
+    const unsigned long long recs = (unsigned long long)c.n[l] * c.n[l] * c.n[l] * c.copies[l];
+    hipLaunchKernelGGL(cell_scatter_fold_kernel, dim3((unsigned)((recs + 255) / 256)), dim3(256), 0, stream,
+                       c.base + c.offset[l], c.n[l], c.copies[l], grid.level(l), gtab);
+  }
+}
+
 // fold the private copies into the gradient table and zero them again: 64 vertices of the dense n1^3 array per workgroup,
 // the copies shared out over its 4 waves (each load is 64 consecutive float2 of one copy)
 __global__ void __launch_bounds__(256) coarse_scatter_reduce_kernel(CoarseScatter c, Lvl lv, float* __restrict__ gtab) {
@@ -659,12 +759,13 @@ struct PropBwdArgs {
   int S;
   int debug_skip;  // CN_DEBUG_SKIP: 8 hash atomics, 16 weight-gradient dots
   CoarseScatter coarse;
+  CellScatter cells;  // cell-major records of the coarse levels (takes precedence over `coarse` for the levels it covers)
 };
 
 template <int L>
 __global__ void __launch_bounds__(TB) proposal_backward_kernel(PropBwdArgs A) {
   constexpr int K = 2 * L, H = 16;
-  __shared__ float lds[(K + H + H + 1 + 4 + 3 + 12) * LD];
+  __shared__ float lds[(K + H + H + 1 + 4 + 3 + 12) * LD + 4 * 64 * 17];
   float* enc = lds;                  // [K]
   float* hid = enc + K * LD;         // [H] post ReLU
   float* dh = hid + H * LD;          // [H] delta hidden
@@ -672,6 +773,7 @@ __global__ void __launch_bounds__(TB) proposal_backward_kernel(PropBwdArgs A) {
   float* misc = dout + LD;           // normalised pos(3) sel(1) world pos(3) per-wave d(pos)(12)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> weights come through s_load
+  float* tb = misc + 19 * LD + wave * (64 * 17);  // this wave's transpose buffer of hash_level_backward_cells
   WGrad<K, H> gW0;
   WGrad<H, 1> gW1;
   gW0.zero();
@@ -739,7 +841,19 @@ __global__ void __launch_bounds__(TB) proposal_backward_kernel(PropBwdArgs A) {
         g1 = fmaf(A.w0[n * K + 2 * l + 1], d, g1);
       }
       if ((A.debug_skip & 8) || ((A.debug_skip >> (8 + l)) & 1)) continue;  // bits 8..14: skip the scatter of level l (profiling)
-      if (l == 0 && A.coarse.base) {
+      if (l < A.cells.num_levels) {
+        const unsigned nl = A.cells.n[l];
+        float* rec = A.cells.base + A.cells.offset[l] +
+                     (size_t)(blockIdx.x % A.cells.copies[l]) * ((size_t)nl * nl * nl * 16);
+        if (A.d_pos)
+          hash_level_backward_cells<true>(rec, nl, tb, A.g_table, A.table, A.grid.level(l), A.grid.pos_offset, misc[lane],
+                                          misc[LD + lane], misc[2 * LD + lane], valid ? g0 : 0.f, valid ? g1 : 0.f, lane, gpx,
+                                          gpy, gpz);
+        else
+          hash_level_backward_cells<false>(rec, nl, tb, A.g_table, A.table, A.grid.level(l), A.grid.pos_offset, misc[lane],
+                                           misc[LD + lane], misc[2 * LD + lane], valid ? g0 : 0.f, valid ? g1 : 0.f, lane, gpx,
+                                           gpy, gpz);
+      } else if (l == 0 && A.coarse.base) {
         float* mine = A.coarse.base + (size_t)(blockIdx.x % A.coarse.copies) * (2u * A.coarse.n1 * A.coarse.n1 * A.coarse.n1);
         if (A.d_pos)
           hash_level_backward_private<true>(mine, A.coarse.n1, A.g_table, A.table, A.grid.level(0), A.grid.pos_offset,
@@ -935,6 +1049,14 @@ extern "C" int cn_proposal_backward(const cn_density_params* params, const cn_de
     A.debug_skip = dbg ? atoi(dbg) : 0;
   }
   A.coarse = cn::make_coarse_scatter(grads->grid);
+  // cell-major records for the levels that hold at most half as many cells as there are samples (merging pays there);
+  // CN_CELL_SCATTER=0 keeps every level on the table path
+  {
+    const char* cs = getenv("CN_CELL_SCATTER");
+    const unsigned long long nsamp = (unsigned long long)num_rays * (unsigned long long)num_samples;
+    if (!cs || atoi(cs) != 0) A.cells = cn::make_cell_scatter(grads->grid, nsamp / 2);
+    if (A.cells.num_levels > 0 && A.coarse.base) A.coarse.base = nullptr;  // level 0 is cell-major then
+  }
   long long ntiles = (num_rays * (long long)num_samples + cn::TS - 1) / cn::TS;
   dim3 grid(cn::grid_for(ntiles, 1, 1024));
   if (L == 5)
@@ -942,14 +1064,14 @@ extern "C" int cn_proposal_backward(const cn_density_params* params, const cn_de
   else
     hipLaunchKernelGGL(cn::proposal_backward_kernel<7>, grid, dim3(cn::TB), 0, cn::as_stream(stream), A);
   cn::launch_coarse_reduce(A.coarse, A.grid, A.g_table, cn::as_stream(stream));
+  cn::launch_cell_fold(A.cells, A.grid, A.g_table, cn::as_stream(stream));
   return cn::check_launch("cn_proposal_backward");
 }
 
 extern "C" size_t cn_grid_scatter_scratch_bytes(const cn_grid* grid) {
   if (!grid || grid->num_levels < 1) return 0;
-  const unsigned n1 = cn::coarse_n1(*grid);
-  if (n1 > cn::COARSE_MAX_N1) return 0;
-  return (size_t)cn::COARSE_COPIES * n1 * n1 * n1 * 2 * sizeof(float);
+  const size_t head = cn::coarse_scratch_bytes(*grid);
+  return head ? head + cn::cell_scratch_layout(*grid, nullptr) : 0;
 }
 
 // ---- shape-generic field backward ------------------------------------------------------------------------------------------

@@ -95,22 +95,36 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 
 
 def test_scatter_scratch_size_is_a_host_computation(lib):
-    """cn_grid_scatter_scratch_bytes: 64 private dense copies of level 0, n = floor(scale_0 + offset) + 2 vertices per axis."""
+    """cn_grid_scatter_scratch_bytes: 64 private dense copies of level 0 (n + 1 = floor(scale_0 + offset) + 2 vertices per axis)
+    + cell-major records (16 floats per cell) of the consecutive coarse levels with at most 2.2e6 cells, the small ones
+    replicated (16 copies up to 8192 cells, 4 up to 65536)."""
     import ctypes as C
+    import math
 
     from cropnerf_amd import _lib
     from cropnerf_amd.config import GridSpec
 
+    def expected(scalings, offset):
+        head = 64 * (math.floor(scalings[0] + offset) + 2) ** 3 * 2 * 4
+        floats = 0
+        for sc in scalings[:8]:
+            cells = (math.floor(sc + offset) + 1) ** 3
+            if cells > 2_200_000:
+                break
+            floats += (16 if cells <= 8192 else 4 if cells <= 65536 else 1) * cells * 16
+        return head + 4 * floats
+
     g = _lib.Grid()
     g.num_levels = 16
     g.log2_table_size = 19
-    for i, sc in enumerate(GridSpec().scalings()):
-        g.scalings[i] = sc
+    sc = GridSpec().scalings()
+    for i, v in enumerate(sc):
+        g.scalings[i] = v
     assert g.scalings[0] == 16.0
-    assert lib.cn_grid_scatter_scratch_bytes(C.byref(g)) == 64 * 18 ** 3 * 2 * 4
+    assert lib.cn_grid_scatter_scratch_bytes(C.byref(g)) == expected(sc, 0.0)
     g.layout = _lib.GRID_TCNN  # tcnn: scale_0 = 15, positions shifted by half a cell -> cells 0..15, vertices 0..16
     g.scalings[0] = 15.0
-    assert lib.cn_grid_scatter_scratch_bytes(C.byref(g)) == 64 * 17 ** 3 * 2 * 4
+    assert lib.cn_grid_scatter_scratch_bytes(C.byref(g)) == expected([15.0] + list(sc[1:]), 0.5)
     g.scalings[0] = 1000.0  # a fine "coarsest level": not worth private copies
     assert lib.cn_grid_scatter_scratch_bytes(C.byref(g)) == 0
     assert lib.cn_grid_scatter_scratch_bytes(None) == 0
