@@ -368,6 +368,25 @@ inline CellScatter make_cell_scatter(const cn_grid& grads_grid, unsigned long lo
   return c;
 }
 
+__device__ __forceinline__ unsigned cell_n_of(const CellScatter& c, int l) {
+  unsigned v = c.n[0];
+#pragma unroll
+  for (int k = 1; k < CN_CELL_LEVELS; ++k) v = l == k ? c.n[k] : v;
+  return v;
+}
+__device__ __forceinline__ unsigned cell_copies_of(const CellScatter& c, int l) {
+  unsigned v = c.copies[0];
+#pragma unroll
+  for (int k = 1; k < CN_CELL_LEVELS; ++k) v = l == k ? c.copies[k] : v;
+  return v;
+}
+__device__ __forceinline__ unsigned long long cell_offset_of(const CellScatter& c, int l) {
+  unsigned long long v = c.offset[0];
+#pragma unroll
+  for (int k = 1; k < CN_CELL_LEVELS; ++k) v = l == k ? c.offset[k] : v;
+  return v;
+}
+
 // per-lane level record by static selects (a per-lane index into the kernarg arrays would go to scratch)
 __device__ __forceinline__ Lvl lane_level(const GridDev& g, int l) {
   Lvl v = g.level(0);

@@ -500,6 +500,7 @@ struct FieldBwdArgs {
   float *d_pos, *d_dir;  // optional [R*S,3] outputs for the camera pose refinement (null: skipped)
   int debug_skip;  // profiling aid (env CN_DEBUG_SKIP): 1 hash atomics, 2 embedding atomics, 4 weight-gradient dots
   CoarseScatter coarse;  // private copies for level 0's gradient (cn_grid.scatter_scratch of the gradient grid)
+  CellScatter cells;     // cell-major records of the coarse levels (take precedence for the levels they cover)
 };
 
 // LDS rows (each LD floats)
@@ -999,9 +1000,15 @@ extern "C" int cn_field_backward(const cn_field_params* params, const cn_field_p
   } else {
     long long ntiles = (nsamp + cn::mf::TSM - 1) / cn::mf::TSM;
     A.coarse = cn::make_coarse_scatter(grads->grid);
+    {  // cell-major records where samples outnumber cells two to one (CN_CELL_SCATTER=0: off)
+      const char* cs = getenv("CN_CELL_SCATTER");
+      if (!cs || atoi(cs) != 0) A.cells = cn::make_cell_scatter(grads->grid, (unsigned long long)nsamp / 2);
+      if (A.cells.num_levels > 0) A.coarse.base = nullptr;  // level 0 is cell-major then
+    }
     hipLaunchKernelGGL(cn::mf::field_backward_mfma_kernel, dim3(cn::grid_for(ntiles, 1, 256)), dim3(cn::mf::NT),
                        cn::mf::LDS_BYTES, cn::as_stream(stream), A);
     cn::launch_coarse_reduce(A.coarse, A.grid, A.g.table, cn::as_stream(stream));
+    cn::launch_cell_fold(A.cells, A.grid, A.g.table, cn::as_stream(stream));
   }
   return cn::check_launch("cn_field_backward");
 }

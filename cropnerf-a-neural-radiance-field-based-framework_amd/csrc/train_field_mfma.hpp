@@ -249,54 +249,14 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
   float p_px = 0.f, p_py = 0.f, p_pz = 0.f, p_wx = 0.f, p_wy = 0.f, p_wz = 0.f, p_self = 0.f, p_g0 = 0.f, p_g1 = 0.f;
   long long p_ismp = 0;
   bool p_valid = false;
-  auto deferred_scatter = [&]() {
-    float gpx = 0.f, gpy = 0.f, gpz = 0.f;
-    if (!(A.debug_skip & 1)) {
-      // (a wave holds two levels, 32 lanes each: the branch below splits it along whole 16-lane rows, which is all the
-      //  DPP run-length reduction and the quad rounds reach across)
-      if (lvl == 0 && A.coarse.base) {
-        float* mine = A.coarse.base + (size_t)(blockIdx.x % A.coarse.copies) * (2u * A.coarse.n1 * A.coarse.n1 * A.coarse.n1);
-        if (A.d_pos)
-          hash_level_backward_private<true>(mine, A.coarse.n1, A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py,
-                                            p_pz, p_g0, p_g1, lane, gpx, gpy, gpz);
-        else
-          hash_level_backward_private<false>(mine, A.coarse.n1, A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py,
-                                             p_pz, p_g0, p_g1, lane, gpx, gpy, gpz);
-      } else if (A.d_pos)
-        hash_level_backward<true>(A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py, p_pz, p_g0, p_g1, lane, gpx,
-                                  gpy, gpz);
-      else
-        hash_level_backward<false>(A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py, p_pz, p_g0, p_g1, lane, gpx,
-                                   gpy, gpz);
-    }
-    if (A.d_pos) {
-      // per-level partials -> LDS (A1 is not written before the s1 phase, two barriers away) -> one thread per sample sums
-      // the 16 levels
-      float* part = A1;
-      part[(3 * lvl + 0) * LDA + s] = gpx;
-      part[(3 * lvl + 1) * LDA + s] = gpy;
-      part[(3 * lvl + 2) * LDA + s] = gpz;
-      __syncthreads();
-      __builtin_amdgcn_sched_barrier(0);
-      if (lvl == 0 && p_valid) {
-        float gx = 0.f, gy = 0.f, gz = 0.f;
-#pragma unroll
-        for (int l = 0; l < 16; ++l) {
-          gx += part[(3 * l + 0) * LDA + s];
-          gy += part[(3 * l + 1) * LDA + s];
-          gz += part[(3 * l + 2) * LDA + s];
-        }
-        normalize_position_backward(A.scene, p_wx, p_wy, p_wz, p_self, gx, gy, gz);
-        A.d_pos[3 * p_ismp] = gx;
-        A.d_pos[3 * p_ismp + 1] = gy;
-        A.d_pos[3 * p_ismp + 2] = gz;
-      }
-    }
-  };
-  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // (the loop makes one trip more than the workgroup has tiles: that trip only issues the last tile's scatter -- written
+  //  once in the loop rather than as a lambda called twice, which hipcc keeps as a closure in scratch memory)
+  for (long long tile = blockIdx.x;; tile += gridDim.x) {
+    const bool live = tile < ntiles;  // workgroup-uniform
+    if (!live && !have_prev) break;
     // ---- gather ------------------------------------------------------------------------------------------------------
     const long long ismp = tile * TSM + s;
-    const bool valid = ismp < total;
+    const bool valid = live && ismp < total;
     const long long ic = valid ? ismp : total - 1;
     const long long r = ic / A.S;
     const float mid = (A.starts[ic] + A.ends[ic]) / 2.f;
@@ -305,7 +265,7 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
                 wz = A.origins[3 * r + 2] + dirz * mid;
     float px = wx, py = wy, pz = wz;
     const float self = normalize_position(A.scene, px, py, pz) ? 1.f : 0.f;
-    {
+    if (live) {
       const float2 f = hash_level(A.p.table, my_lv, A.grid.pos_offset, px, py, pz);
       ENC[(2 * lvl) * LDA + s] = f.x;
       ENC[(2 * lvl + 1) * LDA + s] = f.y;
@@ -347,7 +307,64 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
     }
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    if (have_prev) deferred_scatter();  // the previous tile's hash-table gradient (+ its position gradient)
+    if (have_prev) {  // the previous tile's hash-table gradient (+ its position gradient)
+    float gpx = 0.f, gpy = 0.f, gpz = 0.f;
+    if (!(A.debug_skip & 1)) {
+      // (a wave holds two levels, 32 lanes each: the branch below splits it along whole 16-lane rows, which is all the
+      //  DPP run-length reduction and the quad rounds reach across)
+      if (lvl < A.cells.num_levels) {
+        // cell-major level: the 16 sums of a run go through an LDS buffer per wave.  A2 / D2 / D1 / DCIN (2304 floats each)
+        // are dead from the end of a tile to the s2 phase of the next, three barriers after this point: two waves each.
+        float* tb = (wave < 2 ? A2 : wave < 4 ? D2 : wave < 6 ? D1 : DCIN) + (wave & 1) * (64 * 17);
+        const unsigned nl = cell_n_of(A.cells, lvl);
+        float* rec = A.cells.base + cell_offset_of(A.cells, lvl) +
+                     (size_t)(blockIdx.x % cell_copies_of(A.cells, lvl)) * ((size_t)nl * nl * nl * 16);
+        if (A.d_pos)
+          hash_level_backward_cells<true>(rec, nl, tb, A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py, p_pz, p_g0,
+                                          p_g1, lane, gpx, gpy, gpz);
+        else
+          hash_level_backward_cells<false>(rec, nl, tb, A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py, p_pz, p_g0,
+                                           p_g1, lane, gpx, gpy, gpz);
+      } else if (lvl == 0 && A.coarse.base) {
+        float* mine = A.coarse.base + (size_t)(blockIdx.x % A.coarse.copies) * (2u * A.coarse.n1 * A.coarse.n1 * A.coarse.n1);
+        if (A.d_pos)
+          hash_level_backward_private<true>(mine, A.coarse.n1, A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py,
+                                            p_pz, p_g0, p_g1, lane, gpx, gpy, gpz);
+        else
+          hash_level_backward_private<false>(mine, A.coarse.n1, A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py,
+                                             p_pz, p_g0, p_g1, lane, gpx, gpy, gpz);
+      } else if (A.d_pos)
+        hash_level_backward<true>(A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py, p_pz, p_g0, p_g1, lane, gpx,
+                                  gpy, gpz);
+      else
+        hash_level_backward<false>(A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py, p_pz, p_g0, p_g1, lane, gpx,
+                                   gpy, gpz);
+    }
+    if (A.d_pos) {
+      // per-level partials -> LDS (A1 is not written before the s1 phase, two barriers away) -> one thread per sample sums
+      // the 16 levels
+      float* part = A1;
+      part[(3 * lvl + 0) * LDA + s] = gpx;
+      part[(3 * lvl + 1) * LDA + s] = gpy;
+      part[(3 * lvl + 2) * LDA + s] = gpz;
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      if (lvl == 0 && p_valid) {
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) {
+          gx += part[(3 * l + 0) * LDA + s];
+          gy += part[(3 * l + 1) * LDA + s];
+          gz += part[(3 * l + 2) * LDA + s];
+        }
+        normalize_position_backward(A.scene, p_wx, p_wy, p_wz, p_self, gx, gy, gz);
+        A.d_pos[3 * p_ismp] = gx;
+        A.d_pos[3 * p_ismp + 1] = gy;
+        A.d_pos[3 * p_ismp + 2] = gz;
+      }
+    }
+    }
+    if (!live) break;
     __builtin_amdgcn_sched_barrier(0);
     // ---- h1 = relu(W0 enc + b0) -----------------------------------------------------------------------------------------
     store_blk<true>(H1, n0, s0, blk_fwd<32>(Wb0, 36, n0, ENC, s0, bias4(lds + B_0, n0, lane), lane), lane);
@@ -513,10 +530,7 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (have_prev) {
-    deferred_scatter();  // the last tile's
-    __syncthreads();
-  }
+  __syncthreads();
 
   // ---- flush -------------------------------------------------------------------------------------------------------------
   if (!(A.debug_skip & 4)) {
