@@ -349,14 +349,37 @@ __device__ __forceinline__ void hash_level_backward_cells(float* __restrict__ re
                              dpz);
 }
 
-// fold one cell-major level into the gradient table and zero its touched records: one thread per (copy, cell) record
-__global__ void __launch_bounds__(256) cell_scatter_fold_kernel(float* __restrict__ rec, unsigned n, unsigned copies, Lvl lv,
-                                                               float* __restrict__ gtab) {
+// fold the cell-major levels into the gradient table and zero their touched records: one thread per (copy, cell) record,
+// all levels in one launch (workgroups [first_block[l], first_block[l + 1]) belong to level l)
+struct CellFoldArgs {
+  CellScatter c;
+  unsigned first_block[CN_CELL_LEVELS + 1];
+  Lvl lv[CN_CELL_LEVELS];
+};
+__global__ void __launch_bounds__(256) cell_scatter_fold_kernel(CellFoldArgs F, float* __restrict__ gtab) {
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < CN_CELL_LEVELS; ++k) l = (k < F.c.num_levels && blockIdx.x >= F.first_block[k]) ? k : l;  // block-uniform
+  unsigned n = F.c.n[0], copies = F.c.copies[0], first = F.first_block[0];
+  unsigned long long off = F.c.offset[0];
+  Lvl lv = F.lv[0];
+#pragma unroll
+  for (int k = 1; k < CN_CELL_LEVELS; ++k) {
+    const bool m = l == k;
+    n = m ? F.c.n[k] : n;
+    copies = m ? F.c.copies[k] : copies;
+    first = m ? F.first_block[k] : first;
+    off = m ? F.c.offset[k] : off;
+    lv.off = m ? F.lv[k].off : lv.off;
+    lv.mask = m ? F.lv[k].mask : lv.mask;
+    lv.m1 = m ? F.lv[k].m1 : lv.m1;
+    lv.m2 = m ? F.lv[k].m2 : lv.m2;
+  }
   const unsigned long long cells = (unsigned long long)n * n * n;
-  const unsigned long long i = blockIdx.x * 256ull + threadIdx.x;
+  const unsigned long long i = (blockIdx.x - first) * 256ull + threadIdx.x;
   if (i >= cells * copies) return;
   typedef float f32x4 __attribute__((ext_vector_type(4)));
-  f32x4* p = reinterpret_cast<f32x4*>(rec + i * 16);
+  f32x4* p = reinterpret_cast<f32x4*>(F.c.base + off + i * 16);
   const f32x4 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
   const float v[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
   bool any = false;
@@ -379,12 +402,18 @@ __global__ void __launch_bounds__(256) cell_scatter_fold_kernel(float* __restric
   }
 }
 inline void launch_cell_fold(const CellScatter& c, const GridDev& grid, float* gtab, hipStream_t stream) {
-  if (!c.base) return;
+  if (!c.base || c.num_levels <= 0) return;
+  CellFoldArgs F{};
+  F.c = c;
+  unsigned blocks = 0;
   for (int l = 0; l < c.num_levels; ++l) {
+    F.first_block[l] = blocks;
+    F.lv[l] = grid.level(l);
     const unsigned long long recs = (unsigned long long)c.n[l] * c.n[l] * c.n[l] * c.copies[l];
-    hipLaunchKernelGGL(cell_scatter_fold_kernel, dim3((unsigned)((recs + 255) / 256)), dim3(256), 0, stream,
-                       c.base + c.offset[l], c.n[l], c.copies[l], grid.level(l), gtab);
+    blocks += (unsigned)((recs + 255) / 256);
   }
+  for (int l = c.num_levels; l <= CN_CELL_LEVELS; ++l) F.first_block[l] = blocks;
+  hipLaunchKernelGGL(cell_scatter_fold_kernel, dim3(blocks), dim3(256), 0, stream, F, gtab);
 }
 
 // fold the private copies into the gradient table and zero them again: 64 vertices of the dense n1^3 array per workgroup,
