@@ -793,7 +793,7 @@ struct PropBwdArgs {
 };
 
 template <int L>
-__global__ void __launch_bounds__(TB) proposal_backward_kernel(PropBwdArgs A) {
+__global__ void __launch_bounds__(TB, 4) proposal_backward_kernel(PropBwdArgs A) {
   constexpr int K = 2 * L, H = 16;
   __shared__ float lds[(K + H + H + 1 + 4 + 3 + 12) * LD + 4 * 64 * 17];
   float* enc = lds;                  // [K]
@@ -1031,7 +1031,7 @@ extern "C" int cn_field_backward(const cn_field_params* params, const cn_field_p
     A.coarse = cn::make_coarse_scatter(grads->grid);
     {  // cell-major records where samples outnumber cells two to one (CN_CELL_SCATTER=0: off)
       const char* cs = getenv("CN_CELL_SCATTER");
-      if (!cs || atoi(cs) != 0) A.cells = cn::make_cell_scatter(grads->grid, (unsigned long long)nsamp / 2);
+      if (!cs || atof(cs) != 0.0) A.cells = cn::make_cell_scatter(grads->grid, (unsigned long long)(nsamp * (cs ? atof(cs) : 0.5)));
       if (A.cells.num_levels > 0) A.coarse.base = nullptr;  // level 0 is cell-major then
     }
     hipLaunchKernelGGL(cn::mf::field_backward_mfma_kernel, dim3(cn::grid_for(ntiles, 1, 256)), dim3(cn::mf::NT),
@@ -1090,7 +1090,7 @@ extern "C" int cn_proposal_backward(const cn_density_params* params, const cn_de
   {
     const char* cs = getenv("CN_CELL_SCATTER");
     const unsigned long long nsamp = (unsigned long long)num_rays * (unsigned long long)num_samples;
-    if (!cs || atoi(cs) != 0) A.cells = cn::make_cell_scatter(grads->grid, nsamp / 2);
+    if (!cs || atof(cs) != 0.0) A.cells = cn::make_cell_scatter(grads->grid, (unsigned long long)(nsamp * (cs ? atof(cs) : 0.5)));
     if (A.cells.num_levels > 0 && A.coarse.base) A.coarse.base = nullptr;  // level 0 is cell-major then
   }
   long long ntiles = (num_rays * (long long)num_samples + cn::TS - 1) / cn::TS;
