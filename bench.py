@@ -45,30 +45,39 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_FP32_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32: 64 FLOP/clk/SIMD x 4 SIMD x 256 CU x 2.4 GHz (dense)
 MLP_MAC_PER_SAMPLE = 9216  # the folded field MLPs as the render kernels evaluate them
 ATOMIC_REQUESTS_PER_SEC = 21.07e9  # float-atomic requests the memory side takes (tools/atomic_microbench.hip)
-# float-atomic requests per iteration, MEASURED with the TCC atomic counters on tools/train_probe.py (default method, 4096
-# random rays, 48 field samples per ray): read from the newest profiles/r*_pmc_train_atomics.json (TCC_ATOMIC ==
-# TCC_EA0_ATOMIC); the fallbacks are the round-1 figures (72.94 per field sample, 5.372e6 per proposal launch).
+# float-atomic requests per iteration, MEASURED with the TCC atomic counters on tools/train_probe.py (default method, 48 field
+# samples per ray) at the two batch sizes bench.py times -- the set of cell-major levels depends on the batch size -- read
+# from the newest profiles/r*_pmc_train_atomics.json (TCC_ATOMIC == TCC_EA0_ATOMIC); fallback: the round-1 figures.
 def _measured_atomic_requests():
+    """{rays: requests per iteration} for the iterations bench.py times (every one updates both proposal networks: one field
+    backward, two proposal backwards and their fold kernels), from the newest profiles/r*_pmc_train_atomics.json."""
     import glob
     import json as _json
 
-    field, prop, src = 72.94, 5.372e6 / 4096, "profiles/r01_v7_pmc_train_atomics.json (TCC_ATOMIC per launch, 4096 rays)"
+    per_ray_r1 = 48 * 72.94 + 2 * 5.372e6 / 4096  # round-1 figures (profiles/r01_v7_pmc_train_atomics.json), per ray
+    table = {4096: 4096 * per_ray_r1, 65536: 65536 * per_ray_r1}
+    src = "profiles/r01_v7_pmc_train_atomics.json (TCC_ATOMIC per launch, 4096 rays)"
     here = os.path.dirname(os.path.abspath(__file__))
     files = sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_train_atomics.json")))
     if files:
         try:
             d = _json.load(open(files[-1]))
-            k = d["kernels"]
-            f = next(v for n, v in k.items() if "field_backward_mfma_kernel" in n)["TCC_ATOMIC_sum"]["avg_per_launch"]
-            q = next(v for n, v in k.items() if "proposal_backward_kernel" in n)["TCC_ATOMIC_sum"]["avg_per_launch"]
-            field, prop = f / (4096 * 48), q / 4096
-            src = f"profiles/{os.path.basename(files[-1])} @ {d.get('commit', '?')} (TCC_ATOMIC per launch, 4096 rays)"
+            got = {}
+            for rays, k in d["rays"].items():
+                def avg(part):
+                    return next((v["TCC_ATOMIC_sum"]["avg_per_launch"] for n, v in k.items() if part in n), 0.0)
+                # one field backward + two proposal backwards + three folds of the cell-major records per iteration
+                got[int(rays)] = avg("field_backward_mfma_kernel") + 2 * avg("proposal_backward_kernel") + \
+                    3 * (avg("cell_scatter_fold_kernel") + avg("coarse_scatter_reduce_kernel"))
+            if got:
+                table, src = got, f"profiles/{os.path.basename(files[-1])} @ {d.get('commit', '?')} (TCC_ATOMIC per launch at each batch size)"
         except (KeyError, StopIteration, ValueError, OSError):
             pass
-    return field, prop, src
+    return table, src
 
 
-ATOMIC_REQUESTS_PER_FIELD_SAMPLE, ATOMIC_REQUESTS_PER_PROPOSAL_LAUNCH_PER_RAY, ATOMIC_REQUESTS_SOURCE = _measured_atomic_requests()
+ATOMIC_REQUESTS_PER_ITERATION, ATOMIC_REQUESTS_SOURCE = _measured_atomic_requests()
+
 
 
 def parse_args():
@@ -453,8 +462,7 @@ def secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, o
             # requests per field sample + 2 proposal launches x the measured requests per ray and launch).  Proposal networks
             # take part in one iteration out of `proposal_update_every` after warm-up; the timed iterations are early ones
             # (every iteration updates them), i.e. the expensive case.
-            req = nrays * (tcfg.num_nerf_samples_per_ray * ATOMIC_REQUESTS_PER_FIELD_SAMPLE
-                           + len(tcfg.num_proposal_samples_per_ray) * ATOMIC_REQUESTS_PER_PROPOSAL_LAUNCH_PER_RAY)
+            req = ATOMIC_REQUESTS_PER_ITERATION.get(nrays, nrays / 4096.0 * ATOMIC_REQUESTS_PER_ITERATION.get(4096, 0.0))
             train[str(nrays)]["roofline"] = {
                 "bound": "hbm", "kernel": "train_iteration (field_backward_mfma_kernel + 2 x proposal_backward_kernel scatter)",
                 "achieved": round(req / t / 1e9, 3), "peak": round(ATOMIC_REQUESTS_PER_SEC / 1e9, 2),
