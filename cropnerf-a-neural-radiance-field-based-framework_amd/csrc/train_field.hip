@@ -1258,8 +1258,17 @@ extern "C" int cn_field_backward_general(const cn_field_params* params, const cn
   const long long ntiles = (num_rays * (long long)num_samples + cn::gb::TSG - 1) / cn::gb::TSG;
   const int grid = (int)std::min<long long>(ntiles, nblk);
   A.coarse = cn::make_coarse_scatter(grads->grid);
+  {  // cell-major records (as in cn_field_backward) when the four LDS buffers that carry the hand-over hold two waves each
+    const char* cs = getenv("CN_CELL_SCATTER");
+    const int small = std::min(std::min(p16(params->color.dims[1]), p16(params->color.dims[2])), p16(cin));
+    if ((!cs || atof(cs) != 0.0) && small * cn::gb::LDG >= 2 * 64 * 17 && A.num_levels <= 16)
+      A.cells = cn::make_cell_scatter(grads->grid,
+                                      (unsigned long long)(num_rays * (double)num_samples * (cs ? atof(cs) : 0.5)));
+    if (A.cells.num_levels > 0) A.coarse.base = nullptr;
+  }
   hipLaunchKernelGGL(cn::gb::field_backward_general_kernel, dim3(grid), dim3(cn::gb::NTG), lds, s, A);
   cn::launch_coarse_reduce(A.coarse, A.grid, A.g_table, s);
+  cn::launch_cell_fold(A.cells, A.grid, A.g_table, s);
   rc = cn::check_launch("cn_field_backward_general");
   if (rc) return rc;
   for (int i = 0; i < nt; ++i)

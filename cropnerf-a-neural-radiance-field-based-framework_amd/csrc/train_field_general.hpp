@@ -50,6 +50,7 @@ struct GenArgs {
   long long R;
   int S;
   CoarseScatter coarse;  // private copies for level 0's gradient (cn_grid.scatter_scratch of the gradient grid)
+  CellScatter cells;     // cell-major records of the coarse levels (take precedence for the levels they cover)
 };
 
 __device__ __forceinline__ int opaque_i(int v) {
@@ -349,7 +350,21 @@ __global__ void __launch_bounds__(NTG) field_backward_general_kernel(GenArgs A) 
       const int lc = on ? l : 0;
       const float g0 = on && valid ? DB[(2 * lc) * LDG + s] : 0.f, g1 = on && valid ? DB[(2 * lc + 1) * LDG + s] : 0.f;
       // (a wave holds two levels, 32 lanes each; the branch splits it along whole 16-lane rows)
-      if (on && lc == 0 && A.coarse.base) {
+      if (on && lc < A.cells.num_levels) {
+        // cell-major level: C1 / C2 / CIN / DCIN are dead by now and host the 16-lane hand-over of two waves each (the host
+        // enables the path only when they are large enough)
+        const int wv = tid >> 6;
+        float* tb = (wv < 2 ? C1 : wv < 4 ? C2 : wv < 6 ? CIN : DCIN) + (wv & 1) * (64 * 17);
+        const unsigned nl = cell_n_of(A.cells, lc);
+        float* rec = A.cells.base + cell_offset_of(A.cells, lc) +
+                     (size_t)(blockIdx.x % cell_copies_of(A.cells, lc)) * ((size_t)nl * nl * nl * 16);
+        if (A.d_pos)
+          hash_level_backward_cells<true>(rec, nl, tb, A.g_table, A.table, lds_level_rec(SCL, lc), A.grid.pos_offset, px, py,
+                                          pz, g0, g1, lane, gpx, gpy, gpz);
+        else
+          hash_level_backward_cells<false>(rec, nl, tb, A.g_table, A.table, lds_level_rec(SCL, lc), A.grid.pos_offset, px, py,
+                                           pz, g0, g1, lane, gpx, gpy, gpz);
+      } else if (on && lc == 0 && A.coarse.base) {
         float* mine = A.coarse.base + (size_t)(blockIdx.x % A.coarse.copies) * (2u * A.coarse.n1 * A.coarse.n1 * A.coarse.n1);
         if (A.d_pos)
           hash_level_backward_private<true>(mine, A.coarse.n1, A.g_table, A.table, lds_level_rec(SCL, 0), A.grid.pos_offset,

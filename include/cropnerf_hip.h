@@ -89,9 +89,9 @@ typedef struct cn_grid {
   uint8_t level_bits[CN_MAX_LEVELS];    /* CN_GRID_TCNN: 0 = hashed level, b > 0 = dense level with b bits per axis */
   /* Only read when the grid is a GRADIENT target (the `grads` argument of the backward entry points): optional scratch
    * of cn_grid_scatter_scratch_bytes(grid) bytes, zeroed ONCE by the caller; every backward call leaves it zeroed.  With
-   * it the gradients of the coarse levels do not go to `table` sample by sample: (1) 64 private dense copies of level 0's
-   * vertices (cn_field_backward_general), (2) cell-major records for the levels that hold fewer cells than half the batch
-   * has samples (cn_field_backward, cn_proposal_backward): a sample adds the 16 weighted values of its cell -- 8 corners
+   * it the gradients of the coarse levels do not go to `table` sample by sample: cell-major records for the levels that hold
+   * fewer cells than half the batch has samples (all three backward entry points; 64 private dense copies of level 0's
+   * vertices when that is no level at all): a sample adds the 16 weighted values of its cell -- 8 corners
    * x 2 features -- to the cell's 64-byte record in ONE atomic request (the hash table takes one per x-edge, 4.5 per
    * sample and level), consecutive samples in one cell merge, and a fold kernel launched by the same call adds the
    * touched records to `table` and zeroes them.  NULL: every level goes straight to `table`. */
