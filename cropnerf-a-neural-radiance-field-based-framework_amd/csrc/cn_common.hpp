@@ -351,8 +351,10 @@ inline size_t cell_scratch_layout(const cn_grid& g, CellScatter* out) {
   if (out) *out = c;
   return (size_t)floats * sizeof(float);
 }
-// levels 0 .. k-1 with at most max_cells cells each (the launch passes ~ samples / 2)
-inline CellScatter make_cell_scatter(const cn_grid& grads_grid, unsigned long long max_cells) {
+// levels 0 .. k-1 with at most max_cells cells each (the launch passes ~ samples / 2).  Of a small level's copies only as
+// many are used as the batch needs to keep the requests per record in the low hundreds (a copy in use costs the fold kernel
+// 16 atomics per touched cell): ~ samples / (48 cells), rounded up to a power of two.
+inline CellScatter make_cell_scatter(const cn_grid& grads_grid, unsigned long long max_cells, unsigned long long samples) {
   CellScatter c{};
   if (!grads_grid.scatter_scratch) return c;
   const size_t head = coarse_scratch_bytes(grads_grid);
@@ -364,6 +366,12 @@ inline CellScatter make_cell_scatter(const cn_grid& grads_grid, unsigned long lo
   int k = 0;
   while (k < c.num_levels && (unsigned long long)c.n[k] * c.n[k] * c.n[k] <= max_cells) ++k;
   c.num_levels = k;
+  for (int l = 0; l < k; ++l) {
+    const unsigned long long cells = (unsigned long long)c.n[l] * c.n[l] * c.n[l];
+    unsigned want = 1;
+    while (want < c.copies[l] && (unsigned long long)want * cells * 48ull < samples) want <<= 1;
+    c.copies[l] = want;
+  }
   c.base = k > 0 ? reinterpret_cast<float*>(static_cast<char*>(grads_grid.scatter_scratch) + head) : nullptr;
   return c;
 }

@@ -1031,7 +1031,7 @@ extern "C" int cn_field_backward(const cn_field_params* params, const cn_field_p
     A.coarse = cn::make_coarse_scatter(grads->grid);
     {  // cell-major records where samples outnumber cells two to one (CN_CELL_SCATTER=0: off)
       const char* cs = getenv("CN_CELL_SCATTER");
-      if (!cs || atof(cs) != 0.0) A.cells = cn::make_cell_scatter(grads->grid, (unsigned long long)(nsamp * (cs ? atof(cs) : 0.5)));
+      if (!cs || atof(cs) != 0.0) A.cells = cn::make_cell_scatter(grads->grid, (unsigned long long)(nsamp * (cs ? atof(cs) : 0.5)), (unsigned long long)nsamp);
       if (A.cells.num_levels > 0) A.coarse.base = nullptr;  // level 0 is cell-major then
     }
     hipLaunchKernelGGL(cn::mf::field_backward_mfma_kernel, dim3(cn::grid_for(ntiles, 1, 256)), dim3(cn::mf::NT),
@@ -1090,7 +1090,7 @@ extern "C" int cn_proposal_backward(const cn_density_params* params, const cn_de
   {
     const char* cs = getenv("CN_CELL_SCATTER");
     const unsigned long long nsamp = (unsigned long long)num_rays * (unsigned long long)num_samples;
-    if (!cs || atof(cs) != 0.0) A.cells = cn::make_cell_scatter(grads->grid, (unsigned long long)(nsamp * (cs ? atof(cs) : 0.5)));
+    if (!cs || atof(cs) != 0.0) A.cells = cn::make_cell_scatter(grads->grid, (unsigned long long)(nsamp * (cs ? atof(cs) : 0.5)), nsamp);
     if (A.cells.num_levels > 0 && A.coarse.base) A.coarse.base = nullptr;  // level 0 is cell-major then
   }
   long long ntiles = (num_rays * (long long)num_samples + cn::TS - 1) / cn::TS;
@@ -1263,7 +1263,8 @@ extern "C" int cn_field_backward_general(const cn_field_params* params, const cn
     const int small = std::min(std::min(p16(params->color.dims[1]), p16(params->color.dims[2])), p16(cin));
     if ((!cs || atof(cs) != 0.0) && small * cn::gb::LDG >= 2 * 64 * 17 && A.num_levels <= 16)
       A.cells = cn::make_cell_scatter(grads->grid,
-                                      (unsigned long long)(num_rays * (double)num_samples * (cs ? atof(cs) : 0.5)));
+                                      (unsigned long long)(num_rays * (double)num_samples * (cs ? atof(cs) : 0.5)),
+                                      (unsigned long long)num_rays * (unsigned long long)num_samples);
     if (A.cells.num_levels > 0) A.coarse.base = nullptr;
   }
   hipLaunchKernelGGL(cn::gb::field_backward_general_kernel, dim3(grid), dim3(cn::gb::NTG), lds, s, A);
