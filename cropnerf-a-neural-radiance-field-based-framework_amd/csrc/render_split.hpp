@@ -30,7 +30,9 @@ namespace cn {
 //   one of the two matrix waves of a SIMD defers its compositing to its next half-step               4.88 vs 4.89
 // (with fewer gather waves the gather side becomes the bound; at 8x1 the matrix pipe is ~66 % busy and, MFMA and VALU
 //  cycles being additive on a SIMD, the kernel sits at ~98 % of its issue bound -- DESIGN.md section 4.1)
-// Ablation builds (timing only): -DCN_ABLATE_GATHER=1 2.12 ms, -DCN_ABLATE_MLP=1 1.81 ms, both 1.36 ms per C2 batch
+// Ablation builds (timing only): -DCN_ABLATE_GATHER=1 2.12 ms, -DCN_ABLATE_MLP=1 1.81 ms, both 1.36 ms per C2 batch;
+// -DCN_ABLATE_GATHER_LEVELS=4 / 8 (the coarsest 4 / 8 levels read no table entry and hash nothing): 2.573 / 2.490 ms against
+// 2.597 -- the bound on what a cheaper (e.g. cell-major, one 64-byte line per cell) copy of the coarse levels could give
 // against 2.56 ms for the real thing.
 #ifndef CN_SPLIT_G
 #define CN_SPLIT_G 8
@@ -241,6 +243,10 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
               for (int c = 0; c < 2; ++c) {
 #if CN_ABLATE_GATHER  // timing-only build: no table reads
                 const float2 f = make_float2(px[c] * lv.scale, py[c] + pz[c]);
+#elif defined(CN_ABLATE_GATHER_LEVELS)  // timing-only build: levels below CN_ABLATE_GATHER_LEVELS read no table entry
+                const float2 f = (4 * g + q < CN_ABLATE_GATHER_LEVELS)
+                                     ? make_float2(px[c] * lv.scale, py[c] + pz[c])
+                                     : hash_level_sc<HALF, GENERIC>(A.grid.table, lv, pos_off, px[c], py[c], pz[c]);
 #else
                 const float2 f = hash_level_sc<HALF, GENERIC>(A.grid.table, lv, pos_off, px[c], py[c], pz[c]);
 #endif
