@@ -402,9 +402,10 @@ def test_big_method_trains():
 
 
 def test_private_copies_of_the_coarsest_level_change_nothing(monkeypatch):
-    """cn_grid.scatter_scratch: the coarsest level's gradient accumulated in private dense copies and folded into the table
-    afterwards == the plain scatter (order of additions apart), the scratch is left zeroed, and cells outside the copies
-    (positions outside the box, no scene contraction) take the table path."""
+    """cn_grid.scatter_scratch: the coarse levels' gradients accumulated in cell-major records (or, with CN_CELL_SCATTER=0,
+    level 0's in private vertex copies) and folded into the table afterwards == the plain scatter (order of additions apart),
+    the scratch is left zeroed, and cells outside the records (positions outside the box, no scene contraction) take the
+    table path."""
     from cropnerf_amd import _lib as L
     from cropnerf_amd import ops
     from cropnerf_amd.fruit_nerf.trainer import FruitTrainer
@@ -413,21 +414,26 @@ def test_private_copies_of_the_coarsest_level_change_nothing(monkeypatch):
     tables = ["field.mlp_base_grid.hash_table", "proposal_networks.0.encoding.hash_table",
               "proposal_networks.1.encoding.hash_table", "camera_optimizer.pose_adjustment"]
     got = {}
-    for flag in ("1", "0"):
-        monkeypatch.setenv("CN_SCATTER_SCRATCH", flag)
+    # "cells": cell-major records for the coarse levels (the default); "copies": CN_CELL_SCATTER=0, only level 0 in private
+    # vertex copies; "0": no scratch, every level straight to the table
+    for flag in ("cells", "copies", "0"):
+        monkeypatch.setenv("CN_SCATTER_SCRATCH", "0" if flag == "0" else "1")
+        monkeypatch.setenv("CN_CELL_SCATTER", "0" if flag == "copies" else "0.5")
         model = _hip_model(sc)
         model.training = True
         tr = FruitTrainer(model)
         handles = [tr.grad_field] + tr.grad_props
-        assert all((h._scatter_scratch is not None) == (flag == "1") for h in handles)
+        assert all((h._scatter_scratch is not None) == (flag != "0") for h in handles)
         tr.forward_backward(_hip_rays(sc, idx), {"image": image, "fruit_mask": mask}, jitter=jitter)
         got[flag] = {k: tr.grads[k].clone() for k in tables}
-        if flag == "1":
+        if flag != "0":
             assert all(float(h._scatter_scratch.abs().max()) == 0.0 for h in handles), "scratch not left zeroed"
     for k in tables:
         assert float(got["0"][k].abs().sum()) > 0, k
-        err = float((got["1"][k] - got["0"][k]).norm() / got["0"][k].norm())
-        assert err < 2e-6, f"{k}: {err}"
+        for flag in ("cells", "copies"):
+            err = float((got[flag][k] - got["0"][k]).norm() / got["0"][k].norm())
+            assert err < 2e-6, f"{flag} {k}: {err}"
+    monkeypatch.setenv("CN_CELL_SCATTER", "0.5")
     # ---- no contraction, half of the samples outside the box: their level-0 cells are not in the private copies ----------
     fspec, pspecs = product_specs(sc)
     dp = dev_params(sc)
@@ -442,8 +448,9 @@ def test_private_copies_of_the_coarsest_level_change_nothing(monkeypatch):
     gd, grgb, gs = torch.randn(R, S, generator=g), torch.randn(R, S, 3, generator=g), torch.randn(R, S, generator=g)
     scene = ops.scene_struct(sc.aabb, False)
     res = {}
-    for flag in ("1", "0"):
-        monkeypatch.setenv("CN_SCATTER_SCRATCH", flag)
+    for flag, ratio in (("1", "100"), ("1c", "0"), ("0", "0.5")):  # cell-major records (levels 0-3 for these 1024 samples) / level-0 vertex copies / no scratch
+        monkeypatch.setenv("CN_SCATTER_SCRATCH", "0" if flag == "0" else "1")
+        monkeypatch.setenv("CN_CELL_SCATTER", ratio)
         grads = {k: torch.zeros_like(v) for k, v in dp.items()}
         gh = ops.FieldHandle(grads, fspec).enable_scatter_scratch()
         dpos = torch.zeros(R, S, 3, device="cuda")
@@ -451,8 +458,9 @@ def test_private_copies_of_the_coarsest_level_change_nothing(monkeypatch):
                            to_dev(grgb), to_dev(gs), app_mode=L.APP_PER_CAMERA, d_positions=dpos,
                            d_directions=torch.zeros(R, S, 3, device="cuda"))
         res[flag] = (grads["field.mlp_base_grid.hash_table"].clone(), dpos)
-        if flag == "1":
+        if flag != "0":
             assert float(gh._scatter_scratch.abs().max()) == 0.0
     assert float(res["0"][0].abs().sum()) > 0
-    assert float((res["1"][0] - res["0"][0]).norm() / res["0"][0].norm()) < 2e-6
-    assert float((res["1"][1] - res["0"][1]).norm() / (res["0"][1].norm() + 1e-20)) < 2e-6
+    for flag in ("1", "1c"):
+        assert float((res[flag][0] - res["0"][0]).norm() / res["0"][0].norm()) < 2e-6, flag
+        assert float((res[flag][1] - res["0"][1]).norm() / (res["0"][1].norm() + 1e-20)) < 2e-6, flag
