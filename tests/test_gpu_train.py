@@ -418,7 +418,8 @@ def test_private_copies_of_the_coarsest_level_change_nothing(monkeypatch):
     # vertex copies; "0": no scratch, every level straight to the table
     for flag in ("cells", "copies", "0"):
         monkeypatch.setenv("CN_SCATTER_SCRATCH", "0" if flag == "0" else "1")
-        monkeypatch.setenv("CN_CELL_SCATTER", "0" if flag == "copies" else "0.5")
+        # (ratio 100: with this small batch -- 6144 field samples -- the default 0.5 would select no cell-major level at all)
+        monkeypatch.setenv("CN_CELL_SCATTER", "0" if flag == "copies" else "100")
         model = _hip_model(sc)
         model.training = True
         tr = FruitTrainer(model)
