@@ -465,3 +465,42 @@ def test_private_copies_of_the_coarsest_level_change_nothing(monkeypatch):
     for flag in ("1", "1c"):
         assert float((res[flag][0] - res["0"][0]).norm() / res["0"][0].norm()) < 2e-6, flag
         assert float((res[flag][1] - res["0"][1]).norm() / (res["0"][1].norm() + 1e-20)) < 2e-6, flag
+
+
+def test_cell_major_records_at_a_training_batch_size(monkeypatch):
+    """The default method (2^19-entry levels, (256, 96) + 48 samples) on 8192 random rays: with the default level selection
+    -- field levels 0-4, every proposal level but the finest of the second network, the small levels in several copies --
+    the gradients equal the plain scatter's up to the order of additions, and the scratch is left zeroed."""
+    from cropnerf_amd import config as PC, synthetic
+    from cropnerf_amd.fruit_nerf.fruit_nerf import FruitModel, Semantics
+    from cropnerf_amd.fruit_nerf.trainer import FruitTrainer
+    from cropnerf_amd.rays import Cameras, SceneBox
+
+    cfg = PC.FruitNerfModelConfig()
+    params = synthetic.p_rand(cfg.field_spec(20), cfg.proposal_specs(), seed=3, device="cuda")
+    c2w, intr = synthetic.orbit_cameras(20)
+    cams = Cameras(c2w, intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], 800, 800).to("cuda")
+    g = torch.Generator().manual_seed(11)
+    R = 8192
+    idx = torch.stack([torch.randint(0, 20, (R,), generator=g), torch.randint(0, 800, (R,), generator=g),
+                       torch.randint(0, 800, (R,), generator=g)], -1)
+    rays = cams.generate_rays(idx.cuda())
+    batch = {"image": torch.rand(R, 3, generator=g).cuda(), "fruit_mask": (torch.rand(R, 1, generator=g) > 0.5).float().cuda()}
+    jitter = [torch.rand(R, 1, generator=g) for _ in range(3)]
+    tables = ["field.mlp_base_grid.hash_table", "proposal_networks.0.encoding.hash_table",
+              "proposal_networks.1.encoding.hash_table", "camera_optimizer.pose_adjustment"]
+    got = {}
+    for flag in ("0.5", "0"):
+        monkeypatch.setenv("CN_CELL_SCATTER", flag)
+        model = FruitModel(cfg, SceneBox(torch.tensor([[-1.0, -1, -1], [1, 1, 1]])), 20, {"semantics": Semantics()},
+                           device="cuda", params={k: v.clone() for k, v in params.items()})
+        model.training = True
+        tr = FruitTrainer(model)
+        tr.forward_backward(rays, batch, jitter=jitter)
+        got[flag] = {k: tr.grads[k].clone() for k in tables}
+        assert all(float(h._scatter_scratch.abs().max()) == 0.0 for h in [tr.grad_field] + tr.grad_props)
+    for k in tables:
+        ref = got["0"][k]
+        assert float(ref.abs().sum()) > 0, k
+        err = float((got["0.5"][k] - ref).norm() / ref.norm())
+        assert err < 1e-5, f"{k}: {err}"
