@@ -78,8 +78,11 @@ __device__ __forceinline__ float prop_density_dispatch(const PropNet& n, const S
 // HALF: the proposal nets' hash tables hold half2 entries (CN_TABLE_F16).  TRAIN: the training forward of
 // ProposalNetworkSampler (fruit_nerf.py:549 under model.train()): stratified single-jitter level-0 bins
 // (ray_samplers.py:84-87), PDF resampling at u + rand / nb, and every level's bins / intervals / densities written out.
+#ifndef CN_PROP_SAMPLE_WAVES
+#define CN_PROP_SAMPLE_WAVES 4  // waves per SIMD the register allocation is held to (the kernel is latency-bound: one wave per ray)
+#endif
 template <bool HALF, bool TRAIN>
-__global__ void __launch_bounds__(256) proposal_sample_kernel(PropArgs A) {
+__global__ void __launch_bounds__(256, CN_PROP_SAMPLE_WAVES) proposal_sample_kernel(PropArgs A) {
   extern __shared__ __align__(16) float lds[];
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const int stride = 4 * A.smax + 4;
