@@ -87,6 +87,10 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", choices=["uniform", "proposal"], default="uniform",
                     help="uniform: 192 field evals/ray (headline); proposal: + (256,96) proposal-net evals/ray")
+    ap.add_argument("--variant", choices=["headline", "tcnn_f16", "tcnn_f16_mfma", "split_bf16"], default="headline",
+                    help="profiling aid (rocprofv3 -- python3 bench.py --variant ... --no-secondary --no-cpu-baseline): the "
+                         "timed loop renders the M-uniform workload through another table / matrix mode; the JSON line "
+                         "then names the variant and is NOT the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-image-hint", action="store_true",
                     help="do not tell the renderer that a batch is a pixel run of an 800-wide image (A/B of the XCD stripe mapping)")
@@ -151,8 +155,29 @@ def make_batches(ops, c2w, intr, rank: int, world: int):
     return batches
 
 
+def self_launch(args) -> int:
+    """`python3 bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes under
+    torch.distributed.run (exactly the command the driver documents), before this process has made any GPU call, relay
+    their output (rank 0 prints the one JSON line) and return the launcher's exit code.  Never exec: a process that has
+    touched the GPU must not be replaced, and this one stays a plain parent that has not touched it."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: WORLD_SIZE is unset and --gpus {args.gpus} > 1: launching {' '.join(cmd[1:8])} ...", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))  # before torch.cuda is touched in this process
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
     rank, local, world = setup_dist(args.gpus)
@@ -168,6 +193,9 @@ def main():
         return ops.render_opts(S) if args.no_image_hint else ops.render_opts(S, image_width=W, pixel_start=start)
 
     opts = ops.render_opts(S)
+    fh_run, variant_kw = fh, {}
+    if args.variant != "headline":
+        fh_run, variant_kw = variant_field(args.variant, params, fspec, fh, device)
     gather_buf = None
     if world > 1:
         import torch.distributed as dist
@@ -181,7 +209,9 @@ def main():
 
     def step(i: int):
         o, d, n, f, cam, start = batches[i % DISTINCT_BATCHES]
-        if args.mode == "uniform":
+        if args.mode == "uniform" and args.variant != "headline":
+            out = ops.render_rays(fh_run, scene_u, ops.render_opts(S, image_width=W, pixel_start=start, **variant_kw), o, d, n, f)
+        elif args.mode == "uniform":
             out = ops.render_rays(fh, scene_u, opts_for(start), o, d, n, f)
         else:
             ps = ops.proposal_sample(dh, scene_c, o, d, n, f, cfg.num_proposal_samples_per_ray, S)
@@ -293,6 +323,7 @@ def main():
             "config": {"workload": "plant_1-shaped synthetic scene (P-rand), 800x800, 192 samples/ray, 65536-ray batch"
                                    f", mode M-{args.mode}, fused cn_render_rays, eval (no jitter)",
                        "rays_per_batch": R, "samples_per_ray": S, "image": [H, W], "mode": args.mode,
+                       **({"variant": args.variant + " (profiling aid, not the headline)"} if args.variant != "headline" else {}),
                        "sharding": "ray batches per rank + RCCL all-gather of per-ray outputs" if world > 1 else "none"},
             "rays_per_sec": world * R * args.steps / elapsed,
             "psnr_vs_oracle_db": psnr,
@@ -305,6 +336,32 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def tcnn_f16_field(params, device):
+    """The reference's default module implementation on the bench scene: tcnn grid geometry with half2 table entries (what a
+    reference-trained checkpoint imports to), a seeded random table of that layout, the same MLPs."""
+    from cropnerf_amd import config as _PC
+    from cropnerf_amd import ops
+
+    tcfg_t = _PC.FruitNerfModelConfig(num_nerf_samples_per_ray=S, implementation="tcnn")
+    tspec = tcfg_t.field_spec(num_images=NUM_CAMERAS)
+    gq = torch.Generator(device="cpu").manual_seed(0)
+    packed = ((torch.rand(2 * tspec.grid.num_packed_entries, generator=gq) * 2 - 1) * 0.1).to(device)
+    pt = dict(params)
+    pt["field.mlp_base_grid.hash_table"] = ops.tcnn_grid_pack(tspec.grid, packed, torch.float16)
+    return ops.FieldHandle(pt, tspec), tspec
+
+
+def variant_field(variant, params, fspec, fh, device):
+    from cropnerf_amd import _lib as L
+
+    if variant == "split_bf16":
+        return fh, {"matrix_precision": L.MATRIX_SPLIT_BF16}
+    fht, _ = tcnn_f16_field(params, device)
+    if variant == "tcnn_f16_mfma":
+        return fht, {"matrix_precision": L.MATRIX_F16}
+    return fht, {}
 
 
 def launch_time(fn, n: int) -> float:

@@ -79,7 +79,7 @@ class RenderOpts(C.Structure):
                 ("pixel_start", C.c_int64), ("early_stop_transmittance", C.c_float), ("matrix_precision", C.c_int32)]
 
 
-MATRIX_FP32, MATRIX_SPLIT_BF16 = 0, 1  # cn_render_opts.matrix_precision
+MATRIX_FP32, MATRIX_SPLIT_BF16, MATRIX_F16 = 0, 1, 2  # cn_render_opts.matrix_precision
 
 _P = C.c_void_p
 _I32, _I64, _F = C.c_int32, C.c_int64, C.c_float

@@ -155,7 +155,9 @@ class FruitNerfModelConfig:
     # transmittance falls below this value; 0 keeps the reference's behaviour
     early_stop_transmittance: float = 0.0
     # extension: "fp32" = exact fp32 matrix products (default); "split_bf16" = operands as bf16 hi + lo on the bf16 matrix
-    # pipe with fp32 accumulation in the eval renders that fill the device (cn_render_opts.matrix_precision)
+    # pipe with fp32 accumulation in the eval renders that fill the device (cn_render_opts.matrix_precision); "f16" = the
+    # reference's own arithmetic class (tcnn FullyFusedMLP under mixed_precision=True, fruit_field.py:95,
+    # fruit_nerf_config.py:35): fp16 weights and layer inputs, fp32 accumulation, in every eval render
     matrix_precision: str = "fp32"
     # Which of the reference's two implementations the parameters follow (nerfacto's ``implementation``; FruitField's own
     # default is "tcnn", fruit_field.py:95).  "torch": nerfstudio's torch HashEncoding / MLP (all levels hashed, biases).

@@ -478,6 +478,112 @@ __device__ __forceinline__ float2 hash_level_sc(const void* __restrict__ table, 
   return r;
 }
 
+// Half table, fp16 matrix mode (CN_MATRIX_F16): the two features of an entry stay packed in one register and the trilinear
+// blend runs on v_pk_add_f16 / v_pk_fma_f16 (14 packed instructions for both features instead of 28 fp32 ones plus 16
+// conversions), interpolation weights rounded to fp16 -- the precision class of tcnn's kernel_grid, which accumulates the
+// weighted corners in the parameter type (fp16).  Returns the packed (feature 0, feature 1) pair: one dword of the fp16 MFMA
+// B operand, no conversion anywhere.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+// The gathers are what this mode costs: a CU's L1 looks up ONE cache line per clock for per-lane-addressed loads whose
+// lanes do not share lines (tools/gather_rate_microbench.hip: 64 cycles per wave-level load with 64 lines, whatever the
+// width), and with fp16 MFMAs the render kernel runs at that rate (1.17e9 line lookups per C2 launch = 4.6e6 cycles per CU).
+// So the two x-corners of a (y, z) row are fetched with ONE 8-byte load where they are neighbours: entries e and e ^ 1 (the
+// aligned pair) whenever the cell's x index is even -- true for hashed levels (index = x ^ y*P1 ^ z*P2) and for the dense levels
+// of the tcnn layout (x sits in the low bits) alike.  Lanes with an odd x index fetch their upper corner with a second,
+// 4-byte load under the execution mask: 6 line lookups per level and sample instead of 8.
+// Issued and blended in two steps so that a kernel can keep the next unit's loads in flight under this unit's blend (the
+// conditional load is control flow: hipcc no longer schedules across it, and sinks every blend to the end of the gather
+// phase -- 96 live registers and 370 bytes of scratch -- unless the order is written out, see pk_pin).
+typedef unsigned u32x2p __attribute__((ext_vector_type(2)));
+struct PkLoads {
+  u32x2p pr[4];    // the aligned pair holding the lower-x corner of rows (y, z) = ff, cf, fc, cc
+#ifdef CN_PK_UP_WIDE
+  u32x2p up[4];    // odd x index: the aligned pair that holds the upper-x corner (its first entry: x + 1 is even)
+#else
+  unsigned up[4];  // the upper-x corner of each row, loaded separately when the x index is odd
+#endif
+  unsigned bits;   // bit r: the lower-x corner is the pair's second entry; bit 4: odd x index
+  unsigned wxy, wzz;  // interpolation weights as packed fp16 pairs (x, y) and (z, z)
+};
+template <bool OFFSET = true>
+__device__ __forceinline__ PkLoads hash_level_pk_issue(const void* __restrict__ table, const Lvl& lv, float pos_offset, float px,
+                                                       float py, float pz) {
+  const Cell k = hash_cell<OFFSET>(lv, pos_offset, px, py, pz);
+  const char* base = reinterpret_cast<const char*>(table);
+  const unsigned pair_mask = lv.mask & ~1u;
+  const unsigned hyz[4] = {k.hy0 ^ k.hz0, k.hy1 ^ k.hz0, k.hy0 ^ k.hz1, k.hy1 ^ k.hz1};
+  PkLoads L;
+  {
+    const _Float16 hx = (_Float16)k.ox, hy = (_Float16)k.oy, hz = (_Float16)k.oz;
+    const f16x2 xy = {hx, hy}, zz = {hz, hz};
+    L.wxy = __builtin_bit_cast(unsigned, xy);
+    L.wzz = __builtin_bit_cast(unsigned, zz);
+  }
+  const bool odd = (k.hx0 & 1u) != 0u;
+  L.bits = odd ? 16u : 0u;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {  // level offsets are even, so the aligned pair of entry e is e & ~1
+    const unsigned x = k.hx0 ^ hyz[r];
+    L.bits |= (x & 1u) << r;
+    L.pr[r] = *reinterpret_cast<const u32x2p*>(base + (size_t)(((x & pair_mask) + lv.off) << 2));
+#ifdef CN_PK_UP_WIDE
+    L.up[r] = u32x2p{0u, 0u};
+#else
+    L.up[r] = 0u;
+#endif
+  }
+#if !defined(CN_ABLATE_X1)  // timing-only build: no second load
+  if (odd) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#ifdef CN_PK_UP_WIDE  // 8-byte loads coalesce lane PAIRS (4-byte loads only whole quads): worth it when neighbouring lanes are
+                      // neighbouring pixels
+      L.up[r] = *reinterpret_cast<const u32x2p*>(base + (size_t)((((k.hx1 ^ hyz[r]) & pair_mask) + lv.off) << 2));
+#else
+      L.up[r] = *reinterpret_cast<const unsigned*>(base + (size_t)((((k.hx1 ^ hyz[r]) & lv.mask) + lv.off) << 2));
+#endif
+    }
+  }
+#endif
+  return L;
+}
+__device__ __forceinline__ unsigned hash_level_pk_blend(const PkLoads& L) {
+  const bool odd = (L.bits & 16u) != 0u;
+  f16x2 lo[4], hi[4];  // lower-x / upper-x corner of each row
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bool second = (L.bits & (1u << r)) != 0u;
+    const unsigned a = L.pr[r].x, b = L.pr[r].y;
+    lo[r] = __builtin_bit_cast(f16x2, second ? b : a);
+#ifdef CN_PK_UP_WIDE
+    // x + 1 is even: the upper corner's entry index has the parity of (x ^ y-term ^ z-term) ^ 1, i.e. it is the pair's
+    // second entry exactly when the lower corner (odd x) was its pair's FIRST
+    const unsigned upv = second ? L.up[r].x : L.up[r].y;
+#else
+    const unsigned upv = L.up[r];
+#endif
+    hi[r] = __builtin_bit_cast(f16x2, odd ? upv : (second ? a : b));
+  }
+  const f16x2 wxy = __builtin_bit_cast(f16x2, L.wxy), wz = __builtin_bit_cast(f16x2, L.wzz);
+  const f16x2 wx = {wxy.x, wxy.x}, wy = {wxy.y, wxy.y};
+  // lerp(lo, hi, w) = lo + (hi - lo) w: x toward the upper corner, then y, then z (the order of hash_level_sc)
+  const f16x2 xff = lo[0] + (hi[0] - lo[0]) * wx, xcf = lo[1] + (hi[1] - lo[1]) * wx;
+  const f16x2 xfc = lo[2] + (hi[2] - lo[2]) * wx, xcc = lo[3] + (hi[3] - lo[3]) * wx;
+  const f16x2 yf = xff + (xcf - xff) * wy, yc = xfc + (xcc - xfc) * wy;
+  const f16x2 r = yf + (yc - yf) * wz;
+  return __builtin_bit_cast(unsigned, r);
+}
+// keeps a blended value where the program computed it (an empty volatile asm is ordered against the others)
+__device__ __forceinline__ unsigned pk_pin(unsigned v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+template <bool OFFSET = true>
+__device__ __forceinline__ unsigned hash_level_pk(const void* __restrict__ table, const Lvl& lv, float pos_offset, float px,
+                                                  float py, float pz) {
+  return hash_level_pk_blend(hash_level_pk_issue<OFFSET>(table, lv, pos_offset, px, py, pz));
+}
+
 // hipcc pitfall (ROCm 7.2), found while building a 16-byte "x-pair" gather variant (measured slower and removed:
 // 3.69 vs 3.86 Gsamples/s): __builtin_bit_cast(float, v.y) applied directly to an ext_vector element reads element 0 --
 // copy the element into a scalar first.

@@ -79,9 +79,11 @@ struct PrepArgs {
   int app_mode;
   int app_rows;
   GridDev grid;  // per-level records of the blob
-  int bf16;     // 1: the A-operand region holds split-bf16 images for v_mfma_f32_16x16x32_bf16 (render_split_kernel<.,true>)
-  float* ext;   // [BF16_EXT_FLOATS] the four image blocks that do not fit the fp32 region
+  int mm;       // matrix mode of render_split_kernel: MM_FP32 fp32 A operands; MM_BF16 split-bf16 images for
+                // v_mfma_f32_16x16x32_bf16; MM_F16 fp16 images for v_mfma_f32_16x16x32_f16 (every weight rounded to fp16)
+  float* ext;   // [BF16_EXT_FLOATS] the four split-bf16 image blocks that do not fit the fp32 region
 };
+constexpr int MM_FP32 = CN_MATRIX_FP32, MM_BF16 = CN_MATRIX_SPLIT_BF16, MM_F16 = CN_MATRIX_F16;
 
 // Split-bf16 A operands (cn_render_opts.matrix_precision = 1).  Block b = one (row tile, K block of 32): [hi | lo][lane 64][8 bf16];
 // lane (g, j) holds row 16 mt + j and the eight k values its B operand lane supplies.  B operands are the features of a
@@ -116,6 +118,21 @@ __device__ __forceinline__ float bf16_image_word(const PrepArgs& p, int q) {  //
   return __builtin_bit_cast(float, bits[0] | (bits[1] << 16));
 }
 
+// fp16 A operands (cn_render_opts.matrix_precision = CN_MATRIX_F16): the same 22 (row tile, K block of 32) blocks, block b =
+// [lane 64][8 halves] = 256 floats at OFF_A0 + 256 b (all of them fit the fp32 region).
+__device__ __forceinline__ float f16_image_word(const PrepArgs& p, int q) {
+  const int b = q >> 8, lane = (q >> 2) & 63, w = q & 3;
+  unsigned bits[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const _Float16 v = (_Float16)bf16_logical_weight(p, b, lane >> 4, lane & 15, 2 * w + h);
+    bits[h] = (unsigned)__builtin_bit_cast(unsigned short, v);
+  }
+  return __builtin_bit_cast(float, bits[0] | (bits[1] << 16));
+}
+// a value as the fp16 mode sees it (tcnn casts parameters and inputs to half)
+__device__ __forceinline__ float f16_round(float x) { return (float)(_Float16)x; }
+
 // Embedding.mean(dim=0) for the 32-wide appearance embedding: 8 partial sums per column, combined through LDS
 __global__ void __launch_bounds__(256) prep_mean_kernel(const float* __restrict__ emb, int n, float* __restrict__ mean) {
   __shared__ float part[8][32];
@@ -134,13 +151,17 @@ __global__ void __launch_bounds__(256) prep_mean_kernel(const float* __restrict_
 
 __global__ void __launch_bounds__(256) prep_kernel(PrepArgs p, float* __restrict__ blob, float* __restrict__ app_bias) {
   const int total = BLOB_FLOATS + p.app_rows * 64;
-  if (p.bf16)
+  if (p.mm == MM_BF16)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < BF16_EXT_FLOATS; i += gridDim.x * blockDim.x)
       p.ext[i] = bf16_image_word(p, OFF_B0 + i);
+  const bool f16 = p.mm == MM_F16;
+  auto R16 = [f16](float x) { return f16 ? f16_round(x) : x; };
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     float v = 0.f;
-    if (p.bf16 && i < OFF_B0) {
+    if (p.mm == MM_BF16 && i < OFF_B0) {
       v = bf16_image_word(p, i);
+    } else if (f16 && i < OFF_B0) {
+      v = i < BF16_BLOCKS * 256 ? f16_image_word(p, i) : 0.f;
     } else if (i < OFF_A1) {
       int q = i - OFF_A0;
       int mt = q >> 9, sq = (q >> 8) & 1, lane = (q >> 2) & 63, e = q & 3;
@@ -178,9 +199,9 @@ __global__ void __launch_bounds__(256) prep_kernel(PrepArgs p, float* __restrict
       v = p.bc1[i - OFF_BC1];
     } else if (i < OFF_WRGB) {
       int k = i - OFF_WF;
-      for (int m = 0; m < 64; ++m) v = fmaf(p.wh[m], p.ws1[m * 64 + k], v);
+      for (int m = 0; m < 64; ++m) v = fmaf(p.wh[m], R16(p.ws1[m * 64 + k]), v);
     } else if (i < OFF_MISC) {
-      v = p.wc2[i - OFF_WRGB];
+      v = R16(p.wc2[i - OFF_WRGB]);
     } else if (i < OFF_WSH) {
       int k = i - OFF_MISC;
       if (k == 0) {
@@ -191,7 +212,7 @@ __global__ void __launch_bounds__(256) prep_kernel(PrepArgs p, float* __restrict
       }
     } else if (i < OFF_SCALE) {
       int q = i - OFF_WSH;
-      v = p.wc0[(q >> 4) * 63 + (q & 15)];
+      v = R16(p.wc0[(q >> 4) * 63 + (q & 15)]);
     } else if (i < OFF_LVL) {
       int q = i - OFF_SCALE;  // static selects: a dynamically indexed kernarg array would go to scratch
       v = p.grid.scale[0];
@@ -212,7 +233,7 @@ __global__ void __launch_bounds__(256) prep_kernel(PrepArgs p, float* __restrict
       v = p.bc0[n];
       if (p.app_mode != CN_APP_ZEROS) {
         const float* a = p.app_mode == CN_APP_PER_CAMERA ? p.emb + row * 32 : p.emb_mean;
-        for (int k = 0; k < 32; ++k) v = fmaf(p.wc0[n * 63 + 31 + k], a[k], v);
+        for (int k = 0; k < 32; ++k) v = fmaf(R16(p.wc0[n * 63 + 31 + k]), R16(a[k]), v);
       }
       app_bias[q] = v;
       continue;
@@ -292,11 +313,11 @@ __device__ __forceinline__ float pick4(int g, float a, float b, float c, float d
 // hashed with the same primes and mask, level l at l * T): compile-time multipliers, scalar mask -- the code of the
 // round-1 kernels.  GENERIC = true (tcnn layout: dense and hashed levels mixed): the record comes from the LDS blob.
 template <bool GENERIC>
-__device__ __forceinline__ Lvl lane_level_rec(const float* lds, const GridDev& grid, int level, float scale) {
+__device__ __forceinline__ Lvl lane_level_rec(const float* lvl_records, const GridDev& grid, int level, float scale) {
   Lvl lv;
   if constexpr (GENERIC) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 r = *reinterpret_cast<const u32x4*>(lds + OFF_LVL + 4 * level);
+    const u32x4 r = *reinterpret_cast<const u32x4*>(lvl_records + 4 * level);
     lv.off = r.x;
     lv.mask = r.y;
     lv.m1 = r.z;
@@ -431,7 +452,7 @@ __global__ void __launch_bounds__(FUSED_THREADS, CN_FUSED_MIN_WAVES_PER_SIMD) re
           const f32x4 lvl_scale = *reinterpret_cast<const f32x4*>(lds + OFF_SCALE + 4 * g);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const Lvl lv = lane_level_rec<GENERIC>(lds, A.grid, 4 * g + q, lvl_scale[q]);
+            const Lvl lv = lane_level_rec<GENERIC>(lds + OFF_LVL, A.grid, 4 * g + q, lvl_scale[q]);
             const float pos_off = GENERIC ? A.grid.pos_offset : 0.f;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -636,6 +657,7 @@ __global__ void __launch_bounds__(FUSED_THREADS, CN_FUSED_MIN_WAVES_PER_SIMD) re
 
 }  // namespace cn
 #include "render_split.hpp"
+#include "render_f16.hpp"
 namespace cn {
 
 int validate_field(const cn_field_params& p);  // field_simple.hip
@@ -664,6 +686,7 @@ static size_t fused_workspace_bytes(const cn_field_params* p) {
 struct FusedDevice {
   int split_resident;  // workgroups of render_split_kernel the device holds at once (a multiple of 8 = XCD teams)
   int res_sample, res_density, res_full;  // resident blocks of the render_fused_kernel variants
+  int res_f16_sample, res_f16_density, res_f16_full;  // ... of the render_f16_kernel variants
 };
 
 template <typename K>
@@ -679,14 +702,14 @@ static hipError_t resident_blocks(K kernel, int cus, int* out) {
   return hipSuccess;
 }
 
-template <bool PS, bool BF, bool H>
+template <bool PS, int MM, bool H>
 static hipError_t split_attr() {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<PS, BF, H, false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)(BF ? SPLIT_LDS_BYTES_BF16 : SPLIT_LDS_BYTES));
+  const int bytes = (int)(MM == MM_BF16 ? SPLIT_LDS_BYTES_BF16 : SPLIT_LDS_BYTES);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<PS, MM, H, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<PS, BF, H, true>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BF ? SPLIT_LDS_BYTES_BF16 : SPLIT_LDS_BYTES));
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<PS, MM, H, true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 static hipError_t fused_device_init(int dev, FusedDevice& d) {
@@ -694,16 +717,20 @@ static hipError_t fused_device_init(int dev, FusedDevice& d) {
   hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   if (e != hipSuccess) return e;
 #define CN_TRY(x) if ((e = (x)) != hipSuccess) return e
-  CN_TRY((split_attr<false, false, false>()));
-  CN_TRY((split_attr<true, false, false>()));
-  CN_TRY((split_attr<false, true, false>()));
-  CN_TRY((split_attr<true, true, false>()));
-  CN_TRY((split_attr<false, false, true>()));
-  CN_TRY((split_attr<true, false, true>()));
-  CN_TRY((split_attr<false, true, true>()));
-  CN_TRY((split_attr<true, true, true>()));
+  CN_TRY((split_attr<false, MM_FP32, false>()));
+  CN_TRY((split_attr<true, MM_FP32, false>()));
+  CN_TRY((split_attr<false, MM_BF16, false>()));
+  CN_TRY((split_attr<true, MM_BF16, false>()));
+  CN_TRY((split_attr<false, MM_F16, false>()));
+  CN_TRY((split_attr<true, MM_F16, false>()));
+  CN_TRY((split_attr<false, MM_FP32, true>()));
+  CN_TRY((split_attr<true, MM_FP32, true>()));
+  CN_TRY((split_attr<false, MM_BF16, true>()));
+  CN_TRY((split_attr<true, MM_BF16, true>()));
+  CN_TRY((split_attr<false, MM_F16, true>()));
+  CN_TRY((split_attr<true, MM_F16, true>()));
   int per_cu = 0;
-  CN_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_split_kernel<false, false, false, false>,
+  CN_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_split_kernel<false, MM_FP32, false, false>,
                                                       SPLIT_THREADS, SPLIT_LDS_BYTES));
   if (per_cu < 1) per_cu = 1;
   const int r = cus * per_cu;
@@ -711,6 +738,9 @@ static hipError_t fused_device_init(int dev, FusedDevice& d) {
   CN_TRY(resident_blocks(render_fused_kernel<true, false, false, false>, cus, &d.res_sample));
   CN_TRY(resident_blocks(render_fused_kernel<false, true, false, false>, cus, &d.res_density));
   CN_TRY(resident_blocks(render_fused_kernel<false, false, false, false>, cus, &d.res_full));
+  CN_TRY(resident_blocks(render_f16_kernel<true, false, true, true>, cus, &d.res_f16_sample));
+  CN_TRY(resident_blocks(render_f16_kernel<false, true, true, true>, cus, &d.res_f16_density));
+  CN_TRY(resident_blocks(render_f16_kernel<false, false, true, true>, cus, &d.res_f16_full));
 #undef CN_TRY
   return hipSuccess;
 }
@@ -734,8 +764,9 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   CN_REQUIRE(opts->bg_mode == CN_BG_LAST_SAMPLE || opts->bg_mode == CN_BG_COLOR, CN_ERR_INVALID, "%s: bg_mode %d", who,
              opts->bg_mode);
   CN_REQUIRE(opts->image_width <= 0 || opts->pixel_start >= 0, CN_ERR_INVALID, "%s: negative pixel_start", who);
-  CN_REQUIRE(opts->matrix_precision == CN_MATRIX_FP32 || opts->matrix_precision == CN_MATRIX_SPLIT_BF16, CN_ERR_INVALID,
-             "%s: matrix_precision %d", who, opts->matrix_precision);
+  CN_REQUIRE(opts->matrix_precision == CN_MATRIX_FP32 || opts->matrix_precision == CN_MATRIX_SPLIT_BF16 ||
+                 opts->matrix_precision == CN_MATRIX_F16,
+             CN_ERR_INVALID, "%s: matrix_precision %d", who, opts->matrix_precision);
   int rc = check_fused_shape(*params);
   if (rc) return rc;
   rc = check_grid(params->grid, false, who);
@@ -762,21 +793,29 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   // independent waves of the fused kernel save in proportion to the terminated rays (3.2 -> 0.87 ms), which suits real
   // scenes (a mix of rays that hit a surface and rays that cross empty space) better -- so it is the default there and
   // CN_FUSED_SPLIT=2 forces the split kernel.
-  if (!opts->density_only && split_mode && (PER_SAMPLE || early_stop == 0.f || split_mode > 1)) {
+  // fp16 matrix mode: render_f16_kernel (render_f16.hpp) for every variant and batch size, so that a ray's result does not
+  // depend on the call it is part of.  CN_F16_KERNEL=split selects the fp16 form of the producer/consumer kernel for the
+  // composited and per-sample renders instead (A/B runs; it is bound by its per-half-step barrier there, render_f16.hpp).
+  const bool want_f16 = opts->matrix_precision == CN_MATRIX_F16;
+  const char* f16_env = getenv("CN_F16_KERNEL");
+  const bool f16_split = want_f16 && !opts->density_only && !(f16_env && strcmp(f16_env, "own") == 0);
+  const bool f16_own = want_f16 && !f16_split;
+  if (f16_split || (!want_f16 && !opts->density_only && split_mode && (PER_SAMPLE || early_stop == 0.f || split_mode > 1))) {
     const int resident = dev->split_resident;
     const long long work = PER_SAMPLE ? num_rays * ((opts->num_samples + 63) / 64) : num_rays;  // (ray, chunk) items
     const long long want_s = (((work + SPLIT_PAIRS - 1) / SPLIT_PAIRS) + 7) / 8 * 8;
     // one workgroup per CU carries 8 rays at a time: with fewer rays than that fills the device (the exporters' 512-ray
     // x 3000-sample calls) the 4-wave workgroups of render_fused_kernel spread over more CUs
-    if (want_s >= resident || split_mode > 1) split_blocks = (unsigned)(want_s < resident ? want_s : resident);
+    if (want_s >= resident || split_mode > 1 || f16_split) split_blocks = (unsigned)(want_s < resident ? want_s : resident);
   }
   // split-bf16 matrix products: an option of the producer/consumer kernel only; elsewhere the products stay fp32
-  const bool bf16 = opts->matrix_precision == CN_MATRIX_SPLIT_BF16 && split_blocks > 0;
+  const int mm = (split_blocks > 0 || f16_own) ? opts->matrix_precision : CN_MATRIX_FP32;
+  const bool bf16 = mm == MM_BF16;
   A.grid = make_grid_dev(params->grid);
   const bool half = A.grid.half != 0;
   const bool generic = params->grid.layout != CN_GRID_TORCH;
   PrepArgs P;
-  P.bf16 = bf16 ? 1 : 0;
+  P.mm = mm;
   P.ext = blob + BLOB_FLOATS + (size_t)(params->num_images > 0 ? params->num_images : 1) * 64 + 32;
   P.w0 = params->base.weight[0];
   P.b0 = params->base.bias[0];
@@ -836,25 +875,47 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   if (A.stripes_per_xcd < 1) A.stripes_per_xcd = 1;
   A.pixel_start = opts->pixel_start;
   // persistent grid: exactly the resident block count (a multiple of 8 = XCD groups), never more waves than rays
-  const long long cap = PER_SAMPLE ? dev->res_sample : (opts->density_only ? dev->res_density : dev->res_full);
-  const long long want = (((num_rays + FUSED_WAVES - 1) / FUSED_WAVES) + 7) / 8 * 8;
+  const long long cap = f16_own ? (PER_SAMPLE ? dev->res_f16_sample : (opts->density_only ? dev->res_f16_density : dev->res_f16_full))
+                                : (PER_SAMPLE ? dev->res_sample : (opts->density_only ? dev->res_density : dev->res_full));
+  const long long fused_items = (f16_own && PER_SAMPLE) ? num_rays * ((opts->num_samples + 63) / 64) : num_rays;
+  const long long want = (((fused_items + FUSED_WAVES - 1) / FUSED_WAVES) + 7) / 8 * 8;
   const unsigned blocks = (unsigned)(want < cap ? want : cap);
   if (split_blocks) {
     const size_t lds_bytes = bf16 ? SPLIT_LDS_BYTES_BF16 : SPLIT_LDS_BYTES;
-#define CN_SPLIT_LAUNCH(BF, H)                                                                                       \
+#define CN_SPLIT_LAUNCH(MM, H)                                                                                       \
   do {                                                                                                               \
     if (generic)                                                                                                     \
-      hipLaunchKernelGGL((render_split_kernel<PER_SAMPLE, BF, H, true>), dim3(split_blocks), dim3(SPLIT_THREADS),    \
+      hipLaunchKernelGGL((render_split_kernel<PER_SAMPLE, MM, H, true>), dim3(split_blocks), dim3(SPLIT_THREADS),    \
                          lds_bytes, s, A);                                                                           \
     else                                                                                                             \
-      hipLaunchKernelGGL((render_split_kernel<PER_SAMPLE, BF, H, false>), dim3(split_blocks), dim3(SPLIT_THREADS),   \
+      hipLaunchKernelGGL((render_split_kernel<PER_SAMPLE, MM, H, false>), dim3(split_blocks), dim3(SPLIT_THREADS),   \
                          lds_bytes, s, A);                                                                           \
   } while (0)
-    if (bf16 && half) CN_SPLIT_LAUNCH(true, true);
-    else if (bf16) CN_SPLIT_LAUNCH(true, false);
-    else if (half) CN_SPLIT_LAUNCH(false, true);
-    else CN_SPLIT_LAUNCH(false, false);
+    if (mm == MM_F16 && half) CN_SPLIT_LAUNCH(MM_F16, true);
+    else if (mm == MM_F16) CN_SPLIT_LAUNCH(MM_F16, false);
+    else if (bf16 && half) CN_SPLIT_LAUNCH(MM_BF16, true);
+    else if (bf16) CN_SPLIT_LAUNCH(MM_BF16, false);
+    else if (half) CN_SPLIT_LAUNCH(MM_FP32, true);
+    else CN_SPLIT_LAUNCH(MM_FP32, false);
 #undef CN_SPLIT_LAUNCH
+    return check_launch(who);
+  }
+  if (f16_own) {
+#define CN_F16_LAUNCH1(PS, DO, H)                                                                                  \
+  do {                                                                                                             \
+    if (generic) hipLaunchKernelGGL((render_f16_kernel<PS, DO, H, true>), dim3(blocks), dim3(FUSED_THREADS), 0, s, A);   \
+    else hipLaunchKernelGGL((render_f16_kernel<PS, DO, H, false>), dim3(blocks), dim3(FUSED_THREADS), 0, s, A);          \
+  } while (0)
+#define CN_F16_LAUNCH(PS, DO)              \
+  do {                                     \
+    if (half) CN_F16_LAUNCH1(PS, DO, true);  \
+    else CN_F16_LAUNCH1(PS, DO, false);      \
+  } while (0)
+    if (PER_SAMPLE) CN_F16_LAUNCH(true, false);
+    else if (opts->density_only) CN_F16_LAUNCH(false, true);
+    else CN_F16_LAUNCH(false, false);
+#undef CN_F16_LAUNCH
+#undef CN_F16_LAUNCH1
     return check_launch(who);
   }
 #define CN_FUSED_LAUNCH1(PS, DO, H)                                                                                \

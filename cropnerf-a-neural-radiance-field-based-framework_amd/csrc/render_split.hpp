@@ -71,6 +71,22 @@ __device__ __forceinline__ f32x4 mfma_split(const bf16x8& ah, const bf16x8& al, 
   return acc;
 }
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+// eight fp32 values -> the fp16 B operand of v_mfma_f32_16x16x32_f16 (round to nearest even, as __float2half_rn)
+__device__ __forceinline__ f16x8 cvt_f16x8(const f32x4& a, const f32x4& b) {
+  f16x8 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    r[j] = (_Float16)a[j];
+    r[4 + j] = (_Float16)b[j];
+  }
+  return r;
+}
+__device__ __forceinline__ f32x4 mfma_f16(const f16x8& a, const f16x8& b, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+}
+
 struct SplitRay {
   float ox, oy, oz, dx, dy, dz, sn, sf;
   const float* bins;
@@ -130,11 +146,16 @@ __device__ __forceinline__ void split_fill_edges(const FusedArgs& A, const Split
   __builtin_amdgcn_wave_barrier();
 }
 
-// BF16: the matrix waves run the MLPs on split-bf16 products (cn_render_opts.matrix_precision = 1; the weight images in the
-// blob are then the bf16 ones of prep_kernel, four more blocks of them behind the pair scratch).
+// MM (cn_render_opts.matrix_precision): MM_BF16 -- the matrix waves run the MLPs on split-bf16 products (the weight images in
+// the blob are then the bf16 ones of prep_kernel, four more blocks of them behind the pair scratch); MM_F16 -- on fp16
+// products (v_mfma_f32_16x16x32_f16, fp32 accumulation; tcnn's FullyFusedMLP arithmetic): the gather waves hand over fp16
+// features (16 bytes per lane and sample instead of 32), blended on packed fp16 pairs when the table is a half table.
 // HALF: half2 table entries (CN_TABLE_F16).  GENERIC: per-level index records (tcnn layout), see lane_level_rec.
-template <bool PER_SAMPLE, bool BF16 = false, bool HALF = false, bool GENERIC = false>
+template <bool PER_SAMPLE, int MM = MM_FP32, bool HALF = false, bool GENERIC = false>
 __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A) {
+  constexpr bool BF16 = MM == MM_BF16, F16 = MM == MM_F16;
+  // TEAM (fp16 products, half table): the gather waves of two neighbouring pairs work as a team -- see the gather role
+  constexpr bool TEAM = F16 && HALF && (SPLIT_MPG == 1) && (SPLIT_G % 2 == 0) && !CN_ABLATE_GATHER;
   extern __shared__ __align__(16) float lds[];
   constexpr int OFF_EXT = BLOB_FLOATS + SPLIT_PAIRS * PAIR_SCRATCH;  // BF16 only
   {
@@ -189,12 +210,16 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
   SplitRay ray;
   ray.valid = false;
   SplitRay gray[SPLIT_MPG];  // gather wave: the rays of the matrix waves it feeds
+
 #pragma unroll
   for (int m = 0; m < SPLIT_MPG; ++m) gray[m].valid = false;
   CompositeState st;
   float my_dlogit = 0.f, my_sel = 0.f, my_sem = 0.f, my_r = 0.f, my_g = 0.f, my_b = 0.f;
   bool ray_stopped = false;  // matrix wave: this ray was terminated early (cn_render_opts.early_stop_transmittance)
 
+#ifdef CN_SPLIT_GATHER_PRIO  // A/B: gather waves win the VALU arbitration, so their loads are issued before the matrix waves' MLPs run
+  if (!matrix_role) __builtin_amdgcn_s_setprio(CN_SPLIT_GATHER_PRIO);
+#endif
   // One loop for both roles (same trip count, one workgroup barrier per half-step at its end).
   for (long long step = 0; step <= total; ++step) {
     if (!matrix_role) {
@@ -204,6 +229,104 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
       int lane = lane0;
       asm volatile("" : "+v"(lane));
       const int g = lane >> 4, j = lane & 15;
+      if constexpr (TEAM) {
+        // ---- team gather -------------------------------------------------------------------------------------------------
+        // With fp16 products the kernel runs at the rate the CU's L1 looks up cache lines for per-lane-addressed loads: one
+        // lane per clock, TWO when the lanes of a pair (2k, 2k + 1) of an 8-byte load fall into one line, four when a whole
+        // quad does (tools/gather_rate_microbench.hip).  Consecutive samples of ONE ray are 5e-3 of the box apart and share
+        // cells on the coarsest levels only; the same sample of two NEIGHBOURING pixels is 5e-4 apart and shares its cell --
+        // hence its table entries -- up to level 12 or so.  So the gather waves of pairs 2T and 2T + 1 (neighbouring pixels:
+        // consecutive schedule slots) split the work the other way round: each handles 16 of the half-step's 32 samples
+        // (one column tile) for BOTH rays, the two rays in adjacent lanes, and writes the features into the owning pair's
+        // ring in the layout its matrix wave reads.  Arithmetic per (ray, sample) is unchanged.
+        if (step < total) {
+          const long long qi = step / nhalf;
+          const int k = (int)(step - qi * nhalf);
+          const int pair0 = wave & ~1, sub = wave & 1;
+          // the two rays' parameters live in this wave's own (otherwise unused) gather-edge area of LDS, 16 dwords per ray
+          // {o, d, s(near), s(far), bins pointer, chunk, valid}: kept in scalar registers for a whole ray they spill
+          float* trec = ring + 2 * XCH_FLOATS + 64 + 68;
+          if (k == 0) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              SplitRay tr;
+              split_ray_setup(A, q_first + pair0 + t + qi * stride, items, xcd, striped, rows, cw, first_row, per_xcd,
+                              chunks_per_item_ray, tr);
+              __builtin_amdgcn_wave_barrier();
+              if (lane == 0) {
+                float* w = trec + 16 * t;
+                const unsigned long long bp = reinterpret_cast<unsigned long long>(tr.bins);
+                w[0] = tr.ox; w[1] = tr.oy; w[2] = tr.oz; w[3] = tr.dx;
+                w[4] = tr.dy; w[5] = tr.dz; w[6] = tr.sn; w[7] = tr.sf;
+                reinterpret_cast<unsigned*>(w)[8] = (unsigned)bp;
+                reinterpret_cast<unsigned*>(w)[9] = (unsigned)(bp >> 32);
+                reinterpret_cast<int*>(w)[10] = tr.chunk;
+                reinterpret_cast<int*>(w)[11] = tr.valid ? 1 : 0;
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+          }
+          float* ring0 = lds + BLOB_FLOATS + pair0 * PAIR_SCRATCH;
+          bool act[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            act[t] = reinterpret_cast<const int*>(trec + 16 * t)[11] != 0 &&
+                     !(!PER_SAMPLE && A.early_stop > 0.f &&
+                       reinterpret_cast<volatile int*>(ring0 + t * PAIR_SCRATCH + PAIR_FLAGS)[2] == (int)qi);
+          if (act[0] || act[1]) {
+            const int mcol = lane & 15, rsel = mcol & 1, sidx = mcol >> 1;
+            const bool active = rsel ? act[1] : act[0];
+            if (active) {
+              const f32x4 ra = *reinterpret_cast<const f32x4*>(trec + 16 * rsel);
+              const f32x4 rb = *reinterpret_cast<const f32x4*>(trec + 16 * rsel + 4);
+              const u32x4v rc = *reinterpret_cast<const u32x4v*>(trec + 16 * rsel + 8);
+              const float rox = ra.x, roy = ra.y, roz = ra.z, rdx = ra.w, rdy = rb.x, rdz = rb.y, rsn = rb.z, rsf = rb.w;
+              const float* rbins = reinterpret_cast<const float*>((unsigned long long)rc.x | ((unsigned long long)rc.y << 32));
+              const int chunk = PER_SAMPLE ? (int)rc.z : (k >> 1), half = k & 1;
+              auto edge = [&](int i) -> float {
+                i = min(i, S);
+                return rbins ? rbins[i] : spacing_to_euclid(A.spacing, linspace01(i, S + 1), rsn, rsf);
+              };
+              float px[2], py[2], pz[2];
+              bool sel[2];
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {  // this wave's column tile: samples 16 sub + 8 h + sidx of the half-step
+                const int i0 = chunk * 64 + 32 * half + 16 * sub + 8 * h + sidx;
+                const float mid = (edge(i0) + edge(i0 + 1)) / 2.f;
+                px[h] = rox + rdx * mid;
+                py[h] = roy + rdy * mid;
+                pz[h] = roz + rdz * mid;
+                sel[h] = normalize_position(A.scene, px[h], py[h], pz[h]);
+              }
+              u32x4v featp[2];
+              const f32x4 lvl_scale = *reinterpret_cast<const f32x4*>(lds + OFF_SCALE + 4 * g);
+              const float pos_off = GENERIC ? A.grid.pos_offset : 0.f;
+              PkLoads cur = hash_level_pk_issue<GENERIC>(A.grid.table, lane_level_rec<GENERIC>(lds + OFF_LVL, A.grid, 4 * g, lvl_scale[0]),
+                                                         pos_off, px[0], py[0], pz[0]);
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                PkLoads nxt;
+                if (u < 7) {
+                  const int qn = (u + 1) >> 1, hn = (u + 1) & 1;
+                  nxt = hash_level_pk_issue<GENERIC>(A.grid.table,
+                                                     lane_level_rec<GENERIC>(lds + OFF_LVL, A.grid, 4 * g + qn, lvl_scale[qn]), pos_off,
+                                                     px[hn], py[hn], pz[hn]);
+                }
+                featp[u & 1][u >> 1] = pk_pin(hash_level_pk_blend(cur));
+                if (u < 7) cur = nxt;
+              }
+              float* xs = ring0 + rsel * PAIR_SCRATCH + (int)(step & 1) * XCH_FLOATS;
+              f16x8* xh = reinterpret_cast<f16x8*>(xs);
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                xh[sub * 64 + 16 * g + 8 * h + sidx] = __builtin_bit_cast(f16x8, featp[h]);
+                if (g == 0) xs[XCH_FLOATS - 64 + 16 * sub + 8 * h + sidx] = sel[h] ? 1.f : 0.f;  // selector of column (sub, 8 h + sidx)
+              }
+            }
+          }
+        }
+      } else
       if (step < total) {
         const long long qi = step / nhalf;
         const int k = (int)(step - qi * nhalf);
@@ -234,13 +357,38 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
               sel[c] = normalize_position(A.scene, px[c], py[c], pz[c]);
             }
             f32x4 feat[2][2];
+            u32x4v featp[2];  // F16: the packed fp16 pairs of the four levels = the MFMA B operand as it stands
             const f32x4 lvl_scale = *reinterpret_cast<const f32x4*>(lds + OFF_SCALE + 4 * g);
+            if constexpr (F16 && HALF && !CN_ABLATE_GATHER) {
+              // pair gathers (hash_level_pk_issue): the eight (level, sample) units in program order, unit n + 1's loads
+              // issued before unit n is blended
+              const float pos_off = GENERIC ? A.grid.pos_offset : 0.f;
+              PkLoads cur = hash_level_pk_issue<GENERIC>(A.grid.table, lane_level_rec<GENERIC>(lds + OFF_LVL, A.grid, 4 * g, lvl_scale[0]),
+                                                         pos_off, px[0], py[0], pz[0]);
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                const int q = u >> 1, c = u & 1;
+                PkLoads nxt;
+                if (u < 7) {
+                  const int qn = (u + 1) >> 1, cn_ = (u + 1) & 1;
+                  nxt = hash_level_pk_issue<GENERIC>(A.grid.table,
+                                                     lane_level_rec<GENERIC>(lds + OFF_LVL, A.grid, 4 * g + qn, lvl_scale[qn]), pos_off,
+                                                     px[cn_], py[cn_], pz[cn_]);
+                }
+                featp[c][q] = pk_pin(hash_level_pk_blend(cur));
+                if (u < 7) cur = nxt;
+              }
+            } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const Lvl lv = lane_level_rec<GENERIC>(lds, A.grid, 4 * g + q, lvl_scale[q]);
+              const Lvl lv = lane_level_rec<GENERIC>(lds + OFF_LVL, A.grid, 4 * g + q, lvl_scale[q]);
               const float pos_off = GENERIC ? A.grid.pos_offset : 0.f;
 #pragma unroll
               for (int c = 0; c < 2; ++c) {
+                if constexpr (F16 && HALF) {  // (timing-only ablation build)
+                  featp[c][q] = __builtin_bit_cast(unsigned, px[c] * lv.scale + py[c]) ^ __builtin_bit_cast(unsigned, pz[c]);
+                  continue;
+                }
 #if CN_ABLATE_GATHER  // timing-only build: no table reads
                 const float2 f = make_float2(px[c] * lv.scale, py[c] + pz[c]);
 #elif defined(CN_ABLATE_GATHER_LEVELS)  // timing-only build: levels below CN_ABLATE_GATHER_LEVELS read no table entry
@@ -250,6 +398,11 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
 #else
                 const float2 f = hash_level_sc<HALF, GENERIC>(A.grid.table, lv, pos_off, px[c], py[c], pz[c]);
 #endif
+                if constexpr (F16) {  // float table: blended in fp32, handed over as fp16
+                  f16x2 hp = {(_Float16)f.x, (_Float16)f.y};
+                  featp[c][q] = __builtin_bit_cast(unsigned, hp);
+                  continue;
+                }
                 if (q == 0) { feat[c][0].x = f.x; feat[c][0].y = f.y; }
                 if (q == 1) { feat[c][0].z = f.x; feat[c][0].w = f.y; }
                 if (q == 2) { feat[c][1].x = f.x; feat[c][1].y = f.y; }
@@ -258,12 +411,20 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
               if ((q + 1) % CN_SPLIT_LEVELS_IN_FLIGHT == 0)
                 __builtin_amdgcn_sched_barrier(0);  // bound the gathers in flight (16 per lane and level)
             }
+            }
             float* xs = gring + (int)(step & 1) * XCH_FLOATS;
-            f32x4* xv = reinterpret_cast<f32x4*>(xs);
-            xv[0 * 64 + lane] = feat[0][0];
-            xv[1 * 64 + lane] = feat[0][1];
-            xv[2 * 64 + lane] = feat[1][0];
-            xv[3 * 64 + lane] = feat[1][1];
+            if constexpr (F16) {
+              f16x8* xh = reinterpret_cast<f16x8*>(xs);
+#pragma unroll
+              for (int c = 0; c < 2; ++c)
+                xh[c * 64 + lane] = __builtin_bit_cast(f16x8, featp[c]);
+            } else {
+              f32x4* xv = reinterpret_cast<f32x4*>(xs);
+              xv[0 * 64 + lane] = feat[0][0];
+              xv[1 * 64 + lane] = feat[0][1];
+              xv[2 * 64 + lane] = feat[1][0];
+              xv[3 * 64 + lane] = feat[1][1];
+            }
             xs[XCH_FLOATS - 64 + lane] = (sel[0] ? 1.f : 0.f) + (sel[1] ? 2.f : 0.f);
           }
           __builtin_amdgcn_sched_barrier(0);  // one consumer's half-step at a time
@@ -274,7 +435,6 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
       int lane = lane0;
       asm volatile("" : "+v"(lane));
       const int g = lane >> 4, j = lane & 15;
-      (void)j;
       const long long hs = step - 1;
       const long long qi = hs / nhalf;
       const int k = (int)(hs - qi * nhalf);
@@ -292,6 +452,10 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
           }
           float sh[16];
           sh_deg4(sx, sy, sz, sh);
+          if constexpr (F16) {  // the colour network's inputs are fp16 values (tcnn casts them)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sh[q] = (float)(_Float16)sh[q];
+          }
           const long long row = A.app_per_camera ? A.cam_idx[ray.r] : 0;
           float bias = A.app_bias[row * 64 + lane];
           const f32x4* wsh = reinterpret_cast<const f32x4*>(lds + OFF_WSH + lane * 16);
@@ -319,17 +483,43 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
         const float* xs = ring + (int)(hs & 1) * XCH_FLOATS;
         const f32x4* xv = reinterpret_cast<const f32x4*>(xs);
         f32x4 feat[2][2];
-        feat[0][0] = xv[0 * 64 + lane];
-        feat[0][1] = xv[1 * 64 + lane];
-        feat[1][0] = xv[2 * 64 + lane];
-        feat[1][1] = xv[3 * 64 + lane];
-        const int selbits = (int)xs[XCH_FLOATS - 64 + lane];
+        f16x8 fb[2];  // F16: the features as the gather wave converted them
+        if constexpr (F16) {
+          fb[0] = reinterpret_cast<const f16x8*>(xs)[0 * 64 + lane];
+          fb[1] = reinterpret_cast<const f16x8*>(xs)[1 * 64 + lane];
+        } else {
+          feat[0][0] = xv[0 * 64 + lane];
+          feat[0][1] = xv[1 * 64 + lane];
+          feat[1][0] = xv[2 * 64 + lane];
+          feat[1][1] = xv[3 * 64 + lane];
+        }
+        // selector of this lane's own sample: the gather wave's bit pair per lane, or (TEAM) one float per column
+        const int selbits = TEAM ? ((xs[XCH_FLOATS - 64 + 16 * (g & 1) + j] != 0.f) ? 3 : 0) : (int)xs[XCH_FLOATS - 64 + lane];
         // ---- base MLP (32 -> 64 ReLU -> 16) ---------------------------------------------------------------------------------
         f32x4 h[4][2];
         f32x4 o16[2];
         // image block b: [hi | lo][lane][8 bf16]; 18 blocks sit in the fp32 A region, 4 behind the pair scratch
         auto blk = [&](int b) { return reinterpret_cast<const bf16x8*>(b < 18 ? lds + OFF_A0 + b * 512 : lds + OFF_EXT + (b - 18) * 512); };
-        if constexpr (BF16) {
+        auto blkh = [&](int b) { return reinterpret_cast<const f16x8*>(lds + OFF_A0 + b * 256)[lane]; };  // F16 image block
+        if constexpr (F16) {
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_B0 + 16 * mt + 4 * g);
+            const f16x8 a = blkh(mt);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) h[mt][c] = relu4(mfma_f16(a, fb[c], b));
+          }
+          const f32x4 b1 = *reinterpret_cast<const f32x4*>(lds + OFF_B1 + 4 * g);
+          f32x4 acc[2] = {b1, b1};
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb) {
+            const f16x8 a = blkh(4 + kb);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[c] = mfma_f16(a, cvt_f16x8(h[2 * kb][c], h[2 * kb + 1][c]), acc[c]);
+          }
+          o16[0] = acc[0];
+          o16[1] = acc[1];
+        } else if constexpr (BF16) {
           bf16x8 fh[2], fl[2];
 #pragma unroll
           for (int c = 0; c < 2; ++c) split_bf16(feat[c][0], feat[c][1], fh[c], fl[c]);
@@ -402,17 +592,27 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
         // ---- semantics ------------------------------------------------------------------------------------------------------
         float sem_part[2] = {0.f, 0.f};
         bf16x8 oh[2], ol[2];  // BF16: the 16 base outputs as a K block of 32 (upper half zero)
+        f16x8 o16h[2];        // F16: the same
         if constexpr (BF16) {
           const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int c = 0; c < 2; ++c) split_bf16(o16[c], zero4, oh[c], ol[c]);
+        }
+        if constexpr (F16) {
+          const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < 2; ++c) o16h[c] = cvt_f16x8(o16[c], zero4);
         }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_BS0 + 16 * mt + 4 * g);
           const f32x4 wf = *reinterpret_cast<const f32x4*>(lds + OFF_WF + 16 * mt + 4 * g);
           f32x4 acc[2] = {b, b};
-          if constexpr (BF16) {
+          if constexpr (F16) {
+            const f16x8 a = blkh(6 + mt);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[c] = mfma_f16(a, o16h[c], acc[c]);
+          } else if constexpr (BF16) {
             const bf16x8 ah = blk(6 + mt)[lane], al = blk(6 + mt)[64 + lane];
 #pragma unroll
             for (int c = 0; c < 2; ++c) acc[c] = mfma_split(ah, al, oh[c], ol[c], acc[c]);
@@ -432,7 +632,11 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
         for (int mt = 0; mt < 4; ++mt) {
           const f32x4 cb = *reinterpret_cast<const f32x4*>(scratch + 16 * mt + 4 * g);
           f32x4 acc[2] = {cb, cb};
-          if constexpr (BF16) {
+          if constexpr (F16) {
+            const f16x8 a = blkh(10 + mt);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc[c] = mfma_f16(a, o16h[c], acc[c]);
+          } else if constexpr (BF16) {
             const bf16x8 ah = blk(10 + mt)[lane], al = blk(10 + mt)[64 + lane];
 #pragma unroll
             for (int c = 0; c < 2; ++c) acc[c] = mfma_split(ah, al, oh[c], ol[c], acc[c]);
@@ -450,17 +654,31 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
         // ---- colour layer 1 + rgb head -------------------------------------------------------------------------------------------
         float rgb_part[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
         bf16x8 ch[2][2], cl[2][2];  // BF16: [K block][column tile] operands of colour layer 1
+        f16x8 c1h[2][2];  // F16: the same
         if constexpr (BF16) {
 #pragma unroll
           for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int c = 0; c < 2; ++c) split_bf16(c1[2 * kb][c], c1[2 * kb + 1][c], ch[kb][c], cl[kb][c]);
         }
+        if constexpr (F16) {
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) c1h[kb][c] = cvt_f16x8(c1[2 * kb][c], c1[2 * kb + 1][c]);
+        }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           const f32x4 b = *reinterpret_cast<const f32x4*>(lds + OFF_BC1 + 16 * mt + 4 * g);
           f32x4 acc[2] = {b, b};
-          if constexpr (BF16) {
+          if constexpr (F16) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+              const f16x8 a = blkh(14 + 2 * mt + kb);
+#pragma unroll
+              for (int c = 0; c < 2; ++c) acc[c] = mfma_f16(a, c1h[kb][c], acc[c]);
+            }
+          } else if constexpr (BF16) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
               const bf16x8 ah = blk(14 + 2 * mt + kb)[lane], al = blk(14 + 2 * mt + kb)[64 + lane];

@@ -237,9 +237,11 @@ class FruitModel:
 
     def _matrix_precision(self) -> int:
         mode = getattr(self.config, "matrix_precision", "fp32")
-        if mode not in ("fp32", "split_bf16"):
-            raise ValueError(f"matrix_precision {mode!r}: 'fp32' or 'split_bf16'")
-        return L.MATRIX_SPLIT_BF16 if (mode == "split_bf16" and not self.training) else L.MATRIX_FP32
+        if mode not in ("fp32", "split_bf16", "f16"):
+            raise ValueError(f"matrix_precision {mode!r}: 'fp32', 'split_bf16' or 'f16'")
+        if self.training or mode == "fp32":
+            return L.MATRIX_FP32
+        return L.MATRIX_SPLIT_BF16 if mode == "split_bf16" else L.MATRIX_F16
 
     def _opts(self, num_samples: int, density_only: bool = False) -> L.RenderOpts:
         bg_mode, bg = self._background()

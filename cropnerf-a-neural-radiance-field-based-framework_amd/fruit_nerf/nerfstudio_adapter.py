@@ -146,11 +146,27 @@ class FruitModel(Model):
             tr.set_anneal(step)
 
         def step_cb(step):
+            # AFTER_TRAIN_ITERATION runs behind nerfstudio's optimizer_scaler_step_all: the optimiser has moved the entries
+            # that own a tcnn parameter -- copy them to the alias entries before the next forward reads the table
+            self._tie_tcnn_parameters()
             tr._sampler_step = step
             tr._steps_since_update += 1
 
         return [TrainingCallback([TrainingCallbackLocation.BEFORE_TRAIN_ITERATION], set_anneal, update_every_num_iters=1),
                 TrainingCallback([TrainingCallbackLocation.AFTER_TRAIN_ITERATION], step_cb, update_every_num_iters=1)]
+
+    def _tie_tcnn_parameters(self) -> None:
+        """tcnn layout: several table entries of a dense level may stand for ONE tcnn parameter (``tcnn_grid.hip``).  Their
+        gradients are folded into the owning entry before the optimiser step (``_run_training_step``); after any write to
+        the tables -- an optimiser step of nerfstudio's own ``torch.optim``, a loaded state dict -- the owners' values are
+        copied back to the aliases, as ``FruitTrainer.optimizer_step`` does on this package's own training path."""
+        tr = self.trainer
+        if not tr.tcnn:
+            return
+        from .. import ops
+
+        for spec, key in tr._tcnn_tables:
+            ops.tcnn_grid_tie_parameters(spec, self.hip.params[key])
 
     def setup_inference(self, render_rgb, num_inference_samples):
         self.hip.setup_inference(render_rgb, num_inference_samples)
@@ -252,6 +268,7 @@ class FruitModel(Model):
                 self.hip.params[k].copy_(state[k].to(self.hip.device))
             elif strict:
                 raise KeyError(k)
+        self._tie_tcnn_parameters()  # a torch-named state dict written into a tcnn-layout model: aliases follow their owners
 
 
 def _make_model_config() -> Type:

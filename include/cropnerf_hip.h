@@ -55,6 +55,7 @@ typedef void* cn_stream_t; /* hipStream_t */
 /* background modes of RGBRenderer (fruit_nerf/fruit_nerf.py:170; scripts/semantic_projection.py:158,169) */
 #define CN_MATRIX_FP32 0
 #define CN_MATRIX_SPLIT_BF16 1
+#define CN_MATRIX_F16 2
 
 #define CN_BG_LAST_SAMPLE 0
 #define CN_BG_COLOR 1
@@ -173,7 +174,14 @@ typedef struct cn_render_opts {
    * (v_mfma_f32_16x16x4_f32).  CN_MATRIX_SPLIT_BF16 (1): every operand split into bf16 hi + lo, a.b ~ a_hi.b_hi +
    * a_hi.b_lo + a_lo.b_hi on v_mfma_f32_16x16x32_bf16 with fp32 accumulation -- about 16 mantissa bits per product,
    * i.e. between the reference's two own precisions (fp16 with tcnn, fp32 with torch), at a third of the matrix time.
-   * Honoured by the producer/consumer render kernel (batches that fill the device); elsewhere products stay fp32. */
+   * Honoured by the producer/consumer render kernel (batches that fill the device); elsewhere products stay fp32.
+   * CN_MATRIX_F16 (2): the reference's OWN arithmetic class -- tiny-cuda-nn's FullyFusedMLP under mixed precision
+   * (fruit_nerf/fruit_field.py:95,125-167 build every module with implementation="tcnn"; fruit_nerf_config.py:35
+   * mixed_precision=True): weights and layer inputs rounded to fp16 (a no-op for the weights of an imported tcnn
+   * checkpoint, which are fp16 values already), products on v_mfma_f32_16x16x32_f16 with fp32 accumulation (tcnn
+   * accumulates in fp16: this is at least as precise), the hash-grid interpolation of a half table carried out on
+   * packed fp16 pairs as tcnn's kernel_grid does.  cn_render_rays / cn_render_samples then run the same kernel
+   * whatever the batch size, so that a ray's result does not depend on the call it is part of. */
   int32_t matrix_precision;
 } cn_render_opts;
 

@@ -46,23 +46,47 @@ def test_binding_covers_every_declared_symbol(lib):
     assert sorted(_lib.SIGNATURES) == _declared()
 
 
+# ctypes mirror -> C struct name, for every struct that crosses the boundary by pointer
+BY_POINTER_STRUCTS = {"Grid": "cn_grid", "TcnnGridPlan": "cn_tcnn_grid_plan", "Mlp": "cn_mlp", "FieldParams": "cn_field_params",
+                      "DensityParams": "cn_density_params", "ProposalLevelOut": "cn_proposal_level_out",
+                      "Scene": "cn_scene", "RenderOpts": "cn_render_opts"}
+
+
 def test_struct_layout_matches_header():
-    """sizeof of the by-pointer structs as the C compiler sees them == the ctypes mirrors."""
+    """sizeof AND the offset of every field of all eight by-pointer structs, as the C compiler lays out the header, against
+    the ctypes mirrors of ``_lib.py`` -- the C program is generated from the mirrors' ``_fields_``, so a field that is
+    missing, renamed or reordered on either side fails to compile or to compare."""
     import subprocess
     import tempfile
 
     from cropnerf_amd import _lib
 
-    src = f'#include "{HEADER}"\n#include <stdio.h>\nint main(){{printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(cn_grid),' \
-          " sizeof(cn_mlp), sizeof(cn_field_params), sizeof(cn_density_params), sizeof(cn_scene), sizeof(cn_render_opts));}\n"
+    lines, expect = [], []
+    for py_name, c_name in BY_POINTER_STRUCTS.items():
+        cls = getattr(_lib, py_name)
+        lines.append(f'printf("%zu\\n", sizeof({c_name}));')
+        expect.append((f"sizeof({c_name})", ctypes.sizeof(cls)))
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("%zu\\n", offsetof({c_name}, {fname}));')
+            expect.append((f"offsetof({c_name}, {fname})", getattr(cls, fname).offset))
+            lines.append(f'printf("%zu\\n", sizeof((({c_name}*)0)->{fname}));')
+            expect.append((f"sizeof({c_name}.{fname})", getattr(cls, fname).size))
+    src = f'#include "{HEADER}"\n#include <stddef.h>\n#include <stdio.h>\nint main(void){{\n' + "\n".join(lines) + "\nreturn 0;}\n"
     with tempfile.TemporaryDirectory() as d:
         c = Path(d) / "s.c"
         c.write_text(src)
-        subprocess.run(["gcc", str(c), "-o", str(Path(d) / "s")], check=True)
+        subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", str(c), "-o", str(Path(d) / "s")], check=True)
         out = subprocess.run([str(Path(d) / "s")], check=True, capture_output=True, text=True).stdout.split()
-    sizes = [ctypes.sizeof(x) for x in (_lib.Grid, _lib.Mlp, _lib.FieldParams, _lib.DensityParams, _lib.Scene,
-                                        _lib.RenderOpts)]
-    assert [int(v) for v in out] == sizes
+    assert len(out) == len(expect)
+    wrong = [(what, int(got), want) for (what, want), got in zip(expect, out) if int(got) != want]
+    assert not wrong, f"C layout differs from the ctypes mirror: {wrong}"
+    # and the header declares no field the mirrors lack: count the members of each struct body
+    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    for py_name, c_name in BY_POINTER_STRUCTS.items():
+        body = re.search(r"typedef struct " + c_name + r"\s*\{(.*?)\}\s*" + c_name + r"\s*;", text, flags=re.S)
+        assert body, f"{c_name} not found in the header"
+        members = [m for m in body.group(1).split(";") if m.strip()]
+        assert len(members) == len(getattr(_lib, py_name)._fields_), f"{c_name}: {len(members)} members in the header"
 
 
 def test_error_path_without_gpu(lib):

@@ -199,3 +199,45 @@ def test_bench_two_ranks_rehearsal():
     # value = the samples BOTH ranks rendered per step / the slowest rank's time
     assert abs(d["ms_per_step"] * 1e-3 * d["value"] - 2 * 65536 * 192) / (2 * 65536 * 192) < 1e-6
     assert d["roofline"]["kernel"].startswith("render_")
+
+
+@pytest.mark.gpu
+def test_bench_plain_invocation_launches_its_own_ranks():
+    """``python3 bench.py --gpus 2`` with no launcher around it (WORLD_SIZE unset): bench.py starts the two ranks itself as
+    fresh child processes under ``torch.distributed.run`` before it touches the GPU, relays rank 0's single JSON line and
+    the children's exit code (rehearsal environment as above: both ranks on this box's one GPU over gloo)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(BENCH_REHEARSE_ON_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["gather_check"]["ranks_in_buffer"] == 2
+    assert "launching" in p.stderr
+
+
+def test_bench_self_launch_relays_the_exit_code_without_touching_the_gpu(monkeypatch):
+    """CPU tier: the parent of a plain ``bench.py --gpus 2`` never imports a GPU runtime before it spawns its ranks, passes
+    its own arguments through and returns the launcher's exit code (here the ranks fail at once: this tier has no GPU)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("CPU-tier check of the failure path")
+    assert p.returncode != 0
+    assert "launching -m torch.distributed.run --nnodes=1 --nproc-per-node=2" in p.stderr
+    assert "needs an MI355X" in p.stderr  # every rank refused for the same reason the N = 1 run does

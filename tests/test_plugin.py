@@ -99,12 +99,8 @@ def test_method_specifications_are_nerfstudio_types():
     assert "plugin-types-ok" in out
 
 
-@pytest.mark.gpu
-def test_plugin_model_trains_through_nerfstudio_style_optimizers():
-    """Pipeline -> model construction through the config ``setup()`` chain, ``get_param_groups`` as ``nn.Parameter`` views of
-    the flat buffers, and train iterations driven the way nerfstudio's Trainer drives them (``Optimizers`` of
-    ``torch.optim.Adam`` + ``loss.backward()``), against this package's own ``FruitTrainer`` on the same batches."""
-    out = _run("""
+# a small fruit_nerf pipeline configuration with a synthetic datamanager (shared by the GPU tests below)
+_PIPE_PRELUDE = """
         import functools, torch
         from nerfstudio.engine.optimizers import Optimizers
         from nerfstudio.engine.callbacks import TrainingCallbackAttributes, TrainingCallbackLocation
@@ -150,6 +146,15 @@ def test_plugin_model_trains_through_nerfstudio_style_optimizers():
             num_proposal_samples_per_ray=(64, 32), num_nerf_samples_per_ray=24)
         for k, v in small.items():
             setattr(cfg.pipeline.model, k, v)
+"""
+
+
+@pytest.mark.gpu
+def test_plugin_model_trains_through_nerfstudio_style_optimizers():
+    """Pipeline -> model construction through the config ``setup()`` chain, ``get_param_groups`` as ``nn.Parameter`` views of
+    the flat buffers, and train iterations driven the way nerfstudio's Trainer drives them (``Optimizers`` of
+    ``torch.optim.Adam`` + ``loss.backward()``), against this package's own ``FruitTrainer`` on the same batches."""
+    out = _run(_PIPE_PRELUDE + """
         pipe = cfg.pipeline.setup(device="cuda", test_mode="val")
         assert type(pipe).__name__ == "FruitPipeline" and type(pipe.model).__name__ == "FruitModel"
         groups = pipe.get_param_groups()
@@ -204,3 +209,61 @@ def test_plugin_model_trains_through_nerfstudio_style_optimizers():
         print("plugin-train-ok", skipped)
     """, timeout=900)
     assert "plugin-train-ok" in out
+
+
+@pytest.mark.gpu
+def test_tcnn_alias_entries_follow_their_owners_under_nerfstudio_optimizers():
+    """implementation="tcnn" through the plugin: nerfstudio's own ``torch.optim.Adam`` steps the ``nn.Parameter`` views, so
+    nothing inside the optimiser knows that several entries of a dense level stand for one tcnn parameter.  After every
+    iteration (AFTER_TRAIN_ITERATION callback) the alias entries must equal their owners -- otherwise samples in the upper
+    half-cell of a dense level read stale values and the exported tcnn vector is not what was rendered."""
+    out = _run(_PIPE_PRELUDE + """
+        from cropnerf_amd import ops
+        cfg.pipeline.model.implementation = "tcnn"
+        pipe = cfg.pipeline.setup(device="cuda", test_mode="val")
+        model = pipe.model
+        tr = model.trainer
+        assert tr.tcnn and len(tr._tcnn_tables) == 3
+        groups = pipe.get_param_groups()
+        opt = Optimizers(cfg.optimizers, groups)
+        callbacks = pipe.get_training_callbacks(TrainingCallbackAttributes(optimizers=opt, pipeline=pipe))
+        pipe.train()
+
+        def tied(spec, table):
+            # pack(unpack(table)) gives every entry the value of the tcnn parameter it stands for: the table is tied iff
+            # the round trip returns it unchanged
+            return torch.equal(ops.tcnn_grid_pack(spec, ops.tcnn_grid_unpack(spec, table), torch.float32), table)
+
+        before = {key: model.hip.params[key].clone() for _, key in tr._tcnn_tables}
+        assert all(tied(spec, model.hip.params[key]) for spec, key in tr._tcnn_tables)
+        for step in range(3):
+            for cb in callbacks: cb.run_callback_at_location(step, TrainingCallbackLocation.BEFORE_TRAIN_ITERATION)
+            opt.zero_grad_all()
+            _, loss_dict, metrics = pipe.get_train_loss_dict(step)
+            functools.reduce(torch.add, loss_dict.values()).backward()
+            opt.optimizer_step_all(); opt.scheduler_step_all(step)
+            if step == 0:  # the hazard itself: Adam has moved the owners, the aliases still hold the old values
+                spec, key = tr._tcnn_tables[0]
+                assert not tied(spec, model.hip.params[key])
+            for cb in callbacks: cb.run_callback_at_location(step, TrainingCallbackLocation.AFTER_TRAIN_ITERATION)
+            for spec, key in tr._tcnn_tables:
+                assert tied(spec, model.hip.params[key]), (step, key)
+        for _, key in tr._tcnn_tables:
+            assert not torch.equal(before[key], model.hip.params[key]), key  # training did move the tables
+        # state dict -> a fresh model: what is rendered is what was exported, and a torch-named load re-ties as well
+        sd = model.state_dict()
+        assert "field.mlp_base_grid.tcnn_encoding.params" in sd
+        spec, key = tr._tcnn_tables[0]
+        packed = ops.tcnn_grid_unpack(spec, model.hip.params[key])
+        assert torch.equal(sd["field.mlp_base_grid.tcnn_encoding.params"].float().cuda(), packed)
+        torch_named = {k: v.detach().clone() for k, v in model.hip.params.items()}
+        plan = spec.plan()
+        b0, res0 = int(plan.level_bits[0]), int(plan.resolution[0])
+        alias = res0 | (3 << b0) | (5 << (2 * b0))     # (res, 3, 5) stands for the parameter of (0, 4, 5)
+        torch_named[key][alias] += 1.0                  # a stale alias in the incoming state
+        from cropnerf_amd.fruit_nerf import nerfstudio_io as NIO
+        model.load_state_dict(NIO.nerfstudio_names(torch_named), strict=False)
+        assert tied(spec, model.hip.params[key])
+        print("tcnn-tie-ok")
+    """, timeout=900)
+    assert "tcnn-tie-ok" in out

@@ -44,11 +44,13 @@ def main():
     res = {}
     res["torch_f32"] = time_mode(ops, fh, scene, batches, args.iters)
     res["torch_f32_bf16mm"] = time_mode(ops, fh, scene, batches, args.iters, matrix_precision=L.MATRIX_SPLIT_BF16)
+    res["torch_f32_f16mm"] = time_mode(ops, fh, scene, batches, args.iters, matrix_precision=L.MATRIX_F16)
     ph = dict(params)
     ph["field.mlp_base_grid.hash_table"] = params["field.mlp_base_grid.hash_table"].to(torch.float16)
     fhh = ops.FieldHandle(ph, fspec)
     res["torch_f16"] = time_mode(ops, fhh, scene, batches, args.iters)
     res["torch_f16_bf16mm"] = time_mode(ops, fhh, scene, batches, args.iters, matrix_precision=L.MATRIX_SPLIT_BF16)
+    res["torch_f16_f16mm"] = time_mode(ops, fhh, scene, batches, args.iters, matrix_precision=L.MATRIX_F16)
     # tcnn layout: same MLPs, a random table of that layout
     tcfg = config.FruitNerfModelConfig(num_nerf_samples_per_ray=bench.S, implementation="tcnn")
     tf = tcfg.field_spec(num_images=bench.NUM_CAMERAS)
@@ -60,6 +62,7 @@ def main():
         fht = ops.FieldHandle(pt, tf)
         res[name] = time_mode(ops, fht, scene, batches, args.iters)
         res[name + "_bf16mm"] = time_mode(ops, fht, scene, batches, args.iters, matrix_precision=L.MATRIX_SPLIT_BF16)
+        res[name + "_f16mm"] = time_mode(ops, fht, scene, batches, args.iters, matrix_precision=L.MATRIX_F16)
     for k, v in res.items():
         print(f"{k:22s} {v:7.3f} ms/batch  {bench.R * bench.S / v / 1e6:8.1f} Msamples/s", flush=True)
 

@@ -3,9 +3,10 @@ averages of every counter for the dominant render kernel + its dispatch info) an
 import csv, glob, json, os, shutil, sys
 
 tag = sys.argv[1]
+suffix = sys.argv[2] if len(sys.argv) > 2 else "pmc_render_fused"  # variants of the render: "pmc_variant" (bench.py reads *_pmc_render*)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"pmc_{tag}")
-KERNELS = ("render_split_kernel", "render_fused_kernel<false, false>")
+KERNELS = ("render_split_kernel", "render_fused_kernel<false, false>", "render_f16_kernel")
 out = {}
 for f in glob.glob(os.path.join(src, "*", "**", "*counter_collection.csv"), recursive=True):
     acc = {}
@@ -38,6 +39,6 @@ except Exception:  # noqa: BLE001
     out["commit"] = os.environ.get("CN_PROFILE_COMMIT")
 out["note"] = ("per-launch averages over the launches of the named kernel in `bench.py --steps 3 --warmup 1 "
                "--no-cpu-baseline --no-secondary`, one rocprofv3 --pmc pass per counter group; FETCH_SIZE / WRITE_SIZE in KiB")
-with open(os.path.join(root, "profiles", f"{tag}_pmc_render_fused.json"), "w") as fh:
+with open(os.path.join(root, "profiles", f"{tag}_{suffix}.json"), "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "note"}, indent=1)[:1500])
