@@ -44,10 +44,15 @@ BYTES_PER_RAY_IO = (3 + 3 + 1 + 1) * 4 + (3 + 1 + 1 + 1 + 3) * 4  # o,d,near,far
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_FP32_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32: 64 FLOP/clk/SIMD x 4 SIMD x 256 CU x 2.4 GHz (dense)
 MLP_MAC_PER_SAMPLE = 9216  # the folded field MLPs as the render kernels evaluate them
+MFMA_F16_PEAK_TFLOPS = 2516.6  # v_mfma_f32_16x16x32_f16: 1024 FLOP/clk/SIMD x 4 SIMD x 256 CU x 2.4 GHz (dense; ~2.5 PF)
+L1_LOOKUPS_PER_SEC = 256 * 2.4e9  # per-lane-addressed loads: one L1 line lookup per clock and CU (tools/gather_rate_microbench.hip)
 ATOMIC_REQUESTS_PER_SEC = 21.07e9  # float-atomic requests the memory side takes (tools/atomic_microbench.hip)
 # float-atomic requests per iteration, MEASURED with the TCC atomic counters on tools/train_probe.py (default method, 48 field
 # samples per ray) at the two batch sizes bench.py times -- the set of cell-major levels depends on the batch size -- read
 # from the newest profiles/r*_pmc_train_atomics.json (TCC_ATOMIC == TCC_EA0_ATOMIC); fallback: the round-1 figures.
+FIELD_PART = {}  # {rays: requests of the field backward alone (48 field samples per ray)}, filled below
+
+
 def _measured_atomic_requests():
     """{rays: requests per iteration} for the iterations bench.py times (every one updates both proposal networks: one field
     backward, two proposal backwards and their fold kernels), from the newest profiles/r*_pmc_train_atomics.json."""
@@ -69,6 +74,7 @@ def _measured_atomic_requests():
                 # one field backward + two proposal backwards + three folds of the cell-major records per iteration
                 got[int(rays)] = avg("field_backward_mfma_kernel") + 2 * avg("proposal_backward_kernel") + \
                     3 * (avg("cell_scatter_fold_kernel") + avg("coarse_scatter_reduce_kernel"))
+                FIELD_PART[int(rays)] = avg("field_backward_mfma_kernel")
             if got:
                 table, src = got, f"profiles/{os.path.basename(files[-1])} @ {d.get('commit', '?')} (TCC_ATOMIC per launch at each batch size)"
         except (KeyError, StopIteration, ValueError, OSError):
@@ -98,7 +104,9 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true",
                     help="headline workload only (use under rocprofv3 so per-kernel averages are not mixed with the "
                          "proposal-mode and training launches)")
-    ap.add_argument("--cpu-baseline-chunks", type=int, default=12,
+    ap.add_argument("--no-subsystems", action="store_true",
+                    help="skip the exporter / projection lines (10 M-point export, dense export, projection job)")
+    ap.add_argument("--cpu-baseline-chunks", type=int, default=10,
                     help="timed chunks of the CPU baseline (after 3 warm-ups; the median chunk time is reported)")
     return ap.parse_args()
 
@@ -304,6 +312,8 @@ def main():
     # ---- secondary numbers (rank 0, N=1): proposal-mode render and training iterations --------------------------------
     if rank == 0 and world == 1 and not args.no_secondary:
         extra.update(secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, opts))
+        if not args.no_subsystems:
+            extra.update(subsystem_timings(args, params, device))
 
     if rank == 0:
         samples = world * R * S * args.steps
@@ -379,6 +389,54 @@ def launch_time(fn, n: int) -> float:
     return sum(durs) / len(durs)
 
 
+def launch_stats(fn, n: int = 30, warm: int = 5) -> dict:
+    """Per-CALL HIP-event times of ``fn(i)`` (seconds): median, mean, min, max, sigma over ``n`` calls after ``warm``
+    warm-ups.  Every secondary number of this file is a median of these: round 2 timed each secondary mode with ONE event
+    pair around 20 calls after a single warm-up, so a host-side stall inside that 50 ms window was counted as kernel time
+    (2.65 ms in five runs, 3.1 in two, 3.79 on the driver's box for the same kernel, whose rocprofv3 trace is 2.61 +- 0.11)."""
+    import statistics
+
+    for i in range(warm):
+        fn(i)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for i in range(n):
+        evs[i][0].record()
+        fn(warm + i)
+        evs[i][1].record()
+    torch.cuda.synchronize()
+    t = [a.elapsed_time(b) * 1e-3 for a, b in evs]
+    return {"median": statistics.median(t), "mean": sum(t) / n, "min": min(t), "max": max(t), "sigma": statistics.pstdev(t),
+            "launches": n, "warmups": warm}
+
+
+def _ms(st: dict) -> dict:
+    return {"ms_per_batch": round(st["median"] * 1e3, 3),
+            "spread_ms": {"min": round(st["min"] * 1e3, 3), "mean": round(st["mean"] * 1e3, 3), "max": round(st["max"] * 1e3, 3),
+                          "sigma": round(st["sigma"] * 1e3, 3), "launches": st["launches"], "warmups": st["warmups"]}}
+
+
+def pmc_variant_summary(tag_part: str) -> dict:
+    """Counters of a render VARIANT from the newest profiles/r*<tag_part>*_pmc_variant.json (tools/collect_pmc_variant.sh)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*{tag_part}*_pmc_variant.json")))
+    if not files:
+        return {}
+    try:
+        with open(files[-1]) as fh_:
+            d = json.load(fh_)
+        val = lambda k: d[k]["avg_per_launch"] if k in d else None
+        out = {"source": f"profiles/{os.path.basename(files[-1])}" + (f" @ {d['commit']}" if d.get("commit") else "")}
+        if val("FETCH_SIZE") is not None and val("WRITE_SIZE") is not None:
+            out["traffic"] = int((val("FETCH_SIZE") + val("WRITE_SIZE")) * 1024)
+        if val("TCP_TOTAL_CACHE_ACCESSES_sum") is not None:
+            out["l1_line_lookups"] = int(val("TCP_TOTAL_CACHE_ACCESSES_sum"))
+        return out
+    except Exception as e:  # noqa: BLE001
+        return {"source": f"unreadable: {e}"}
+
+
 def pmc_summary() -> dict:
     """Memory-side bytes per launch of the render kernel from the committed rocprofv3 PMC passes of this same command
     (``profiles/r*_pmc_render*.json``, written by tools/collect_pmc.sh + tools/summarise_pmc.py: FETCH_SIZE and WRITE_SIZE,
@@ -404,82 +462,89 @@ def pmc_summary() -> dict:
 
 
 def secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, opts):
-    """Not the headline: M-proposal render (256+96 proposal-net evals + 192 field evals per ray) and the training
-    iteration of the default method config (4096 rays: (256, 96) proposal + 48 field samples, forward + backward + Adam)."""
+    """Not the headline: the same M-uniform workload through the optional matrix modes and the tcnn-layout fp16 table (what a
+    reference checkpoint imports to), the M-proposal render (256+96 proposal-net evals + 192 field evals per ray) and the
+    training iteration of the default method config.  Every figure is the MEDIAN of per-call HIP-event times after five
+    warm-ups (launch_stats), with the spread printed beside it."""
     out = {}
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-
-    def timed(fn, n):
-        fn(0)
-        torch.cuda.synchronize()
-        ev0.record()
-        for i in range(n):
-            fn(i)
-        ev1.record()
-        ev1.synchronize()
-        return ev0.elapsed_time(ev1) * 1e-3 / n
-
-    def prop(i):
-        o, d, n, f, cam, start = batches[i % DISTINCT_BATCHES]
-        ps = ops.proposal_sample(dh, scene_c, o, d, n, f, cfg.num_proposal_samples_per_ray, S)
-        o_ = opts if args.no_image_hint else ops.render_opts(S, image_width=W, pixel_start=start)
-        ops.render_rays(fh, scene_c, o_, o, d, n, f, bins=ps["euclidean_bins"])
-
-    # the headline workload with the optional split-bf16 matrix products (cn_render_opts.matrix_precision = 1; NOT the
-    # headline, which is exact fp32): same batches, same kernel, same parity bar against the oracle (tests)
     from cropnerf_amd import _lib as L
     from cropnerf_amd import ops as _ops
 
     scene_u = _ops.scene_struct(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), contraction=False)
 
-    def split_bf16(i):
-        o, d, n, f, cam, start = batches[i % DISTINCT_BATCHES]
-        o_ = ops.render_opts(S, matrix_precision=L.MATRIX_SPLIT_BF16, **({} if args.no_image_hint else
-                                                                           {"image_width": W, "pixel_start": start}))
-        return ops.render_rays(fh, scene_u, o_, o, d, n, f)
+    def hint(start):
+        return {} if args.no_image_hint else {"image_width": W, "pixel_start": start}
 
-    t = timed(split_bf16, 20)
-    o, d, n, f, cam, start = batches[0]
-    exact = ops.render_rays(fh, scene_u, ops.render_opts(S, image_width=W, pixel_start=start), o, d, n, f)["rgb"]
-    mse = float(((split_bf16(0)["rgb"] - exact) ** 2).mean())
+    def render(handle, **kw):
+        def fn(i):
+            o, d, n, f, cam, start = batches[i % DISTINCT_BATCHES]
+            return ops.render_rays(handle, scene_u, ops.render_opts(S, **kw, **hint(start)), o, d, n, f)
+        return fn
+
+    def psnr(a, b):
+        mse = float(((a - b) ** 2).mean())
+        return round(-10.0 * math.log10(max(mse, 1e-30)), 1)
+
+    flops = R * S * 2 * MLP_MAC_PER_SAMPLE
+    # ---- split-bf16 matrix products on the headline table (cn_render_opts.matrix_precision = 1; NOT the headline) ----------
+    st = launch_stats(render(fh, matrix_precision=L.MATRIX_SPLIT_BF16))
+    t = st["median"]
     out["uniform_mode_split_bf16_matrix"] = {
-        "ms_per_batch": round(t * 1e3, 3), "samples_per_sec": R * S / t, "rays_per_sec": R / t,
-        "psnr_vs_fp32_render_db": round(-10.0 * math.log10(max(mse, 1e-30)), 1),
+        **_ms(st), "samples_per_sec": R * S / t, "rays_per_sec": R / t,
+        "psnr_vs_fp32_render_db": psnr(render(fh, matrix_precision=L.MATRIX_SPLIT_BF16)(0)["rgb"], render(fh)(0)["rgb"]),
         "note": "optional arithmetic (operands split into bf16 hi + lo, fp32 accumulation); the headline value is exact fp32"}
 
     # ---- the reference's default module implementation: tcnn grid geometry, half2 table entries (512 B per sample) ------
-    from cropnerf_amd import config as _PC
-
-    tcfg_t = _PC.FruitNerfModelConfig(num_nerf_samples_per_ray=S, implementation="tcnn")
-    tspec = tcfg_t.field_spec(num_images=NUM_CAMERAS)
-    gq = torch.Generator(device="cpu").manual_seed(0)
-    packed = ((torch.rand(2 * tspec.grid.num_packed_entries, generator=gq) * 2 - 1) * 0.1).to(batches[0][0].device)
-    pt = dict(params)
-    pt["field.mlp_base_grid.hash_table"] = ops.tcnn_grid_pack(tspec.grid, packed, torch.float16)
-    fht = ops.FieldHandle(pt, tspec)
-
-    def tcnn_half(i):
-        o, d, n, f, cam, start = batches[i % DISTINCT_BATCHES]
-        o_ = ops.render_opts(S, **({} if args.no_image_hint else {"image_width": W, "pixel_start": start}))
-        return ops.render_rays(fht, scene_u, o_, o, d, n, f)
-
-    t = timed(tcnn_half, 20)
+    fht, tspec = tcnn_f16_field(params, batches[0][0].device)
     alg = R * (S * BYTES_PER_SAMPLE_F16 + BYTES_PER_RAY_IO)
+    st = launch_stats(render(fht))
+    t = st["median"]
+    exact_t = render(fht)(0)["rgb"]
     out["uniform_mode_tcnn_f16_table"] = {
-        "ms_per_batch": round(t * 1e3, 3), "samples_per_sec": R * S / t, "rays_per_sec": R / t,
-        "roofline": {"bound": "hbm", "kernel": "render_split_kernel<.,.,half,generic>", "achieved": round(alg / t / 1e9, 1),
-                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(alg / t / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
-                     "bytes_per_sample": BYTES_PER_SAMPLE_F16, "mfma_frac": round(R * S * 2 * MLP_MAC_PER_SAMPLE / t / 1e12 / MFMA_FP32_PEAK_TFLOPS, 4)},
+        **_ms(st), "samples_per_sec": R * S / t, "rays_per_sec": R / t,
+        "roofline": {"bound": "hbm", "kernel": "render_split_kernel<.,fp32,half,generic>", "achieved": round(alg / t / 1e9, 1),
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(alg / t / 1e9 / HBM_PEAK_GBPS, 4),
+                     "traffic": pmc_variant_summary("tcnn_f16").get("traffic"),
+                     "traffic_source": pmc_variant_summary("tcnn_f16").get("source"),
+                     "bytes_per_sample": BYTES_PER_SAMPLE_F16, "mfma_frac": round(flops / t / 1e12 / MFMA_FP32_PEAK_TFLOPS, 4),
+                     "limited_by": "SIMD issue (fp32 MFMA + VALU), as the headline"},
         "note": "tcnn-compatible layout (dense coarse levels, +0.5 offset) with fp16 table entries -- what a reference-trained "
-                "checkpoint imports to; arithmetic stays fp32; the headline is the fp32 torch-layout table"}
+                "checkpoint imports to; arithmetic stays exact fp32 on those values"}
+    # ---- ... in the reference's OWN arithmetic class: fp16 operands on v_mfma_f32_16x16x32_f16, fp32 accumulation ---------------
+    st = launch_stats(render(fht, matrix_precision=L.MATRIX_F16))
+    t = st["median"]
+    pv = pmc_variant_summary("f16")
+    lookups = pv.get("l1_line_lookups")
+    out["uniform_mode_tcnn_f16_mfma"] = {
+        **_ms(st), "samples_per_sec": R * S / t, "rays_per_sec": R / t,
+        "psnr_vs_fp32_render_db": psnr(render(fht, matrix_precision=L.MATRIX_F16)(0)["rgb"], exact_t),
+        "roofline": {"bound": "hbm", "kernel": "render_split_kernel<.,f16,half,generic>", "achieved": round(alg / t / 1e9, 1),
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(alg / t / 1e9 / HBM_PEAK_GBPS, 4),
+                     "traffic": pv.get("traffic"), "traffic_source": pv.get("source"),
+                     "bytes_per_sample": BYTES_PER_SAMPLE_F16,
+                     "mfma_frac": round(flops / t / 1e12 / MFMA_F16_PEAK_TFLOPS, 5),
+                     "mfma_peak_tflops": MFMA_F16_PEAK_TFLOPS,
+                     "l1_line_lookups_per_launch": lookups,
+                     "l1_lookup_frac": (round(lookups / t / L1_LOOKUPS_PER_SEC, 4) if lookups else None),
+                     "limited_by": "the L1's line-lookup rate for per-lane-addressed loads (one per clock and CU) plus two "
+                                   "cycles per L1 miss fill; matrix work is 44 fp16 MFMAs per 32 samples (DESIGN.md 4.12)"},
+        "note": "cn_render_opts.matrix_precision = CN_MATRIX_F16: tcnn's FullyFusedMLP arithmetic (fruit_field.py:95,125-167, "
+                "fruit_nerf_config.py:35 mixed_precision) -- fp16 weights and layer inputs, fp32 accumulation, packed-fp16 "
+                "grid interpolation; parity against oracle tcnn_half_activations in tests/test_gpu_f16.py"}
 
-    t = timed(prop, 10)
-    out["proposal_mode"] = {"ms_per_batch": round(t * 1e3, 3), "rays_per_sec": R / t, "field_samples_per_sec": R * S / t,
+    def prop(i):
+        o, d, n, f, cam, start = batches[i % DISTINCT_BATCHES]
+        ps = ops.proposal_sample(dh, scene_c, o, d, n, f, cfg.num_proposal_samples_per_ray, S)
+        ops.render_rays(fh, scene_c, ops.render_opts(S, **hint(start)), o, d, n, f, bins=ps["euclidean_bins"])
+
+    st = launch_stats(prop, 20)
+    t = st["median"]
+    out["proposal_mode"] = {**_ms(st), "rays_per_sec": R / t, "field_samples_per_sec": R * S / t,
                             "network_evals_per_sec": R * (S + sum(cfg.num_proposal_samples_per_ray)) / t}
     # the sampler kernel on its own: SURVEY.md 8(d) prices a proposal sample at 320 B of table reads
     n_prop = sum(cfg.num_proposal_samples_per_ray)
-    tp = launch_time(lambda i: ops.proposal_sample(dh, scene_c, *batches[i % DISTINCT_BATCHES][:4],
-                                                   cfg.num_proposal_samples_per_ray, S), 10)
+    tp = launch_stats(lambda i: ops.proposal_sample(dh, scene_c, *batches[i % DISTINCT_BATCHES][:4],
+                                                    cfg.num_proposal_samples_per_ray, S), 20)["median"]
     alg = R * n_prop * BYTES_PER_PROPOSAL_SAMPLE
     out["proposal_mode"]["roofline"] = {
         "bound": "hbm", "kernel": "proposal_sample_kernel", "achieved": round(alg / tp / 1e9, 1), "peak": HBM_PEAK_GBPS,
@@ -487,47 +552,174 @@ def secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, o
         "algorithmic_bytes_per_launch": alg, "bytes_per_sample": BYTES_PER_PROPOSAL_SAMPLE, "avg_launch_ms": round(tp * 1e3, 4),
         "limited_by": "VALU issue (hashing, 10->16->1 MLP on scalar-operand FMAs, inverse-cdf search); the two 10 MB tables "
                       "are L2-resident, so the algorithmic rate can exceed what HBM could deliver"}
+
+    def timed(fn, n):
+        import statistics
+
+        fn(0)
+        fn(1)
+        torch.cuda.synchronize()
+        ts = []
+        for i in range(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(i)
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e-3)
+        return statistics.median(ts)
+
     if not args.no_train:
         from cropnerf_amd import config as PC
         from cropnerf_amd.fruit_nerf.fruit_nerf import FruitModel, Semantics
         from cropnerf_amd.fruit_nerf.trainer import FruitTrainer
         from cropnerf_amd.rays import RayBundle, SceneBox
 
-        tcfg = PC.FruitNerfModelConfig()  # reference defaults: 48 field samples, (256, 96) proposal samples
-        model = FruitModel(tcfg, SceneBox(torch.tensor([[-1.0, -1, -1], [1, 1, 1]])), NUM_CAMERAS,
-                           {"semantics": Semantics()}, device=batches[0][0].device, params=params)
-        model.training = True
-        tr = FruitTrainer(model)
         g = torch.Generator().manual_seed(0)
         train = {}
         from cropnerf_amd import synthetic
         from cropnerf_amd.rays import Cameras
 
+        dev = batches[0][0].device
         c2w, intr = synthetic.orbit_cameras(NUM_CAMERAS, height=H, width=W, focal=FOCAL)
-        cams = Cameras(c2w, intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], H, W).to(batches[0][0].device)
-        for nrays in (4096, 65536):
+        cams = Cameras(c2w, intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], H, W).to(dev)
+        # (rays per batch, field samples per ray): the reference's default batch, the same at C2's batch size, and C2's
+        # training half at its stated size (BASELINE.json configs[1]: 192 samples/ray, 65k-ray batch)
+        for nrays, spp in ((4096, 48), (65536, 48), (65536, 192)):
+            tcfg = PC.FruitNerfModelConfig(num_nerf_samples_per_ray=spp)  # (256, 96) proposal samples
+            model = FruitModel(tcfg, SceneBox(torch.tensor([[-1.0, -1, -1], [1, 1, 1]])), NUM_CAMERAS,
+                               {"semantics": Semantics()}, device=dev, params={k: v.clone() for k, v in params.items()})
+            model.training = True
+            tr = FruitTrainer(model)  # a fresh trainer: the 7 iterations below are steps 0..6, all of which update the proposal nets
             # training batches are random pixels over all images (PixelSampler), not a block of one image
             idx = torch.stack([torch.randint(0, NUM_CAMERAS, (nrays,), generator=g), torch.randint(0, H, (nrays,), generator=g),
                                torch.randint(0, W, (nrays,), generator=g)], -1)
-            rb = cams.generate_rays(idx.to(batches[0][0].device))
+            rb = cams.generate_rays(idx.to(dev))
             batch = {"image": torch.rand(nrays, 3, generator=g), "fruit_mask": (torch.rand(nrays, 1, generator=g) > 0.5).float()}
-            batch = {k: v.to(batches[0][0].device) for k, v in batch.items()}
+            batch = {k: v.to(dev) for k, v in batch.items()}
             t = timed(lambda i: tr.train_iteration(rb, batch), 5)
-            train[str(nrays)] = {"ms_per_iter": round(t * 1e3, 3), "rays_per_sec": nrays / t}
+            key = str(nrays) if spp == 48 else f"{nrays}x{spp}"
+            train[key] = {"ms_per_iter": round(t * 1e3, 3), "rays_per_sec": nrays / t, "field_samples_per_ray": spp,
+                          "field_samples_per_sec": nrays * spp / t}
             # The iteration's bound is the rate at which the memory side takes float-atomic requests (hash-grid gradient
-            # scatter), not HBM bytes or MFMA: requests per iteration = rays x (48 field samples x the measured
-            # requests per field sample + 2 proposal launches x the measured requests per ray and launch).  Proposal networks
-            # take part in one iteration out of `proposal_update_every` after warm-up; the timed iterations are early ones
-            # (every iteration updates them), i.e. the expensive case.
+            # scatter), not HBM bytes or MFMA.  Requests per iteration are MEASURED (TCC_ATOMIC) at 48 field
+            # samples per ray for both batch sizes; at 192 the field backward's share is scaled by 4 (same requests per field
+            # sample, an upper bound: more samples per cell merge more) and labelled as an estimate.
             req = ATOMIC_REQUESTS_PER_ITERATION.get(nrays, nrays / 4096.0 * ATOMIC_REQUESTS_PER_ITERATION.get(4096, 0.0))
-            train[str(nrays)]["roofline"] = {
+            src = ATOMIC_REQUESTS_SOURCE
+            if spp != 48:
+                fld = FIELD_PART.get(nrays, 0.6 * req)
+                req = req + fld * (spp / 48.0 - 1.0)
+                src += f"; field-backward share scaled x{spp // 48} from the 48-sample measurement (estimate)"
+            train[key]["roofline"] = {
                 "bound": "hbm", "kernel": "train_iteration (field_backward_mfma_kernel + 2 x proposal_backward_kernel scatter)",
                 "achieved": round(req / t / 1e9, 3), "peak": round(ATOMIC_REQUESTS_PER_SEC / 1e9, 2),
                 "unit": "G atomic requests/s (memory side; 64-byte read-modify-writes)", "frac": round(req / t / ATOMIC_REQUESTS_PER_SEC, 4),
                 "traffic": None, "atomic_requests_per_iteration": int(req),
-                "requests_source": ATOMIC_REQUESTS_SOURCE,
+                "requests_source": src,
                 "hbm_equivalent_GBps": round(req * 64 / t / 1e9, 1)}
+            del tr, model
         out["train_iteration"] = train
+    return out
+
+
+def subsystem_timings(args, params, device):
+    """The other three subsystems the north star replaces, at the reference's own call shapes (driver-timed: round 2 only had
+    builder probes under tools/).  Outside the headline's timed region; each with its algorithmic bytes and fraction of HBM
+    peak.  Same synthetic scene (P-rand) with a density / fruit-logit offset so that the exporters keep points."""
+    from cropnerf_amd import config as PC
+    from cropnerf_amd import synthetic
+    from cropnerf_amd.fruit_nerf.data.fruit_datamanager import FruitDataManagerConfig
+    from cropnerf_amd.fruit_nerf.export.exporter_utils import sample_volume
+    from cropnerf_amd.fruit_nerf.export.exporter_utils_nerfacto import generate_point_cloud
+    from cropnerf_amd.fruit_nerf.fruit_nerf import background_color_override_context
+    from cropnerf_amd.fruit_nerf.fruit_pipeline import FruitPipeline, FruitPipelineConfig
+    from cropnerf_amd.rays import Cameras, SceneBox
+
+    out = {}
+    cfg = PC.FruitNerfModelConfig()  # the default method: (256, 96) proposal samples + 48 field samples per ray
+    p2 = {k: v.clone() for k, v in params.items()}
+    p2["field.mlp_base_mlp.layers.1.bias"][0] += 4.0  # some density ...
+    p2["field.field_head_semantics.net.bias"] += 3.0   # ... and fruit, so the exporters keep points
+    c2w, intr = synthetic.orbit_cameras(NUM_CAMERAS, height=H, width=W, focal=FOCAL)
+    cams = Cameras(c2w, intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], H, W)
+    box = SceneBox(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]))
+    n_prop = sum(cfg.num_proposal_samples_per_ray)
+    bytes_per_ray_default = n_prop * BYTES_PER_PROPOSAL_SAMPLE + cfg.num_nerf_samples_per_ray * BYTES_PER_SAMPLE
+
+    def wall(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, r
+
+    # ---- ns-export pointcloud (BASELINE.json configs[3]): random training rays in 2 048-ray calls until 10 M points are kept --
+    # exporter_utils_nerfacto.py:125-183 (debug/exporter_nerfacto.py:91: 2 048 rays per call); no outlier removal in the timed part
+    pipe = FruitPipeline(FruitPipelineConfig(FruitDataManagerConfig(2048, 2048), cfg), device, cams, box, test_mode="test", params=p2)
+    generate_point_cloud(pipe, num_points=200_000, remove_outliers=False)  # warm-up: first-call initialisation, graph capture
+    pipe.datamanager.train_count = 0
+    t, pcd = wall(lambda: generate_point_cloud(pipe, num_points=10_000_000, remove_outliers=False))
+    calls = pipe.datamanager.train_count
+    rays = calls * 2048
+    out["export_pointcloud_c4"] = {
+        "seconds": round(t, 3), "kept_points": int(pcd["points"].shape[0]), "calls": calls, "rays_per_call": 2048,
+        "rays_per_sec": rays / t, "points_per_sec": int(pcd["points"].shape[0]) / t,
+        "roofline": {"bound": "hbm", "kernel": "proposal_sample_kernel + render kernel + pointcloud_compact per call (HIP-graph replay)",
+                     "achieved": round(rays * bytes_per_ray_default / t / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(rays * bytes_per_ray_default / t / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "bytes_per_ray": bytes_per_ray_default,
+                     "limited_by": "2 048-ray calls (the reference's call size): ~15 small launches each, far below the device's "
+                                   "capacity per launch; the loop is a replayed HIP graph"},
+        "workload": "ns-export pointcloud --num-points 10000000 on the synthetic scene, default method (48 field + 352 proposal "
+                    "samples per ray), reference: exporter_utils_nerfacto.py:125-183"}
+    # ---- exporter.py semantic-pointcloud (dense volume export): 512-ray calls x 3 000 samples per ray -----------------------------
+    # scripts/exporter.py:75-77, exporter_utils.py:93-172; the reference's full job is 3000 x 3000 rays, timed here on 512 x 512
+    pipe_e = FruitPipeline(FruitPipelineConfig(FruitDataManagerConfig(4096, 512), cfg), device, cams, box, test_mode="export", params=p2)
+    pipe_e.model.setup_inference(True, 3000)
+    aabb_e = ((-1, -1, -1 + .318), (1, 1, 1 + .318))
+    n_rays = pipe_e.datamanager.setup_inference(aabb_e, 64)
+    sample_volume(pipe_e, n_rays, transform_json={"scale": 1.0, "transform": None}, capacity=1 << 26)  # warm-up
+    side = 512
+    n_rays = pipe_e.datamanager.setup_inference(aabb_e, side)
+    t, pcds = wall(lambda: sample_volume(pipe_e, n_rays, transform_json={"scale": 1.0, "transform": None}, capacity=1 << 26))
+    ns = n_rays * 3000
+    out["dense_export"] = {
+        "seconds": round(t, 3), "rays": n_rays, "samples_per_ray": 3000, "rays_per_call": 512, "field_samples_per_sec": ns / t,
+        "kept": {k: int(v["points"].shape[0]) for k, v in pcds.items()},
+        "full_3000x3000_estimate_s": round(t * (3000 * 3000) / n_rays, 2),
+        "roofline": {"bound": "hbm", "kernel": "render_split_kernel<per-sample> + export_compact", "achieved": round(ns * BYTES_PER_SAMPLE / t / 1e9, 1),
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ns * BYTES_PER_SAMPLE / t / 1e9 / HBM_PEAK_GBPS, 4),
+                     "traffic": None, "bytes_per_sample": BYTES_PER_SAMPLE,
+                     "limited_by": "SIMD issue of the render kernel (as the headline) + 28 B per sample of per-sample outputs"},
+        "workload": f"exporter.py semantic-pointcloud: {side} x {side} surface rays (reference: 3000 x 3000) x 3000 samples, 512 rays per "
+                    "call; reference: scripts/exporter.py:75-77, export/exporter_utils.py:93-172"}
+    # ---- semantic projection: one (camera, sub-cluster AABB) job at 800 x 800, both passes (fruit_nerf.py:283-315) -----------------
+    m = pipe.model
+    aabb = SceneBox(torch.tensor([[-0.15, -0.15, -0.15], [0.15, 0.15, 0.15]]))
+    import statistics
+
+    with background_color_override_context(torch.zeros(3)):
+        m.project_cluster(cams[0], aabb, 0)
+        ts = []
+        for i in range(10):
+            tj, _ = wall(lambda: m.project_cluster(cams[i], aabb, i))
+            ts.append(tj)
+        rays_in = [int((cams[i].to(device).generate_rays(camera_indices=0, keep_shape=True, aabb_box=aabb).nears < 1e10).sum())
+                   for i in range(10)]
+    tj = statistics.median(ts)
+    vr = statistics.median(rays_in)
+    out["projection_job"] = {
+        "ms_per_job": round(tj * 1e3, 3), "spread_ms": {"min": round(min(ts) * 1e3, 3), "max": round(max(ts) * 1e3, 3), "jobs": 10},
+        "image": [H, W], "rays_inside_aabb": int(vr), "passes": 2, "rays_per_sec": 2 * vr / tj,
+        "roofline": {"bound": "hbm", "kernel": "proposal_sample_kernel + render kernels (full pass, density-only occlusion pass)",
+                     "achieved": round(2 * vr * bytes_per_ray_default / tj / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(2 * vr * bytes_per_ray_default / tj / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "bytes_per_ray_and_pass": bytes_per_ray_default,
+                     "limited_by": "ray generation + AABB test for all 640 000 pixels, host-side masking / packing between the two "
+                                   "passes, then the two renders of the rays inside the box"},
+        "workload": "get_outputs_for_projections, one camera x one sub-cluster AABB (0.3-wide box at the origin), 800 x 800: the "
+                    "AABB-restricted render and the occlusion pass; reference: fruit_nerf.py:283-315"}
     return out
 
 

@@ -30,7 +30,9 @@ __device__ __forceinline__ unsigned mix(unsigned x) {
 constexpr int UNROLL = 16;
 
 // GROUP: lanes per shared line (64 same, 16 row16, 4 quad, 2 pair, 1 lane).  W: dwords per load (1, 2, 4).
-template <int GROUP, int W>
+// POLICY: 0 plain loads, 1 agent-scope relaxed atomic loads (global_load ... sc1: served by the L2, no L1 allocation),
+// 2 non-temporal loads (nt).
+template <int GROUP, int W, int POLICY = 0>
 __global__ void __launch_bounds__(512) gather(const unsigned* __restrict__ table, unsigned line_mask, int iters, unsigned* out) {
   const unsigned lane = threadIdx.x & 63;
   const unsigned wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -46,11 +48,19 @@ __global__ void __launch_bounds__(512) gather(const unsigned* __restrict__ table
       h = h * 1664525u + 1013904223u;  // one v_mad per address; the high bits of an LCG are the good ones
       const unsigned line = (h >> 7) & line_mask;
       const unsigned* p = table + (size_t)line * 32u + dw;
-      if (W == 1) v[u][0] = *p;
+      if (W == 1) {
+        if (POLICY == 0) v[u][0] = *p;
+        if (POLICY == 1) v[u][0] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (POLICY == 2) v[u][0] = __builtin_nontemporal_load(p);
+      }
       if (W == 2) {
-        const uint2 t = *reinterpret_cast<const uint2*>(p);
-        v[u][0] = t.x;
-        v[u][1] = t.y;
+        unsigned long long t = 0;
+        const unsigned long long* p8 = reinterpret_cast<const unsigned long long*>(p);
+        if (POLICY == 0) t = *p8;
+        if (POLICY == 1) t = __hip_atomic_load(p8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (POLICY == 2) t = __builtin_nontemporal_load(p8);
+        v[u][0] = (unsigned)t;
+        v[u][1] = (unsigned)(t >> 32);
       }
       if (W == 4) {
         const uint4 t = *reinterpret_cast<const uint4*>(p);
@@ -68,15 +78,15 @@ __global__ void __launch_bounds__(512) gather(const unsigned* __restrict__ table
   out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
-template <int GROUP, int W>
+template <int GROUP, int W, int POLICY = 0>
 static float run(const unsigned* table, unsigned line_mask, int iters, unsigned* out, int blocks) {
   hipEvent_t a, b;
   (void)hipEventCreate(&a);
   (void)hipEventCreate(&b);
-  hipLaunchKernelGGL((gather<GROUP, W>), dim3(blocks), dim3(512), 0, 0, table, line_mask, iters / 4, out);
+  hipLaunchKernelGGL((gather<GROUP, W, POLICY>), dim3(blocks), dim3(512), 0, 0, table, line_mask, iters / 4, out);
   (void)hipDeviceSynchronize();
   (void)hipEventRecord(a, 0);
-  hipLaunchKernelGGL((gather<GROUP, W>), dim3(blocks), dim3(512), 0, 0, table, line_mask, iters, out);
+  hipLaunchKernelGGL((gather<GROUP, W, POLICY>), dim3(blocks), dim3(512), 0, 0, table, line_mask, iters, out);
   (void)hipEventRecord(b, 0);
   (void)hipEventSynchronize(b);
   float ms = 0.f;
@@ -118,6 +128,13 @@ int main() {
     ROW(2, "8 B")
     ROW(4, "16 B")
 #undef ROW
+    // cache policies on the patterns that matter for a fine hashed level (every lane / every lane pair its own line)
+    report("8 B", "lane sc1", run<1, 2, 1>(table, mask, sz.iters, out, blocks));
+    report("8 B", "pair sc1", run<2, 2, 1>(table, mask, sz.iters, out, blocks));
+    report("8 B", "lane nt", run<1, 2, 2>(table, mask, sz.iters, out, blocks));
+    report("8 B", "pair nt", run<2, 2, 2>(table, mask, sz.iters, out, blocks));
+    report("4 B", "lane sc1", run<1, 1, 1>(table, mask, sz.iters, out, blocks));
+    report("4 B", "lane nt", run<1, 1, 2>(table, mask, sz.iters, out, blocks));
   }
   return 0;
 }
