@@ -359,10 +359,20 @@ inline CellScatter make_cell_scatter(const cn_grid& grads_grid, unsigned long lo
   if (!grads_grid.scatter_scratch) return c;
   const size_t head = coarse_scratch_bytes(grads_grid);
   const size_t need = cell_scratch_layout(grads_grid, &c);
-  if (need == 0 || grads_grid.scatter_scratch_bytes < head + need) {
+  if (need == 0 || grads_grid.scatter_scratch_bytes < head) {
     c = CellScatter{};
     return c;
   }
+  // the scratch may hold a PREFIX of the levels (cn_grid_scatter_scratch_bytes_for: sized for a maximum batch): use the
+  // levels whose records fit it
+  int fit = 0;
+  while (fit < c.num_levels) {
+    const unsigned long long cells = (unsigned long long)c.n[fit] * c.n[fit] * c.n[fit];
+    const unsigned long long end = (c.offset[fit] + c.copies[fit] * cells * 16ull) * sizeof(float);
+    if (head + end > grads_grid.scatter_scratch_bytes) break;
+    ++fit;
+  }
+  c.num_levels = fit;
   int k = 0;
   while (k < c.num_levels && (unsigned long long)c.n[k] * c.n[k] * c.n[k] <= max_cells) ++k;
   c.num_levels = k;

@@ -28,6 +28,15 @@ namespace cn {
 //   one loop per role instead of one loop with a role branch                                        4.65 vs 4.93
 //   the gather waves also run the base MLP (96 of the 288 MFMAs) and hand over its 16 outputs        4.29 vs 4.87
 //   one of the two matrix waves of a SIMD defers its compositing to its next half-step               4.88 vs 4.89
+//   round 3: pairs that advance independently (the gather side owns a pair's progress and labels every half-step in the
+//   ring with its schedule slot and index, the matrix wave follows the labels, the workgroup runs until every pair reports
+//   its slot list exhausted), so that a pair whose ray terminated early takes its next slot instead of idling: results
+//   bit-identical, but 2.69 vs 2.60 ms on the headline, 1.72 vs 1.60 ms in fp16 mode (labels and flags through LDS, ten more
+//   registers), and NO gain on the opaque C2 batch of tools/early_stop_probe.py (1.126 ms either way): there every ray
+//   stops after its first chunk, and what the split kernel pays over render_fused_kernel (0.87 ms) is the half-step the
+//   gather wave is always ahead of its matrix wave -- produced for a ray that has just been terminated -- not lock-step
+//   idling.  Interleaving two rays per pair at chunk granularity would hide it (the decision on ray A falls while the
+//   gather wave works on ray B) at the price of two compositing states per matrix wave; not built.
 // (with fewer gather waves the gather side becomes the bound; at 8x1 the matrix pipe is ~66 % busy and, MFMA and VALU
 //  cycles being additive on a SIMD, the kernel sits at ~98 % of its issue bound -- DESIGN.md section 4.1)
 // Ablation builds (timing only): -DCN_ABLATE_GATHER=1 2.12 ms, -DCN_ABLATE_MLP=1 1.81 ms, both 1.36 ms per C2 batch;

@@ -1110,6 +1110,26 @@ extern "C" size_t cn_grid_scatter_scratch_bytes(const cn_grid* grid) {
   return head ? head + cn::cell_scratch_layout(*grid, nullptr) : 0;
 }
 
+// The same, sized for batches of at most `max_samples` samples per backward call: a level is kept cell-major only when it
+// has at most (CN_CELL_SCATTER, default 0.5, at most 2) x samples cells, so the records of levels with more than
+// 2 x max_samples cells would never be touched -- at the reference's 4 096-ray batches that is most of the 160-180 MB per
+// gradient grid.  max_samples <= 0: every level (= cn_grid_scatter_scratch_bytes).
+extern "C" size_t cn_grid_scatter_scratch_bytes_for(const cn_grid* grid, int64_t max_samples) {
+  if (!grid || grid->num_levels < 1) return 0;
+  const size_t head = cn::coarse_scratch_bytes(*grid);
+  if (!head) return 0;
+  cn::CellScatter c{};
+  const size_t all = cn::cell_scratch_layout(*grid, &c);
+  if (max_samples <= 0) return head + all;
+  size_t bytes = 0;
+  for (int l = 0; l < c.num_levels; ++l) {
+    const unsigned long long cells = (unsigned long long)c.n[l] * c.n[l] * c.n[l];
+    if (cells > 2ull * (unsigned long long)max_samples) break;
+    bytes = (size_t)(c.offset[l] + c.copies[l] * cells * 16ull) * sizeof(float);
+  }
+  return head + bytes;
+}
+
 // ---- shape-generic field backward ------------------------------------------------------------------------------------------
 namespace cn {
 static bool general_family_ok(const cn_field_params& p) {

@@ -199,9 +199,28 @@ def latest_checkpoint(load_dir) -> pathlib.Path:
     return ckpts[-1]
 
 
-def load_checkpoint(path) -> Tuple[int, Dict[str, torch.Tensor], Dict[str, Any]]:
-    """-> (step, model state dict without prefixes, the whole loaded dict)."""
-    loaded = torch.load(path, map_location="cpu", weights_only=False)
+def load_checkpoint(path, trusted: Optional[bool] = None) -> Tuple[int, Dict[str, torch.Tensor], Dict[str, Any]]:
+    """-> (step, model state dict without prefixes, the whole loaded dict).
+
+    A step-*.ckpt is a pickle, and run directories now come from outside this package (reference-trained runs handed to
+    ``eval_setup`` / ``--load-dir``): the file is read with ``weights_only=True`` first -- tensors, numbers, strings and
+    containers, which is all a nerfstudio checkpoint's ``pipeline`` entry holds and all the exporters need.  Only if that
+    fails AND the caller vouches for the file (``trusted=True``, or ``CROPNERF_TRUST_CHECKPOINTS=1`` in the environment: this
+    package's own checkpoints carry generator states and per-rank stream objects for ``--load-dir`` resumes) is it
+    unpickled without restrictions."""
+    import os
+    import pickle
+
+    try:
+        loaded = torch.load(path, map_location="cpu", weights_only=True)
+    except (pickle.UnpicklingError, RuntimeError, TypeError) as e:
+        if trusted is None:
+            trusted = os.environ.get("CROPNERF_TRUST_CHECKPOINTS") == "1"
+        if not trusted:
+            raise ValueError(
+                f"{path}: holds objects beyond tensors and plain containers ({type(e).__name__}: {str(e)[:200]}); loading it "
+                "runs arbitrary pickle code -- pass trusted=True / set CROPNERF_TRUST_CHECKPOINTS=1 only for files you wrote") from e
+        loaded = torch.load(path, map_location="cpu", weights_only=False)
     if "pipeline" not in loaded:
         raise ValueError(f"{path}: not a nerfstudio checkpoint (no 'pipeline' entry)")
     return int(loaded["step"]), model_state_from_pipeline(loaded["pipeline"]), loaded

@@ -101,6 +101,9 @@ def train(method: str, data: Path, output_dir: Path = Path("outputs"), max_num_i
             # by a different number of ranks gives new streams derived from (seed, rank, step) instead of duplicates
             ranks = opt.get("rank_states") or []
             mine = ranks[rank] if len(ranks) == world else None
+            if len(ranks) != world:
+                say(f"[resume] WARNING: {ck} was written by {len(ranks)} rank(s), this run has {world}: the per-rank random "
+                    "streams (ray jitter, pixel sampler) cannot be continued and are re-derived from (seed, rank, step)")
             trainer.load_state_dict(opt, load_generator=False)
             if mine is not None:
                 trainer._gen.set_state(mine["generator"])
@@ -117,11 +120,18 @@ def train(method: str, data: Path, output_dir: Path = Path("outputs"), max_num_i
         timestamp or datetime.now().strftime("%Y-%m-%d_%H%M%S"))
 
     def checkpoint(step: int) -> Path:
-        # the random streams of EVERY rank go into the checkpoint (rank 0 writes it)
+        # the random streams of EVERY rank go into the checkpoint (rank 0 writes it).  The gather below is a collective: every
+        # rank must reach it for the same step, or the job hangs -- so rank 0's step is broadcast first and a rank that
+        # disagrees fails loudly instead
         mine = {"generator": trainer._gen.get_state(), "datamanager_generator": dm._gen.get_state(),
                 "train_count": dm.train_count}
         rank_states = [mine]
         if world > 1:
+            agreed = [step]
+            dist.broadcast_object_list(agreed, src=0)
+            if agreed[0] != step:
+                raise RuntimeError(f"rank {rank} reached checkpoint({step}) while rank 0 is at checkpoint({agreed[0]}): the ranks "
+                                   "must save at the same steps")
             rank_states = [None] * world if rank == 0 else None
             dist.gather_object(mine, rank_states, dst=0)
         if rank != 0:

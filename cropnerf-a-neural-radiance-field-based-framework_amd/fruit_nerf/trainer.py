@@ -132,9 +132,10 @@ class FruitTrainer:
             off += pad4(sizes[k])
         model.field = ops.FieldHandle(model.params, model.field_spec)
         model.proposal_networks = [ops.DensityHandle(model.params, i, ps) for i, ps in enumerate(model.proposal_specs)]
-        self.grad_field = ops.FieldHandle(self.grads, model.field_spec).enable_scatter_scratch()
-        self.grad_props = [ops.DensityHandle(self.grads, i, ps).enable_scatter_scratch()
-                           for i, ps in enumerate(model.proposal_specs)]
+        # gradient handles; their scatter scratch (cn_grid.scatter_scratch) is attached by forward_backward, sized for the
+        # batch it sees (160-180 MB per grid when sized for any batch, a few MB at the reference's 4 096 rays)
+        self.grad_field = ops.FieldHandle(self.grads, model.field_spec)
+        self.grad_props = [ops.DensityHandle(self.grads, i, ps) for i, ps in enumerate(model.proposal_specs)]
         self.step = 0
         self.group_steps = {g: 0 for g in self.group_range}  # Adam's per-parameter step count, per group
         self._steps_since_update = 0  # ProposalNetworkSampler state (_steps_since_update, _step)
@@ -180,6 +181,9 @@ class FruitTrainer:
         nears = rb.nears if rb.nears is not None else torch.full((R, 1), float(cfg.near_plane), device=dev)
         fars = rb.fars if rb.fars is not None else torch.full((R, 1), float(cfg.far_plane), device=dev)
         n_lvl = len(m.proposal_networks)
+        self.grad_field.enable_scatter_scratch(R * int(cfg.num_nerf_samples_per_ray))
+        for i, gp in enumerate(self.grad_props):
+            gp.enable_scatter_scratch(R * int(cfg.num_proposal_samples_per_ray[i]))
         jitter_rows = None
         if jitter is None:
             # one draw, one host-to-device copy: rows = the samplers' per-ray uniforms, level by level

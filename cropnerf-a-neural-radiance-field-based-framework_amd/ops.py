@@ -126,10 +126,11 @@ def _mlp_struct(params: Dict[str, Tensor], prefix: str, num_layers: int) -> L.Ml
     return m
 
 
-def _attach_scatter_scratch(grid: L.Grid, device) -> Optional[Tensor]:
-    """``cn_grid.scatter_scratch`` for a GRADIENT grid: a zeroed buffer of ``cn_grid_scatter_scratch_bytes`` (the backward
-    kernels accumulate the coarsest level's gradient in private copies there and leave it zeroed)."""
-    n = int(L.load().cn_grid_scatter_scratch_bytes(C.byref(grid)))
+def _attach_scatter_scratch(grid: L.Grid, device, max_samples: Optional[int] = None) -> Optional[Tensor]:
+    """``cn_grid.scatter_scratch`` for a GRADIENT grid: a zeroed buffer of ``cn_grid_scatter_scratch_bytes_for`` (the backward
+    kernels accumulate the coarse levels' gradients in private copies / cell-major records there and leave it zeroed).
+    ``max_samples``: the largest backward call it has to serve (None: any size -- 160-180 MB per grid of the default method)."""
+    n = int(L.load().cn_grid_scatter_scratch_bytes_for(C.byref(grid), int(max_samples or 0)))
     if n <= 0:
         return None
     buf = torch.zeros(n // 4, dtype=torch.float32, device=device)
@@ -161,10 +162,14 @@ class FieldHandle:
         self._workspace: Optional[Tensor] = None
         self._scatter_scratch: Optional[Tensor] = None
 
-    def enable_scatter_scratch(self) -> "FieldHandle":
-        """For a handle over GRADIENT buffers: private copies for the coarsest level's scatter (``cn_grid.scatter_scratch``)."""
-        if self._scatter_scratch is None and os.environ.get("CN_SCATTER_SCRATCH", "1") != "0":
-            self._scatter_scratch = _attach_scatter_scratch(self.struct.grid, self.device)
+    def enable_scatter_scratch(self, max_samples: Optional[int] = None) -> "FieldHandle":
+        """For a handle over GRADIENT buffers: ``cn_grid.scatter_scratch``, sized for backward calls of at most ``max_samples``
+        samples (None: any size).  Called again with a larger size it re-allocates."""
+        if os.environ.get("CN_SCATTER_SCRATCH", "1") != "0" and (
+                self._scatter_scratch is None or (getattr(self, "_scratch_samples", 0) or 0) < (max_samples or 0) or
+                (max_samples is None and getattr(self, "_scratch_samples", None) is not None)):
+            self._scatter_scratch = _attach_scatter_scratch(self.struct.grid, self.device, max_samples)
+            self._scratch_samples = max_samples
         return self
 
     def workspace(self) -> Tensor:
@@ -184,11 +189,14 @@ class DensityHandle:
         self.struct = p
         self._scatter_scratch: Optional[Tensor] = None
 
-    def enable_scatter_scratch(self) -> "DensityHandle":
+    def enable_scatter_scratch(self, max_samples: Optional[int] = None) -> "DensityHandle":
         """For a handle over GRADIENT buffers (see ``FieldHandle.enable_scatter_scratch``)."""
-        if self._scatter_scratch is None and os.environ.get("CN_SCATTER_SCRATCH", "1") != "0":
+        if os.environ.get("CN_SCATTER_SCRATCH", "1") != "0" and (
+                self._scatter_scratch is None or (getattr(self, "_scratch_samples", 0) or 0) < (max_samples or 0) or
+                (max_samples is None and getattr(self, "_scratch_samples", None) is not None)):
             self._scatter_scratch = _attach_scatter_scratch(
-                self.struct.grid, self.params[next(k for k in self.params if k.endswith("hash_table"))].device)
+                self.struct.grid, self.params[next(k for k in self.params if k.endswith("hash_table"))].device, max_samples)
+            self._scratch_samples = max_samples
         return self
 
 

@@ -100,6 +100,9 @@ typedef struct cn_grid {
   uint64_t scatter_scratch_bytes;
 } cn_grid;
 size_t cn_grid_scatter_scratch_bytes(const cn_grid* grid);
+/* The same for backward calls of at most max_samples samples: only the levels that such a call can select (at most
+ * 2 x max_samples cells) -- the scratch may be any prefix of the full layout; <= 0: every level. */
+size_t cn_grid_scatter_scratch_bytes_for(const cn_grid* grid, int64_t max_samples);
 
 /* tiny-cuda-nn grid geometry for (n_levels, log2_hashmap_size, base_resolution, per_level_scale) -- what nerfstudio's
  * HashEncoding(implementation="tcnn") passes to tcnn.Encoding -- and this library's table layout for it. host struct. */

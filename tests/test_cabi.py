@@ -149,6 +149,22 @@ def test_scatter_scratch_size_is_a_host_computation(lib):
     g.layout = _lib.GRID_TCNN  # tcnn: scale_0 = 15, positions shifted by half a cell -> cells 0..15, vertices 0..16
     g.scalings[0] = 15.0
     assert lib.cn_grid_scatter_scratch_bytes(C.byref(g)) == expected([15.0] + list(sc[1:]), 0.5)
+    # sized for a maximum batch: only the consecutive levels with at most 2 x max_samples cells (a prefix of the layout)
+    def expected_for(scalings, offset, max_samples):
+        head = 64 * (math.floor(scalings[0] + offset) + 2) ** 3 * 2 * 4
+        floats = 0
+        for s_ in scalings[:8]:
+            cells = (math.floor(s_ + offset) + 1) ** 3
+            if cells > 2_200_000 or cells > 2 * max_samples:
+                break
+            floats += (16 if cells <= 8192 else 4 if cells <= 65536 else 1) * cells * 16
+        return head + 4 * floats
+
+    tc = [15.0] + list(sc[1:])
+    for ms in (4096 * 48, 6144, 65536 * 192, 1):
+        assert lib.cn_grid_scatter_scratch_bytes_for(C.byref(g), ms) == expected_for(tc, 0.5, ms), ms
+    assert lib.cn_grid_scatter_scratch_bytes_for(C.byref(g), 0) == lib.cn_grid_scatter_scratch_bytes(C.byref(g))
+    assert lib.cn_grid_scatter_scratch_bytes_for(C.byref(g), 4096 * 48) < lib.cn_grid_scatter_scratch_bytes(C.byref(g)) // 2
     g.scalings[0] = 1000.0  # a fine "coarsest level": not worth private copies
     assert lib.cn_grid_scatter_scratch_bytes(C.byref(g)) == 0
     assert lib.cn_grid_scatter_scratch_bytes(None) == 0

@@ -550,28 +550,36 @@ def test_big_shapes_in_the_tcnn_layout_forward_and_backward(max_res, monkeypatch
     rs = OSM.spaced_sampler(rb, S, "uniform")
     gd, grgb, gsem = (torch.randn(R, S, generator=g), torch.randn(R, S, 3, generator=g), torch.randn(R, S, generator=g))
     # ---- oracle at the fp32 master values + autograd ----------------------------------------------------------------------
+    pos = rs.positions()
     real = TCM._as_compute
     TCM._as_compute = lambda q, half: q.to(torch.float32)
     try:
-        pos = rs.positions()
         # Conditioning.  At max_res 4096+ one ulp of a position moves the finest levels' interpolation weights by 2e-4 and the
         # base MLP's hidden pre-activations by ~1e-5; a hidden unit that close to zero has its ReLU gate decided by the order
         # of the position arithmetic, and ONE flipped gate among the 34k moves the base MLP's and the grid's gradient by
         # 1e-3..1e-2 of its norm (measured per sample; the oracle shows the same on itself when its positions are moved by one
-        # ulp: 7e-3).  So the samples holding such a unit get no upstream gradient (a few per cent of them), and the rest
-        # is held to the tolerance of the well-conditioned default shape.
+        # ulp: 7e-3).  So the tight comparison gives the samples holding such a unit no upstream gradient (a few per cent of
+        # them); EVERY sample is still exercised by the second, un-masked comparison below at the tolerance that one flipped
+        # gate needs.
         x01, _ = OF.normalized_positions(pos, sc.aabb, True)
         enc = TC.hash_grid(x01.reshape(-1, 3), state["field.mlp_base_grid.tcnn_encoding.params"], TC.grid_spec_of(ospec.grid),
                            half_params=False)
         pre = enc @ TC.mlp_matrices(state["field.mlp_base_mlp.tcnn_encoding.params"], 32, 31, 64, 1)[0][:, :32].t()
         keep = (pre.abs().min(dim=1).values > 5e-4 * pre.abs().max()).view(R, S)
-        assert 0.8 < float(keep.float().mean()) < 1.0, float(keep.float().mean())
-        gd, grgb, gsem = gd * keep, grgb * keep[..., None], gsem * keep
-        p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
-        fo = OF.field_forward(pos, rb.directions, cam, p, ospec, sc.aabb, True, "val", training=True)
-        geo = OF.field_density(pos, p, ospec, sc.aabb, True)[1].detach()
-        sem = OF.semantics_from_geo(geo.reshape(-1, 30), p, ospec).view(R, S)
-        ((fo["density"][..., 0] * gd).sum() + (fo["rgb"] * grgb).sum() + (sem * gsem).sum()).backward()
+        kept = float(keep.float().mean())
+        print(f"samples kept for the tight comparison: {100 * kept:.1f} %")
+        assert 0.88 < kept < 1.0, kept  # measured: 90.6 % (max_res 4096), the rest hold a hidden unit within 5e-4 of a ReLU edge
+
+        def oracle_grads(gd_, grgb_, gsem_):
+            p = {k: v.clone().requires_grad_(True) for k, v in state.items()}
+            fo = OF.field_forward(pos, rb.directions, cam, p, ospec, sc.aabb, True, "val", training=True)
+            geo = OF.field_density(pos, p, ospec, sc.aabb, True)[1].detach()
+            sem = OF.semantics_from_geo(geo.reshape(-1, 30), p, ospec).view(R, S)
+            ((fo["density"][..., 0] * gd_).sum() + (fo["rgb"] * grgb_).sum() + (sem * gsem_).sum()).backward()
+            return p, fo, sem
+
+        p_masked, fo, sem = oracle_grads(gd * keep, grgb * keep[..., None], gsem * keep)
+        p_all, _, _ = oracle_grads(gd, grgb, gsem)
     finally:
         TCM._as_compute = real
     # ---- HIP: forward through every implementation that takes this shape ------------------------------------------------------
@@ -591,29 +599,34 @@ def test_big_shapes_in_the_tcnn_layout_forward_and_backward(max_res, monkeypatch
         assert_close(out["rgb"], fo["rgb"].detach(), RTOL, ATOL, f"rgb ({impl})")
         assert_close(out["semantics"], sem.detach(), RTOL, 5e-5, f"semantics ({impl})")
     monkeypatch.delenv("CN_FIELD_EVAL_IMPL")
-    # ---- HIP: backward ------------------------------------------------------------------------------------------------------------
-    grads = {k: torch.zeros_like(v) for k, v in dp.items()}
-    O.field_backward_general(fh, O.FieldHandle(grads, pspec), scene, to_dev(rb.origins), to_dev(rb.directions), to_dev(cam[:, 0]),
-                             to_dev(rs.starts[..., 0]), to_dev(rs.ends[..., 0]), to_dev(gd), to_dev(grgb), to_dev(gsem))
-    O.tcnn_grid_tie_gradients(pspec.grid, grads["field.mlp_base_grid.hash_table"])
-    for name in TP.frozen_parameter_names(pspec, []):
-        grads[name].zero_()
-    got = TP.to_tcnn_state_dict(grads, pspec, [])
+    # ---- HIP: backward, with the masked upstream gradients (tight) and with all of them (every sample exercised) ---------------
     dims = {"field.mlp_base_mlp": (32, 31, 64, 1), "field.mlp_semantics": (30, 64, 128, 2), "field.mlp_head": (16 + 30 + 32, 3, 64, 2)}
-    worst = {}
-    for k, v in p.items():
-        assert v.grad is not None and v.grad.abs().sum() > 0, k
-        a, b = got[k], v.grad
-        if k[: -len(".tcnn_encoding.params")] in dims:
-            # compare what is a free parameter on both sides: tcnn's gradient is the same in EVERY padded (constant one)
-            # input column, here the first padded column is the bias and the others are frozen at zero
-            n_in, n_out, width, n_hidden = dims[k[: -len(".tcnn_encoding.params")]]
-            ma, mb = TC.mlp_matrices(a, n_in, n_out, width, n_hidden), TC.mlp_matrices(b, n_in, n_out, width, n_hidden)
-            ma[0], mb[0] = ma[0][:, : n_in + 1], mb[0][:, : n_in + 1]
-            a, b = torch.cat([m.reshape(-1) for m in ma]), torch.cat([m.reshape(-1) for m in mb])
-        worst[k] = float((a - b).norm() / (b.norm() + 1e-12))
-    bad = {k: e for k, e in worst.items() if e > 1e-3}
-    assert not bad, f"{bad} (all: {worst})"
+
+    def compare(p, gd_, grgb_, gsem_, tol, what):
+        grads = {k: torch.zeros_like(v) for k, v in dp.items()}
+        O.field_backward_general(fh, O.FieldHandle(grads, pspec), scene, to_dev(rb.origins), to_dev(rb.directions), to_dev(cam[:, 0]),
+                                 to_dev(rs.starts[..., 0]), to_dev(rs.ends[..., 0]), to_dev(gd_), to_dev(grgb_), to_dev(gsem_))
+        O.tcnn_grid_tie_gradients(pspec.grid, grads["field.mlp_base_grid.hash_table"])
+        for name in TP.frozen_parameter_names(pspec, []):
+            grads[name].zero_()
+        got = TP.to_tcnn_state_dict(grads, pspec, [])
+        worst = {}
+        for k, v in p.items():
+            assert v.grad is not None and v.grad.abs().sum() > 0, k
+            a, b = got[k], v.grad
+            if k[: -len(".tcnn_encoding.params")] in dims:
+                # compare what is a free parameter on both sides: tcnn's gradient is the same in EVERY padded (constant one)
+                # input column, here the first padded column is the bias and the others are frozen at zero
+                n_in, n_out, width, n_hidden = dims[k[: -len(".tcnn_encoding.params")]]
+                ma, mb = TC.mlp_matrices(a, n_in, n_out, width, n_hidden), TC.mlp_matrices(b, n_in, n_out, width, n_hidden)
+                ma[0], mb[0] = ma[0][:, : n_in + 1], mb[0][:, : n_in + 1]
+                a, b = torch.cat([m.reshape(-1) for m in ma]), torch.cat([m.reshape(-1) for m in mb])
+            worst[k] = float((a - b).norm() / (b.norm() + 1e-12))
+        bad = {k: e for k, e in worst.items() if e > tol}
+        assert not bad, f"{what}: {bad} (all: {worst})"
+
+    compare(p_masked, gd * keep, grgb * keep[..., None], gsem * keep, 1e-3, "ill-conditioned samples masked")
+    compare(p_all, gd, grgb, gsem, 2e-2, "every sample")
 
 
 def test_seven_level_proposal_net_in_the_tcnn_layout(ops):

@@ -424,8 +424,12 @@ def test_private_copies_of_the_coarsest_level_change_nothing(monkeypatch):
         model.training = True
         tr = FruitTrainer(model)
         handles = [tr.grad_field] + tr.grad_props
-        assert all((h._scatter_scratch is not None) == (flag != "0") for h in handles)
         tr.forward_backward(_hip_rays(sc, idx), {"image": image, "fruit_mask": mask}, jitter=jitter)
+        # attached by the first forward_backward, sized for its batch (cn_grid_scatter_scratch_bytes_for)
+        assert all((h._scatter_scratch is not None) == (flag != "0") for h in handles)
+        if flag != "0":
+            full = ops._attach_scatter_scratch(L.Grid.from_buffer_copy(tr.grad_field.struct.grid), "cuda").numel()
+            assert tr.grad_field._scatter_scratch.numel() < full / 4, "scratch of a 128-ray batch sized like any batch's"
         got[flag] = {k: tr.grads[k].clone() for k in tables}
         if flag != "0":
             assert all(float(h._scatter_scratch.abs().max()) == 0.0 for h in handles), "scratch not left zeroed"

@@ -188,3 +188,29 @@ def test_checkpoint_names(tmp_path):
     assert "_model.field.aabb" in loaded["pipeline"] and "proposal_networks.0.encoding.hash_table" in state
     with pytest.raises(FileNotFoundError):
         NIO.latest_checkpoint(tmp_path)
+
+
+def test_checkpoint_with_arbitrary_objects_is_refused_unless_trusted(tmp_path, monkeypatch):
+    """step-*.ckpt files may come from outside (reference-trained runs): they are read with ``weights_only=True``; a file that
+    needs unrestricted unpickling is refused unless the caller vouches for it."""
+    import torch
+
+    from cropnerf_amd.fruit_nerf import nerfstudio_io as NIO
+
+    import fractions
+
+    def Payload():  # noqa: N802 -- any class off torch's allow-list makes the restricted unpickler stop
+        return fractions.Fraction(1, 3)
+
+    plain = tmp_path / "step-000000001.ckpt"
+    torch.save({"step": 1, "pipeline": {"_model.field.w": torch.ones(2)}, "optimizers": {"lr": 0.01, "m": [torch.zeros(1)]}}, plain)
+    step, state, loaded = NIO.load_checkpoint(plain)
+    assert step == 1 and torch.equal(state["field.w"], torch.ones(2))
+    odd = tmp_path / "step-000000002.ckpt"
+    torch.save({"step": 2, "pipeline": {"_model.field.w": torch.ones(2)}, "extra": Payload()}, odd)
+    monkeypatch.delenv("CROPNERF_TRUST_CHECKPOINTS", raising=False)
+    with pytest.raises(ValueError, match="arbitrary pickle code"):
+        NIO.load_checkpoint(odd)
+    assert NIO.load_checkpoint(odd, trusted=True)[0] == 2
+    monkeypatch.setenv("CROPNERF_TRUST_CHECKPOINTS", "1")
+    assert NIO.load_checkpoint(odd)[0] == 2
