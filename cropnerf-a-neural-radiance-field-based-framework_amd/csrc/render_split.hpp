@@ -123,8 +123,16 @@ __device__ __forceinline__ void split_ray_setup(const FusedArgs& A, long long q,
     rr = xcd * per_xcd + q;
   }
   if (chunks_per_ray > 0) {  // work items are (ray, chunk) pairs
+#ifdef CN_PER_SAMPLE_RAY_MAJOR  // round-1 order: consecutive items = consecutive chunks of one ray
     ray.chunk = (int)(rr % chunks_per_ray);
     rr /= chunks_per_ray;
+#else
+    // chunk-major: consecutive items -- the pairs of a workgroup, the adjacent lanes of a team gather -- are the SAME chunk
+    // of consecutive rays (neighbouring points of the exporters' surface grid: they share grid cells), not chunks 64
+    // samples apart on one ray
+    ray.chunk = (int)(rr / A.num_rays);
+    rr -= (long long)ray.chunk * A.num_rays;
+#endif
   }
   const long long r = __builtin_amdgcn_readfirstlane((int)rr);
   ray.r = r;
