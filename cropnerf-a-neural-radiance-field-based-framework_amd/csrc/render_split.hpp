@@ -43,6 +43,20 @@ namespace cn {
 // -DCN_ABLATE_GATHER_LEVELS=4 / 8 (the coarsest 4 / 8 levels read no table entry and hash nothing): 2.573 / 2.490 ms against
 // 2.597 -- the bound on what a cheaper (e.g. cell-major, one 64-byte line per cell) copy of the coarse levels could give
 // against 2.56 ms for the real thing.
+// rays per team of the team gather (fp16 mode, half table): 2 = two neighbouring pixels of a row in a lane pair; 4 = a 2 x 2
+// pixel block in a lane quad, each gather wave taking 8 of the half-step's 32 samples for all four (default).  Measured at C2
+// (ms per batch, mean over the ten batches): 2 rays 1.60, 4 consecutive pixels of a row 1.48, 2 x 2 block 1.39; the 2 x 2
+// walk alone with 2-ray teams 1.55, and on the exact-fp32 kernel (no team gather) it costs 1.5 %, so only the team kernel walks
+// its stripes that way
+#ifndef CN_TEAM_RAYS
+#define CN_TEAM_RAYS 4
+#endif
+#ifndef CN_TEAM_RAYS_PS  // the same for per-sample outputs; 512 x 3 000-sample export calls: no team 8.8, 2-ray teams 8.3,
+#define CN_TEAM_RAYS_PS 1  // 4-ray teams 7.4 Gsamples/s -- consecutive samples of the exporters' rays are as close as their rays
+#endif
+#ifndef CN_TEAM_ROW_WALK  // 1: the four rays of a team are four consecutive pixels of a row (A/B)
+#define CN_TEAM_ROW_WALK 0
+#endif
 #ifndef CN_SPLIT_G
 #define CN_SPLIT_G 8
 #endif
@@ -104,7 +118,10 @@ struct SplitRay {
   bool valid;
 };
 
-// ray of schedule slot q for this pair (same mapping as render_fused_kernel)
+// ray of schedule slot q for this pair (same mapping as render_fused_kernel).  QUAD: a column stripe is walked in 2 x 2
+// pixel blocks -- four consecutive slots are one block, (x, y), (x + 1, y), (x, y + 1), (x + 1, y + 1) -- instead of pixel by
+// pixel along its rows: the four-ray team gather puts a block into a lane quad.
+template <bool QUAD = false>
 __device__ __forceinline__ void split_ray_setup(const FusedArgs& A, long long q, long long items, int xcd, bool striped,
                                                 long long rows, int cw, long long first_row, long long per_xcd,
                                                 int chunks_per_ray, SplitRay& ray) {
@@ -113,12 +130,26 @@ __device__ __forceinline__ void split_ray_setup(const FusedArgs& A, long long q,
   if (q >= items) return;
   long long rr;
   if (striped) {
+    if constexpr (QUAD) {
+    const int cwb = (cw + 1) >> 1;
+    const long long per_stripe = ((rows + 1) >> 1) * cwb * 4;
+    const long long sq = q / per_stripe;
+    const long long qq = q - sq * per_stripe;
+    const long long b = qq >> 2;
+    const int w = (int)(qq & 3);
+    const long long vrow = 2 * (b / cwb) + (w >> 1);
+    const int cx = 2 * (int)(b % cwb) + (w & 1);
+    const int col = (int)(sq * 8 + xcd) * cw + cx;
+    rr = (first_row + vrow) * A.image_width + col - A.pixel_start;
+    if (cx >= cw || vrow >= rows || col >= A.image_width || rr < 0 || rr >= A.num_rays) return;
+    } else {
     const long long sq = q / (rows * cw);
     const long long qq = q - sq * rows * cw;
     const long long vrow = qq / cw;
     const int col = (int)(sq * 8 + xcd) * cw + (int)(qq - vrow * cw);
     rr = (first_row + vrow) * A.image_width + col - A.pixel_start;
     if (col >= A.image_width || rr < 0 || rr >= A.num_rays) return;
+    }
   } else {
     rr = xcd * per_xcd + q;
   }
@@ -172,7 +203,11 @@ template <bool PER_SAMPLE, int MM = MM_FP32, bool HALF = false, bool GENERIC = f
 __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A) {
   constexpr bool BF16 = MM == MM_BF16, F16 = MM == MM_F16;
   // TEAM (fp16 products, half table): the gather waves of two neighbouring pairs work as a team -- see the gather role
-  constexpr bool TEAM = F16 && HALF && (SPLIT_MPG == 1) && (SPLIT_G % 2 == 0) && !CN_ABLATE_GATHER;
+  // rays (= pairs = gather waves) per team: 2 or 4 (1 = no team).  Per-sample outputs (the exporters' parallel rays, whose
+  // neighbouring SAMPLES are as close as neighbouring rays) keep 16 consecutive samples of one ray per lane row: no team
+  constexpr int TR = PER_SAMPLE ? CN_TEAM_RAYS_PS : CN_TEAM_RAYS;
+  constexpr bool TEAM = F16 && HALF && TR > 1 && (SPLIT_MPG == 1) && (SPLIT_G % TR == 0) && !CN_ABLATE_GATHER;
+  constexpr bool QUAD = TEAM && TR == 4 && !CN_TEAM_ROW_WALK;  // stripes walked in 2 x 2 pixel blocks (split_ray_setup)
   extern __shared__ __align__(16) float lds[];
   constexpr int OFF_EXT = BLOB_FLOATS + SPLIT_PAIRS * PAIR_SCRATCH;  // BF16 only
   {
@@ -215,7 +250,8 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
   const long long last_row = striped ? (A.pixel_start + A.num_rays - 1) / A.image_width : 0;
   const long long rows = last_row - first_row + 1;
   const long long items =
-      striped ? rows * cw * A.stripes_per_xcd : min(per_xcd, max(nwork - xcd * per_xcd, 0LL));
+      !striped ? min(per_xcd, max(nwork - xcd * per_xcd, 0LL))
+               : (QUAD ? ((rows + 1) >> 1) * ((cw + 1) >> 1) * 4 : rows * cw) * A.stripes_per_xcd;
 
   // every wave of the workgroup runs the same number of half-steps (the barrier count must match): the schedule slots
   // of pair 0, the longest list; a slot without a ray (past the end, outside the image) is an idle step
@@ -259,15 +295,17 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
         if (step < total) {
           const long long qi = step / nhalf;
           const int k = (int)(step - qi * nhalf);
-          const int pair0 = wave & ~1, sub = wave & 1;
-          // the two rays' parameters live in this wave's own (otherwise unused) gather-edge area of LDS, 16 dwords per ray
+          constexpr int SPW = 32 / TR;  // samples of the half-step one gather wave takes (for all TR rays): 16 or 8
+          const int pair0 = wave & ~(TR - 1), sub = wave & (TR - 1);
+          // the rays' parameters live in this wave's own (otherwise unused) gather-edge area of LDS, 16 dwords per ray
           // {o, d, s(near), s(far), bins pointer, chunk, valid}: kept in scalar registers for a whole ray they spill
           float* trec = ring + 2 * XCH_FLOATS + 64 + 68;
+          static_assert(TR * 16 <= 68, "ray records fit the gather-edge area");
           if (k == 0) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < TR; ++t) {
               SplitRay tr;
-              split_ray_setup(A, q_first + pair0 + t + qi * stride, items, xcd, striped, rows, cw, first_row, per_xcd,
+              split_ray_setup<QUAD>(A, q_first + pair0 + t + qi * stride, items, xcd, striped, rows, cw, first_row, per_xcd,
                               chunks_per_item_ray, tr);
               __builtin_amdgcn_wave_barrier();
               if (lane == 0) {
@@ -285,15 +323,17 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
             __builtin_amdgcn_wave_barrier();
           }
           float* ring0 = lds + BLOB_FLOATS + pair0 * PAIR_SCRATCH;
-          bool act[2];
+          const int mcol = lane & 15, rsel = mcol & (TR - 1), sidx = mcol / TR;
+          bool any = false, active = false;
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
-            act[t] = reinterpret_cast<const int*>(trec + 16 * t)[11] != 0 &&
-                     !(!PER_SAMPLE && A.early_stop > 0.f &&
-                       reinterpret_cast<volatile int*>(ring0 + t * PAIR_SCRATCH + PAIR_FLAGS)[2] == (int)qi);
-          if (act[0] || act[1]) {
-            const int mcol = lane & 15, rsel = mcol & 1, sidx = mcol >> 1;
-            const bool active = rsel ? act[1] : act[0];
+          for (int t = 0; t < TR; ++t) {
+            const bool a = reinterpret_cast<const int*>(trec + 16 * t)[11] != 0 &&
+                           !(!PER_SAMPLE && A.early_stop > 0.f &&
+                             reinterpret_cast<volatile int*>(ring0 + t * PAIR_SCRATCH + PAIR_FLAGS)[2] == (int)qi);
+            any = any || a;
+            active = rsel == t ? a : active;
+          }
+          if (any) {
             if (active) {
               const f32x4 ra = *reinterpret_cast<const f32x4*>(trec + 16 * rsel);
               const f32x4 rb = *reinterpret_cast<const f32x4*>(trec + 16 * rsel + 4);
@@ -307,9 +347,11 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
               };
               float px[2], py[2], pz[2];
               bool sel[2];
+              int col[2];  // column of the half-step (0..31) of this lane's two samples
 #pragma unroll
-              for (int h = 0; h < 2; ++h) {  // this wave's column tile: samples 16 sub + 8 h + sidx of the half-step
-                const int i0 = chunk * 64 + 32 * half + 16 * sub + 8 * h + sidx;
+              for (int h = 0; h < 2; ++h) {  // this wave's samples: SPW sub + (SPW / 2) h + sidx of the half-step
+                col[h] = SPW * sub + (SPW / 2) * h + sidx;
+                const int i0 = chunk * 64 + 32 * half + col[h];
                 const float mid = (edge(i0) + edge(i0 + 1)) / 2.f;
                 px[h] = rox + rdx * mid;
                 py[h] = roy + rdy * mid;
@@ -336,9 +378,9 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
               float* xs = ring0 + rsel * PAIR_SCRATCH + (int)(step & 1) * XCH_FLOATS;
               f16x8* xh = reinterpret_cast<f16x8*>(xs);
 #pragma unroll
-              for (int h = 0; h < 2; ++h) {
-                xh[sub * 64 + 16 * g + 8 * h + sidx] = __builtin_bit_cast(f16x8, featp[h]);
-                if (g == 0) xs[XCH_FLOATS - 64 + 16 * sub + 8 * h + sidx] = sel[h] ? 1.f : 0.f;  // selector of column (sub, 8 h + sidx)
+              for (int h = 0; h < 2; ++h) {  // column c of the half-step = column tile c >> 4, column c & 15 of the matrix wave
+                xh[(col[h] >> 4) * 64 + 16 * g + (col[h] & 15)] = __builtin_bit_cast(f16x8, featp[h]);
+                if (g == 0) xs[XCH_FLOATS - 64 + col[h]] = sel[h] ? 1.f : 0.f;  // selector of that column
               }
             }
           }
@@ -353,7 +395,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
           float* gring = ring + m * PAIR_SCRATCH;
           float* tb_g = gring + 2 * XCH_FLOATS + 64 + 68;
           if (k == 0)
-            split_ray_setup(A, q_first + pair + m + qi * stride, items, xcd, striped, rows, cw, first_row, per_xcd, chunks_per_item_ray, gr);
+            split_ray_setup<QUAD>(A, q_first + pair + m + qi * stride, items, xcd, striped, rows, cw, first_row, per_xcd, chunks_per_item_ray, gr);
           // early termination: the matrix wave publishes the schedule slot of a ray it has finished early; the rest of
           // that ray's half-steps are then idle for the pair (the workgroup still runs them in lock-step: the time is
           // saved when the 8 rays in flight -- neighbouring pixels -- go opaque at about the same depth)
@@ -456,7 +498,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
       const long long qi = hs / nhalf;
       const int k = (int)(hs - qi * nhalf);
       if (k == 0) {
-        split_ray_setup(A, q_first + pair + qi * stride, items, xcd, striped, rows, cw, first_row, per_xcd, chunks_per_item_ray, ray);
+        split_ray_setup<QUAD>(A, q_first + pair + qi * stride, items, xcd, striped, rows, cw, first_row, per_xcd, chunks_per_item_ray, ray);
         st = CompositeState();
         ray_stopped = false;
         if (ray.valid) {
