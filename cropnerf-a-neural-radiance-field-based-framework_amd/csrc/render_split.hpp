@@ -54,6 +54,13 @@ namespace cn {
 #ifndef CN_TEAM_RAYS_PS  // the same for per-sample outputs; 512 x 3 000-sample export calls: no team 8.8, 2-ray teams 8.3,
 #define CN_TEAM_RAYS_PS 1  // 4-ray teams 7.4 Gsamples/s -- consecutive samples of the exporters' rays are as close as their rays
 #endif
+// The team gather serves the fp16 and the split-bf16 matrix modes on either table type -- C2, ms per batch without / with
+// 4-ray teams: fp16 mode on the fp32 torch table 2.14 / 1.69, split-bf16 on it 1.81 / 1.71, split-bf16 on a tcnn fp16 table
+// 2.06 / 1.57 -- but NOT the exact-fp32 kernel, which is bound by SIMD issue, hides its gathers under the fp32 MFMAs and only
+// pays for the per-lane ray parameters: 2.59 / 2.78 (CN_TEAM_ALL=1 forces it there too, A/B).
+#ifndef CN_TEAM_ALL
+#define CN_TEAM_ALL 0
+#endif
 #ifndef CN_TEAM_ROW_WALK  // 1: the four rays of a team are four consecutive pixels of a row (A/B)
 #define CN_TEAM_ROW_WALK 0
 #endif
@@ -202,11 +209,11 @@ __device__ __forceinline__ void split_fill_edges(const FusedArgs& A, const Split
 template <bool PER_SAMPLE, int MM = MM_FP32, bool HALF = false, bool GENERIC = false>
 __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A) {
   constexpr bool BF16 = MM == MM_BF16, F16 = MM == MM_F16;
-  // TEAM (fp16 products, half table): the gather waves of two neighbouring pairs work as a team -- see the gather role
+  // TEAM (fp16 or split-bf16 products): the gather waves of neighbouring pairs work as a team -- see the gather role
   // rays (= pairs = gather waves) per team: 2 or 4 (1 = no team).  Per-sample outputs (the exporters' parallel rays, whose
   // neighbouring SAMPLES are as close as neighbouring rays) keep 16 consecutive samples of one ray per lane row: no team
   constexpr int TR = PER_SAMPLE ? CN_TEAM_RAYS_PS : CN_TEAM_RAYS;
-  constexpr bool TEAM = F16 && HALF && TR > 1 && (SPLIT_MPG == 1) && (SPLIT_G % TR == 0) && !CN_ABLATE_GATHER;
+  constexpr bool TEAM = (CN_TEAM_ALL || MM != MM_FP32) && TR > 1 && (SPLIT_MPG == 1) && (SPLIT_G % TR == 0) && !CN_ABLATE_GATHER;
   constexpr bool QUAD = TEAM && TR == 4 && !CN_TEAM_ROW_WALK;  // stripes walked in 2 x 2 pixel blocks (split_ray_setup)
   extern __shared__ __align__(16) float lds[];
   constexpr int OFF_EXT = BLOB_FLOATS + SPLIT_PAIRS * PAIR_SCRATCH;  // BF16 only
@@ -359,27 +366,54 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
                 sel[h] = normalize_position(A.scene, px[h], py[h], pz[h]);
               }
               u32x4v featp[2];
+              f32x4 feat[2][2];
               const f32x4 lvl_scale = *reinterpret_cast<const f32x4*>(lds + OFF_SCALE + 4 * g);
               const float pos_off = GENERIC ? A.grid.pos_offset : 0.f;
-              PkLoads cur = hash_level_pk_issue<GENERIC>(A.grid.table, lane_level_rec<GENERIC>(lds + OFF_LVL, A.grid, 4 * g, lvl_scale[0]),
-                                                         pos_off, px[0], py[0], pz[0]);
+              if constexpr (F16 && HALF) {
+                PkLoads cur = hash_level_pk_issue<GENERIC>(A.grid.table, lane_level_rec<GENERIC>(lds + OFF_LVL, A.grid, 4 * g, lvl_scale[0]),
+                                                           pos_off, px[0], py[0], pz[0]);
 #pragma unroll
-              for (int u = 0; u < 8; ++u) {
-                PkLoads nxt;
-                if (u < 7) {
-                  const int qn = (u + 1) >> 1, hn = (u + 1) & 1;
-                  nxt = hash_level_pk_issue<GENERIC>(A.grid.table,
-                                                     lane_level_rec<GENERIC>(lds + OFF_LVL, A.grid, 4 * g + qn, lvl_scale[qn]), pos_off,
-                                                     px[hn], py[hn], pz[hn]);
+                for (int u = 0; u < 8; ++u) {
+                  PkLoads nxt;
+                  if (u < 7) {
+                    const int qn = (u + 1) >> 1, hn = (u + 1) & 1;
+                    nxt = hash_level_pk_issue<GENERIC>(A.grid.table,
+                                                       lane_level_rec<GENERIC>(lds + OFF_LVL, A.grid, 4 * g + qn, lvl_scale[qn]), pos_off,
+                                                       px[hn], py[hn], pz[hn]);
+                  }
+                  featp[u & 1][u >> 1] = pk_pin(hash_level_pk_blend(cur));
+                  if (u < 7) cur = nxt;
                 }
-                featp[u & 1][u >> 1] = pk_pin(hash_level_pk_blend(cur));
-                if (u < 7) cur = nxt;
+              } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const Lvl lv = lane_level_rec<GENERIC>(lds + OFF_LVL, A.grid, 4 * g + q, lvl_scale[q]);
+#pragma unroll
+                  for (int h = 0; h < 2; ++h) {
+                    const float2 f = hash_level_sc<HALF, GENERIC>(A.grid.table, lv, pos_off, px[h], py[h], pz[h]);
+                    if constexpr (F16) {
+                      const f16x2 hp = {(_Float16)f.x, (_Float16)f.y};
+                      featp[h][q] = __builtin_bit_cast(unsigned, hp);
+                    } else {
+                      if (q == 0) { feat[h][0].x = f.x; feat[h][0].y = f.y; }
+                      if (q == 1) { feat[h][0].z = f.x; feat[h][0].w = f.y; }
+                      if (q == 2) { feat[h][1].x = f.x; feat[h][1].y = f.y; }
+                      if (q == 3) { feat[h][1].z = f.x; feat[h][1].w = f.y; }
+                    }
+                  }
+                  if ((q + 1) % CN_SPLIT_LEVELS_IN_FLIGHT == 0) __builtin_amdgcn_sched_barrier(0);
+                }
               }
               float* xs = ring0 + rsel * PAIR_SCRATCH + (int)(step & 1) * XCH_FLOATS;
-              f16x8* xh = reinterpret_cast<f16x8*>(xs);
 #pragma unroll
               for (int h = 0; h < 2; ++h) {  // column c of the half-step = column tile c >> 4, column c & 15 of the matrix wave
-                xh[(col[h] >> 4) * 64 + 16 * g + (col[h] & 15)] = __builtin_bit_cast(f16x8, featp[h]);
+                if constexpr (F16) {
+                  reinterpret_cast<f16x8*>(xs)[(col[h] >> 4) * 64 + 16 * g + (col[h] & 15)] = __builtin_bit_cast(f16x8, featp[h]);
+                } else {
+                  f32x4* xv = reinterpret_cast<f32x4*>(xs);
+                  xv[(2 * (col[h] >> 4) + 0) * 64 + 16 * g + (col[h] & 15)] = feat[h][0];
+                  xv[(2 * (col[h] >> 4) + 1) * 64 + 16 * g + (col[h] & 15)] = feat[h][1];
+                }
                 if (g == 0) xs[XCH_FLOATS - 64 + col[h]] = sel[h] ? 1.f : 0.f;  // selector of that column
               }
             }
