@@ -675,24 +675,34 @@ def subsystem_timings(args, params, device):
                     "samples per ray), reference: exporter_utils_nerfacto.py:125-183"}
     # ---- exporter.py semantic-pointcloud (dense volume export): 512-ray calls x 3 000 samples per ray -----------------------------
     # scripts/exporter.py:75-77, exporter_utils.py:93-172; the reference's full job is 3000 x 3000 rays, timed here on 512 x 512
-    # (density offset chosen so that about 1 % of the samples pass the exporter's density >= 70 threshold -- the P-rand
-    #  density logits are -0.095 +- 0.01 -- instead of none or all of them)
+    aabb_e = ((-1, -1, -1 + .318), (1, 1, 1 + .318))
+    side = 512
+
+    def dense(params_e):
+        pipe_e = FruitPipeline(FruitPipelineConfig(FruitDataManagerConfig(4096, 512), cfg), device, cams, box, test_mode="export",
+                               params=params_e)
+        pipe_e.model.setup_inference(True, 3000)
+        n_small = pipe_e.datamanager.setup_inference(aabb_e, 64)
+        sample_volume(pipe_e, n_small, transform_json={"scale": 1.0, "transform": None}, capacity=1 << 26)  # warm-up
+        n_rays = pipe_e.datamanager.setup_inference(aabb_e, side)
+        t, pcds = wall(lambda: sample_volume(pipe_e, n_rays, transform_json={"scale": 1.0, "transform": None}, capacity=1 << 26))
+        return t, n_rays, {k: int(v["points"].shape[0]) for k, v in pcds.items()}
+
+    # (a) the scene as it is: no sample passes the exporter's density >= 70 threshold -- the device side alone (render + masks +
+    # compaction); (b) a density offset chosen so that ~1 % of the samples pass (the P-rand density logits are -0.095 +- 0.01):
+    # the kept points of the three sets then also cross PCIe and become float64 arrays on the host, as the exporter hands them on
+    t, n_rays, kept0 = dense(p2)
     p3 = {k: v.clone() for k, v in params.items()}
     p3["field.mlp_base_mlp.layers.1.bias"][0] += 4.323
     p3["field.field_head_semantics.net.bias"] += 3.0
-    pipe_e = FruitPipeline(FruitPipelineConfig(FruitDataManagerConfig(4096, 512), cfg), device, cams, box, test_mode="export", params=p3)
-    pipe_e.model.setup_inference(True, 3000)
-    aabb_e = ((-1, -1, -1 + .318), (1, 1, 1 + .318))
-    n_rays = pipe_e.datamanager.setup_inference(aabb_e, 64)
-    sample_volume(pipe_e, n_rays, transform_json={"scale": 1.0, "transform": None}, capacity=1 << 26)  # warm-up
-    side = 512
-    n_rays = pipe_e.datamanager.setup_inference(aabb_e, side)
-    t, pcds = wall(lambda: sample_volume(pipe_e, n_rays, transform_json={"scale": 1.0, "transform": None}, capacity=1 << 26))
+    t1, _, kept1 = dense(p3)
     ns = n_rays * 3000
     out["dense_export"] = {
         "seconds": round(t, 3), "rays": n_rays, "samples_per_ray": 3000, "rays_per_call": 512, "field_samples_per_sec": ns / t,
-        "kept": {k: int(v["points"].shape[0]) for k, v in pcds.items()},
-        "full_3000x3000_estimate_s": round(t * (3000 * 3000) / n_rays, 2),
+        "kept": kept0, "full_3000x3000_estimate_s": round(t * (3000 * 3000) / n_rays, 2),
+        "with_1pct_kept": {"seconds": round(t1, 3), "kept": kept1, "field_samples_per_sec": ns / t1,
+                           "note": "the kept points of the three sets (3 x 7 floats each) copied to the host and converted to "
+                                   "float64 arrays inside the timed region, as sample_volume returns them"},
         "roofline": {"bound": "hbm", "kernel": "render_split_kernel<per-sample> + export_compact", "achieved": round(ns * BYTES_PER_SAMPLE / t / 1e9, 1),
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ns * BYTES_PER_SAMPLE / t / 1e9 / HBM_PEAK_GBPS, 4),
                      "traffic": None, "bytes_per_sample": BYTES_PER_SAMPLE,
