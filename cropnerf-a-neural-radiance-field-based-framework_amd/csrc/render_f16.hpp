@@ -1,20 +1,23 @@
-// render_f16_kernel -- the fused renderer in the reference's OWN arithmetic class (cn_render_opts.matrix_precision =
+// render_f16_kernel -- the single-wave renderer in the reference's OWN arithmetic class (cn_render_opts.matrix_precision =
 // CN_MATRIX_F16): tiny-cuda-nn's FullyFusedMLP under mixed precision (fruit_nerf/fruit_field.py:95,125-167 build every
 // module with implementation="tcnn"; fruit_nerf_config.py:35 mixed_precision=True).  Included by render_fused.hip.
 //
-// Why its own kernel and not a mode of render_split_kernel.  With fp16 operands the whole MLP chain of 32 samples is 44
-// v_mfma_f32_16x16x32_f16 (704 matrix-pipe cycles) instead of 288 fp32 MFMAs (9 216 cycles): the matrix side shrinks to a
-// tenth and the kernel is the hash-grid gather.  The producer/consumer kernel was built to hide gathers under a LONG matrix
-// phase; its one workgroup barrier per half-step keeps the eight gather waves of a CU in lock-step (all compute addresses,
-// all wait, all blend), so once the matrix phase is short the gather time and the rest simply add: measured at C2 with a
-// tcnn fp16 table 2.15 ms, 0.68 ms of it with the table reads removed, 1.32 ms with half of them removed.  Here every wave
-// owns a ray, gathers, multiplies and composites for itself, nothing synchronises two waves, and 16-20 waves per CU drift
-// apart so that one wave's memory wait is another's arithmetic.
+// What it is for.  The DENSITY-ONLY pass of the fp16 mode (get_density_for_camera_ray_bundle, the occlusion pass of the
+// projection: render_split_kernel has no such variant), and an A/B alternative for the composited and per-sample renders
+// (CN_F16_KERNEL=own).  It was built as THE fp16 kernel on this reasoning: with fp16 operands the MLP chain of 32 samples is 44
+// v_mfma_f32_16x16x32_f16 instead of 288 fp32 MFMAs, the kernel is its hash-grid gathers, and the producer/consumer kernel's
+// barrier per half-step keeps its gather waves in lock-step -- so let every wave own a ray end to end, 16-20 independent waves
+// per CU (28.8 KB LDS image: five workgroups fit), one wave's memory wait another's arithmetic.  Measured at C2 on a tcnn fp16
+// table: 3.83 ms against the split kernel's 2.15 (2.87 against 1.77 once both had the x-pair gathers; 1.39 now).  What the
+// gathers cost is L1 line lookups and L1 misses, not exposed latency: twice the rays in flight per CU, at
+// unrelated depths, evict each other's lines from the 32 KB L1, while the split kernel's eight rays -- neighbouring pixels at
+// the SAME depth -- share them.  Lock-step is a feature there.
 //
 // Arithmetic (the parity bar is oracle/tcnn.py with tcnn_half_activations=True, tests/test_gpu_f16.py):
 //   * weights rounded to fp16 in prep_kernel (a no-op for an imported tcnn checkpoint, whose parameters are fp16 values);
-//   * half table: the trilinear blend runs on packed fp16 pairs (hash_level_pk: v_pk_fma_f16, 14 instructions for both
-//     features), as tcnn's kernel_grid accumulates in the parameter type; float table: fp32 blend, result rounded to fp16;
+//   * half table: the trilinear blend runs on packed fp16 pairs (hash_level_pk_*: v_pk_fma_f16, 14 instructions for both
+//     features, x-pair gathers), as tcnn's kernel_grid accumulates in the parameter type; float table: fp32 blend, result
+//     rounded to fp16;
 //   * every layer input rounded to fp16 (v_cvt_pk_f16_f32, round to nearest even), products summed in fp32 by the MFMA
 //     (tcnn accumulates in fp16: this is at least as precise), biases / heads / sigmoid / compositing in fp32.
 // Ray -> wave scheduling (XCD column stripes), compositing and early termination are render_fused_kernel's.

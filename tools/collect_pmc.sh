@@ -17,4 +17,4 @@ rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $O/l
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d $O/sq -- python3 $B > $O/sq.log 2>&1
 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr --output-format csv -d $O/tcp -- python3 $B > $O/tcp.log 2>&1
 cd $ROOT
-python3 tools/summarise_pmc.py $TAG
+python3 tools/summarise_pmc.py $TAG || true
