@@ -508,3 +508,55 @@ def test_cell_major_records_at_a_training_batch_size(monkeypatch):
         assert float(ref.abs().sum()) > 0, k
         err = float((got["0.5"][k] - ref).norm() / ref.norm())
         assert err < 1e-5, f"{k}: {err}"
+
+
+def test_c2_training_batch_at_its_stated_size_is_the_mean_of_its_chunks():
+    """BASELINE.json configs[1], training half: 65 536 rays x 192 field samples (+ (256, 96) proposal samples) through one
+    ``forward_backward`` -- 12.6 M field samples and 23 M proposal samples per call, cell-major records for the coarse levels,
+    every loss a mean over the rays.  The oracle cannot run this size; the property that can be checked is LINEARITY: each
+    loss and every gradient of the full batch equals the mean over its eight 8 192-ray chunks run one by one (gradients differ
+    only in the order of float additions), and at 8 192 rays the kernels ARE checked against autograd (test_gradients_*, the
+    big-shape tests).  Also: everything finite, scratch left zeroed."""
+    from cropnerf_amd import config as PC, synthetic
+    from cropnerf_amd.fruit_nerf.fruit_nerf import FruitModel, Semantics
+    from cropnerf_amd.fruit_nerf.trainer import FruitTrainer
+    from cropnerf_amd.rays import Cameras, SceneBox
+
+    cfg = PC.FruitNerfModelConfig(num_nerf_samples_per_ray=192)
+    params = synthetic.p_rand(cfg.field_spec(20), cfg.proposal_specs(), seed=3, device="cuda")
+    c2w, intr = synthetic.orbit_cameras(20)
+    cams = Cameras(c2w, intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], 800, 800).to("cuda")
+    g = torch.Generator().manual_seed(12)
+    R, C = 65536, 8
+    idx = torch.stack([torch.randint(0, 20, (R,), generator=g), torch.randint(0, 800, (R,), generator=g),
+                       torch.randint(0, 800, (R,), generator=g)], -1)
+    rays = cams.generate_rays(idx.cuda())
+    image = torch.rand(R, 3, generator=g).cuda()
+    mask = (torch.rand(R, 1, generator=g) > 0.5).float().cuda()
+    jitter = [torch.rand(R, 1, generator=g) for _ in range(3)]
+
+    def run(lo, hi):
+        model = FruitModel(cfg, SceneBox(torch.tensor([[-1.0, -1, -1], [1, 1, 1]])), 20, {"semantics": Semantics()},
+                           device="cuda", params={k: v.clone() for k, v in params.items()})
+        model.training = True
+        tr = FruitTrainer(model)
+        out = tr.forward_backward(rays[lo:hi], {"image": image[lo:hi], "fruit_mask": mask[lo:hi]},
+                                  jitter=[j[lo:hi] for j in jitter])
+        torch.cuda.synchronize()
+        assert all(float(h._scatter_scratch.abs().max()) == 0.0 for h in [tr.grad_field] + tr.grad_props)
+        return {k: float(v) for k, v in out["loss_dict"].items()}, tr.flat_grads.clone()
+
+    full_loss, full_grad = run(0, R)
+    assert torch.isfinite(full_grad).all() and float(full_grad.abs().sum()) > 0
+    mean_loss, mean_grad = {k: 0.0 for k in full_loss}, torch.zeros_like(full_grad)
+    for c in range(C):
+        ld, gr = run(c * R // C, (c + 1) * R // C)
+        for k, v in ld.items():
+            mean_loss[k] += v / C
+        mean_grad += gr / C
+    for k in full_loss:
+        if k == "camera_opt_regularizer":  # a function of the parameters, not of the batch
+            continue
+        assert abs(full_loss[k] - mean_loss[k]) <= 2e-5 * abs(mean_loss[k]) + 1e-8, (k, full_loss[k], mean_loss[k])
+    err = float((full_grad - mean_grad).norm() / mean_grad.norm())
+    assert err < 2e-5, f"gradient of the full batch vs the mean of its chunks: relative L2 {err:.3e}"
