@@ -282,6 +282,77 @@ __device__ __forceinline__ float2 hash_level(const void* __restrict__ table, con
   return r;
 }
 
+// hash_level with x-pair gathers (round 3).  A CU's L1 looks up one cache line per clock for per-lane-addressed loads
+// (tools/gather_rate_microbench.hip), and the gather-heavy kernels run at that rate; the two x-corners of a (y, z) row are
+// entries e and e ^ 1 -- one aligned pair -- whenever the cell's x index is even (hashed levels: index = x ^ y*P1 ^ z*P2;
+// dense levels of the tcnn layout: x in the low bits).  So each row is ONE load of the aligned pair that holds the lower
+// corner (16 bytes of float2 entries, 8 bytes of half2 entries: one lookup either way), and lanes with an odd x index fetch
+// their upper corner with a second load under the execution mask: 6 lookups per level instead of 8.  Same values, same
+// blend as hash_level (results may differ in the last bit where hipcc contracts the multiply-adds differently).  The two
+// results are pinned with an empty asm: the conditional load is control flow, and without it hipcc sinks the blends of
+// all levels behind the last level's loads.
+template <bool HALF = false>
+__device__ __forceinline__ float2 hash_level_xpair(const void* __restrict__ table, const Lvl& lv, float pos_offset, float px,
+                                                   float py, float pz) {
+  const Cell k = hash_cell(lv, pos_offset, px, py, pz);
+  const char* base = reinterpret_cast<const char*>(table);
+  const unsigned pair_mask = lv.mask & ~1u;
+  const unsigned hyz[4] = {k.hy0 ^ k.hz0, k.hy1 ^ k.hz0, k.hy0 ^ k.hz1, k.hy1 ^ k.hz1};  // rows (y, z) = ff, cf, fc, cc
+  const bool odd = (k.hx0 & 1u) != 0u;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  float2 lo[4], hi[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const unsigned x = k.hx0 ^ hyz[r];
+    const bool second = (x & 1u) != 0u;
+    const unsigned e = (x & pair_mask) + lv.off;  // first entry of the aligned pair (level offsets are even)
+    float2 a, b;
+    if constexpr (HALF) {
+      const h4 v = *reinterpret_cast<const h4*>(base + (size_t)(e << 2));
+      a = make_float2((float)v.x, (float)v.y);
+      b = make_float2((float)v.z, (float)v.w);
+    } else {
+      const f4 v = *reinterpret_cast<const f4*>(base + (size_t)(e << 3));
+      a = make_float2(v.x, v.y);
+      b = make_float2(v.z, v.w);
+    }
+    lo[r] = second ? b : a;
+    hi[r] = second ? a : b;  // the upper-x corner when x is even
+  }
+  if (odd) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const unsigned e = ((k.hx1 ^ hyz[r]) & lv.mask) + lv.off;
+      if constexpr (HALF) {
+        const h2 v = *reinterpret_cast<const h2*>(base + (size_t)(e << 2));
+        hi[r] = make_float2((float)v.x, (float)v.y);
+      } else {
+        hi[r] = *reinterpret_cast<const float2*>(base + (size_t)(e << 3));
+      }
+    }
+  }
+  const float ox = k.ox, oy = k.oy, oz = k.oz;
+  const float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  auto V = [](float2 t) {
+    v2f v;
+    v.x = t.x;
+    v.y = t.y;
+    return v;
+  };
+  const v2f f03 = V(hi[3]) * ox + V(lo[3]) * mx, f12 = V(hi[2]) * ox + V(lo[2]) * mx;
+  const v2f f56 = V(hi[0]) * ox + V(lo[0]) * mx, f47 = V(hi[1]) * ox + V(lo[1]) * mx;
+  const v2f a2 = f03 * oy + f12 * my, b2 = f47 * oy + f56 * my;
+  const v2f rv = a2 * oz + b2 * mz;
+  float2 r;
+  r.x = rv.x;
+  r.y = rv.y;
+  asm volatile("" : "+v"(r.x), "+v"(r.y));
+  return r;
+}
+
 // Private accumulation of the coarsest level's gradient (cn_grid.scatter_scratch): `copies` dense [n1^3][2] arrays,
 // vertex (x, y, z) at x + n1 * (y + n1 * z); a workgroup adds to copy blockIdx.x % copies.  base == nullptr: off.
 struct CoarseScatter {

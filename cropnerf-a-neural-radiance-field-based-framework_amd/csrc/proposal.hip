@@ -13,6 +13,11 @@
 
 namespace cn {
 
+// x-pair gathers in the sampler (hash_level_xpair): the kernel runs at the L1's line-lookup rate -- 40 gathers per sample,
+// ~25 lookups after coalescing along the ray, 5.8e8 per C2 launch = 2.3e6 of its 2.5e6 cycles per CU
+#ifndef CN_PROP_XPAIR
+#define CN_PROP_XPAIR 1
+#endif
 constexpr int PROP_MAX_LEVELS = 3;   // proposal iterations
 constexpr int PROP_MAX_SAMPLES = 512;
 
@@ -53,7 +58,11 @@ __device__ __forceinline__ float prop_density(const PropNet& n, const SceneDev& 
   float enc[2 * L];
 #pragma unroll
   for (int l = 0; l < L; ++l) {
+#if CN_PROP_XPAIR
+    float2 f = hash_level_xpair<HALF>(n.grid.table, n.grid.level(l), n.grid.pos_offset, px, py, pz);
+#else
     float2 f = hash_level<HALF>(n.grid.table, n.grid.level(l), n.grid.pos_offset, px, py, pz);
+#endif
     enc[2 * l] = f.x;
     enc[2 * l + 1] = f.y;
   }
