@@ -14,6 +14,13 @@ that holds only the libraries they use, and runs them on seeded inputs:
     fruit_nerf/data/fruit_datamanager.py                    get_corners_of_aabb :42-69, sample_surface_points :71-121
     segmentation/merger.py                                  get_component :26-74, calc_affinity :335-355
                                                             (with segmentation/lpa.py, which imports as is)
+    fruit_nerf/components/ray_samplers.py                   UniformSamplerWithNoise.generate_ray_samples :54-104 (round 3): the
+                                                            method's definition, run as a plain function on an object that holds
+                                                            the five attributes its constructor sets (:39-51) and a ray bundle
+                                                            whose get_ray_samples() RECORDS its keyword arguments -- the bins,
+                                                            the jitter arithmetic and spacing_to_euclidean_fn are the reference's
+    fruit_nerf/components/ray_generators.py                 class OrthographicRayGenerator :22-66 (round 3): the class definition,
+                                                            on torch's real nn.Module, with RayBundle a record of its keywords
 
 Nothing of the reference is copied into the repository: the fixture holds inputs and outputs only.  The oracle
 (``oracle/zbuffer.py``, ``oracle/rays.py``), the host mirrors (``cropnerf_amd/segmentation/merger.py``,
@@ -48,6 +55,30 @@ def extract(path, names, namespace):
     if missing:
         raise RuntimeError(f"{path}: functions not found: {sorted(missing)}")
     return namespace
+
+
+def extract_class(path, class_name, namespace, method=None):
+    """exec the ClassDef `class_name` of the module at `path` inside `namespace`; with `method`, only that method's
+    FunctionDef, as a module-level function."""
+    with open(path, encoding="utf-8") as f:
+        tree = ast.parse(f.read(), filename=path)
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == class_name:
+            if method is None:
+                exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), namespace)
+                return namespace
+            for sub in node.body:
+                if isinstance(sub, ast.FunctionDef) and sub.name == method:
+                    exec(compile(ast.Module(body=[sub], type_ignores=[]), path, "exec"), namespace)
+                    return namespace
+    raise RuntimeError(f"{path}: {class_name}.{method} not found")
+
+
+class Record:
+    """A container of keyword arguments (stands where nerfstudio's RayBundle / RaySamples dataclasses would: no arithmetic)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
 
 
 def orbit_c2w(rng):
@@ -151,11 +182,83 @@ def merger_cases(out):
     out["num_mg"] = np.array(case)
 
 
+def sampler_cases(out):
+    """UniformSamplerWithNoise.generate_ray_samples (components/ray_samplers.py:54-104) in eval and in training with both
+    jitter kinds.  torch.rand is seeded right before the call; the same seed regenerates the jitter for the fixture."""
+    from types import SimpleNamespace
+    from typing import Optional
+
+    ns = extract_class(f"{REF}/fruit_nerf/components/ray_samplers.py", "UniformSamplerWithNoise",
+                       {"torch": torch, "Optional": Optional, "RayBundle": Record, "RaySamples": Record},
+                       method="generate_ray_samples")
+    fn = ns["generate_ray_samples"]
+    g = torch.Generator().manual_seed(40)
+    case = 0
+    for num_samples, num_rays, training, single in ((64, 7, False, False), (192, 5, False, False), (3000, 3, False, False),
+                                                    (48, 9, True, True), (48, 9, True, False), (100, 4, True, True)):
+        nears = torch.rand(num_rays, 1, generator=g) * 0.5
+        fars = nears + 0.5 + torch.rand(num_rays, 1, generator=g) * 2.0
+        rec = {}
+
+        def get_ray_samples(**kw):
+            rec.update(kw)
+            return Record(**kw)
+
+        bundle = Record(origins=torch.zeros(num_rays, 3), nears=nears, fars=fars, get_ray_samples=get_ray_samples)
+        # what UniformSamplerWithNoise.__init__ (:39-51) hands to SpacedSampler: identity spacing functions
+        self_ = SimpleNamespace(num_samples=None, train_stratified=True, single_jitter=single, training=training,
+                                spacing_fn=lambda x: x, spacing_fn_inv=lambda x: x)
+        seed = 1000 + case
+        torch.manual_seed(seed)
+        fn(self_, bundle, num_samples)
+        torch.manual_seed(seed)
+        t_rand = torch.rand((num_rays, 1 if single else num_samples + 1)) if training else torch.zeros(0)
+        k = f"us{case}"
+        out[f"{k}/num_samples"], out[f"{k}/training"], out[f"{k}/single_jitter"] = np.array(num_samples), np.array(training), np.array(single)
+        out[f"{k}/nears"], out[f"{k}/fars"], out[f"{k}/t_rand"] = nears.numpy(), fars.numpy(), t_rand.numpy()
+        for name in ("bin_starts", "bin_ends", "spacing_starts", "spacing_ends"):
+            v = rec[name]
+            out[f"{k}/{name}"] = v.expand(num_rays, num_samples, 1).numpy().copy()
+        x = torch.linspace(0, 1, 5)[None, :].expand(num_rays, 5)
+        out[f"{k}/s2e_at_quarters"] = rec["spacing_to_euclidean_fn"](x).numpy()
+        case += 1
+    out["num_us"] = np.array(case)
+
+
+def ortho_cases(out):
+    """OrthographicRayGenerator (components/ray_generators.py:22-66): constructor + forward(count) for first, middle and
+    ragged last batches."""
+    from torch import Tensor, nn
+
+    ns = extract_class(f"{REF}/fruit_nerf/components/ray_generators.py", "OrthographicRayGenerator",
+                       {"torch": torch, "nn": nn, "Tensor": Tensor, "RayBundle": Record})
+    cls = ns["OrthographicRayGenerator"]
+    g = torch.Generator().manual_seed(41)
+    case = 0
+    for n_pts, batch, plane in ((37, 8, [[0.0, 0.0, 2.0]]), (64, 16, [[0.0, 1.5, 0.0]]), (10, 512, [[0.3, -0.4, 1.2]])):
+        pts = torch.rand(n_pts, 3, generator=g) * 2 - 1
+        plane_t = torch.tensor(plane)
+        gen = cls(pts, plane_t, batch, "cpu", None)
+        counts = sorted({1, 2, (n_pts + batch - 1) // batch})
+        for count in counts:
+            if batch * (count - 1) >= n_pts:
+                continue
+            rb = gen(count)
+            k = f"og{case}"
+            out[f"{k}/points"], out[f"{k}/plane"], out[f"{k}/batch"], out[f"{k}/count"] = pts.numpy(), plane_t.numpy(), np.array(batch), np.array(count)
+            for name in ("origins", "directions", "pixel_area", "nears", "fars"):
+                out[f"{k}/{name}"] = getattr(rb, name).numpy()
+            case += 1
+    out["num_og"] = np.array(case)
+
+
 def main():
     out = {}
     projection_cases(out)
     datamanager_cases(out)
     merger_cases(out)
+    sampler_cases(out)
+    ortho_cases(out)
     path = os.path.join(HERE, "reference_functions.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path), "bytes", len(out), "arrays")

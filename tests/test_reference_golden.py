@@ -6,7 +6,11 @@
   (``fruit_nerf/scripts/depth_based_semantic_projection.py:31-49,84-105``),
 * ``oracle/rays.py`` ``corners_of_aabb`` / ``surface_points`` and the product's surface grid (``cn_surface_grid``;
   ``fruit_nerf/data/fruit_datamanager.py:42-121``),
-* the merger's ``calc_affinity`` / ``get_component`` host mirrors (``segmentation/merger.py:26-74,335-355``).
+* the merger's ``calc_affinity`` / ``get_component`` host mirrors (``segmentation/merger.py:26-74,335-355``),
+* (round 3) ``oracle/samplers.py: spaced_sampler`` and ``cn_sample_spaced`` -- the reference's own
+  ``UniformSamplerWithNoise.generate_ray_samples`` (``fruit_nerf/components/ray_samplers.py:54-104``) in eval and with both
+  kinds of training jitter -- and ``oracle/rays.py: ortho_rays`` / ``cn_raygen_ortho`` against the reference's
+  ``OrthographicRayGenerator`` (``fruit_nerf/components/ray_generators.py:22-66``).
 """
 
 import os
@@ -61,6 +65,45 @@ def test_oracle_surface_grid_reproduces_the_reference(gold):
         pts, plane = ORY.surface_points(corners, int(gold[f"dm{i}/n"]))
         assert np.array_equal(pts.numpy(), gold[f"dm{i}/points"])
         assert np.array_equal(plane.numpy(), gold[f"dm{i}/plane"])
+
+
+def _sampler_case(gold, c):
+    k = f"us{c}"
+    S = int(gold[f"{k}/num_samples"])
+    t = torch.from_numpy(gold[f"{k}/t_rand"]) if bool(gold[f"{k}/training"]) else None
+    return k, S, torch.from_numpy(gold[f"{k}/nears"]), torch.from_numpy(gold[f"{k}/fars"]), t
+
+
+def test_oracle_uniform_sampler_reproduces_the_reference(gold):
+    """``UniformSamplerWithNoise.generate_ray_samples`` executed from the reference's source: bins, stratified jitter (single
+    and per-bin) and the spacing -> euclidean map, bit for bit."""
+    from oracle import rays as ORY
+    from oracle import samplers as OSM
+
+    assert int(gold["num_us"]) == 6
+    for c in range(int(gold["num_us"])):
+        k, S, nears, fars, t = _sampler_case(gold, c)
+        R = nears.shape[0]
+        rb = ORY.RayBundle(torch.zeros(R, 3), torch.zeros(R, 3), torch.zeros(R, 1), None, nears, fars)
+        rs = OSM.spaced_sampler(rb, S, "uniform", t_rand=t)
+        assert np.array_equal(rs.starts.numpy(), gold[f"{k}/bin_starts"]), k
+        assert np.array_equal(rs.ends.numpy(), gold[f"{k}/bin_ends"]), k
+        assert np.array_equal(rs.spacing_starts.expand(R, S, 1).numpy(), gold[f"{k}/spacing_starts"]), k
+        assert np.array_equal(rs.spacing_ends.expand(R, S, 1).numpy(), gold[f"{k}/spacing_ends"]), k
+        x = torch.linspace(0, 1, 5)[None, :].expand(R, 5)
+        assert np.array_equal((x * fars + (1 - x) * nears).numpy(), gold[f"{k}/s2e_at_quarters"]), k
+
+
+def test_oracle_ortho_rays_reproduce_the_reference(gold):
+    from oracle import rays as ORY
+
+    assert int(gold["num_og"]) >= 6
+    for c in range(int(gold["num_og"])):
+        k = f"og{c}"
+        rb = ORY.ortho_rays(torch.from_numpy(gold[f"{k}/points"]), torch.from_numpy(gold[f"{k}/plane"]), int(gold[f"{k}/batch"]),
+                            int(gold[f"{k}/count"]))
+        for name in ("origins", "directions", "pixel_area", "nears", "fars"):
+            assert np.array_equal(getattr(rb, name).numpy(), gold[f"{k}/{name}"]), (k, name)
 
 
 def test_host_corners_mirror_reproduces_the_reference(gold):
@@ -128,3 +171,41 @@ def test_hip_surface_grid_reproduces_the_reference(gold):
         # torch.linspace on the host vs the kernel's lerp: the last bit of an interior grid coordinate may differ
         assert np.allclose(pts.cpu().numpy(), want, rtol=0, atol=2.4e-7)
         assert np.array_equal(plane.numpy(), gold[f"dm{i}/plane"])
+
+
+@pytest.mark.gpu
+def test_hip_uniform_sampler_reproduces_the_reference(gold):
+    """``cn_sample_spaced`` against the reference's own ``generate_ray_samples``: eval bins, single and per-bin jitter.  The
+    kernel evaluates linspace and the lerp in its own order: 1e-6 absolute on values in [0, 3.5] (the sampler bar of
+    DESIGN.md section 2 is 1e-5 relative)."""
+    from cropnerf_amd import _lib as L
+    from cropnerf_amd import ops
+
+    for c in range(int(gold["num_us"])):
+        k, S, nears, fars, t = _sampler_case(gold, c)
+        out = ops.sample_spaced(nears.cuda(), fars.cuda(), S, L.SPACING_UNIFORM, None if t is None else t.cuda().contiguous())
+        for mine, ref in (("starts", "bin_starts"), ("ends", "bin_ends"), ("spacing_starts", "spacing_starts"),
+                          ("spacing_ends", "spacing_ends")):
+            got, want = out[mine].cpu().numpy(), gold[f"{k}/{ref}"][..., 0]
+            assert got.shape == want.shape
+            err = np.abs(got - want).max()
+            assert err <= 1e-6, f"{k} {mine}: max abs err {err:.3e}"
+
+
+@pytest.mark.gpu
+def test_hip_ortho_raygen_reproduces_the_reference(gold):
+    from cropnerf_amd import ops
+
+    for c in range(int(gold["num_og"])):
+        k = f"og{c}"
+        pts = torch.from_numpy(gold[f"{k}/points"]).cuda()
+        batch, count = int(gold[f"{k}/batch"]), int(gold[f"{k}/count"])
+        start = batch * (count - 1)
+        n = min(batch * count, pts.shape[0]) - start
+        out = ops.raygen_ortho(pts, [float(v) for v in gold[f"{k}/plane"][0]], start, n)
+        assert np.array_equal(out["origins"].cpu().numpy(), gold[f"{k}/origins"])
+        assert np.array_equal(out["pixel_area"].cpu().numpy(), gold[f"{k}/pixel_area"])
+        assert np.array_equal(out["nears"].cpu().numpy(), gold[f"{k}/nears"])
+        for name in ("directions", "fars"):
+            err = np.abs(out[name].cpu().numpy() - gold[f"{k}/{name}"]).max()
+            assert err <= 2.4e-7, f"{k} {name}: {err:.3e}"  # normalize / norm: one fp32 ulp of a value <= 2

@@ -6,8 +6,12 @@ from cropnerf_amd import config as PC, synthetic
 from cropnerf_amd.fruit_nerf.fruit_nerf import FruitModel, Semantics
 from cropnerf_amd.rays import Cameras, SceneBox
 
-cfg = PC.FruitNerfModelConfig()
-params = synthetic.p_rand(cfg.field_spec(100), cfg.proposal_specs(), seed=0, device="cuda")
+# IMPLEMENTATION=tcnn TABLE_DTYPE=float16 MATRIX_PRECISION=f16: a model as an imported reference checkpoint is (tcnn layout, fp16
+# tables, random values) rendered in tcnn's own arithmetic class
+impl = os.environ.get("IMPLEMENTATION", "torch")
+cfg = PC.FruitNerfModelConfig(implementation=impl, hash_table_dtype=os.environ.get("TABLE_DTYPE", "float32"),
+                              matrix_precision=os.environ.get("MATRIX_PRECISION", "fp32"))
+params = synthetic.p_rand(cfg.field_spec(100), cfg.proposal_specs(), seed=0, device="cuda") if impl == "torch" else None
 c2w, intr = synthetic.orbit_cameras(100)
 cams = Cameras(c2w, intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], 800, 800).to("cuda")
 res = {}
