@@ -14,6 +14,8 @@ from typing import Dict, List, Tuple, Union
 import numpy as np
 import torch
 
+from .fruit_nerf.components.field_heads import SemanticFieldHead
+
 
 @dataclass
 class GridSpec:
@@ -202,8 +204,7 @@ def param_shapes(spec: FieldSpec, prop_specs: List[ProposalSpec]) -> Dict[str, T
     add_mlp("field.mlp_base_mlp", g.num_levels * g.features_per_level, 2, spec.hidden_dim, 1 + spec.geo_feat_dim)
     add_mlp("field.mlp_semantics", spec.geo_feat_dim, spec.num_layers_semantic, spec.hidden_dim_semantics,
             spec.hidden_dim_transient)
-    shapes["field.field_head_semantics.net.weight"] = (1, spec.hidden_dim_transient)
-    shapes["field.field_head_semantics.net.bias"] = (1,)
+    shapes.update(SemanticFieldHead(spec.hidden_dim_transient, 1).shapes())
     add_mlp("field.mlp_head", 16 + spec.geo_feat_dim + spec.appearance_embedding_dim, spec.num_layers_color,
             spec.hidden_dim_color, 3)
     shapes["field.embedding_appearance.embedding.weight"] = (spec.num_images, spec.appearance_embedding_dim)

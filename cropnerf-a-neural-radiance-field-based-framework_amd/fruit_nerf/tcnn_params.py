@@ -38,6 +38,7 @@ import torch
 from torch import Tensor
 
 from ..config import FieldSpec, ProposalSpec
+from .components.field_heads import SemanticFieldHead
 
 MLP_ALIGN = 16
 SH_FLIPPED = (1, 3, 5, 7, 9, 11, 13, 15)  # components whose sign differs between tcnn and nerfstudio's torch SH
@@ -161,8 +162,7 @@ def from_tcnn_state_dict(state: Dict[str, Tensor], field_spec: FieldSpec, prop_s
     w0[:, list(SH_FLIPPED)] *= -1.0  # tcnn SH sign convention -> the kernels' (nerfstudio torch) convention
     head[0] = (w0, head[0][1])
     put_mlp("field.mlp_head", head)
-    for k in ("field.field_head_semantics.net.weight", "field.field_head_semantics.net.bias",
-              "field.embedding_appearance.embedding.weight"):
+    for k in SemanticFieldHead.keys + ("field.embedding_appearance.embedding.weight",):
         out[k] = state[k].detach().to(device=device, dtype=torch.float32).contiguous()
     for i, ps in enumerate(prop_specs):
         p = state[f"proposal_networks.{i}.mlp_base.tcnn_encoding.params"]
@@ -203,8 +203,8 @@ def to_tcnn_state_dict(params: Dict[str, Tensor], field_spec: FieldSpec, prop_sp
     head[0][0][:, list(SH_FLIPPED)] *= -1.0
     out["field.mlp_head.tcnn_encoding.params"] = linear_to_mlp(head, head_in, 3, fs.hidden_dim_color,
                                                                fs.num_layers_color - 1)
-    for k in ("field.field_head_semantics.net.weight", "field.field_head_semantics.net.bias",
-              "field.embedding_appearance.embedding.weight", "camera_optimizer.pose_adjustment"):
+    for k in SemanticFieldHead.keys + ("field.embedding_appearance.embedding.weight",
+                                       "camera_optimizer.pose_adjustment"):
         out[k] = params[k].detach().cpu().to(torch.float32)
     for i, ps in enumerate(prop_specs):
         pin = ps.grid.num_levels * ps.grid.features_per_level

@@ -18,6 +18,7 @@ from torch import Tensor
 
 from . import _lib as L
 from .config import FieldSpec, GridSpec, ProposalSpec
+from .fruit_nerf.components.field_heads import SemanticFieldHead
 
 
 def _stream(t: Tensor):
@@ -149,8 +150,9 @@ class FieldHandle:
         p.grid = _grid_struct(params["field.mlp_base_grid.hash_table"], spec.grid)
         p.base = _mlp_struct(params, "field.mlp_base_mlp", 2)
         p.semantics = _mlp_struct(params, "field.mlp_semantics", spec.num_layers_semantic)
-        p.sem_head_weight = _f32(params["field.field_head_semantics.net.weight"], "sem head w").data_ptr()
-        p.sem_head_bias = _f32(params["field.field_head_semantics.net.bias"], "sem head b").data_ptr()
+        head_w, head_b = SemanticFieldHead(spec.hidden_dim_transient, 1).check(params)
+        p.sem_head_weight = _f32(head_w, "sem head w").data_ptr()
+        p.sem_head_bias = _f32(head_b, "sem head b").data_ptr()
         p.color = _mlp_struct(params, "field.mlp_head", spec.num_layers_color)
         emb = _f32(params["field.embedding_appearance.embedding.weight"], "appearance embedding")
         p.appearance = emb.data_ptr()

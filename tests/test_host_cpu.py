@@ -156,3 +156,33 @@ def test_oriented_box():
     assert torch.allclose(box.R @ box.R.T, torch.eye(3), atol=1e-6)
     rpy = OrientedBox.from_params((0, 0, 0), (0.3, -0.2, 0.7), (1, 1, 1)).R
     assert torch.allclose(rpy @ torch.tensor([0.0, 0.0, 1.0]), torch.tensor([0.04521531, -0.3482963, 0.93629336]), atol=1e-5)
+
+
+def test_semantic_field_head_names_shapes_and_the_separate_op():
+    """``components/field_heads.py:29-40``: Linear(in_dim, num_classes), no activation.  The class is where the package
+    takes the head's state-dict names and shapes from; as a separate op it equals the oracle's head on the same features."""
+    from cropnerf_amd.config import FieldSpec, GridSpec, init_params, param_shapes
+    from cropnerf_amd.fruit_nerf.components.field_heads import SemanticFieldHead
+
+    spec = FieldSpec(grid=GridSpec(4, 16, 64, 10, 2), num_images=3)
+    head = SemanticFieldHead(spec.hidden_dim_transient, 1)
+    shapes = param_shapes(spec, [])
+    assert {k: shapes[k] for k in head.keys} == head.shapes() == {
+        "field.field_head_semantics.net.weight": (1, 64), "field.field_head_semantics.net.bias": (1,)}
+    params = init_params(spec, [], seed=1)
+    w, b = head.check(params)
+    assert float(w.abs().max()) <= 1.0 / math.sqrt(64) and float(b.abs().max()) <= 1.0 / math.sqrt(64)
+    x = torch.randn(5, 7, 64, generator=torch.Generator().manual_seed(0))
+    assert torch.allclose(head(x, params), x @ w.T + b, atol=1e-6)
+    g = torch.Generator().manual_seed(2)
+    fresh = head.init(g)
+    assert {k: tuple(v.shape) for k, v in fresh.items()} == head.shapes()
+    assert all(float(v.abs().max()) <= 0.125 for v in fresh.values())
+    with pytest.raises(ValueError, match="shape"):
+        head.check({**params, head.weight_key: torch.zeros(1, 32)})
+    with pytest.raises(KeyError):
+        head.check({})
+    with pytest.raises(NotImplementedError, match="one semantic logit"):
+        SemanticFieldHead(64, 2)
+    with pytest.raises(ValueError, match="activation"):
+        SemanticFieldHead(64, 1, activation=torch.nn.ReLU())
