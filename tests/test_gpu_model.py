@@ -414,7 +414,9 @@ def test_bench_line_contract():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-secondary",
+    # (10 steps after 5 warm-ups: with 3 + 1 the whole timed region is 8 ms and fell inside the clock ramp of an idle device
+    #  once -- 16 ms per step on a fresh box)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "5", "--no-secondary",
                         "--cpu-baseline-chunks", "10"], capture_output=True, text=True, timeout=600, cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
@@ -423,7 +425,7 @@ def test_bench_line_contract():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 5 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["unit"] == "samples/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and 0 < r["frac"] <= 1.0
