@@ -1,17 +1,28 @@
 // Can the fine-level gradient scatter of the training backward leave the float-atomic path?  (the field
-// backward issues 127e6 float-atomic requests for its nine fine levels at 65 536 rays, ~6 ms at the 21e9 requests/s the memory
-// side takes.)  Alternative priced here: every workgroup APPENDS its (entry, g0, g1) records to private per-bucket lists
-// (bucket = a 2^14-entry slice of one level's table; slot numbers from an LDS counter; plain 12-byte stores), and a second
-// kernel -- one workgroup per bucket -- sums a bucket's lists in LDS (ds_add_f32) and writes the slice out with plain stores.
+// backward issues 127e6 float-atomic requests for its nine fine levels at 65 536 rays.)  Alternative priced here: every
+// workgroup APPENDS its (entry, g0, g1) records to private per-bucket lists (bucket = a slice of one level's table; slot numbers
+// from an LDS counter; plain 12-byte stores), and a second kernel -- one workgroup per bucket -- sums a bucket's lists in LDS and
+// adds the slice to the table with plain loads and stores.
 //
-//   hipcc -O3 --offload-arch=gfx950 tools/bucket_scatter_microbench.hip -o bucket_scatter && ./bucket_scatter
+//   hipcc -O3 --offload-arch=gfx950 [-DSLICES_PER_LEVEL=28|56] [-DFOLD_MODE=m] tools/bucket_scatter_microbench.hip -o bucket_scatter
 //
 // Workload: LEVELS x 2^19 entries x 2 floats, UPDATES random (level, entry) records per launch (uniform: hashed levels).
+// FOLD_MODE: 0 two ds_add_f32 per record; 1 list reads only; 2 ds_add_f32 only; 3 one ds_add_u64; 4 two ds_add_f64 (needs 56
+// slices: 16 B of LDS per entry); 5 two ds_add_u64 (64-bit fixed point).  Results (MI355X, profiles/r03_append_scatter.txt), 226e6
+// records: naive atomics 21.7 ms (the kernels' x-edge form needs ~6); append 1.05 ms (252 lists per workgroup) / 1.72 ms (504);
+// fold 0.65 ms reading only, 2.28 ms with ds_add_f32 -- a third of a lane per clock and CU, whatever the unroll --, 0.73 ms with
+// ds_add_f64 or ds_add_u64, which run at the rate the records stream in.  Built into field_backward_mfma_kernel (doubles, 56 slices,
+// per-level list capacities, overflow to the atomics; gradients equal to 2e-6) it did NOT pay: the kernel stayed at 10.2 ms, the
+// fold added 0.73 ms, the iteration went 19.4 -> 20.1 ms.  The fine levels' atomics were already hidden under the kernel's other
+// phases -- switching their scatter off altogether only buys 1.3 ms.  The integration was removed again; this file is the record.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
+#ifndef FOLD_MODE
+#define FOLD_MODE 0
+#endif
 #ifndef SLICES_PER_LEVEL
 #define SLICES_PER_LEVEL 28  // 9 x 28 = 252 buckets <= 256 CUs, 18 725 entries = 149.8 KB of LDS each (56: two workgroups per CU)
 #endif
@@ -19,7 +30,11 @@ constexpr int LEVELS = 9, LOG2_T = 19;
 constexpr int SLICES = SLICES_PER_LEVEL;
 constexpr int SLICE_LEN = ((1 << LOG2_T) + SLICES - 1) / SLICES;
 constexpr int BUCKETS = LEVELS * SLICES;
+constexpr int ACC_BYTES = (FOLD_MODE == 4 || FOLD_MODE == 5 ? 16 : 8) * SLICE_LEN;
 constexpr int PRODUCERS = 256, PTHREADS = 512;
+#ifndef FOLD_MODE
+#define FOLD_MODE 0
+#endif
 #ifndef FOLD_UNROLL
 #define FOLD_UNROLL 4
 #endif
@@ -77,9 +92,10 @@ __global__ void __launch_bounds__(PTHREADS) scatter_append(Rec* lists, unsigned*
 __global__ void __launch_bounds__(1024) fold_buckets(const Rec* lists, const unsigned* counts, int cap, float* table) {
   extern __shared__ float acc[];  // 2 * SLICE_LEN floats
   const int b = blockIdx.x;
-  for (int i = threadIdx.x; i < 2 * SLICE_LEN; i += 1024) acc[i] = 0.f;
+  for (int i = threadIdx.x; i < ACC_BYTES / 4; i += 1024) acc[i] = 0.f;
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float keep = 0.f;
   for (int p = wave; p < PRODUCERS; p += 16) {
     const unsigned n = counts[p * BUCKETS + b];
     const Rec* src = lists + ((size_t)p * BUCKETS + b) * cap;
@@ -88,17 +104,34 @@ __global__ void __launch_bounds__(1024) fold_buckets(const Rec* lists, const uns
 #pragma unroll
       for (int u = 0; u < FOLD_UNROLL; ++u) {
         const unsigned i = i0 + 64 * u + lane;
+#if FOLD_MODE == 2  // LDS atomics only (timing): no list reads
+        r[u] = Rec{mix(i * 747796405u + p) % SLICE_LEN, 1.f, 0.5f};
+#else
         r[u] = i < n ? src[i] : Rec{0u, 0.f, 0.f};
+#endif
       }
 #pragma unroll
       for (int u = 0; u < FOLD_UNROLL; ++u) {
         if (i0 + 64 * u + lane < n) {
+#if FOLD_MODE == 1  // loads only (timing)
+          keep += r[u].g0 + r[u].g1 + (float)r[u].idx;
+#elif FOLD_MODE == 3  // one 8-byte LDS atomic per record (timing: u64 integer add on the float pair's bits)
+          atomicAdd(reinterpret_cast<unsigned long long*>(&acc[2 * r[u].idx]), (unsigned long long)__float_as_uint(r[u].g0));
+#elif FOLD_MODE == 4  // (timing, build with SLICES_PER_LEVEL=56) two f64 LDS atomics per record
+          atomicAdd(reinterpret_cast<double*>(acc) + 2 * r[u].idx, (double)r[u].g0);
+          atomicAdd(reinterpret_cast<double*>(acc) + 2 * r[u].idx + 1, (double)r[u].g1);
+#elif FOLD_MODE == 5  // (timing, SLICES_PER_LEVEL=56) two u64 LDS atomics per record: 64-bit fixed point
+          atomicAdd(reinterpret_cast<unsigned long long*>(acc) + 2 * r[u].idx, (unsigned long long)(long long)(r[u].g0 * 0x1p40f));
+          atomicAdd(reinterpret_cast<unsigned long long*>(acc) + 2 * r[u].idx + 1, (unsigned long long)(long long)(r[u].g1 * 0x1p40f));
+#else
           atomicAdd(&acc[2 * r[u].idx], r[u].g0);
           atomicAdd(&acc[2 * r[u].idx + 1], r[u].g1);
+#endif
         }
       }
     }
   }
+  if (keep == 12345.678f) acc[0] = keep;
   __syncthreads();
   const int level = b / SLICES, slice = b % SLICES;
   const int len = min(SLICE_LEN, (1 << LOG2_T) - slice * SLICE_LEN);
@@ -112,7 +145,7 @@ int main() {
   (void)hipMalloc(&table, table_floats * 4);
   unsigned* counts;
   (void)hipMalloc(&counts, (size_t)PRODUCERS * BUCKETS * 4);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fold_buckets), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * SLICE_LEN);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fold_buckets), hipFuncAttributeMaxDynamicSharedMemorySize, ACC_BYTES);
   hipEvent_t e0, e1, e2;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventCreate(&e2);
   printf("%12s %10s %12s %12s %12s %12s %10s\n", "updates", "cap", "atomic ms", "append ms", "fold ms", "sum ms", "check");
@@ -137,7 +170,7 @@ int main() {
       (void)hipEventRecord(e0, 0);
       hipLaunchKernelGGL(scatter_append, dim3(PRODUCERS), dim3(PTHREADS), 0, 0, lists, counts, cap, table, per_thread);
       (void)hipEventRecord(e1, 0);
-      hipLaunchKernelGGL(fold_buckets, dim3(BUCKETS), dim3(1024), 8 * SLICE_LEN, 0, lists, counts, cap, table);
+      hipLaunchKernelGGL(fold_buckets, dim3(BUCKETS), dim3(1024), ACC_BYTES, 0, lists, counts, cap, table);
       (void)hipEventRecord(e2, 0);
       (void)hipEventSynchronize(e2);
       (void)hipEventElapsedTime(&ms_p, e0, e1);
