@@ -282,6 +282,45 @@ __device__ __forceinline__ float2 hash_level(const void* __restrict__ table, con
   return r;
 }
 
+// hash_level that also returns the Jacobian of the two features with respect to the NORMALISED position (d f / d x etc., the
+// level's scale included): the trilinear blend is linear in each in-cell offset, so the derivatives are differences of the
+// partial blends the interpolation forms anyway.  The training backward takes the position gradient of a (sample, level) as
+// g0 * J.x + g1 * J.y from these six numbers instead of gathering the eight corners a second time once g is known.
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 hash_level_jac(const void* __restrict__ table, const Lvl& lv, float pos_offset, float px, float py,
+                                                 float pz, v2f_t& jx, v2f_t& jy, v2f_t& jz) {
+  const Cell k = hash_cell(lv, pos_offset, px, py, pz);
+  const float ox = k.ox, oy = k.oy, oz = k.oz;
+  float2 ccc = hash_gather<false>(table, ((k.hx1 ^ k.hy1 ^ k.hz1) & lv.mask) + lv.off);
+  float2 cfc = hash_gather<false>(table, ((k.hx1 ^ k.hy0 ^ k.hz1) & lv.mask) + lv.off);
+  float2 ffc = hash_gather<false>(table, ((k.hx0 ^ k.hy0 ^ k.hz1) & lv.mask) + lv.off);
+  float2 fcc = hash_gather<false>(table, ((k.hx0 ^ k.hy1 ^ k.hz1) & lv.mask) + lv.off);
+  float2 ccf = hash_gather<false>(table, ((k.hx1 ^ k.hy1 ^ k.hz0) & lv.mask) + lv.off);
+  float2 cff = hash_gather<false>(table, ((k.hx1 ^ k.hy0 ^ k.hz0) & lv.mask) + lv.off);
+  float2 fff = hash_gather<false>(table, ((k.hx0 ^ k.hy0 ^ k.hz0) & lv.mask) + lv.off);
+  float2 fcf = hash_gather<false>(table, ((k.hx0 ^ k.hy1 ^ k.hz0) & lv.mask) + lv.off);
+  const float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
+  auto V = [](float2 t) {
+    v2f_t v;
+    v.x = t.x;
+    v.y = t.y;
+    return v;
+  };
+  const v2f_t f03 = V(ccc) * ox + V(fcc) * mx, f12 = V(cfc) * ox + V(ffc) * mx;
+  const v2f_t f56 = V(cff) * ox + V(fff) * mx, f47 = V(ccf) * ox + V(fcf) * mx;
+  const v2f_t a = f03 * oy + f12 * my, b = f47 * oy + f56 * my;
+  const v2f_t rv = a * oz + b * mz;
+  // x: the four x-edges' differences blended over y and z; y: the (y = 1) minus the (y = 0) partial blends over z; z: a - b
+  const v2f_t d03 = V(ccc) - V(fcc), d12 = V(cfc) - V(ffc), d56 = V(cff) - V(fff), d47 = V(ccf) - V(fcf);
+  jx = ((d03 * oy + d12 * my) * oz + (d47 * oy + d56 * my) * mz) * lv.scale;
+  jy = ((f03 - f12) * oz + (f47 - f56) * mz) * lv.scale;
+  jz = (a - b) * lv.scale;
+  float2 r;
+  r.x = rv.x;
+  r.y = rv.y;
+  return r;
+}
+
 // hash_level with x-pair gathers (round 3).  A CU's L1 looks up one cache line per clock for per-lane-addressed loads
 // (tools/gather_rate_microbench.hip), and the gather-heavy kernels run at that rate; the two x-corners of a (y, z) row are
 // entries e and e ^ 1 -- one aligned pair -- whenever the cell's x index is even (hashed levels: index = x ^ y*P1 ^ z*P2;

@@ -265,8 +265,11 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
                 wz = A.origins[3 * r + 2] + dirz * mid;
     float px = wx, py = wy, pz = wz;
     const float self = normalize_position(A.scene, px, py, pz) ? 1.f : 0.f;
+    // (the Jacobian of the level's two features with respect to the normalised position comes out of the same eight corners:
+    //  the position gradient of the tile is g0 * J.x + g1 * J.y at its end, no second gather -- hash_level_jac)
+    v2f_t jx = {0.f, 0.f}, jy = {0.f, 0.f}, jz = {0.f, 0.f};
     if (live) {
-      const float2 f = hash_level(A.p.table, my_lv, A.grid.pos_offset, px, py, pz);
+      const float2 f = hash_level_jac(A.p.table, my_lv, A.grid.pos_offset, px, py, pz, jx, jy, jz);
       ENC[(2 * lvl) * LDA + s] = f.x;
       ENC[(2 * lvl + 1) * LDA + s] = f.y;
     }
@@ -307,9 +310,9 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
     }
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    if (have_prev) {  // the previous tile's hash-table gradient (+ its position gradient)
-    float gpx = 0.f, gpy = 0.f, gpz = 0.f;
+    if (have_prev) {  // the previous tile's hash-table gradient; its position gradient: the per-level partials are in A1
     if (!(A.debug_skip & 1)) {
+      float gpx = 0.f, gpy = 0.f, gpz = 0.f;  // (unused: the <false> forms do not touch them)
       // (a wave holds two levels, 32 lanes each: the branch below splits it along whole 16-lane rows, which is all the
       //  DPP run-length reduction and the quad rounds reach across)
       if (lvl < A.cells.num_levels) {
@@ -319,36 +322,20 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
         const unsigned nl = cell_n_of(A.cells, lvl);
         float* rec = A.cells.base + cell_offset_of(A.cells, lvl) +
                      (size_t)(blockIdx.x % cell_copies_of(A.cells, lvl)) * ((size_t)nl * nl * nl * 16);
-        if (A.d_pos)
-          hash_level_backward_cells<true>(rec, nl, tb, A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py, p_pz, p_g0,
-                                          p_g1, lane, gpx, gpy, gpz);
-        else
-          hash_level_backward_cells<false>(rec, nl, tb, A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py, p_pz, p_g0,
-                                           p_g1, lane, gpx, gpy, gpz);
+        hash_level_backward_cells<false>(rec, nl, tb, A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py, p_pz, p_g0,
+                                         p_g1, lane, gpx, gpy, gpz);
       } else if (lvl == 0 && A.coarse.base) {
         float* mine = A.coarse.base + (size_t)(blockIdx.x % A.coarse.copies) * (2u * A.coarse.n1 * A.coarse.n1 * A.coarse.n1);
-        if (A.d_pos)
-          hash_level_backward_private<true>(mine, A.coarse.n1, A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py,
-                                            p_pz, p_g0, p_g1, lane, gpx, gpy, gpz);
-        else
-          hash_level_backward_private<false>(mine, A.coarse.n1, A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py,
-                                             p_pz, p_g0, p_g1, lane, gpx, gpy, gpz);
-      } else if (A.d_pos)
-        hash_level_backward<true>(A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py, p_pz, p_g0, p_g1, lane, gpx,
-                                  gpy, gpz);
-      else
+        hash_level_backward_private<false>(mine, A.coarse.n1, A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py,
+                                           p_pz, p_g0, p_g1, lane, gpx, gpy, gpz);
+      } else
         hash_level_backward<false>(A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py, p_pz, p_g0, p_g1, lane, gpx,
                                    gpy, gpz);
     }
     if (A.d_pos) {
-      // per-level partials -> LDS (A1 is not written before the s1 phase, two barriers away) -> one thread per sample sums
-      // the 16 levels
-      float* part = A1;
-      part[(3 * lvl + 0) * LDA + s] = gpx;
-      part[(3 * lvl + 1) * LDA + s] = gpy;
-      part[(3 * lvl + 2) * LDA + s] = gpz;
-      __syncthreads();
-      __builtin_amdgcn_sched_barrier(0);
+      // one thread per sample sums the 16 levels' partials, written at the end of the previous trip (A1 is not written before
+      // the s1 phase, two barriers away)
+      const float* part = A1;
       if (lvl == 0 && p_valid) {
         float gx = 0.f, gy = 0.f, gz = 0.f;
 #pragma unroll
@@ -516,6 +503,12 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
       const bool lvl_off = (A.debug_skip >> (8 + lvl)) & 1;  // bits 8..23: skip the scatter of level l (profiling)
       p_g0 = valid && !lvl_off ? D1[(2 * lvl) * LDA + s] : 0.f;
       p_g1 = valid && !lvl_off ? D1[(2 * lvl + 1) * LDA + s] : 0.f;
+      if (A.d_pos) {  // this (sample, level)'s share of d(loss)/d(normalised position); A1 is dead since the d_c1 phase
+        const bool pos_off = (A.debug_skip & 1) != 0;
+        A1[(3 * lvl + 0) * LDA + s] = pos_off ? 0.f : p_g0 * jx.x + p_g1 * jx.y;
+        A1[(3 * lvl + 1) * LDA + s] = pos_off ? 0.f : p_g0 * jy.x + p_g1 * jy.y;
+        A1[(3 * lvl + 2) * LDA + s] = pos_off ? 0.f : p_g0 * jz.x + p_g1 * jz.y;
+      }
       p_px = px;
       p_py = py;
       p_pz = pz;
