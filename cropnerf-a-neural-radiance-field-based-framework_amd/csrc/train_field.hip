@@ -833,9 +833,16 @@ __global__ void __launch_bounds__(TB, 4) proposal_backward_kernel(PropBwdArgs A)
       misc[3 * LD + lane] = sel_f;
     }
     __syncthreads();
-    for (int l = wave; l < L; l += 4) {
-      float2 f = hash_level(A.table, A.grid.level(l), A.grid.pos_offset, misc[lane], misc[LD + lane],
-                            misc[2 * LD + lane]);
+    // (levels shared out as in the scatter below, so that the Jacobian of a level's features with respect to the position --
+    //  hash_level_jac: the position gradient without a second gather -- stays in the registers of the wave that needs it)
+    v2f_t jx[2], jy[2], jz[2];
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+      const int l = round == 0 ? L - 1 - wave : L - 8 + wave;
+      jx[round] = jy[round] = jz[round] = v2f_t{0.f, 0.f};
+      if (l < 0) continue;
+      float2 f = hash_level_jac(A.table, A.grid.level(l), A.grid.pos_offset, misc[lane], misc[LD + lane],
+                                misc[2 * LD + lane], jx[round], jy[round], jz[round]);
       enc[(2 * l) * LD + lane] = f.x;
       enc[(2 * l + 1) * LD + lane] = f.y;
     }
@@ -860,6 +867,7 @@ __global__ void __launch_bounds__(TB, 4) proposal_backward_kernel(PropBwdArgs A)
     float gpx = 0.f, gpy = 0.f, gpz = 0.f;
     // the finest level costs most (one request per x-edge, no runs to merge) and the coarsest least: the waves take the
     // levels from the fine end, the second round from the other side (L = 5: {4}, {3}, {2}, {1, 0})
+#pragma unroll
     for (int round = 0; round < 2; ++round) {
       const int l = round == 0 ? L - 1 - wave : L - 8 + wave;
       if (l < 0) continue;
@@ -871,36 +879,25 @@ __global__ void __launch_bounds__(TB, 4) proposal_backward_kernel(PropBwdArgs A)
         g1 = fmaf(A.w0[n * K + 2 * l + 1], d, g1);
       }
       if ((A.debug_skip & 8) || ((A.debug_skip >> (8 + l)) & 1)) continue;  // bits 8..14: skip the scatter of level l (profiling)
+      g0 = valid ? g0 : 0.f;
+      g1 = valid ? g1 : 0.f;
+      gpx += g0 * jx[round].x + g1 * jx[round].y;
+      gpy += g0 * jy[round].x + g1 * jy[round].y;
+      gpz += g0 * jz[round].x + g1 * jz[round].y;
+      float ux = 0.f, uy = 0.f, uz = 0.f;  // (unused: the <false> forms do not touch them)
       if (l < A.cells.num_levels) {
         const unsigned nl = A.cells.n[l];
         float* rec = A.cells.base + A.cells.offset[l] +
                      (size_t)(blockIdx.x % A.cells.copies[l]) * ((size_t)nl * nl * nl * 16);
-        if (A.d_pos)
-          hash_level_backward_cells<true>(rec, nl, tb, A.g_table, A.table, A.grid.level(l), A.grid.pos_offset, misc[lane],
-                                          misc[LD + lane], misc[2 * LD + lane], valid ? g0 : 0.f, valid ? g1 : 0.f, lane, gpx,
-                                          gpy, gpz);
-        else
-          hash_level_backward_cells<false>(rec, nl, tb, A.g_table, A.table, A.grid.level(l), A.grid.pos_offset, misc[lane],
-                                           misc[LD + lane], misc[2 * LD + lane], valid ? g0 : 0.f, valid ? g1 : 0.f, lane, gpx,
-                                           gpy, gpz);
+        hash_level_backward_cells<false>(rec, nl, tb, A.g_table, A.table, A.grid.level(l), A.grid.pos_offset, misc[lane],
+                                         misc[LD + lane], misc[2 * LD + lane], g0, g1, lane, ux, uy, uz);
       } else if (l == 0 && A.coarse.base) {
         float* mine = A.coarse.base + (size_t)(blockIdx.x % A.coarse.copies) * (2u * A.coarse.n1 * A.coarse.n1 * A.coarse.n1);
-        if (A.d_pos)
-          hash_level_backward_private<true>(mine, A.coarse.n1, A.g_table, A.table, A.grid.level(0), A.grid.pos_offset,
-                                            misc[lane], misc[LD + lane], misc[2 * LD + lane], valid ? g0 : 0.f,
-                                            valid ? g1 : 0.f, lane, gpx, gpy, gpz);
-        else
-          hash_level_backward_private<false>(mine, A.coarse.n1, A.g_table, A.table, A.grid.level(0), A.grid.pos_offset,
-                                             misc[lane], misc[LD + lane], misc[2 * LD + lane], valid ? g0 : 0.f,
-                                             valid ? g1 : 0.f, lane, gpx, gpy, gpz);
-      } else if (A.d_pos)
-        hash_level_backward<true>(A.g_table, A.table, A.grid.level(l), A.grid.pos_offset, misc[lane],
-                                  misc[LD + lane], misc[2 * LD + lane], valid ? g0 : 0.f, valid ? g1 : 0.f, lane, gpx,
-                                  gpy, gpz);
-      else
+        hash_level_backward_private<false>(mine, A.coarse.n1, A.g_table, A.table, A.grid.level(0), A.grid.pos_offset,
+                                           misc[lane], misc[LD + lane], misc[2 * LD + lane], g0, g1, lane, ux, uy, uz);
+      } else
         hash_level_backward<false>(A.g_table, A.table, A.grid.level(l), A.grid.pos_offset, misc[lane],
-                                   misc[LD + lane], misc[2 * LD + lane], valid ? g0 : 0.f, valid ? g1 : 0.f, lane, gpx,
-                                   gpy, gpz);
+                                   misc[LD + lane], misc[2 * LD + lane], g0, g1, lane, ux, uy, uz);
     }
     if (A.d_pos) {
       misc[(7 + 3 * wave) * LD + lane] = gpx;
