@@ -13,8 +13,13 @@
 
 namespace cn {
 
-// x-pair gathers in the sampler (hash_level_xpair): the kernel runs at the L1's line-lookup rate -- 40 gathers per sample,
-// ~25 lookups after coalescing along the ray, 5.8e8 per C2 launch = 2.3e6 of its 2.5e6 cycles per CU
+// x-pair gathers in the sampler (hash_level_xpair): 40 gathers per sample become 30, ~25 line lookups after coalescing along
+// the ray (5.8e8 per C2 launch): 1.054 -> 1.030 ms.  The lookups are NOT what bounds this kernel, though: round 3 also built
+// the team form of the render kernels here -- the four waves of a workgroup (four consecutive rays, neighbouring pixels) each
+// evaluating 16 samples of a chunk for all four rays, rays in adjacent lanes, densities handed over through LDS; bit-identical
+// results -- and the launch stayed at 1.028 ms.  ~700 VALU instructions per network evaluation are 0.41 ms of issue time per
+// launch; the rest is the latency of one dependent chain per ray (gather -> MLP -> compositing scan -> cdf -> inverse cdf, twice)
+// at the four waves per SIMD the registers allow.  The team form was removed again.
 #ifndef CN_PROP_XPAIR
 #define CN_PROP_XPAIR 1
 #endif
