@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 
 #include "../../include/cropnerf_hip.h"
 
@@ -330,49 +331,68 @@ __device__ __forceinline__ float2 hash_level_jac(const void* __restrict__ table,
 // blend as hash_level (results may differ in the last bit where hipcc contracts the multiply-adds differently).  The two
 // results are pinned with an empty asm: the conditional load is control flow, and without it hipcc sinks the blends of
 // all levels behind the last level's loads.
-template <bool HALF = false>
-__device__ __forceinline__ float2 hash_level_xpair(const void* __restrict__ table, const Lvl& lv, float pos_offset, float px,
-                                                   float py, float pz) {
-  const Cell k = hash_cell(lv, pos_offset, px, py, pz);
-  const char* base = reinterpret_cast<const char*>(table);
-  const unsigned pair_mask = lv.mask & ~1u;
-  const unsigned hyz[4] = {k.hy0 ^ k.hz0, k.hy1 ^ k.hz0, k.hy0 ^ k.hz1, k.hy1 ^ k.hz1};  // rows (y, z) = ff, cf, fc, cc
-  const bool odd = (k.hx0 & 1u) != 0u;
+// Two halves, so that a caller can put other work -- the next level's loads -- between them: `issue` sends the four pair loads
+// AND, for lanes with an odd x index, the four single loads of the upper corners back to back (nothing between them reads a loaded
+// value: one round trip to the cache, not two); `blend` waits and interpolates.
+template <bool HALF>
+struct XpLoads {
   typedef float f4 __attribute__((ext_vector_type(4)));
   typedef _Float16 h4 __attribute__((ext_vector_type(4)));
   typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-  float2 lo[4], hi[4];
+  typename std::conditional<HALF, h4, f4>::type pr[4];   // aligned pairs, rows (y, z) = ff, cf, fc, cc
+  typename std::conditional<HALF, h2, float2>::type up[4];  // upper-x corners of lanes with an odd x index
+  unsigned bits;  // bit r: the lower corner is the SECOND entry of pair r; bit 4: odd x index
+  float ox, oy, oz;
+};
+template <bool HALF = false>
+__device__ __forceinline__ XpLoads<HALF> hash_level_xpair_issue(const void* __restrict__ table, const Lvl& lv, float pos_offset,
+                                                                float px, float py, float pz) {
+  const Cell k = hash_cell(lv, pos_offset, px, py, pz);
+  const char* base = reinterpret_cast<const char*>(table);
+  const unsigned pair_mask = lv.mask & ~1u;
+  const unsigned hyz[4] = {k.hy0 ^ k.hz0, k.hy1 ^ k.hz0, k.hy0 ^ k.hz1, k.hy1 ^ k.hz1};
+  const bool odd = (k.hx0 & 1u) != 0u;
+  XpLoads<HALF> L;
+  L.bits = odd ? 16u : 0u;
+  L.ox = k.ox;
+  L.oy = k.oy;
+  L.oz = k.oz;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const unsigned x = k.hx0 ^ hyz[r];
-    const bool second = (x & 1u) != 0u;
+    L.bits |= (x & 1u) << r;
     const unsigned e = (x & pair_mask) + lv.off;  // first entry of the aligned pair (level offsets are even)
-    float2 a, b;
-    if constexpr (HALF) {
-      const h4 v = *reinterpret_cast<const h4*>(base + (size_t)(e << 2));
-      a = make_float2((float)v.x, (float)v.y);
-      b = make_float2((float)v.z, (float)v.w);
-    } else {
-      const f4 v = *reinterpret_cast<const f4*>(base + (size_t)(e << 3));
-      a = make_float2(v.x, v.y);
-      b = make_float2(v.z, v.w);
-    }
-    lo[r] = second ? b : a;
-    hi[r] = second ? a : b;  // the upper-x corner when x is even
+    if constexpr (HALF) L.pr[r] = *reinterpret_cast<const typename XpLoads<HALF>::h4*>(base + (size_t)(e << 2));
+    else L.pr[r] = *reinterpret_cast<const typename XpLoads<HALF>::f4*>(base + (size_t)(e << 3));
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if constexpr (HALF) L.up[r] = typename XpLoads<HALF>::h2{(_Float16)0.f, (_Float16)0.f};
+    else L.up[r] = make_float2(0.f, 0.f);
   }
   if (odd) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const unsigned e = ((k.hx1 ^ hyz[r]) & lv.mask) + lv.off;
-      if constexpr (HALF) {
-        const h2 v = *reinterpret_cast<const h2*>(base + (size_t)(e << 2));
-        hi[r] = make_float2((float)v.x, (float)v.y);
-      } else {
-        hi[r] = *reinterpret_cast<const float2*>(base + (size_t)(e << 3));
-      }
+      if constexpr (HALF) L.up[r] = *reinterpret_cast<const typename XpLoads<HALF>::h2*>(base + (size_t)(e << 2));
+      else L.up[r] = *reinterpret_cast<const float2*>(base + (size_t)(e << 3));
     }
   }
-  const float ox = k.ox, oy = k.oy, oz = k.oz;
+  return L;
+}
+template <bool HALF = false>
+__device__ __forceinline__ float2 hash_level_xpair_blend(const XpLoads<HALF>& L) {
+  const bool odd = (L.bits & 16u) != 0u;
+  float2 lo[4], hi[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bool second = ((L.bits >> r) & 1u) != 0u;
+    const float2 a = make_float2((float)L.pr[r].x, (float)L.pr[r].y), b = make_float2((float)L.pr[r].z, (float)L.pr[r].w);
+    const float2 u = make_float2((float)L.up[r].x, (float)L.up[r].y);
+    lo[r] = second ? b : a;
+    hi[r] = odd ? u : (second ? a : b);  // the other entry of the pair is the upper-x corner when x is even
+  }
+  const float ox = L.ox, oy = L.oy, oz = L.oz;
   const float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
   typedef float v2f __attribute__((ext_vector_type(2)));
   auto V = [](float2 t) {
@@ -390,6 +410,11 @@ __device__ __forceinline__ float2 hash_level_xpair(const void* __restrict__ tabl
   r.y = rv.y;
   asm volatile("" : "+v"(r.x), "+v"(r.y));
   return r;
+}
+template <bool HALF = false>
+__device__ __forceinline__ float2 hash_level_xpair(const void* __restrict__ table, const Lvl& lv, float pos_offset, float px,
+                                                   float py, float pz) {
+  return hash_level_xpair_blend<HALF>(hash_level_xpair_issue<HALF>(table, lv, pos_offset, px, py, pz));
 }
 
 // Private accumulation of the coarsest level's gradient (cn_grid.scatter_scratch): `copies` dense [n1^3][2] arrays,

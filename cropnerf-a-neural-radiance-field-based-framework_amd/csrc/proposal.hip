@@ -23,6 +23,9 @@ namespace cn {
 #ifndef CN_PROP_XPAIR
 #define CN_PROP_XPAIR 1
 #endif
+#ifndef CN_PROP_ABLATE
+#define CN_PROP_ABLATE 0
+#endif
 constexpr int PROP_MAX_LEVELS = 3;   // proposal iterations
 constexpr int PROP_MAX_SAMPLES = 512;
 
@@ -57,10 +60,86 @@ struct PropArgs {
   float *final_starts, *final_ends;    // [R, s_final] (optional): euclidean_bins[:, :-1] / [:, 1:] as contiguous arrays
 };
 
+// The 2L -> 16 -> 1 MLP of a proposal network on the fp32 matrix cores (CN_PROP_MLP_MFMA, default).  On the VALU it was the
+// larger half of the kernel (ablation builds, C2 batch: 0.21 ms without any network, 0.58 ms with the hash encoding, 1.04 ms
+// with the MLP: 176 multiply-adds per evaluation, whose 193 weights do not fit the scalar registers and were re-fetched with
+// scalar loads for every 64 evaluations).  Here the wave's 64 evaluations are four 16-column tiles of one product
+// hid[16 x 64] = W0[16 x K] enc[K x 64]: W0 (K padded to a multiple of 4 with zero columns) is the A operand, held in K / 4
+// registers per lane for a whole level; the encodings change lanes through a wave-private LDS block [k][sample] (row stride 80:
+// the four k-rows a B operand reads fall into different banks); the accumulators start from the bias, and the second layer is four
+// multiply-adds per lane and tile plus a three-step butterfly over the four lane groups that leaves evaluation l in lane l.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int PROP_ENC_STRIDE = 80, PROP_ENC_ROWS = 16;  // per wave: [16][80] floats
+struct PropMlp {
+  float a[4];   // W0[m = lane & 15][k = 4 kb + (lane >> 4)], kb < K / 4 (0 for k >= 2L)
+  f32x4 b0;     // b0[4 q + r]
+  f32x4 w1;     // w1[4 q + r]
+  float b1;
+};
+template <int L>
+__device__ __forceinline__ PropMlp prop_mlp_load(const PropNet& n, float* encT, int lane) {
+  constexpr int K = 2 * L, KB = (K + 3) / 4;
+  const int m = lane & 15, q = lane >> 4;
+  PropMlp w;
+#pragma unroll
+  for (int kb = 0; kb < 4; ++kb) w.a[kb] = (kb < KB && 4 * kb + q < K) ? n.w0[m * K + 4 * kb + q] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    w.b0[r] = n.b0[4 * q + r];
+    w.w1[r] = n.w1[4 * q + r];
+  }
+  w.b1 = n.b1[0];
+  // the padding rows of the encoding block are read as B operands (against zero weights): keep them finite
+#pragma unroll
+  for (int k = K; k < 4 * KB; ++k) encT[k * PROP_ENC_STRIDE + lane] = 0.f;
+  return w;
+}
+__device__ __forceinline__ float xor_lane(float v, int mask) { return __shfl_xor(v, mask, 64); }
+template <int L>
+__device__ __forceinline__ float prop_mlp_mfma(const PropMlp& w, float* encT, const float (&enc)[2 * L], int lane) {
+  constexpr int K = 2 * L, KB = (K + 3) / 4;
+  const int i = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int k = 0; k < K; ++k) encT[k * PROP_ENC_STRIDE + lane] = enc[k];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float part[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    f32x4 acc = w.b0;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.a[kb], encT[(4 * kb + q) * PROP_ENC_STRIDE + 16 * t + i], acc, 0, 0, 0);
+    float sdot = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sdot = fmaf(w.w1[r], fmaxf(acc[r], 0.f), sdot);
+    part[t] = sdot;  // hidden units 4q .. 4q+3 of evaluation 16 t + i
+  }
+  __builtin_amdgcn_wave_barrier();  // (the block is rewritten by the next call)
+  // butterfly over the lane groups q: lane (i, q) ends with the sum over all 16 hidden units of evaluation 16 q + i
+  const bool q0 = (q & 1) != 0, q1 = (q & 2) != 0;
+  // step 1 (partner q ^ 1): keep the tiles t with (t & 1) == (q & 1)
+  const float send_a = q0 ? part[0] : part[1], send_b = q0 ? part[2] : part[3];
+  const float keep_a = q0 ? part[1] : part[0], keep_b = q0 ? part[3] : part[2];
+  const float ra = keep_a + xor_lane(send_a, 16), rb = keep_b + xor_lane(send_b, 16);  // tiles (q & 1), 2 + (q & 1)
+  // step 2 (partner q ^ 2): keep the tile with bit 1 == (q & 2)
+  const float send = q1 ? ra : rb, keep = q1 ? rb : ra;
+  return w.b1 + (keep + xor_lane(send, 32));
+}
+
+#ifndef CN_PROP_MLP_MFMA
+#define CN_PROP_MLP_MFMA 1
+#endif
 template <int L, int H, bool HALF>
-__device__ __forceinline__ float prop_density(const PropNet& n, const SceneDev& sc, float px, float py, float pz) {
+__device__ __forceinline__ float prop_density(const PropNet& n, const PropMlp& mlp, float* encT, int lane, const SceneDev& sc, float px,
+                                              float py, float pz) {
   bool sel = normalize_position(sc, px, py, pz);
+#if CN_PROP_ABLATE == 1  // timing only: no network at all
+  return (px + py + pz) * (sel ? 1.f : 0.f);
+#endif
   float enc[2 * L];
+  // (Software-pipelining the levels -- level l + 1's loads issued before level l is blended, hash_level_xpair_issue / _blend --
+  //  measured slower: 0.85 vs 0.67 ms per C2 launch, the second level in flight costs 20 registers and spills.)
 #pragma unroll
   for (int l = 0; l < L; ++l) {
 #if CN_PROP_XPAIR
@@ -71,6 +150,18 @@ __device__ __forceinline__ float prop_density(const PropNet& n, const SceneDev& 
     enc[2 * l] = f.x;
     enc[2 * l + 1] = f.y;
   }
+#if CN_PROP_ABLATE == 2  // timing only: the encoding without the MLP
+  {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2 * L; ++k) acc += enc[k];
+    return expf(acc) * (sel ? 1.f : 0.f);
+  }
+#endif
+#if CN_PROP_MLP_MFMA
+  static_assert(H == 16, "one 16-row tile of hidden units");
+  const float out = prop_mlp_mfma<L>(mlp, encT, enc, lane);
+#else
   float out = n.b1[0];
 #pragma unroll
   for (int h = 0; h < H; ++h) {
@@ -79,14 +170,15 @@ __device__ __forceinline__ float prop_density(const PropNet& n, const SceneDev& 
     for (int k = 0; k < 2 * L; ++k) a = fmaf(n.w0[h * 2 * L + k], enc[k], a);
     out = fmaf(n.w1[h], fmaxf(a, 0.f), out);
   }
+#endif
   return expf(out) * (sel ? 1.f : 0.f);
 }
 
 template <bool HALF>
-__device__ __forceinline__ float prop_density_dispatch(const PropNet& n, const SceneDev& sc, float px, float py,
-                                                       float pz) {
-  if (n.grid.num_levels == 5) return prop_density<5, 16, HALF>(n, sc, px, py, pz);
-  return prop_density<7, 16, HALF>(n, sc, px, py, pz);
+__device__ __forceinline__ float prop_density_dispatch(const PropNet& n, const PropMlp& mlp, float* encT, int lane, const SceneDev& sc,
+                                                       float px, float py, float pz) {
+  if (n.grid.num_levels == 5) return prop_density<5, 16, HALF>(n, mlp, encT, lane, sc, px, py, pz);
+  return prop_density<7, 16, HALF>(n, mlp, encT, lane, sc, px, py, pz);
 }
 
 // HALF: the proposal nets' hash tables hold half2 entries (CN_TABLE_F16).  TRAIN: the training forward of
@@ -104,6 +196,7 @@ __global__ void __launch_bounds__(256, CN_PROP_SAMPLE_WAVES) proposal_sample_ker
   float* bins_b = bins_a + A.smax + 1;    // [smax+1] next level
   float* wts = bins_b + A.smax + 1;       // [smax]
   float* cdf = wts + A.smax;              // [smax+1]
+  float* encT = lds + 4 * stride + wave * (PROP_ENC_ROWS * PROP_ENC_STRIDE);  // this wave's encoding block of prop_mlp_mfma
   const long long waves = (long long)gridDim.x * 4;
   for (long long rr = blockIdx.x * 4LL + wave; rr < A.num_rays; rr += waves) {
     const long long r = __builtin_amdgcn_readfirstlane((int)rr);
@@ -132,6 +225,7 @@ __global__ void __launch_bounds__(256, CN_PROP_SAMPLE_WAVES) proposal_sample_ker
     for (int lvl = 0; lvl < A.num_levels; ++lvl) {
       const int S = A.s_prop[lvl];
       const PropNet& net = A.net[lvl];
+      const PropMlp mlp = net.grid.num_levels == 5 ? prop_mlp_load<5>(net, encT, lane) : prop_mlp_load<7>(net, encT, lane);
       CompositeState st;
       for (int c0 = 0; c0 < S; c0 += 64) {
         const int i = c0 + lane;
@@ -140,7 +234,7 @@ __global__ void __launch_bounds__(256, CN_PROP_SAMPLE_WAVES) proposal_sample_ker
         const float t0 = spacing_to_euclid(CN_SPACING_PIECEWISE, cur[ic], sn, sf);
         const float t1 = spacing_to_euclid(CN_SPACING_PIECEWISE, cur[ic + 1], sn, sf);
         const float mid = (t0 + t1) / 2.f;
-        const float den = prop_density_dispatch<HALF>(net, A.scene, ox + dx * mid, oy + dy * mid, oz + dz * mid);
+        const float den = prop_density_dispatch<HALF>(net, mlp, encT, lane, A.scene, ox + dx * mid, oy + dy * mid, oz + dz * mid);
         const float w = composite_chunk(st, valid, i == S - 1, t1 - t0, den, mid, 0.f, 0.f, 0.f, 0.f, false);
         if (valid) wts[i] = w;
         if constexpr (TRAIN) {
@@ -254,7 +348,7 @@ static int proposal_sample_launch(const char* who, const cn_density_params* cons
   A.jitter = jitter;
   A.final_starts = final_starts;
   A.final_ends = final_ends;
-  const size_t lds = (size_t)4 * (4 * A.smax + 4) * sizeof(float);
+  const size_t lds = ((size_t)4 * (4 * A.smax + 4) + 4 * PROP_ENC_ROWS * PROP_ENC_STRIDE) * sizeof(float);
   const dim3 grid(grid_for(num_rays, 4, 256 * 8)), block(256);
   const bool half = A.net[0].grid.half;
 #define CN_PROP_LAUNCH(H, T) hipLaunchKernelGGL((proposal_sample_kernel<H, T>), grid, block, lds, as_stream(stream), A)
