@@ -8,6 +8,8 @@
 // Built for the proposal shapes the reference configs use: 5 or 7 levels, hidden 16
 // (nerfacto defaults / fruit_nerf_config.py:143-146); other shapes return CN_ERR_UNSUPPORTED and the caller
 // composes cn_sample_spaced + cn_proposal_density + cn_composite + cn_sample_pdf instead.
+#include <algorithm>
+
 #include "composite_dev.hpp"
 #include "sampler_dev.hpp"
 
@@ -40,6 +42,7 @@ struct PropArgs {
   int s_prop[PROP_MAX_LEVELS];
   int s_final;
   int smax;
+  int enc_rows;  // rows of a wave's encoding block (prop_mlp_mfma): 2 L rounded up to a multiple of 4, of the largest net
   float anneal;
   SceneDev scene;
   const float* origins;
@@ -69,7 +72,7 @@ struct PropArgs {
 // the four k-rows a B operand reads fall into different banks); the accumulators start from the bias, and the second layer is four
 // multiply-adds per lane and tile plus a three-step butterfly over the four lane groups that leaves evaluation l in lane l.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int PROP_ENC_STRIDE = 80, PROP_ENC_ROWS = 16;  // per wave: [16][80] floats
+constexpr int PROP_ENC_STRIDE = 80;  // per wave: [enc_rows][80] floats, enc_rows = 12 (5-level nets) or 16 (7 levels)
 struct PropMlp {
   float a[4];   // W0[m = lane & 15][k = 4 kb + (lane >> 4)], kb < K / 4 (0 for k >= 2L)
   f32x4 b0;     // b0[4 q + r]
@@ -196,7 +199,7 @@ __global__ void __launch_bounds__(256, CN_PROP_SAMPLE_WAVES) proposal_sample_ker
   float* bins_b = bins_a + A.smax + 1;    // [smax+1] next level
   float* wts = bins_b + A.smax + 1;       // [smax]
   float* cdf = wts + A.smax;              // [smax+1]
-  float* encT = lds + 4 * stride + wave * (PROP_ENC_ROWS * PROP_ENC_STRIDE);  // this wave's encoding block of prop_mlp_mfma
+  float* encT = lds + 4 * stride + wave * (A.enc_rows * PROP_ENC_STRIDE);  // this wave's encoding block of prop_mlp_mfma
   const long long waves = (long long)gridDim.x * 4;
   for (long long rr = blockIdx.x * 4LL + wave; rr < A.num_rays; rr += waves) {
     const long long r = __builtin_amdgcn_readfirstlane((int)rr);
@@ -348,7 +351,9 @@ static int proposal_sample_launch(const char* who, const cn_density_params* cons
   A.jitter = jitter;
   A.final_starts = final_starts;
   A.final_ends = final_ends;
-  const size_t lds = ((size_t)4 * (4 * A.smax + 4) + 4 * PROP_ENC_ROWS * PROP_ENC_STRIDE) * sizeof(float);
+  A.enc_rows = 0;
+  for (int l = 0; l < num_levels; ++l) A.enc_rows = std::max(A.enc_rows, (2 * A.net[l].grid.num_levels + 3) / 4 * 4);
+  const size_t lds = ((size_t)4 * (4 * A.smax + 4) + (size_t)4 * A.enc_rows * PROP_ENC_STRIDE) * sizeof(float);
   const dim3 grid(grid_for(num_rays, 4, 256 * 8)), block(256);
   const bool half = A.net[0].grid.half;
 #define CN_PROP_LAUNCH(H, T) hipLaunchKernelGGL((proposal_sample_kernel<H, T>), grid, block, lds, as_stream(stream), A)
