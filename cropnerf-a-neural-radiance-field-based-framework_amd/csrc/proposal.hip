@@ -15,15 +15,19 @@
 
 namespace cn {
 
-// x-pair gathers in the sampler (hash_level_xpair): 40 gathers per sample become 30, ~25 line lookups after coalescing along
-// the ray (5.8e8 per C2 launch): 1.054 -> 1.030 ms.  The lookups are NOT what bounds this kernel, though: round 3 also built
-// the team form of the render kernels here -- the four waves of a workgroup (four consecutive rays, neighbouring pixels) each
-// evaluating 16 samples of a chunk for all four rays, rays in adjacent lanes, densities handed over through LDS; bit-identical
-// results -- and the launch stayed at 1.028 ms.  ~700 VALU instructions per network evaluation are 0.41 ms of issue time per
-// launch; the rest is the latency of one dependent chain per ray (gather -> MLP -> compositing scan -> cdf -> inverse cdf, twice)
-// at the four waves per SIMD the registers allow.  The team form was removed again.
+// What bounds this kernel, and what was tried (round 3; C2 batch, eval):
+//  * x-pair gathers (hash_level_xpair: 40 gathers per evaluation become 30, 5.8e8 L1 line lookups per launch) bought 2 % while the
+//    MLP ran on the VALU (1.054 -> 1.030 ms) and LOSE now that it does not (0.678 vs 0.609 ms with plain hash_level): the selects and
+//    the branch of the pair form are VALU instructions, and VALU issue is what is left.  CN_PROP_XPAIR=1 builds it.
+//  * the team form of the render kernels -- the four waves of a workgroup (four consecutive rays, neighbouring pixels) each
+//    evaluating 16 samples of a chunk for all four rays, rays in adjacent lanes, densities handed over through LDS; bit-identical
+//    results -- left the launch at 1.028 ms: the L1 lookups never bounded it.  Removed.
+//  * one round trip per level instead of two (pair loads and odd-x loads issued back to back): 1.043 ms; levels software-pipelined:
+//    0.85 vs 0.67 ms (spills); five waves per SIMD: 0.70 vs 0.67 ms (spills).
+//  * ablation builds (-DCN_PROP_ABLATE=1 / 2), MLP on the VALU: 0.21 ms without any network, 0.58 ms with the hash encoding, 1.04 ms
+//    complete -- the MLP was the larger half; see prop_mlp_mfma.
 #ifndef CN_PROP_XPAIR
-#define CN_PROP_XPAIR 1
+#define CN_PROP_XPAIR 0
 #endif
 #ifndef CN_PROP_ABLATE
 #define CN_PROP_ABLATE 0
