@@ -527,7 +527,8 @@ struct FieldBwdArgs {
   long long R;
   int S;
   float *d_pos, *d_dir;  // optional [R*S,3] outputs for the camera pose refinement (null: skipped)
-  int debug_skip;  // profiling aid (env CN_DEBUG_SKIP): 1 hash atomics, 2 embedding atomics, 4 weight-gradient dots
+  int debug_skip;  // profiling aid (env CN_DEBUG_SKIP): 1 hash atomics, 2 embedding atomics, 4 weight-gradient dots,
+                   // 32 semantic branch, 64 forward gathers (matrix-core kernel), bits 8 + l: the scatter of level l
   CoarseScatter coarse;  // private copies for level 0's gradient (cn_grid.scatter_scratch of the gradient grid)
   CellScatter cells;     // cell-major records of the coarse levels (take precedence for the levels they cover)
 };

@@ -271,7 +271,9 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
     //  the position gradient of the tile is g0 * J.x + g1 * J.y at its end, no second gather -- hash_level_jac)
     v2f_t jx = {0.f, 0.f}, jy = {0.f, 0.f}, jz = {0.f, 0.f};
     if (live) {
-      const float2 f = hash_level_jac(A.p.table, my_lv, A.grid.pos_offset, px, py, pz, jx, jy, jz);
+      // (bit 64, timing only: no table gathers in the forward recompute)
+      const float2 f = (A.debug_skip & 64) ? make_float2(px * 0.01f, py * 0.01f)
+                                           : hash_level_jac(A.p.table, my_lv, A.grid.pos_offset, px, py, pz, jx, jy, jz);
       ENC[(2 * lvl) * LDA + s] = f.x;
       ENC[(2 * lvl + 1) * LDA + s] = f.y;
     }
@@ -374,6 +376,7 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     // ---- semantic branch (its input is the DETACHED geo: nothing flows back to the base MLP) ---------------------------
+    if (!(A.debug_skip & 32)) {  // (bit 32, timing only: the semantic branch's four phases skipped)
     store_blk<true>(A1, n0, s0, blk_fwd<16>(Ws0, 20, n0, O16 + LDA, s0, bias4(lds + B_S0, n0, lane), lane), lane);
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
@@ -394,6 +397,7 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
     }
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
+    }
     // ---- colour branch -----------------------------------------------------------------------------------------------------
     if (wave < 4) gX = blk_dw(D1, 16 * wave, O16 + LDA, 0, gX, lane);                               // dW sem0
     store_blk<true>(A1, n0, s0, blk_fwd<64>(Wc0, 68, n0, CIN, s0, bias4(lds + B_C0, n0, lane), lane), lane);  // c1
