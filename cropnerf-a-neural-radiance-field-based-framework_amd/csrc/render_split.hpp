@@ -58,6 +58,9 @@ namespace cn {
 // 4-ray teams: fp16 mode on the fp32 torch table 2.14 / 1.69, split-bf16 on it 1.81 / 1.71, split-bf16 on a tcnn fp16 table
 // 2.06 / 1.57 -- but NOT the exact-fp32 kernel, which is bound by SIMD issue, hides its gathers under the fp32 MFMAs and only
 // pays for the per-lane ray parameters: 2.59 / 2.78 (CN_TEAM_ALL=1 forces it there too, A/B).
+#ifndef CN_TEAM_XPAIR
+#define CN_TEAM_XPAIR 1
+#endif
 #ifndef CN_TEAM_ALL
 #define CN_TEAM_ALL 0
 #endif
@@ -390,7 +393,12 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
                   const Lvl lv = lane_level_rec<GENERIC>(lds + OFF_LVL, A.grid, 4 * g + q, lvl_scale[q]);
 #pragma unroll
                   for (int h = 0; h < 2; ++h) {
+#if CN_TEAM_XPAIR  // aligned 16-byte (float table) / 8-byte (half table) pair gathers for the fp32 blend too: split-bf16 on the
+                    // headline table 1.726 -> 1.686 ms (the fp16 blend of a half table has its own pair form above)
+                    const float2 f = hash_level_xpair<HALF>(A.grid.table, lv, pos_off, px[h], py[h], pz[h]);
+#else
                     const float2 f = hash_level_sc<HALF, GENERIC>(A.grid.table, lv, pos_off, px[h], py[h], pz[h]);
+#endif
                     if constexpr (F16) {
                       const f16x2 hp = {(_Float16)f.x, (_Float16)f.y};
                       featp[h][q] = __builtin_bit_cast(unsigned, hp);
