@@ -530,25 +530,23 @@ class FruitModel:
         if not self.compat_projection_cam0:
             rays.camera_indices = torch.full_like(rays.camera_indices, cam_idx)
         H, W = rays.origins.shape[:2]
-        valid = rays.nears < 1e10  # [H,W,1]
+        # The reference indexes with the boolean mask six times (:289-315); every such indexing is a nonzero() with a host
+        # round trip.  Here the pixel indices of the rays that hit the box are formed ONCE and reused -- same values.
+        idx = (rays.nears.reshape(-1) < 1e10).nonzero(as_tuple=False).squeeze(1)  # the job's one synchronisation
         img = torch.zeros(H * W, 3, device=self.device)
-        if int(valid.sum()) < 10:  # fruit_nerf.py:293
+        if idx.numel() < 10:  # fruit_nerf.py:293
             z = img.reshape(H, W, 3)
             return z, z.clone()
-        vmask = valid.squeeze(-1)
-        sub = rays[vmask]
+        sub = rays.flatten()[idx]
         out = self.get_outputs_for_camera_jagged_ray_bundle(sub)
-        img[vmask.reshape(-1)] = out["semantics"]  # logit sum, un-sigmoided (reference quirk, :302)
-        img = img.reshape(H, W, 3)
-        wo_occ = img.clone()
-        occ = rays.clone()
-        occ.fars[valid] = rays.nears[valid]
-        occ.nears[valid] = 0.0
-        weights = torch.zeros(H * W, device=self.device)
-        weights[vmask.reshape(-1)] = self.get_density_for_camera_ray_bundle(occ[vmask])
-        mark = (weights >= 0.5).reshape(H, W)
-        img[mark] = 0.0
-        return wo_occ, img
+        img[idx] = out["semantics"]  # logit sum, un-sigmoided (reference quirk, :302); [N,1] broadcast over the channels
+        wo_occ = img.reshape(H, W, 3).clone()
+        occ = sub.clone()  # the occlusion pass: from the camera to the box's near side (:305-308)
+        occ.fars = sub.nears.clone()
+        occ.nears = torch.zeros_like(sub.nears)
+        hidden = self.get_density_for_camera_ray_bundle(occ) >= 0.5  # [N]
+        img[idx] = torch.where(hidden[:, None], torch.zeros((), device=self.device), img[idx])
+        return wo_occ, img.reshape(H, W, 3)
 
     # ------------------------------------------------------------------------------------------ metrics
     def get_metrics_dict(self, outputs, batch) -> Dict[str, Tensor]:
