@@ -658,6 +658,19 @@ def subsystem_timings(args, params, device):
         torch.cuda.synchronize()
         return time.perf_counter() - t0, r
 
+    # Algorithmic bytes of a default-method ray: the field's 48 x 1 024 B come from the 64 MB table (priced against HBM, like the
+    # headline), the 352 x 320 B of the proposal networks from 10 MB that stay in the L2s (priced against the guide's L2 gather
+    # rate).  `frac` = the time those two rates allow / the measured time.
+    field_bytes_per_ray = cfg.num_nerf_samples_per_ray * BYTES_PER_SAMPLE
+    prop_bytes_per_ray = n_prop * BYTES_PER_PROPOSAL_SAMPLE
+
+    def mixed_roofline(rays_, t_, kernel, limited_by):
+        bound_t = rays_ * (field_bytes_per_ray / (HBM_PEAK_GBPS * 1e9) + prop_bytes_per_ray / (L2_GATHER_PEAK_GBPS * 1e9))
+        return {"bound": "hbm+l2", "kernel": kernel, "achieved": round(rays_ * bytes_per_ray_default / t_ / 1e9, 1), "unit": "GB/s",
+                "peak": {"field_bytes_hbm": HBM_PEAK_GBPS, "proposal_bytes_l2": L2_GATHER_PEAK_GBPS},
+                "frac": round(bound_t / t_, 4), "traffic": None, "bytes_per_ray": bytes_per_ray_default,
+                "field_bytes_per_ray": field_bytes_per_ray, "proposal_bytes_per_ray": prop_bytes_per_ray, "limited_by": limited_by}
+
     # ---- ns-export pointcloud (BASELINE.json configs[3]): random training rays in 2 048-ray calls until 10 M points are kept --
     # exporter_utils_nerfacto.py:125-183 (debug/exporter_nerfacto.py:91: 2 048 rays per call); no outlier removal in the timed part
     pipe = FruitPipeline(FruitPipelineConfig(FruitDataManagerConfig(2048, 2048), cfg), device, cams, box, test_mode="test", params=p2)
@@ -669,12 +682,9 @@ def subsystem_timings(args, params, device):
     out["export_pointcloud_c4"] = {
         "seconds": round(t, 3), "kept_points": int(pcd["points"].shape[0]), "calls": calls, "rays_per_call": 2048,
         "rays_per_sec": rays / t, "points_per_sec": int(pcd["points"].shape[0]) / t,
-        "roofline": {"bound": "hbm", "kernel": "proposal_sample_kernel + render kernel + pointcloud_compact per call (HIP-graph replay)",
-                     "achieved": round(rays * bytes_per_ray_default / t / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(rays * bytes_per_ray_default / t / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
-                     "bytes_per_ray": bytes_per_ray_default,
-                     "limited_by": "2 048-ray calls (the reference's call size): ~15 small launches each, far below the device's "
-                                   "capacity per launch; the loop is a replayed HIP graph"},
+        "roofline": mixed_roofline(rays, t, "proposal_sample_kernel + render kernel + pointcloud_compact per call (HIP-graph replay)",
+                                   "2 048-ray calls (the reference's call size): ~15 small launches each, far below the device's "
+                                   "capacity per launch; the loop is a replayed HIP graph"),
         "workload": "ns-export pointcloud --num-points 10000000 on the synthetic scene, default method (48 field + 352 proposal "
                     "samples per ray), reference: exporter_utils_nerfacto.py:125-183"}
     # ---- exporter.py semantic-pointcloud (dense volume export): 512-ray calls x 3 000 samples per ray -----------------------------
@@ -731,14 +741,39 @@ def subsystem_timings(args, params, device):
     out["projection_job"] = {
         "ms_per_job": round(tj * 1e3, 3), "spread_ms": {"min": round(min(ts) * 1e3, 3), "max": round(max(ts) * 1e3, 3), "jobs": 10},
         "image": [H, W], "rays_inside_aabb": int(vr), "passes": 2, "rays_per_sec": 2 * vr / tj,
-        "roofline": {"bound": "hbm", "kernel": "proposal_sample_kernel + render kernels (full pass, density-only occlusion pass)",
-                     "achieved": round(2 * vr * bytes_per_ray_default / tj / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(2 * vr * bytes_per_ray_default / tj / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
-                     "bytes_per_ray_and_pass": bytes_per_ray_default,
-                     "limited_by": "ray generation + AABB test for all 640 000 pixels, host-side masking / packing between the two "
-                                   "passes, then the two renders of the rays inside the box"},
+        "roofline": mixed_roofline(2 * vr, tj, "proposal_sample_kernel + render kernels (full pass, density-only occlusion pass)",
+                                   "ray generation + AABB test for all 640 000 pixels, one index list of the rays inside the box, "
+                                   "then the two renders of those rays (sampler and 48-sample field pass each)"),
         "workload": "get_outputs_for_projections, one camera x one sub-cluster AABB (0.3-wide box at the origin), 800 x 800: the "
                     "AABB-restricted render and the occlusion pass; reference: fruit_nerf.py:283-315"}
+    # ---- one whole 800 x 800 eval image of the default method (fruit_nerf.py:377-404: chunks of eval_num_rays_per_chunk) ------------
+    # exact fp32 on the torch-layout model above, and a model as an imported reference checkpoint is -- tcnn layout, fp16 tables --
+    # in tcnn's own arithmetic class (matrix_precision = "f16")
+    from cropnerf_amd.fruit_nerf.fruit_nerf import FruitModel, Semantics
+
+    def image_ms(model):
+        model.get_outputs_for_camera_ray_bundle(cams.to(device).generate_rays(0, keep_shape=True))
+        ts_ = []
+        for i in range(1, 8):
+            ti, _ = wall(lambda: model.get_outputs_for_camera_ray_bundle(cams.to(device).generate_rays(i, keep_shape=True)))
+            ts_.append(ti)
+        ts_.sort()
+        return ts_[len(ts_) // 2], ts_
+    ti, ts_ = image_ms(m)
+    out["eval_image_800"] = {
+        "ms_per_image": round(ti * 1e3, 3), "spread_ms": {"min": round(ts_[0] * 1e3, 3), "max": round(ts_[-1] * 1e3, 3), "images": len(ts_)},
+        "rays_per_sec": H * W / ti, "chunk_rays": int(cfg.eval_num_rays_per_chunk),
+        "roofline": mixed_roofline(H * W, ti, "proposal_sample_kernel + render_split_kernel per 32 768-ray chunk",
+                                   "the sampler (0.6 ms per 65 536 rays) and a 48-sample field pass whose last 16-column tile of every "
+                                   "ray is empty (a quarter of the matrix work)"),
+        "workload": "get_outputs_for_camera_ray_bundle, default method ((256, 96) proposal + 48 field samples), ray generation "
+                    "included; reference: fruit_nerf.py:377-404"}
+    cfg16 = PC.FruitNerfModelConfig(implementation="tcnn", hash_table_dtype="float16", matrix_precision="f16")
+    m16 = FruitModel(cfg16, box, NUM_CAMERAS, {"semantics": Semantics()}, device=device, test_mode="test")
+    t16, ts16 = image_ms(m16)
+    out["eval_image_800"]["tcnn_f16_mode"] = {
+        "ms_per_image": round(t16 * 1e3, 3), "spread_ms": {"min": round(ts16[0] * 1e3, 3), "max": round(ts16[-1] * 1e3, 3), "images": len(ts16)},
+        "note": "tcnn layout, fp16 tables (random values), matrix_precision = f16: what an imported reference checkpoint renders as"}
     return out
 
 
