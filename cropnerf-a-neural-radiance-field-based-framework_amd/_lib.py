@@ -113,6 +113,8 @@ SIGNATURES = {
     "cn_proposal_sample_workspace_bytes": (C.c_size_t, [_I64, C.POINTER(_I32), _I32, _I32]),
     "cn_proposal_sample": (C.c_int, [C.POINTER(C.POINTER(DensityParams)), _I32, C.POINTER(Scene), _P, _P, _P, _P, _I64,
                                      C.POINTER(_I32), _I32, _F, _P, _P, _P, _P, C.c_size_t, _P]),
+    "cn_proposal_sample_mp": (C.c_int, [C.POINTER(C.POINTER(DensityParams)), _I32, C.POINTER(Scene), _P, _P, _P, _P, _I64,
+                                        C.POINTER(_I32), _I32, _F, _P, _P, _P, _I32, _P]),
     "cn_grid_scatter_scratch_bytes": (C.c_size_t, [C.POINTER(Grid)]),
     "cn_grid_scatter_scratch_bytes_for": (C.c_size_t, [C.POINTER(Grid), _I64]),
     "cn_proposal_sample_train": (C.c_int, [C.POINTER(C.POINTER(DensityParams)), _I32, C.POINTER(Scene), _P, _P, _P, _P,

@@ -134,6 +134,75 @@ __device__ __forceinline__ float prop_mlp_mfma(const PropMlp& w, float* encT, co
   return w.b1 + (keep + xor_lane(send, 32));
 }
 
+// fp16 matrix mode of the sampler (cn_proposal_sample_mp with CN_MATRIX_F16 on half tables): tiny-cuda-nn's arithmetic class for the
+// proposal networks too -- the grid interpolated on packed fp16 pairs (hash_level_pk), the 2L -> 16 layer ONE
+// v_mfma_f32_16x16x16_f16 per 16-column tile (fp16 weights and inputs, fp32 accumulation; k = 2 level + feature, so a lane group's
+// four k are the packed words of two levels as they stand), the hidden units rounded to fp16, the output rounded to fp16 as a
+// tcnn network returns it.  Half the blend instructions and an eighth of the matrix cycles of the fp32 form.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+struct PropMlpH {
+  f16x4 a;     // W0[m = lane & 15][k = 4 q .. 4 q + 3] as fp16 (0 for k >= 2L)
+  f32x4 b0;    // b0[4 q + r]
+  f32x4 w1;    // w1[4 q + r], fp16 values
+  float b1;
+};
+template <int L>
+__device__ __forceinline__ PropMlpH prop_mlp_load_h(const PropNet& n, unsigned* encw, int lane) {
+  constexpr int K = 2 * L;
+  static_assert(K <= 16, "one K = 16 block");
+  const int m = lane & 15, q = lane >> 4;
+  PropMlpH w;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) w.a[e] = (4 * q + e < K) ? (_Float16)n.w0[m * K + 4 * q + e] : (_Float16)0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    w.b0[r] = n.b0[4 * q + r];
+    w.w1[r] = (float)(_Float16)n.w1[4 * q + r];
+  }
+  w.b1 = n.b1[0];
+#pragma unroll
+  for (int l = L; l < 8; ++l) encw[l * PROP_ENC_STRIDE + lane] = 0u;  // the levels the K block has room for and the grid lacks
+  return w;
+}
+template <int L>
+__device__ __forceinline__ float prop_mlp_f16(const PropMlpH& w, unsigned* encw, const unsigned (&featp)[L], int lane) {
+  const int i = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int l = 0; l < L; ++l) encw[l * PROP_ENC_STRIDE + lane] = featp[l];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float part[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const unsigned lo = encw[(2 * q) * PROP_ENC_STRIDE + 16 * t + i], hi = encw[(2 * q + 1) * PROP_ENC_STRIDE + 16 * t + i];
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 words = {lo, hi};
+    const f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x16f16(w.a, __builtin_bit_cast(f16x4, words), w.b0, 0, 0, 0);
+    float sdot = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sdot = fmaf(w.w1[r], (float)(_Float16)fmaxf(acc[r], 0.f), sdot);
+    part[t] = sdot;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const bool q0 = (q & 1) != 0, q1 = (q & 2) != 0;
+  const float send_a = q0 ? part[0] : part[1], send_b = q0 ? part[2] : part[3];
+  const float keep_a = q0 ? part[1] : part[0], keep_b = q0 ? part[3] : part[2];
+  const float ra = keep_a + xor_lane(send_a, 16), rb = keep_b + xor_lane(send_b, 16);
+  const float send = q1 ? ra : rb, keep = q1 ? rb : ra;
+  return (float)(_Float16)(w.b1 + (keep + xor_lane(send, 32)));
+}
+template <int L>
+__device__ __forceinline__ float prop_density_f16(const PropNet& n, const PropMlpH& mlp, unsigned* encw, int lane, const SceneDev& sc,
+                                                  float px, float py, float pz) {
+  const bool sel = normalize_position(sc, px, py, pz);
+  unsigned featp[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l)  // pinned level by level: left alone hipcc sinks every blend behind the last level's loads and spills
+    featp[l] = pk_pin(hash_level_pk<true>(n.grid.table, n.grid.level(l), n.grid.pos_offset, px, py, pz));
+  // (hash_level_pk_plain -- eight 4-byte gathers, no selects, no branch -- measured slower here: 0.646 vs 0.587 ms per launch)
+  return expf(prop_mlp_f16<L>(mlp, encw, featp, lane)) * (sel ? 1.f : 0.f);
+}
+
 #ifndef CN_PROP_MLP_MFMA
 #define CN_PROP_MLP_MFMA 1
 #endif
@@ -194,8 +263,9 @@ __device__ __forceinline__ float prop_density_dispatch(const PropNet& n, const P
 #ifndef CN_PROP_SAMPLE_WAVES
 #define CN_PROP_SAMPLE_WAVES 4  // waves per SIMD the register allocation is held to (the kernel is latency-bound: one wave per ray)
 #endif
-template <bool HALF, bool TRAIN>
+template <bool HALF, bool TRAIN, bool F16 = false>
 __global__ void __launch_bounds__(256, CN_PROP_SAMPLE_WAVES) proposal_sample_kernel(PropArgs A) {
+  static_assert(!F16 || (HALF && !TRAIN), "the fp16 mode evaluates half tables, eval only");
   extern __shared__ __align__(16) float lds[];
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const int stride = 4 * A.smax + 4;
@@ -232,7 +302,14 @@ __global__ void __launch_bounds__(256, CN_PROP_SAMPLE_WAVES) proposal_sample_ker
     for (int lvl = 0; lvl < A.num_levels; ++lvl) {
       const int S = A.s_prop[lvl];
       const PropNet& net = A.net[lvl];
-      const PropMlp mlp = net.grid.num_levels == 5 ? prop_mlp_load<5>(net, encT, lane) : prop_mlp_load<7>(net, encT, lane);
+      PropMlp mlp{};
+      PropMlpH mlph{};
+      if constexpr (F16) {
+        mlph = net.grid.num_levels == 5 ? prop_mlp_load_h<5>(net, reinterpret_cast<unsigned*>(encT), lane)
+                                        : prop_mlp_load_h<7>(net, reinterpret_cast<unsigned*>(encT), lane);
+      } else {
+        mlp = net.grid.num_levels == 5 ? prop_mlp_load<5>(net, encT, lane) : prop_mlp_load<7>(net, encT, lane);
+      }
       CompositeState st;
       for (int c0 = 0; c0 < S; c0 += 64) {
         const int i = c0 + lane;
@@ -241,7 +318,14 @@ __global__ void __launch_bounds__(256, CN_PROP_SAMPLE_WAVES) proposal_sample_ker
         const float t0 = spacing_to_euclid(CN_SPACING_PIECEWISE, cur[ic], sn, sf);
         const float t1 = spacing_to_euclid(CN_SPACING_PIECEWISE, cur[ic + 1], sn, sf);
         const float mid = (t0 + t1) / 2.f;
-        const float den = prop_density_dispatch<HALF>(net, mlp, encT, lane, A.scene, ox + dx * mid, oy + dy * mid, oz + dz * mid);
+        float den;
+        if constexpr (F16) {
+          unsigned* encw = reinterpret_cast<unsigned*>(encT);
+          den = net.grid.num_levels == 5 ? prop_density_f16<5>(net, mlph, encw, lane, A.scene, ox + dx * mid, oy + dy * mid, oz + dz * mid)
+                                         : prop_density_f16<7>(net, mlph, encw, lane, A.scene, ox + dx * mid, oy + dy * mid, oz + dz * mid);
+        } else {
+          den = prop_density_dispatch<HALF>(net, mlp, encT, lane, A.scene, ox + dx * mid, oy + dy * mid, oz + dz * mid);
+        }
         const float w = composite_chunk(st, valid, i == S - 1, t1 - t0, den, mid, 0.f, 0.f, 0.f, 0.f, false);
         if (valid) wts[i] = w;
         if constexpr (TRAIN) {
@@ -297,9 +381,12 @@ static int proposal_sample_launch(const char* who, const cn_density_params* cons
                                   const float* nears, const float* fars, int64_t num_rays, const int32_t* s_prop,
                                   int32_t s_final, float anneal, const float* jitter,
                                   const cn_proposal_level_out* levels, float* euclidean_bins, float* spacing_bins,
-                                  float* prop_depth, float* final_starts, float* final_ends, cn_stream_t stream) {
+                                  float* prop_depth, float* final_starts, float* final_ends, cn_stream_t stream,
+                                  int matrix_precision = CN_MATRIX_FP32) {
   CN_REQUIRE(props && scene && origins && directions && nears && fars && s_prop && euclidean_bins, CN_ERR_INVALID,
              "%s: null argument", who);
+  CN_REQUIRE(matrix_precision == CN_MATRIX_FP32 || matrix_precision == CN_MATRIX_SPLIT_BF16 || matrix_precision == CN_MATRIX_F16,
+             CN_ERR_INVALID, "%s: matrix_precision %d", who, matrix_precision);
   CN_REQUIRE(num_levels >= 1 && num_levels <= PROP_MAX_LEVELS, CN_ERR_UNSUPPORTED,
              "%s: %d proposal iterations (max %d)", who, num_levels, PROP_MAX_LEVELS);
   CN_REQUIRE(s_final >= 1 && s_final <= PROP_MAX_SAMPLES, CN_ERR_UNSUPPORTED, "%s: s_final %d", who, s_final);
@@ -361,6 +448,11 @@ static int proposal_sample_launch(const char* who, const cn_density_params* cons
   const dim3 grid(grid_for(num_rays, 4, 256 * 8)), block(256);
   const bool half = A.net[0].grid.half;
 #define CN_PROP_LAUNCH(H, T) hipLaunchKernelGGL((proposal_sample_kernel<H, T>), grid, block, lds, as_stream(stream), A)
+  // fp16 mode: half tables only (a float table keeps the fp32 form: the mode is the arithmetic of an imported tcnn model; the
+  // split-bf16 option has nothing to split here -- the sampler's matrix work is a tenth of its instructions -- and runs fp32 too)
+  if (!train && half && matrix_precision == CN_MATRIX_F16) {
+    hipLaunchKernelGGL((proposal_sample_kernel<true, false, true>), grid, block, lds, as_stream(stream), A);
+  } else
   if (train) {
     if (half) CN_PROP_LAUNCH(true, true); else CN_PROP_LAUNCH(false, true);
   } else {
@@ -379,6 +471,16 @@ extern "C" int cn_proposal_sample(const cn_density_params* const* props, int32_t
   return cn::proposal_sample_launch("cn_proposal_sample", props, num_levels, scene, origins, directions, nears, fars,
                                     num_rays, s_prop, s_final, anneal, nullptr, nullptr, euclidean_bins, spacing_bins,
                                     prop_depth, nullptr, nullptr, stream);
+}
+
+extern "C" int cn_proposal_sample_mp(const cn_density_params* const* props, int32_t num_levels, const cn_scene* scene,
+                                     const float* origins, const float* directions, const float* nears, const float* fars,
+                                     int64_t num_rays, const int32_t* s_prop, int32_t s_final, float anneal,
+                                     float* euclidean_bins, float* spacing_bins, float* prop_depth, int32_t matrix_precision,
+                                     cn_stream_t stream) {
+  return cn::proposal_sample_launch("cn_proposal_sample_mp", props, num_levels, scene, origins, directions, nears, fars,
+                                    num_rays, s_prop, s_final, anneal, nullptr, nullptr, euclidean_bins, spacing_bins,
+                                    prop_depth, nullptr, nullptr, stream, matrix_precision);
 }
 
 extern "C" int cn_proposal_sample_train(const cn_density_params* const* props, int32_t num_levels,

@@ -268,7 +268,8 @@ class FruitModel:
         cfg = self.config
         S = cfg.num_nerf_samples_per_ray
         ps = ops.proposal_sample(self.proposal_networks, self._scene(self._prop_contraction), o, d, n, f,
-                                 cfg.num_proposal_samples_per_ray, S, anneal=self._anneal)
+                                 cfg.num_proposal_samples_per_ray, S, anneal=self._anneal,
+                                 matrix_precision=self._matrix_precision())
         if not self._fused_shape:
             out = self._render_general(o, d, n, f, cam, S, ps["euclidean_bins"], density_only)
         else:

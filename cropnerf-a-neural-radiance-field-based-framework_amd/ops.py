@@ -342,8 +342,10 @@ def sample_pdf(prev_spacing_bins: Tensor, weights: Tensor, nears: Tensor, fars: 
 
 
 def proposal_sample(props: Sequence[DensityHandle], scene: L.Scene, origins: Tensor, directions: Tensor,
-                    nears: Tensor, fars: Tensor, s_prop: Sequence[int], s_final: int, anneal: float = 1.0
-                    ) -> Dict[str, Tensor]:
+                    nears: Tensor, fars: Tensor, s_prop: Sequence[int], s_final: int, anneal: float = 1.0,
+                    matrix_precision: int = L.MATRIX_FP32) -> Dict[str, Tensor]:
+    """``cn_proposal_sample`` / ``cn_proposal_sample_mp``: ``matrix_precision=MATRIX_F16`` evaluates half-table proposal networks in
+    tiny-cuda-nn's arithmetic class (the sampler's side of ``FruitNerfModelConfig.matrix_precision = "f16"``)."""
     lib = L.load()
     R = origins.shape[0]
     dev = origins.device
@@ -353,10 +355,16 @@ def proposal_sample(props: Sequence[DensityHandle], scene: L.Scene, origins: Ten
     eu = torch.empty(R, s_final + 1, device=dev)
     sp = torch.empty(R, s_final + 1, device=dev)
     depth = torch.empty(n, R, device=dev)
-    L.check(lib.cn_proposal_sample(arr, n, C.byref(scene), _p(_f32(origins, "origins")),
-                                   _p(_f32(directions, "directions")), _p(_f32(nears, "nears")), _p(_f32(fars, "fars")),
-                                   R, sp_arr, s_final, anneal, _p(eu), _p(sp), _p(depth), C.c_void_p(0), 0,
-                                   _stream(origins)))
+    if matrix_precision != L.MATRIX_FP32:
+        L.check(lib.cn_proposal_sample_mp(arr, n, C.byref(scene), _p(_f32(origins, "origins")),
+                                          _p(_f32(directions, "directions")), _p(_f32(nears, "nears")), _p(_f32(fars, "fars")),
+                                          R, sp_arr, s_final, anneal, _p(eu), _p(sp), _p(depth), int(matrix_precision),
+                                          _stream(origins)))
+    else:
+        L.check(lib.cn_proposal_sample(arr, n, C.byref(scene), _p(_f32(origins, "origins")),
+                                       _p(_f32(directions, "directions")), _p(_f32(nears, "nears")), _p(_f32(fars, "fars")),
+                                       R, sp_arr, s_final, anneal, _p(eu), _p(sp), _p(depth), C.c_void_p(0), 0,
+                                       _stream(origins)))
     return {"euclidean_bins": eu, "spacing_bins": sp, "prop_depth": depth}
 
 

@@ -349,6 +349,16 @@ int cn_proposal_sample(const cn_density_params* const* props_host, int32_t num_l
                        float* euclidean_bins, float* spacing_bins, float* prop_depth, void* workspace,
                        size_t workspace_bytes, cn_stream_t stream);
 
+/* The same with the arithmetic of the proposal networks chosen like cn_render_opts.matrix_precision: CN_MATRIX_F16 on half
+ * tables (CN_TABLE_F16) evaluates them as tiny-cuda-nn does under the method's mixed_precision=True (fruit_nerf_config.py:35;
+ * HashMLPDensityField with implementation="tcnn", fruit_nerf.py:133-142) -- packed-fp16 grid interpolation, fp16 weights and
+ * layer inputs, fp32 accumulation, fp16 network output; every other combination computes as cn_proposal_sample does. */
+int cn_proposal_sample_mp(const cn_density_params* const* props_host, int32_t num_levels, const cn_scene* scene,
+                          const float* origins, const float* directions, const float* nears, const float* fars,
+                          int64_t num_rays, const int32_t* s_prop_host, int32_t s_final, float anneal,
+                          float* euclidean_bins, float* spacing_bins, float* prop_depth, int32_t matrix_precision,
+                          cn_stream_t stream);
+
 /* The same sampler under model.train() (fruit_nerf/fruit_nerf.py:549 -> ProposalNetworkSampler.generate_ray_samples with
  * the samplers' train_stratified / single_jitter defaults, components/ray_samplers.py:84-87): level-0 bins jittered by ONE
  * uniform random per ray, every PDF resampling at u + rand / nb with one random per ray, and every level's spacing bins,

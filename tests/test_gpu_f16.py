@@ -165,3 +165,50 @@ def test_unknown_matrix_precision_is_rejected(ops, L):
     args = [to_dev(x) for x in (rb.origins, rb.directions, rb.nears, rb.fars)]
     with pytest.raises(L.CropNerfHipError, match="matrix_precision"):
         ops.render_rays(fh, ops.scene_struct(scene.aabb, False), ops.render_opts(64, matrix_precision=7), *args)
+
+
+def test_proposal_sampler_in_fp16_mode(ops, L):
+    """``cn_proposal_sample_mp`` with ``CN_MATRIX_F16`` on half tables: the proposal networks in tiny-cuda-nn's arithmetic class
+    (packed-fp16 grid interpolation, fp16 weights / layer inputs / network output, fp32 accumulation) against the oracle with
+    ``tcnn_half_activations=True`` on the proposal networks too.  The kernel rounds where tcnn rounds but not in tcnn's ORDER (the
+    oracle accumulates the eight corners one by one in fp16, the kernel blends pairs), so densities agree to fp16 noise and the
+    resampled bins to a small fraction of a bin: stated bar 2 % of the bin's own width for 99.9 % of the edges [measured
+    worst case in the message], and everything downstream -- a render on those bins -- inside the fp16 render bars.  A float
+    table keeps the fp32 sampler (same bits as ``cn_proposal_sample``)."""
+    scene = make_tcnn_scene(seed=3, grid_scale=1.0)
+    fspec, pspecs = product_specs(scene)
+    dp16 = dev_params(scene, table_dtype=torch.float16)
+    fh = ops.FieldHandle(dp16, fspec)
+    dh = [ops.DensityHandle(dp16, i, ps) for i, ps in enumerate(pspecs)]
+    assert all(dp16[f"proposal_networks.{i}.encoding.hash_table"].dtype == torch.float16 for i in range(len(pspecs)))
+    rb = ORY.image_rays(scene.c2w, scene.intr, 5, scene.height, scene.width).slice(0, 600)
+    half = dataclasses.replace(scene, fspec=dataclasses.replace(scene.fspec, tcnn_half_activations=True),
+                               pspecs=[dataclasses.replace(p, tcnn_half_activations=True) for p in scene.pspecs])
+    ref = oracle_model(half, "test").forward(rb)
+    o, d = to_dev(rb.origins).clone(), to_dev(rb.directions).clone()
+    ops.apply_pose_adjustment(dp16["camera_optimizer.pose_adjustment"], to_dev(rb.camera_indices[:, 0]), o, d)
+    R = len(rb)
+    nears, fars = torch.zeros(R, 1, device="cuda"), torch.full((R, 1), 1000.0, device="cuda")
+    sc = ops.scene_struct(scene.aabb, True)
+    ps16 = ops.proposal_sample(dh, sc, o, d, nears, fars, (256, 96), 48, matrix_precision=L.MATRIX_F16)
+    ps32 = ops.proposal_sample(dh, sc, o, d, nears, fars, (256, 96), 48)
+    ref_bins = torch.cat([ref["_starts"][..., 0], ref["_ends"][:, -1:, 0]], -1)
+    got = ps16["euclidean_bins"].cpu()
+    width = (ref_bins[:, 1:] - ref_bins[:, :-1]).clamp_min(1e-9)
+    width = torch.cat([width, width[:, -1:]], -1)
+    dev_frac = (got - ref_bins).abs() / width
+    assert float((dev_frac <= 0.02).float().mean()) >= 0.999, f"bin edges: worst {float(dev_frac.max()):.3g} of a bin width"
+    assert not torch.equal(ps16["euclidean_bins"], ps32["euclidean_bins"])  # it IS another arithmetic
+    assert float((ps16["euclidean_bins"] - ps32["euclidean_bins"]).abs().max()) < 1e-2
+    out = ops.render_rays(fh, sc, ops.render_opts(48, matrix_precision=L.MATRIX_F16), o, d, nears, fars,
+                          bins=ps16["euclidean_bins"], camera_indices=None)
+    assert_close(out["rgb"], ref["rgb"], 0.0, 5e-4, "rgb: fp16 sampler + fp16 render vs the half-activation oracle")
+    assert_close(out["accumulation"], ref["accumulation"], 2e-4, 5e-5, "accumulation")
+    # float tables: the mode has no fp16 sampler to offer and must not change a bit
+    dp32 = dev_params(scene, table_dtype=torch.float32)
+    dh32 = [ops.DensityHandle(dp32, i, ps) for i, ps in enumerate(pspecs)]
+    a = ops.proposal_sample(dh32, sc, o, d, nears, fars, (256, 96), 48, matrix_precision=L.MATRIX_F16)
+    b = ops.proposal_sample(dh32, sc, o, d, nears, fars, (256, 96), 48)
+    assert torch.equal(a["euclidean_bins"], b["euclidean_bins"])
+    with pytest.raises(L.CropNerfHipError, match="matrix_precision"):
+        ops.proposal_sample(dh, sc, o, d, nears, fars, (256, 96), 48, matrix_precision=9)
