@@ -718,28 +718,8 @@ __device__ __forceinline__ unsigned hash_level_pk_blend(const PkLoads& L) {
   const f16x2 r = yf + (yc - yf) * wz;
   return __builtin_bit_cast(unsigned, r);
 }
-// The same blend on eight plain 4-byte gathers (no pairs, no selects, no branch): for kernels that are bound by VALU issue rather
-// than by the L1's line lookups -- the proposal sampler -- where the pair form's bookkeeping costs more than its lookups save.
-template <bool OFFSET = true>
-__device__ __forceinline__ unsigned hash_level_pk_plain(const void* __restrict__ table, const Lvl& lv, float pos_offset, float px,
-                                                        float py, float pz) {
-  const Cell k = hash_cell<OFFSET>(lv, pos_offset, px, py, pz);
-  const unsigned* base = reinterpret_cast<const unsigned*>(table);
-  const unsigned hyz[4] = {k.hy0 ^ k.hz0, k.hy1 ^ k.hz0, k.hy0 ^ k.hz1, k.hy1 ^ k.hz1};  // rows (y, z) = ff, cf, fc, cc
-  f16x2 lo[4], hi[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    lo[r] = __builtin_bit_cast(f16x2, base[((k.hx0 ^ hyz[r]) & lv.mask) + lv.off]);
-    hi[r] = __builtin_bit_cast(f16x2, base[((k.hx1 ^ hyz[r]) & lv.mask) + lv.off]);
-  }
-  const _Float16 hx = (_Float16)k.ox, hy = (_Float16)k.oy, hz = (_Float16)k.oz;
-  const f16x2 wx = {hx, hx}, wy = {hy, hy}, wz = {hz, hz};
-  const f16x2 xff = lo[0] + (hi[0] - lo[0]) * wx, xcf = lo[1] + (hi[1] - lo[1]) * wx;
-  const f16x2 xfc = lo[2] + (hi[2] - lo[2]) * wx, xcc = lo[3] + (hi[3] - lo[3]) * wx;
-  const f16x2 yf = xff + (xcf - xff) * wy, yc = xfc + (xcc - xfc) * wy;
-  const f16x2 r = yf + (yc - yf) * wz;
-  return __builtin_bit_cast(unsigned, r);
-}
+// (The same blend on eight plain 4-byte gathers -- no pairs, no selects, no branch -- was tried for the proposal sampler's fp16 mode,
+//  which is bound by VALU issue rather than by lookups: 0.646 vs 0.587 ms per launch with the pair form, so it is not kept.)
 // keeps a blended value where the program computed it (an empty volatile asm is ordered against the others)
 __device__ __forceinline__ unsigned pk_pin(unsigned v) {
   asm volatile("" : "+v"(v));

@@ -199,7 +199,6 @@ __device__ __forceinline__ float prop_density_f16(const PropNet& n, const PropMl
 #pragma unroll
   for (int l = 0; l < L; ++l)  // pinned level by level: left alone hipcc sinks every blend behind the last level's loads and spills
     featp[l] = pk_pin(hash_level_pk<true>(n.grid.table, n.grid.level(l), n.grid.pos_offset, px, py, pz));
-  // (hash_level_pk_plain -- eight 4-byte gathers, no selects, no branch -- measured slower here: 0.646 vs 0.587 ms per launch)
   return expf(prop_mlp_f16<L>(mlp, encw, featp, lane)) * (sel ? 1.f : 0.f);
 }
 
