@@ -40,7 +40,8 @@ def make_scene(seed: int = 0, log2_T: int = 19, num_images: int = 6, height: int
 
 
 def make_tcnn_scene(seed: int = 0, log2_T: int = 19, num_images: int = 6, height: int = 40, width: int = 40,
-                    focal: float = 55.0, grid_scale: float = 0.1, prop_log2_T: int = 17) -> Scene:
+                    focal: float = 55.0, grid_scale: float = 0.1, prop_log2_T: int = 17,
+                    second_prop=(5, 256)) -> Scene:
     """The same scene shape with the reference's default implementation: tcnn modules, parameters under nerfstudio's
     tcnn state-dict names (fp32 master values, as a checkpoint holds them)."""
     from cropnerf_amd import synthetic
@@ -48,7 +49,7 @@ def make_tcnn_scene(seed: int = 0, log2_T: int = 19, num_images: int = 6, height
 
     fspec = OF.FieldSpec(grid=OF.GridSpec(log2_hashmap_size=log2_T), num_images=num_images, implementation="tcnn")
     pspecs = [OF.ProposalSpec(OF.GridSpec(5, 16, 128, prop_log2_T), implementation="tcnn"),
-              OF.ProposalSpec(OF.GridSpec(5, 16, 256, prop_log2_T), implementation="tcnn")]
+              OF.ProposalSpec(OF.GridSpec(second_prop[0], 16, second_prop[1], prop_log2_T), implementation="tcnn")]
     params = TC.random_params(fspec, pspecs, seed=seed, grid_scale=grid_scale)
     g = torch.Generator().manual_seed(seed + 99)
     params["camera_optimizer.pose_adjustment"] = (torch.rand(num_images, 6, generator=g) - 0.5) * 0.02

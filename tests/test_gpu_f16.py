@@ -167,7 +167,8 @@ def test_unknown_matrix_precision_is_rejected(ops, L):
         ops.render_rays(fh, ops.scene_struct(scene.aabb, False), ops.render_opts(64, matrix_precision=7), *args)
 
 
-def test_proposal_sampler_in_fp16_mode(ops, L):
+@pytest.mark.parametrize("second_prop", [(5, 256), (7, 2048)])  # the default method's second network / fruit_nerf_method_big's
+def test_proposal_sampler_in_fp16_mode(ops, L, second_prop):
     """``cn_proposal_sample_mp`` with ``CN_MATRIX_F16`` on half tables: the proposal networks in tiny-cuda-nn's arithmetic class
     (packed-fp16 grid interpolation, fp16 weights / layer inputs / network output, fp32 accumulation) against the oracle with
     ``tcnn_half_activations=True`` on the proposal networks too.  The kernel rounds where tcnn rounds but not in tcnn's ORDER (the
@@ -175,12 +176,13 @@ def test_proposal_sampler_in_fp16_mode(ops, L):
     resampled bins to a small fraction of a bin: stated bar 2 % of the bin's own width for 99.9 % of the edges [measured
     worst case in the message], and everything downstream -- a render on those bins -- inside the fp16 render bars.  A float
     table keeps the fp32 sampler (same bits as ``cn_proposal_sample``)."""
-    scene = make_tcnn_scene(seed=3, grid_scale=1.0)
+    scene = make_tcnn_scene(seed=3, grid_scale=1.0, second_prop=second_prop)
     fspec, pspecs = product_specs(scene)
     dp16 = dev_params(scene, table_dtype=torch.float16)
     fh = ops.FieldHandle(dp16, fspec)
     dh = [ops.DensityHandle(dp16, i, ps) for i, ps in enumerate(pspecs)]
     assert all(dp16[f"proposal_networks.{i}.encoding.hash_table"].dtype == torch.float16 for i in range(len(pspecs)))
+    assert pspecs[1].grid.num_levels == second_prop[0]
     rb = ORY.image_rays(scene.c2w, scene.intr, 5, scene.height, scene.width).slice(0, 600)
     half = dataclasses.replace(scene, fspec=dataclasses.replace(scene.fspec, tcnn_half_activations=True),
                                pspecs=[dataclasses.replace(p, tcnn_half_activations=True) for p in scene.pspecs])
