@@ -550,6 +550,51 @@ def test_full_size_chunk_properties(ops):
     assert_close(out["accumulation"][idx.cuda()], ref["accumulation"], RTOL, ATOL, "acc spot check")
 
 
+def test_full_size_proposal_sampler_properties(ops):
+    """The proposal sampler on a C2-size batch of the default method (65 536 rays, (256, 96) proposal + 48 field samples,
+    2^17-entry proposal tables, scene contraction): properties that do not depend on the size -- bins ordered and inside
+    [near, far], every ray independent of the call it is part of and of its place in it -- and a 256-ray spot check of the
+    whole chain (sampler, then a render on its bins) against the oracle."""
+    sc_ = make_scene(seed=3, height=800, width=800, focal=1111.1, num_images=4, grid_scale=1.0)
+    fspec, pspecs = product_specs(sc_)
+    dp = dev_params(sc_)
+    fh = ops.FieldHandle(dp, fspec)
+    dh = [ops.DensityHandle(dp, i, ps) for i, ps in enumerate(pspecs)]
+    R = 65536
+    rays = ops.raygen_pinhole(to_dev(sc_.c2w), to_dev(sc_.intr), cam=1, height=800, width=800, pixel_start=800 * 300,
+                              num_rays=R)
+    o, d = rays["origins"], rays["directions"]
+    n, f = torch.full((R, 1), 0.05, device="cuda"), torch.full((R, 1), 1000.0, device="cuda")  # the method's collider
+    sc = ops.scene_struct(sc_.aabb, True)
+    ps = ops.proposal_sample(dh, sc, o, d, n, f, (256, 96), 48)
+    eu, sp = ps["euclidean_bins"], ps["spacing_bins"]
+    assert torch.isfinite(eu).all() and torch.isfinite(sp).all()
+    assert (eu[:, 1:] >= eu[:, :-1]).all() and (sp[:, 1:] >= sp[:, :-1]).all(), "bins out of order"
+    assert (eu[:, :1] >= n * (1 - 1e-6)).all() and (eu[:, -1:] <= f * (1 + 1e-6)).all()
+    assert (sp >= 0).all() and (sp <= 1).all()
+    assert (ps["prop_depth"] >= 0.05 * (1 - 1e-6)).all() and (ps["prop_depth"] <= 1000.0 * (1 + 1e-6)).all()
+    # any sub-range sampled alone gives bit-identical rows (one wave owns one ray; nothing is shared between rays)
+    lo, hi = 12345, 23456
+    sub = ops.proposal_sample(dh, sc, o[lo:hi].contiguous(), d[lo:hi].contiguous(), n[lo:hi].contiguous(),
+                              f[lo:hi].contiguous(), (256, 96), 48)
+    assert torch.equal(sub["euclidean_bins"], eu[lo:hi]) and torch.equal(sub["prop_depth"], ps["prop_depth"][:, lo:hi])
+    # and so does any permutation of the rays
+    perm = torch.randperm(R, generator=torch.Generator().manual_seed(5)).cuda()
+    pp = ops.proposal_sample(dh, sc, o[perm].contiguous(), d[perm].contiguous(), n[perm].contiguous(), f[perm].contiguous(),
+                             (256, 96), 48)
+    assert torch.equal(pp["euclidean_bins"], eu[perm])
+    # 256 rays of it against the oracle: final bins, and the render on them
+    idx = torch.arange(0, R, R // 256)[:256]
+    rb = ORY.RayBundle(o.cpu()[idx], d.cpu()[idx], torch.zeros(256, 1), None, n.cpu()[idx], f.cpu()[idx])
+    m = oracle_model(sc_, "inference")
+    ref = m.forward(rb)
+    ref_bins = torch.cat([ref["_starts"][..., 0], ref["_ends"][:, -1:, 0]], -1)
+    assert_close(eu[idx.cuda()], ref_bins, 2e-3, 1e-4, "final euclidean bins (spot check)", frac_ok=0.999)
+    out = ops.render_rays(fh, sc, ops.render_opts(48), o[idx.cuda()].contiguous(), d[idx.cuda()].contiguous(),
+                          n[idx.cuda()].contiguous(), f[idx.cuda()].contiguous(), bins=eu[idx.cuda()].contiguous())
+    assert_close(out["rgb"], ref["rgb"], 0.0, 2e-3, "rgb on the sampler's own bins (spot check)", frac_ok=0.99)
+
+
 # ------------------------------------------------------------------------------------------------ edge cases
 @pytest.mark.parametrize("R,S", [(1, 1), (3, 2), (5, 65), (130, 1)])
 def test_render_rays_tiny_shapes(scene, ops, handles, R, S):
