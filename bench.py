@@ -621,7 +621,11 @@ def secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, o
                 "unit": "G atomic requests/s (memory side; 64-byte read-modify-writes)", "frac": round(req / t / ATOMIC_REQUESTS_PER_SEC, 4),
                 "traffic": None, "atomic_requests_per_iteration": int(req),
                 "requests_source": src,
-                "hbm_equivalent_GBps": round(req * 64 / t / 1e9, 1)}
+                "hbm_equivalent_GBps": round(req * 64 / t / 1e9, 1),
+                "limited_by": "the field backward (about half the iteration): 17 barrier-separated matrix phases per 32-sample tile "
+                              "(5.5 ms at 65 536 rays with the memory operations switched off) plus its gathers and scatter, which "
+                              "add to them; the atomic-request rate priced here is a floor of the iteration, not its cost "
+                              "(DESIGN.md 4.10: a store-based scatter that removed most requests did not shorten it)"}
             del tr, model
         out["train_iteration"] = train
     return out
