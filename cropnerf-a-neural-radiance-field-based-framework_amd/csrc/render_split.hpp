@@ -343,28 +343,11 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
             any = any || a;
             active = rsel == t ? a : active;
           }
-          // samples past the end of the ray (S = 48: the last 16 columns of every second half-step) are whole waves of the team:
-          // they hand over zeros and read nothing -- a quarter of the lookups of a 48-sample render.  (The same skip in the
-          // one-ray gather branch below -- a wave-uniform branch around the second column tile -- bought nothing on a 48-sample
-          // image, 15.28 vs 15.29 ms, and cost the exact-fp32 headline 3.5 %, 2.68 vs 2.59 ms: not built in.)
-          const bool past_end = !PER_SAMPLE && (k >> 1) * 64 + 32 * (k & 1) + SPW * sub >= S;
-          if (any && past_end) {
-            if (active) {
-              float* xs = ring0 + rsel * PAIR_SCRATCH + (int)(step & 1) * XCH_FLOATS;
-#pragma unroll
-              for (int h = 0; h < 2; ++h) {
-                const int c = SPW * sub + (SPW / 2) * h + sidx;
-                if constexpr (F16) {
-                  reinterpret_cast<u32x4v*>(xs)[(c >> 4) * 64 + 16 * g + (c & 15)] = u32x4v{0u, 0u, 0u, 0u};
-                } else {
-                  f32x4* xv = reinterpret_cast<f32x4*>(xs);
-                  xv[(2 * (c >> 4) + 0) * 64 + 16 * g + (c & 15)] = f32x4{0.f, 0.f, 0.f, 0.f};
-                  xv[(2 * (c >> 4) + 1) * 64 + 16 * g + (c & 15)] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-                if (g == 0) xs[XCH_FLOATS - 64 + c] = 0.f;
-              }
-            }
-          } else if (any) {
+          // (Skipping the team's waves whose columns lie past the end of a ray -- S = 48: the last 16 columns of every second
+          //  half-step; zeros handed over, nothing read -- and the same skip in the one-ray branch below were both built and
+          //  measured on one box: the 48-sample eval image does not move (11.30 vs 11.29 ms in fp16 mode, 15.28 vs 15.29 in fp32)
+          //  and the 192-sample batch pays for the extra path, 1.417 vs 1.385 ms in fp16 mode, 2.68 vs 2.59 ms in fp32.  Not built in.)
+          if (any) {
             if (active) {
               const f32x4 ra = *reinterpret_cast<const f32x4*>(trec + 16 * rsel);
               const f32x4 rb = *reinterpret_cast<const f32x4*>(trec + 16 * rsel + 4);
