@@ -24,6 +24,9 @@ namespace cn {
 //    results -- left the launch at 1.028 ms: the L1 lookups never bounded it.  Removed.
 //  * one round trip per level instead of two (pair loads and odd-x loads issued back to back): 1.043 ms; levels software-pipelined:
 //    0.85 vs 0.67 ms (spills); five waves per SIMD: 0.70 vs 0.67 ms (spills).
+//  * the sampler scaffolding (0.21 of the 0.61 ms): linspace step and the pdf_u constants hoisted out of their loops by hand and the
+//    inverse-cdf search written without data-dependent control flow (bit-identical results): 0.616 vs 0.608 ms -- hipcc had hoisted
+//    what is invariant, and ten uniform steps cost what nine divergent ones do.  Not kept.
 //  * ablation builds (-DCN_PROP_ABLATE=1 / 2), MLP on the VALU: 0.21 ms without any network, 0.58 ms with the hash encoding, 1.04 ms
 //    complete -- the MLP was the larger half; see prop_mlp_mfma.
 #ifndef CN_PROP_XPAIR
