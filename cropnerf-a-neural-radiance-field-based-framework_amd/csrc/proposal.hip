@@ -27,6 +27,10 @@ namespace cn {
 //  * the sampler scaffolding (0.21 of the 0.61 ms): linspace step and the pdf_u constants hoisted out of their loops by hand and the
 //    inverse-cdf search written without data-dependent control flow (bit-identical results): 0.616 vs 0.608 ms -- hipcc had hoisted
 //    what is invariant, and ten uniform steps cost what nine divergent ones do.  Not kept.
+//  * where the instructions are now (SQ_INSTS_VALU per ray, profiles/r03e_pmc_proposal_sampler.json and ablation builds of the
+//    scaffolding): 4 213 in all -- the two networks 2 210 (352 evaluations x ~362 / 64 lanes), the scaffolding 2 003 = the two cdfs 217
+//    + their inversions 497 + the compositing scans 375 + bins, positions, spacing functions and outputs 877; 84 % of the SIMDs'
+//    issue slots are taken.
 //  * ablation builds (-DCN_PROP_ABLATE=1 / 2), MLP on the VALU: 0.21 ms without any network, 0.58 ms with the hash encoding, 1.04 ms
 //    complete -- the MLP was the larger half; see prop_mlp_mfma.
 #ifndef CN_PROP_XPAIR
