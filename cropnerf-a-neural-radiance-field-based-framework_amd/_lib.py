@@ -81,6 +81,14 @@ class RenderOpts(C.Structure):
 
 MATRIX_FP32, MATRIX_SPLIT_BF16, MATRIX_F16 = 0, 1, 2  # cn_render_opts.matrix_precision
 
+
+class ProjectionJob(C.Structure):
+    """``cn_projection_job`` (a device array: filled on the host, copied over as bytes)"""
+    _fields_ = [("c2w", C.c_float * 12), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("aabb", C.c_float * 6), ("x0", C.c_int32), ("y0", C.c_int32), ("w", C.c_int32), ("h", C.c_int32),
+                ("camera_index", C.c_int32), ("reserved", C.c_int32), ("slot_offset", C.c_int64)]
+
+
 _P = C.c_void_p
 _I32, _I64, _F = C.c_int32, C.c_int64, C.c_float
 
@@ -99,6 +107,10 @@ SIGNATURES = {
     "cn_raygen_ortho": (C.c_int, [_P, C.POINTER(_F), _I64, _I64, _P, _P, _P, _P, _P, _P]),
     "cn_surface_grid": (C.c_int, [_F, _F, _I32, _F, _F, _I32, _F, _P, _P]),
     "cn_apply_pose_adjustment": (C.c_int, [_P, _P, _I64, _P, _P, _P]),
+    "cn_projection_test": (C.c_int, [_P, _I32, _I64, _I32, _I32, _P, _P, _P, _P]),
+    "cn_projection_gather": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "cn_projection_scatter": (C.c_int, [_P, _P, _P, _I64, _F, _P, _P, _P, _P, _P]),
+    "cn_projection_paste": (C.c_int, [_P, _P, _P, _I64, _P, _I32, _I32, _I32, _P, _P]),
     "cn_sample_spaced": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _I32, _P, _P, _P, _P, _P]),
     "cn_sample_pdf": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _F, _I32, _P, _I32, _P, _P, _P]),
     "cn_proposal_density": (C.c_int, [C.POINTER(DensityParams), C.POINTER(Scene), _P, _P, _P, _P, _I64, _I32, _P, _P]),

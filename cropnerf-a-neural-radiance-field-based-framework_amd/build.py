@@ -22,9 +22,13 @@ BUILD = HERE / "build"
 ARCH = "gfx950"
 
 SOURCES = ["api_common.cpp", "raygen.hip", "sampler.hip", "field_simple.hip", "composite.hip", "render_fused.hip",
-           "proposal.hip", "export.hip", "train_render.hip", "train_field.hip", "zbuffer.hip", "knn.hip", "cluster.hip", "tcnn_grid.hip", "contour.hip"]
-HEADERS = ["cn_common.hpp", "wave_ops.hpp", "sampler_dev.hpp", "composite_dev.hpp", "train_field_mfma.hpp", "train_field_general.hpp", "render_split.hpp", "field_regw.hpp",
-           "../../include/cropnerf_hip.h"]
+           "proposal.hip", "export.hip", "train_render.hip", "train_field.hip", "zbuffer.hip", "knn.hip", "cluster.hip", "tcnn_grid.hip", "contour.hip", "projection.hip"]
+
+
+def _headers():
+    """Every header a translation unit may include: all of csrc/*.hpp (globbed, so a new header cannot be forgotten and
+    leave a stale object behind) and the public C header."""
+    return sorted(CSRC.glob("*.hpp")) + [HERE.parent / "include" / "cropnerf_hip.h"]
 
 
 def _hipcc() -> str:
@@ -44,7 +48,7 @@ def _stale(target: Path, deps) -> bool:
 def build(force: bool = False, verbose: bool = False) -> Path:
     hipcc = _hipcc()
     BUILD.mkdir(exist_ok=True)
-    headers = [CSRC / h for h in HEADERS]
+    headers = _headers()
     flags = ["-O3", f"--offload-arch={ARCH}", "-fPIC", "-std=c++17", "-x", "hip", "-Wno-unused-result"]
     flags += os.environ.get("CN_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DCN_FUSED_PIPELINE=0 for A/B builds
     jobs = []

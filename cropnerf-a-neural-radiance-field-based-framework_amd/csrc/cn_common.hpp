@@ -143,11 +143,18 @@ inline int check_grid(const cn_grid& g, bool need_f32, const char* who) {
     for (int l = 0; l < g.num_levels; ++l) {
       const int b = g.level_bits[l];
       CN_REQUIRE(b <= 9, CN_ERR_UNSUPPORTED, "%s: dense level %d with %d bits per axis", who, l, b);
+      // the x-pair gathers (hash_level_xpair_issue / hash_level_pk_issue) read entries e and e ^ 1 as ONE aligned pair
+      CN_REQUIRE(g.level_offset[l] % 2 == 0, CN_ERR_INVALID, "%s: level %d starts at the odd entry %u", who, l,
+                 g.level_offset[l]);
       const unsigned long long end = (unsigned long long)g.level_offset[l] + (b ? 1ull << (3 * b) : 1ull << g.log2_table_size);
       if (end > entries) entries = end;
     }
   }
   CN_REQUIRE(entries * 8ull <= (1ull << 31), CN_ERR_UNSUPPORTED, "%s: hash table larger than 2 GiB", who);
+  // an aligned entry pair is one dwordx4 load of a float table, one dwordx2 load of a half table
+  const uintptr_t align = g.table_dtype == CN_TABLE_F16 ? 7u : 15u;
+  CN_REQUIRE((reinterpret_cast<uintptr_t>(g.table) & align) == 0, CN_ERR_INVALID,
+             "%s: the hash table must be %u-byte aligned", who, (unsigned)align + 1u);
   return CN_OK;
 }
 

@@ -5,21 +5,9 @@
 // fruit_nerf/export/exporter_utils_nerfacto.py:266-268, fruit_nerf/components/ray_generators.py:46-66,
 // fruit_nerf/data/fruit_datamanager.py:71-121, fruit_nerf/fruit_nerf.py:547.
 #include "cn_common.hpp"
+#include "raygen_dev.hpp"
 
 namespace cn {
-
-__device__ __forceinline__ void rotate_normalize(const float* __restrict__ m /*3x4 row-major*/, float cx, float cy,
-                                                 float& dx, float& dy, float& dz, float& norm) {
-  // d = sum_j dir[j] * R[i][j], dir = (cx, cy, -1)
-  float x = cx * m[0] + cy * m[1] - m[2];
-  float y = cx * m[4] + cy * m[5] - m[6];
-  float z = cx * m[8] + cy * m[9] - m[10];
-  float n = fmaxf(sqrtf(x * x + y * y + z * z), 1e-7f);
-  dx = x / n;
-  dy = y / n;
-  dz = z / n;
-  norm = n;
-}
 
 __global__ void __launch_bounds__(256)
 raygen_pinhole_kernel(const float* __restrict__ c2w, const float* __restrict__ intr,
@@ -43,7 +31,8 @@ raygen_pinhole_kernel(const float* __restrict__ c2w, const float* __restrict__ i
     const float* m = c2w + 12 * c;
     float fx = intr[4 * c + 0], fy = intr[4 * c + 1], px = intr[4 * c + 2], py = intr[4 * c + 3];
     float y = (float)row + 0.5f, x = (float)col + 0.5f;
-    float cx0 = (x - px) / fx, cy0 = -(y - py) / fy;
+    float cx0, cy0;
+    pixel_camera_coords(fx, fy, px, py, row, col, cx0, cy0);
     float cx1 = (x - px + 1.f) / fx, cy1 = -(y - py + 1.f) / fy;
     float d0x, d0y, d0z, n0, d1x, d1y, d1z, n1, d2x, d2y, d2z, n2;
     rotate_normalize(m, cx0, cy0, d0x, d0y, d0z, n0);
@@ -75,16 +64,10 @@ intersect_aabb_kernel(const float* __restrict__ o, const float* __restrict__ d, 
   for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x) {
     float ox = o[3 * r], oy = o[3 * r + 1], oz = o[3 * r + 2];
     float dx = d[3 * r], dy = d[3 * r + 1], dz = d[3 * r + 2];
-    float ax = (lx - ox) / dx, bx = (hx - ox) / dx;
-    float ay = (ly - oy) / dy, by = (hy - oy) / dy;
-    float az = (lz - oz) / dz, bz = (hz - oz) / dz;
-    float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-    float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-    tmin = fminf(fmaxf(tmin, 0.f), 1e10f);
-    tmax = fminf(fmaxf(tmax, 0.f), 1e10f);
-    bool miss = tmax <= tmin;
-    nears[r] = miss ? 1e10f : tmin;
-    fars[r] = miss ? 1e10f : tmax;
+    float tn, tf;
+    slab_test(ox, oy, oz, dx, dy, dz, lx, ly, lz, hx, hy, hz, tn, tf);
+    nears[r] = tn;
+    fars[r] = tf;
   }
 }
 

@@ -443,25 +443,26 @@ class FruitModel:
                 "density": out["density"], "semantics_colormap": out["semantics_colormap"]}
 
     # ------------------------------------------------------------------------------------------ chunked renders
-    def _chunked(self, camera_ray_bundle: RayBundle, fn, image_width: int = 0) -> Dict[str, Tensor]:
+    def _chunked(self, camera_ray_bundle: RayBundle, fn, image_width: int = 0, keys: Optional[Sequence[str]] = None,
+                 min_chunk: int = 1 << 15) -> Dict[str, Tensor]:
         """``image_width`` > 0: the bundle is a whole row-major image, so every chunk is a pixel run -- passed to the
-        renderer as a scheduling hint (cn_render_opts.image_width / pixel_start)."""
+        renderer as a scheduling hint (cn_render_opts.image_width / pixel_start).  ``keys``: keep only these outputs."""
         # the reference's chunk size bounds ITS memory (materialised [R,S,.] tensors); rays are independent, so any size
         # gives the same image here and chunks below 32 768 rays (the projection CLI asks for 4096) only add launches
-        chunk = max(int(self.config.eval_num_rays_per_chunk), 1 << 15)
+        chunk = max(int(self.config.eval_num_rays_per_chunk), int(min_chunk))
         flat = camera_ray_bundle.flatten()
         n = len(flat)
         lists: Dict[str, List[Tensor]] = {}
         for i in range(0, n, chunk):
             self._image_hint = (image_width, i)
             try:
-                out = fn(flat.get_row_major_sliced_ray_bundle(i, i + chunk))
+                out = fn(flat if n <= chunk else flat.get_row_major_sliced_ray_bundle(i, i + chunk))
             finally:
                 self._image_hint = (0, 0)
             for k, v in out.items():
-                if isinstance(v, Tensor):
+                if isinstance(v, Tensor) and (keys is None or k in keys):
                     lists.setdefault(k, []).append(v)
-        return {k: torch.cat(v) for k, v in lists.items()}
+        return {k: (v[0] if len(v) == 1 else torch.cat(v)) for k, v in lists.items()}
 
     @torch.no_grad()
     def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
@@ -470,17 +471,22 @@ class FruitModel:
         out = self._chunked(camera_ray_bundle, self.forward, image_width=image_width)
         return {k: v.view(image_height, image_width, -1) for k, v in out.items()}
 
+    # a jagged bundle has no image to stripe: larger chunks only save launches (one C2-sized batch at a time)
+    JAGGED_CHUNK = 1 << 17
+
     @torch.no_grad()
-    def get_outputs_for_camera_jagged_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, Tensor]:
-        """``fruit_nerf.py:346-374``: same for an arbitrary list of rays ([N,C] outputs)."""
-        return self._chunked(camera_ray_bundle, self.forward)
+    def get_outputs_for_camera_jagged_ray_bundle(self, camera_ray_bundle: RayBundle,
+                                                 keys: Optional[Sequence[str]] = None) -> Dict[str, Tensor]:
+        """``fruit_nerf.py:346-374``: same for an arbitrary list of rays ([N,C] outputs).  ``keys`` (extension): only these
+        outputs are collected."""
+        return self._chunked(camera_ray_bundle, self.forward, keys=keys, min_chunk=self.JAGGED_CHUNK)
 
     @torch.no_grad()
     def get_density_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Tensor:
         """``fruit_nerf.py:320-344``: sum_s w per ray (no pose tweak, no collider); density-only kernel variant."""
         out = self._chunked(camera_ray_bundle,
                             lambda rb: self._sample_and_render(rb.flatten().to(self.device)._map(lambda t: t.contiguous()),
-                                                               density_only=True))
+                                                               density_only=True), min_chunk=self.JAGGED_CHUNK)
         return out["accumulation"][:, 0]
 
     # ------------------------------------------------------------------------------------------ projection
@@ -488,18 +494,31 @@ class FruitModel:
     def get_outputs_for_projections(self, train_dataset, camera_optimizer=None,
                                     pcd_path: str = "/opt/data/artifacts/pear/pcd/all_super_cluster_info_nsub_2.npy",
                                     output_root: str = "/opt/data/artifacts/pear/projection",
-                                    pcd_data=None, save: bool = True):
+                                    pcd_data=None, save: bool = True, batched: bool = True, return_run: bool = False):
         """``fruit_nerf.py:254-318``: per (super-cluster, camera, sub-cluster AABB) an unoccluded semantic render and an
-        occlusion-masked one, written as PNGs.  Returns {(i_sc, cam_idx, i): (wo_occ, visible)} when ``save`` is False."""
+        occlusion-masked one, written as PNGs (``save``), else returned as {(i_sc, cam_idx, i): (wo_occ, visible)} float
+        images.  ``batched`` (default): the jobs run many at a time through ``projection.project_all`` -- rays only for the
+        pixels a box can cover, one host synchronisation per batch, PNG files written by worker threads behind the GPU; the
+        per-job loop of the reference (``batched=False`` -> ``project_cluster``) computes the same values.  ``return_run``:
+        return the compact ``ProjectionRun`` instead (what the in-process merger reads; nothing is expanded to frames)."""
         cameras: Cameras = train_dataset.cameras
         segmentation_files = train_dataset.metadata["semantics"].filenames
         if pcd_data is None:
             pcd_data = np.load(pcd_path, allow_pickle=True)
-        results = {}
         from ..distributed import world as _world
 
         rank, world_size = _world()  # (camera x sub-cluster) jobs are independent: dealt round-robin over the ranks,
-        job = -1                     # no communication (every rank writes its own PNGs / returns its own results)
+        if batched:                  # no communication (every rank writes its own PNGs / returns its own results)
+            from .projection import project_all
+
+            run = project_all(self, cameras.to(self.device), pcd_data, output_root=output_root if save else None,
+                              segmentation_files=segmentation_files, want_float=not save and not return_run,
+                              keep=return_run or not save, rank=rank, world_size=world_size)
+            if return_run:
+                return run
+            return None if save else run.float_results()
+        results = {}
+        job = -1
         for i_sc in range(len(pcd_data)):
             cluster_aabb = np.asarray(pcd_data[i_sc]["aabb"])
             save_dir = os.path.join(output_root, f"super_cluster_{i_sc}")

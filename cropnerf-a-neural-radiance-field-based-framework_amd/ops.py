@@ -301,6 +301,103 @@ def apply_pose_adjustment(pose_adjustment: Tensor, camera_indices: Tensor, origi
                                          _stream(origins)))
 
 
+# --------------------------------------------------------------------------------------------------------------
+# batched semantic projection (fruit_nerf.py:254-318): the ray side of many (camera, box) jobs in one launch sequence
+# --------------------------------------------------------------------------------------------------------------
+
+def _u8(t: Optional[Tensor], name: str) -> Optional[Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.uint8 or not t.is_contiguous() or not t.is_cuda:
+        raise TypeError(f"{name}: expected a contiguous uint8 device tensor")
+    return t
+
+
+def _i32(t: Optional[Tensor], name: str) -> Optional[Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.int32 or not t.is_contiguous() or not t.is_cuda:
+        raise TypeError(f"{name}: expected a contiguous int32 device tensor")
+    return t
+
+
+def _jobs(jobs: Tensor) -> Tuple[Tensor, int]:
+    size = C.sizeof(L.ProjectionJob)
+    jobs = _u8(jobs, "jobs")
+    if jobs.numel() % size or jobs.data_ptr() % 8:
+        raise ValueError(f"jobs: a byte image of cn_projection_job records ({size} B each, 8-byte aligned)")
+    return jobs, jobs.numel() // size
+
+
+def projection_test(jobs: Tensor, num_slots: int, image_width: int, min_rays: int = 10) -> Dict[str, Tensor]:
+    """``cn_projection_test``: ``jobs`` = the device copy of a ``cn_projection_job`` array as bytes.  Returns ``flags`` [P] uint8
+    (1 = the slot's ray hits its job's box and the job has at least ``min_rays`` such rays), ``job_of_slot`` [P] int32 and
+    ``hit_count`` [J] int32 (before the ``min_rays`` rule)."""
+    lib = L.load()
+    jobs, J = _jobs(jobs)
+    dev = jobs.device
+    out = {"flags": torch.empty(num_slots, dtype=torch.uint8, device=dev),
+           "job_of_slot": torch.empty(num_slots, dtype=torch.int32, device=dev),
+           "hit_count": torch.empty(J, dtype=torch.int32, device=dev)}
+    L.check(lib.cn_projection_test(_p(jobs), J, num_slots, image_width, min_rays, _p(out["flags"]), _p(out["job_of_slot"]),
+                                   _p(out["hit_count"]), _stream(jobs)))
+    return out
+
+
+def projection_gather(jobs: Tensor, job_of_slot: Tensor, hit_slots: Tensor, image_width: int,
+                      want_job_pixel: bool = False) -> Dict[str, Tensor]:
+    """``cn_projection_gather``: the jagged ray bundle of the listed slots."""
+    lib = L.load()
+    jobs, _ = _jobs(jobs)
+    dev = jobs.device
+    N = hit_slots.numel()
+    out = {"origins": torch.empty(N, 3, device=dev), "directions": torch.empty(N, 3, device=dev),
+           "nears": torch.empty(N, 1, device=dev), "fars": torch.empty(N, 1, device=dev),
+           "camera_indices": torch.empty(N, 1, dtype=torch.int64, device=dev)}
+    if want_job_pixel:
+        out["ray_job"] = torch.empty(N, dtype=torch.int32, device=dev)
+        out["ray_pixel"] = torch.empty(N, dtype=torch.int32, device=dev)
+    L.check(lib.cn_projection_gather(_p(jobs), _p(_i32(job_of_slot, "job_of_slot")), _p(_i64(hit_slots, "hit_slots")), N,
+                                     image_width, _p(out["origins"]), _p(out["directions"]), _p(out["nears"]),
+                                     _p(out["fars"]), _p(out["camera_indices"]), _p(out.get("ray_job")),
+                                     _p(out.get("ray_pixel")), _stream(jobs)))
+    return out
+
+
+def projection_scatter(semantics: Tensor, occlusion: Tensor, hit_slots: Tensor, num_slots: int,
+                       occlusion_threshold: float = 0.5, want_float: bool = False, want_u8: bool = True) -> Dict[str, Tensor]:
+    """``cn_projection_scatter``: per-slot ``wo_occ`` / ``visible`` values (zero where no ray hit), float and / or uint8."""
+    lib = L.load()
+    dev = semantics.device
+    out: Dict[str, Tensor] = {}
+    if want_float:
+        out["wo_occ_f32"], out["visible_f32"] = torch.zeros(num_slots, device=dev), torch.zeros(num_slots, device=dev)
+    if want_u8:
+        out["wo_occ_u8"] = torch.zeros(num_slots, dtype=torch.uint8, device=dev)
+        out["visible_u8"] = torch.zeros(num_slots, dtype=torch.uint8, device=dev)
+    sem = _f32(semantics.reshape(-1), "semantics")
+    occ = _f32(occlusion.reshape(-1), "occlusion")
+    N = hit_slots.numel()
+    if sem.numel() != N or occ.numel() != N:
+        raise ValueError(f"semantics / occlusion hold {sem.numel()} / {occ.numel()} rays for {N} hit slots")
+    L.check(lib.cn_projection_scatter(_p(sem), _p(occ), _p(_i64(hit_slots, "hit_slots")), N, occlusion_threshold,
+                                      _p(out.get("wo_occ_f32")), _p(out.get("visible_f32")), _p(out.get("wo_occ_u8")),
+                                      _p(out.get("visible_u8")), _stream(semantics)))
+    return out
+
+
+def projection_paste(jobs: Tensor, job_of_slot: Tensor, slot_values: Tensor, image_of_job: Tensor, images: Tensor) -> Tensor:
+    """``cn_projection_paste``: job rectangles of per-slot uint8 values into ``images`` [num_images, H, W] (in place)."""
+    lib = L.load()
+    jobs, J = _jobs(jobs)
+    if image_of_job.numel() != J or images.dim() != 3:
+        raise ValueError("image_of_job: one image index per job; images: [num_images, H, W]")
+    L.check(lib.cn_projection_paste(_p(jobs), _p(_i32(job_of_slot, "job_of_slot")), _p(_u8(slot_values, "slot_values")),
+                                    slot_values.numel(), _p(_i32(image_of_job, "image_of_job")), images.shape[0],
+                                    images.shape[1], images.shape[2], _p(_u8(images, "images")), _stream(jobs)))
+    return images
+
+
 def embedding_mean(embedding: Tensor) -> Tensor:
     lib = L.load()
     out = torch.empty(embedding.shape[1], device=embedding.device)

@@ -67,6 +67,18 @@ LIGHT = (0.3, 0.5, 0.81)
 def analytic_render(origins: torch.Tensor, directions: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Closed-form image of the analytic plant for rays [..., 3] (unit directions): rgb [...,3], fruit mask [...,1]
     (1 where a boll is the first hit), depth [...,1] (1e10 on a miss).  Lambert-like view-independent shading."""
+    rgb, mask, depth, _ = _analytic_hits(origins, directions)
+    return rgb, mask, depth
+
+
+def analytic_instance_labels(origins: torch.Tensor, directions: torch.Tensor) -> torch.Tensor:
+    """Instance label per ray [...] uint8: b + 1 where boll b is the first hit, 0 elsewhere -- the analytic plant's stand-in
+    for the instance-segmentation frames (``label_frame*.png``) the merger reads beside the projections
+    (``segmentation/merger.py:221,240-248``)."""
+    return _analytic_hits(origins, directions)[3]
+
+
+def _analytic_hits(origins: torch.Tensor, directions: torch.Tensor):
     o, d = origins.to(torch.float32), directions.to(torch.float32)
     dev = o.device
     light = torch.tensor(LIGHT, device=dev)
@@ -74,12 +86,13 @@ def analytic_render(origins: torch.Tensor, directions: torch.Tensor) -> Tuple[to
     best_t = torch.full(o.shape[:-1], 1e10, device=dev)
     rgb = torch.tensor(BACKGROUND, device=dev).expand(*o.shape[:-1], 3).clone()
     mask = torch.zeros(*o.shape[:-1], device=dev)
+    inst = torch.zeros(o.shape[:-1], dtype=torch.uint8, device=dev)
 
     def shade(base, normal):
         k = 0.55 + 0.45 * (normal * light).sum(-1).clamp(min=0.0)
         return torch.tensor(base, device=dev) * k[..., None]
 
-    for centre, radius, colour in BOLLS:
+    for b_id, (centre, radius, colour) in enumerate(BOLLS):
         c = torch.tensor(centre, device=dev)
         oc = o - c
         b = (oc * d).sum(-1)
@@ -89,6 +102,7 @@ def analytic_render(origins: torch.Tensor, directions: torch.Tensor) -> Tuple[to
         n = (oc + d * t[..., None]) / radius
         rgb = torch.where(hit[..., None], shade(colour, n), rgb)
         mask = torch.where(hit, torch.ones_like(mask), mask)
+        inst = torch.where(hit, torch.full_like(inst, b_id + 1), inst)
         best_t = torch.where(hit, t, best_t)
     radius, z0, z1, colour = STEM
     a = (d[..., :2] ** 2).sum(-1).clamp(min=1e-12)
@@ -102,8 +116,9 @@ def analytic_render(origins: torch.Tensor, directions: torch.Tensor) -> Tuple[to
     n = torch.cat([p[..., :2] / radius, torch.zeros_like(p[..., :1])], -1)
     rgb = torch.where(hit[..., None], shade(colour, n), rgb)
     mask = torch.where(hit, torch.zeros_like(mask), mask)
+    inst = torch.where(hit, torch.zeros_like(inst), inst)
     best_t = torch.where(hit, t, best_t)
-    return rgb, mask[..., None], best_t[..., None]
+    return rgb, mask[..., None], best_t[..., None], inst
 
 
 def analytic_dataset(cameras, device="cuda") -> Tuple[torch.Tensor, torch.Tensor]:

@@ -261,6 +261,66 @@ int cn_apply_pose_adjustment(const float* pose_adjustment /*[C,6]*/, const int64
                              int64_t num_rays, float* origins, float* directions, cn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Batched semantic projection (FruitModel.get_outputs_for_projections, fruit_nerf/fruit_nerf.py:254-318)
+ *
+ * The reference loops over (super-cluster, camera, sub-cluster box) jobs and, per job, generates the rays of a whole
+ * frame with the box's slab test (:283), renders the rays that hit (:299-301), renders (0, near) of the same rays for the
+ * occlusion weight (:305-310) and writes two full-frame images (:302-304, :311-315).  These entry points do the ray side
+ * of that for a BATCH of jobs: per job the caller gives the camera, the box and a screen rectangle that contains every
+ * pixel whose ray can hit the box (projected box corners; the whole frame is always a valid rectangle).  The pixels of all
+ * rectangles, job after job and row-major inside a rectangle, are the batch's "slots"; slot_offset = a job's first slot.
+ * ------------------------------------------------------------------------------------------- */
+
+/* One projection job.  DEVICE array (the kernels read it); the host fills it and copies it over. */
+typedef struct cn_projection_job {
+  float c2w[12];        /* camera-to-world, 3x4 row-major                                           */
+  float fx;             /* intrinsics of that camera                                                */
+  float fy;
+  float cx;
+  float cy;
+  float aabb[6];        /* the sub-cluster box: min xyz, max xyz                                    */
+  int32_t x0;           /* screen rectangle: first column ...                                       */
+  int32_t y0;           /* ... first row ...                                                        */
+  int32_t w;            /* ... width and ...                                                        */
+  int32_t h;            /* ... height in pixels (inside the frame; may be empty)                    */
+  int32_t camera_index; /* value written to camera_indices (the reference writes 0, :283)           */
+  int32_t reserved;
+  int64_t slot_offset;  /* sum of w*h of the jobs before this one                                   */
+} cn_projection_job;
+
+/* Step 1.  Per slot: the ray of its pixel (bit for bit cn_raygen_pinhole's) and the slab test against its job's box
+ * (cn_intersect_aabb's): flags[slot] = 1 when it hits (valid_rays_mask, :285), job_of_slot[slot], hit_count[job]
+ * (zeroed here).  Then every flag of a job with fewer than min_rays hits is cleared (:293 writes black images for
+ * such a job).  The caller lists the set flags -- its one synchronisation per batch. */
+int cn_projection_test(const cn_projection_job* jobs, int32_t num_jobs, int64_t num_slots, int32_t image_width,
+                       int32_t min_rays, uint8_t* flags /*[P]*/, int32_t* job_of_slot /*[P]*/,
+                       int32_t* hit_count /*[num_jobs]*/, cn_stream_t stream);
+
+/* Step 2.  hit_slots [N] (ascending slot numbers of the set flags) -> ONE jagged ray bundle: origins, directions [N,3],
+ * nears, fars [N] from the slab test, camera_indices [N] = the job's camera_index; optionally the job and the pixel
+ * (row * image_width + col) of every ray. */
+int cn_projection_gather(const cn_projection_job* jobs, const int32_t* job_of_slot, const int64_t* hit_slots,
+                         int64_t num_hits, int32_t image_width, float* origins, float* directions, float* nears,
+                         float* fars, int64_t* camera_indices, int32_t* ray_job /*or NULL*/,
+                         int32_t* ray_pixel /*or NULL*/, cn_stream_t stream);
+
+/* Step 3, after the two renders of the bundle.  semantics [N] = outputs['semantics'] of the box-restricted render,
+ * occlusion [N] = sum of the weights on (0, near).  Per ray, into its slot: wo_occ = semantics (:302), visible =
+ * semantics where occlusion < occlusion_threshold, else 0 (:311-313).  As floats and / or as the uint8 that
+ * torchvision.utils.save_image writes (clamp(0,1) * 255 + 0.5, truncated).  Outputs may be NULL; the caller zeroes them
+ * first (slots without a hit stay 0 = the black of the reference's images). */
+int cn_projection_scatter(const float* semantics, const float* occlusion, const int64_t* hit_slots, int64_t num_hits,
+                          float occlusion_threshold, float* wo_occ_f32, float* visible_f32, uint8_t* wo_occ_u8,
+                          uint8_t* visible_u8, cn_stream_t stream);
+
+/* Slot values -> full frames: images[image_of_job[j]] ([num_images, H, W] uint8, zeroed by the caller) receives job j's
+ * rectangle (an index outside [0, num_images): skipped).  For consumers that want whole images on the device (the merger's contour
+ * stage); the PNG writer assembles its frames on the host from the slot values instead. */
+int cn_projection_paste(const cn_projection_job* jobs, const int32_t* job_of_slot, const uint8_t* slot_values,
+                        int64_t num_slots, const int32_t* image_of_job, int32_t num_images, int32_t image_height,
+                        int32_t image_width, uint8_t* images, cn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Samplers
  * ------------------------------------------------------------------------------------------- */
 

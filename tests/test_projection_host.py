@@ -1,0 +1,134 @@
+"""CPU tier of the batched semantic projection (``cropnerf_amd/fruit_nerf/projection.py``): the host geometry that decides
+which pixels are ever turned into rays, the job table that crosses the C ABI, and the PNG writer."""
+
+import ctypes
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import rays as ORY
+
+
+def _hit_mask(c2w, intr, cam, H, W, box):
+    rb = ORY.image_rays(c2w, intr, cam, H, W)
+    rays = ORY.with_aabb_near_far(rb, torch.as_tensor(box, dtype=torch.float32).reshape(-1))
+    return (rays.nears < 1e10).reshape(H, W).numpy()
+
+
+def test_screen_rectangle_contains_every_pixel_that_hits_the_box():
+    """The rectangle is a pure optimisation: a pixel outside it must miss the box.  Checked against the oracle's ray
+    generator + slab test (the arithmetic of ``fruit_nerf.py:283-285``) on random boxes -- inside the frame, cut by its
+    border, outside it, around and behind the camera."""
+    from cropnerf_amd import synthetic
+    from cropnerf_amd.fruit_nerf.projection import box_screen_rects
+
+    H, W = 60, 80
+    c2w, intr = synthetic.orbit_cameras(5, height=H, width=W, focal=70.0)
+    rng = np.random.default_rng(0)
+    cases = 0
+    for cam in range(5):
+        boxes = []
+        for _ in range(40):
+            c = rng.uniform(-0.9, 0.9, 3)
+            half = rng.uniform(0.01, 0.25, 3)
+            boxes.append(np.stack([c - half, c + half]))
+        o = c2w[cam, :, 3].numpy()
+        boxes.append(np.stack([o - 0.05, o + 0.05]))  # the camera sits inside this one
+        boxes.append(np.stack([o + 3.0 * (o / np.linalg.norm(o)) - 0.1, o + 3.0 * (o / np.linalg.norm(o)) + 0.1]))  # behind it
+        boxes = np.stack(boxes).astype(np.float32)
+        rects = box_screen_rects(c2w[cam].numpy(), *[float(v) for v in intr[cam]], H, W, boxes)
+        assert rects.dtype == np.int32 and rects.shape == (len(boxes), 4)
+        for b, (x0, y0, w, h) in zip(boxes, rects):
+            assert 0 <= x0 and 0 <= y0 and x0 + w <= W and y0 + h <= H
+            hit = _hit_mask(c2w, intr, cam, H, W, b)
+            outside = hit.copy()
+            outside[y0:y0 + h, x0:x0 + w] = False
+            assert not outside.any(), f"camera {cam}: {outside.sum()} hitting pixels outside the rectangle {(x0, y0, w, h)}"
+            if hit.any() and x0 > 0 and y0 > 0 and x0 + w < W and y0 + h < H:  # and tight (whole box inside the frame)
+                ys, xs = np.nonzero(hit)
+                assert x0 >= xs.min() - 4 and x0 + w <= xs.max() + 5 and y0 >= ys.min() - 4 and y0 + h <= ys.max() + 5
+            cases += 1
+        # the box around the camera keeps the whole frame
+        assert tuple(rects[-2]) == (0, 0, W, H)
+    assert cases == 5 * 42
+
+
+def test_job_table_dtype_is_the_c_struct():
+    from cropnerf_amd import _lib
+    from cropnerf_amd.fruit_nerf.projection import JOB_DTYPE
+
+    assert JOB_DTYPE.itemsize == ctypes.sizeof(_lib.ProjectionJob) == 120
+    for name, _ in _lib.ProjectionJob._fields_:
+        assert JOB_DTYPE.fields[name][1] == getattr(_lib.ProjectionJob, name).offset
+
+
+def test_plan_jobs_numbers_and_deals_jobs_as_the_reference_loop_does():
+    """Jobs are numbered in the reference's loop order (super-cluster, camera, sub-cluster: ``fruit_nerf.py:267-281``) and
+    dealt round-robin over the ranks; the plan itself is camera-major."""
+    from cropnerf_amd import synthetic
+    from cropnerf_amd.fruit_nerf.projection import plan_jobs
+    from cropnerf_amd.rays import Cameras
+
+    c2w, intr = synthetic.orbit_cameras(3, height=32, width=32, focal=40.0)
+    cams = Cameras(c2w, intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], 32, 32)
+    pcd = [{"aabb": np.tile(np.array([[[-.1, -.1, -.1], [.1, .1, .1]]]), (2, 1, 1))},
+           {"aabb": np.tile(np.array([[[.2, .2, .2], [.3, .3, .3]]]), (3, 1, 1))}]
+    order = [(s, c, i) for s, k in ((0, 2), (1, 3)) for c in range(3) for i in range(k)]
+    all_keys = []
+    for rank in range(2):
+        keys, table = plan_jobs(cams, pcd, rank, 2)
+        assert len(keys) == len(table)
+        assert keys == sorted(keys, key=lambda k: (k[1], k[0], k[2]))
+        assert all(order.index(k) % 2 == rank for k in keys)
+        assert (table["camera_index"] == [k[1] for k in keys]).all()
+        all_keys += keys
+    assert sorted(all_keys) == sorted(order)
+    keys0, table0 = plan_jobs(cams, pcd, 0, 1, compat_cam0=True)
+    assert (table0["camera_index"] == 0).all() and len(keys0) == len(order)
+
+
+@pytest.mark.parametrize("rect", [(37, 20, 30, 25), (0, 0, 8, 8), (70, 50, 10, 10), (0, 0, 80, 60), (5, 5, 0, 0)])
+def test_png_writer_decodes_to_the_image_save_image_would_write(rect, tmp_path):
+    """The reference writes its projections with ``torchvision.utils.save_image`` (``fruit_nerf.py:304,315``) and the merger
+    reads them back with OpenCV: what has to agree is the decoded pixels.  The spliced stream (cached all-zero bands) is
+    decoded by PIL and compared with the per-job path's ``save_image``."""
+    from PIL import Image
+
+    from cropnerf_amd.fruit_nerf.fruit_nerf import save_image
+    from cropnerf_amd.fruit_nerf.projection import PngWriter, encode_png_gray_rect
+
+    H, W = 60, 80
+    x0, y0, w, h = rect
+    g = torch.Generator().manual_seed(1)
+    vals = torch.rand(h, w, generator=g) * 1.4 - 0.2  # beyond [0, 1] on both sides
+    frame = torch.zeros(H, W)
+    frame[y0:y0 + h, x0:x0 + w] = vals
+    crop = vals.clamp(0, 1).mul(255).add(0.5).clamp(0, 255).to(torch.uint8).numpy()
+    data = encode_png_gray_rect(crop, x0, y0, H, W)
+    im = Image.open(io.BytesIO(data))
+    assert im.mode == "RGB" and im.size == (W, H)
+    got = np.asarray(im)
+    ref_path = tmp_path / "ref.png"
+    save_image(frame[..., None].repeat(1, 1, 3), str(ref_path))
+    ref = np.asarray(Image.open(ref_path))
+    assert (got == ref).all()
+    # and through the worker pool, into a directory that does not exist yet
+    wr = PngWriter(workers=2)
+    for i in range(4):
+        wr.submit(str(tmp_path / "a" / f"cam_{i}" / "x.png"), crop, x0, y0, H, W)
+    wr.close()
+    assert wr.files == 4
+    for i in range(4):
+        assert (np.asarray(Image.open(tmp_path / "a" / f"cam_{i}" / "x.png")) == ref).all()
+
+
+def test_png_writer_reports_a_failed_file(tmp_path):
+    from cropnerf_amd.fruit_nerf.projection import PngWriter
+
+    (tmp_path / "blocker").write_text("a file where a directory should be")
+    wr = PngWriter(workers=1)
+    wr.submit(str(tmp_path / "blocker" / "x.png"), np.zeros((2, 2), np.uint8), 0, 0, 8, 8)
+    with pytest.raises(OSError):
+        wr.close()

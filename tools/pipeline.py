@@ -1,6 +1,6 @@
 """BASELINE.json configs[4] on one GPU, on the analytic plant: train -> semantic point-cloud export -> segmenter
-(super-clusters + k-means sub-clusters) -> NeRF projection of every (super-cluster, camera, sub-cluster) and the
-depth-based projection.  Reports the seconds of each stage and the fruit count (super-clusters) against the number of
+(super-clusters + k-means sub-clusters) -> NeRF projection of every (super-cluster, camera, sub-cluster) -> merger (image
+stage on the device projections, affinity graph, partition, count) and the depth-based projection.  Reports the seconds of each stage and the fruit count (super-clusters) against the number of
 bolls of the closed-form plant.
 
     python tools/pipeline.py [--iters 2000] [--res 200] [--side 800] [--views 8]
@@ -89,11 +89,39 @@ def main(a):
         cameras = Cameras(cams.camera_to_worlds[sel], cams.fx[sel], cams.fy[sel], cams.cx[sel], cams.cy[sel], cams.height, cams.width)
         metadata = {"semantics": Semantics()}
 
+    from cropnerf_amd.fruit_nerf.fruit_nerf import background_color_override_context
+
     t = clock()
-    res = model.get_outputs_for_projections(_Dataset, None, pcd_data=info, save=False)
+    with background_color_override_context(torch.zeros(3)):  # scripts/semantic_projection.py:169
+        if a.png_dir:  # the reference's file tree, written by worker threads behind the GPU
+            model.get_outputs_for_projections(_Dataset, None, pcd_data=info, output_root=a.png_dir, save=True)
+        run = model.get_outputs_for_projections(_Dataset, None, pcd_data=info, save=False, return_run=True)
     out["projection_s"] = round(clock() - t, 3)
-    out["projection_jobs"] = len(res)
-    out["projection_visible_jobs"] = int(sum(bool((v[1] > 0).any()) for v in res.values()))
+    out["projection_jobs"] = int(run.stats["jobs"])
+    out["projection_rays"] = int(run.stats["rays"])
+    out["projection_batches"] = len(run.batches)
+
+    # --- merger.py: per sub-cluster and camera the un-occluded / visible areas and the instance label under the visible part
+    # (image stage, :219-333), affinity + graph partition (:335-355, :26-74) -> fruit count.  The projections go in straight
+    # from device memory; the instance-label frames (GroundedSAM's in the reference) are the analytic plant's own.
+    from cropnerf_amd.segmentation import merger as MG
+
+    t = clock()
+    pc = _Dataset.cameras.to(model.device)
+    labels = torch.stack([synthetic.analytic_instance_labels(rb.origins, rb.directions)
+                          for rb in (pc.generate_rays(i, keep_shape=True) for i in range(len(pc)))])
+    props, visible_jobs = [], 0
+    for i_sc in range(len(info)):
+        k = np.asarray(info[i_sc]["aabb"]).shape[0]
+        wo, vis = run.images_u8(i_sc, k)
+        visible_jobs += int((vis.flatten(2) > 0).any(-1).sum())
+        props.append(MG.process_super_cluster(wo, vis, labels, binary_thresh=a.binary_threshold, frame_sampling_interval=1,
+                                              device=model.device))
+    total, node_labels = MG.count_fruit(props, a.graph_partition)
+    out["merger_s"] = round(clock() - t, 3)
+    out["projection_visible_jobs"] = visible_jobs
+    out["merged_fruit_count"] = int(total)
+    out["merger_labels"] = [[int(v) for v in l] for l in node_labels]
 
     # --- depth_based_semantic_projection.py: z-buffer splat of the density cloud (occluder) + the sub-clusters
     t = clock()
@@ -108,7 +136,7 @@ def main(a):
         n_depth += len(r)
     out["depth_projection_s"] = round(clock() - t, 3)
     out["depth_projection_jobs"] = n_depth
-    out["total_s"] = round(sum(out[k] for k in ("train_s", "export_s", "segment_s", "projection_s", "depth_projection_s")), 2)
+    out["total_s"] = round(sum(out[k] for k in ("train_s", "export_s", "segment_s", "projection_s", "merger_s", "depth_projection_s")), 2)
     print(json.dumps(out))
 
 
@@ -120,6 +148,9 @@ if __name__ == "__main__":
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--sem-thresh", type=float, default=3.0)
     ap.add_argument("--den-thresh", type=float, default=70.0)
-    ap.add_argument("--matrix-precision", choices=["fp32", "split_bf16"], default="fp32")
+    ap.add_argument("--matrix-precision", choices=["fp32", "split_bf16", "f16"], default="fp32")
+    ap.add_argument("--png-dir", default="", help="also write the projection PNG tree (the reference's artefact) there")
+    ap.add_argument("--binary-threshold", type=int, default=100)  # merger.py:375
+    ap.add_argument("--graph-partition", default="clique")  # merger.py:373
     ap.add_argument("--plant", type=int, default=0, help="first plant id (rank r of a replicated launch takes plant + r)")
     main(ap.parse_args())
