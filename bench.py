@@ -679,22 +679,59 @@ def subsystem_timings(args, params, device):
                 "frac": round(bound_t / t_, 4), "traffic": None, "bytes_per_ray": bytes_per_ray_default,
                 "field_bytes_per_ray": field_bytes_per_ray, "proposal_bytes_per_ray": prop_bytes_per_ray, "limited_by": limited_by}
 
-    # ---- ns-export pointcloud (BASELINE.json configs[3]): random training rays in 2 048-ray calls until 10 M points are kept --
-    # exporter_utils_nerfacto.py:125-183 (debug/exporter_nerfacto.py:91: 2 048 rays per call); no outlier removal in the timed part
+    # ---- ns-export pointcloud (BASELINE.json configs[3]): random training rays until 10 M points are kept ---------------------
+    # exporter_utils_nerfacto.py:125-183.  Call sizes: 2 048 rays (the reference's copy, debug/exporter_nerfacto.py:91) and
+    # 32 768 (upstream ns-export, README.md:125); no outlier removal in the timed part.  The scene keeps a few per cent of the
+    # rays (a boll fills little of a frame): the semantic head's bias is set, on a sample of the exporter's own rays, so that
+    # ~3 % of them end above the 0.9 threshold -- the compaction rejects 97 %, 10 M points take ~3.3e8 rays.
+    def keep_fraction_bias(target_frac):
+        pipe_c = FruitPipeline(FruitPipelineConfig(FruitDataManagerConfig(2048, 2048), cfg), device, cams, box, test_mode="test",
+                               params={k: v.clone() for k, v in p2.items()})
+        first = torch.zeros(1, dtype=torch.int64, device=device)
+        idx = ops_.pixel_sample(pipe_c.datamanager.export_seed, first, 32, 2048, NUM_CAMERAS, H, W)
+        o_ = pipe_c.model(pipe_c.datamanager.cameras.generate_rays(idx))
+        sem, acc = o_["semantics"][:, 0].double(), o_["accumulation"][:, 0].double()
+        lo_b, hi_b = -20.0, 20.0  # composited logit = sum w * (logit + b) = sem + b * acc: monotone in b
+        for _ in range(40):
+            mid = 0.5 * (lo_b + hi_b)
+            if float(((sem + mid * acc) > math.log(9.0)).double().mean()) > target_frac:
+                hi_b = mid
+            else:
+                lo_b = mid
+        return 0.5 * (lo_b + hi_b)
+
+    from cropnerf_amd import ops as ops_
+
+    bias = keep_fraction_bias(0.03)
+    p_c4 = {k: v.clone() for k, v in p2.items()}
+    p_c4["field.field_head_semantics.net.bias"] += bias
+
+    def export_case(rays_per_call, launch_rays, num_points):
+        pipe_x = FruitPipeline(FruitPipelineConfig(FruitDataManagerConfig(rays_per_call, rays_per_call), cfg), device, cams, box,
+                               test_mode="test", params=p_c4)
+        generate_point_cloud(pipe_x, num_points=20_000, remove_outliers=False, launch_rays=launch_rays)  # warm-up / graph capture
+        st = {}
+        t_, pcd_ = wall(lambda: generate_point_cloud(pipe_x, num_points=num_points, remove_outliers=False, launch_rays=launch_rays,
+                                                     stats=st))
+        kept_ = int(pcd_["points"].shape[0])
+        return {"seconds": round(t_, 3), "kept_points": kept_, "calls": st["calls"], "rays_per_call": rays_per_call,
+                "calls_per_launch": st["calls_per_launch"], "rays_rendered": st["rays"], "kept_fraction": round(kept_ / st["rays"], 4),
+                "rays_per_sec": st["rays"] / t_, "points_per_sec": kept_ / t_, "seconds_to_10M_points": round(t_ * 1e7 / kept_, 2),
+                "roofline": mixed_roofline(st["rays"], t_, "pixel_sample + raygen + proposal_sample_kernel + render kernel + "
+                                           "pointcloud_compact_calls per launch",
+                                           f"{st['calls_per_launch']} call(s) of {rays_per_call} rays per launch sequence"
+                                           + (" (HIP-graph replay)" if st.get("graph") else ""))}
+
+    c4 = export_case(2048, 1 << 16, 10_000_000)
+    c4["call_size_32768"] = export_case(32768, 1 << 16, 10_000_000)
+    c4["one_call_per_launch_2048"] = export_case(2048, None, 1_000_000)  # the reference's loop shape, graph-replayed (round 3)
+    c4["semantic_bias_for_3pct"] = round(bias, 4)
+    c4["workload"] = ("ns-export pointcloud --num-points 10000000 on the synthetic scene with ~3 % of the rays kept, default method (48 "
+                      "field + 352 proposal samples per ray); 2 048-ray calls (debug/exporter_nerfacto.py:91) grouped 32 per launch, "
+                      "32 768-ray calls (upstream ns-export) 2 per launch, and the one-call-per-launch loop on 1 M points beside them; "
+                      "reference: exporter_utils_nerfacto.py:125-183")
+    out["export_pointcloud_c4"] = c4
     pipe = FruitPipeline(FruitPipelineConfig(FruitDataManagerConfig(2048, 2048), cfg), device, cams, box, test_mode="test", params=p2)
-    generate_point_cloud(pipe, num_points=200_000, remove_outliers=False)  # warm-up: first-call initialisation, graph capture
-    pipe.datamanager.train_count = 0
-    t, pcd = wall(lambda: generate_point_cloud(pipe, num_points=10_000_000, remove_outliers=False))
-    calls = pipe.datamanager.train_count
-    rays = calls * 2048
-    out["export_pointcloud_c4"] = {
-        "seconds": round(t, 3), "kept_points": int(pcd["points"].shape[0]), "calls": calls, "rays_per_call": 2048,
-        "rays_per_sec": rays / t, "points_per_sec": int(pcd["points"].shape[0]) / t,
-        "roofline": mixed_roofline(rays, t, "proposal_sample_kernel + render kernel + pointcloud_compact per call (HIP-graph replay)",
-                                   "2 048-ray calls (the reference's call size): ~15 small launches each, far below the device's "
-                                   "capacity per launch; the loop is a replayed HIP graph"),
-        "workload": "ns-export pointcloud --num-points 10000000 on the synthetic scene, default method (48 field + 352 proposal "
-                    "samples per ray), reference: exporter_utils_nerfacto.py:125-183"}
     # ---- exporter.py semantic-pointcloud (dense volume export): 512-ray calls x 3 000 samples per ray -----------------------------
     # scripts/exporter.py:75-77, exporter_utils.py:93-172; the reference's full job is 3000 x 3000 rays, timed here on 512 x 512
     aabb_e = ((-1, -1, -1 + .318), (1, 1, 1 + .318))
@@ -764,11 +801,11 @@ def subsystem_timings(args, params, device):
 
     from cropnerf_amd.fruit_nerf.fruit_nerf import Semantics as _Sem
 
-    def boll_boxes(width_lo, width_hi, seed):
-        """8 bolls split in two along a random axis, as k-means with k = 2 splits a super-cluster (segmenter.py:153-181)."""
+    def boll_boxes(width_lo, width_hi, seed, count):
+        """`count` bolls split in two along a random axis, as k-means with k = 2 splits a super-cluster (segmenter.py:153-181)."""
         rng = np.random.default_rng(seed)
         boxes = []
-        for _ in range(8):
+        for _ in range(count):
             c = rng.uniform(-0.3, 0.3, 3)
             half = rng.uniform(width_lo / 2, width_hi / 2, 3)
             ax = int(rng.integers(0, 3))
@@ -785,10 +822,10 @@ def subsystem_timings(args, params, device):
         cameras = cams16
         metadata = {"semantics": _Sem()}
 
-    n_jobs = 8 * 16 * 2
-    n_sub = 2 * 16 * 2  # the per-job loop is timed on a quarter of the jobs (2 super-clusters)
+    n_sub = 2 * 16 * 2  # the per-job loop is timed on 2 super-clusters
 
     def projection_case(sc_boxes, what):
+        n_jobs = len(sc_boxes) * 16 * 2
         tmp = tempfile.mkdtemp(prefix="cn_proj_")
         try:
             with background_color_override_context(torch.zeros(3)):
@@ -806,7 +843,7 @@ def subsystem_timings(args, params, device):
             shutil.rmtree(tmp, ignore_errors=True)
         rays_run = int(run.stats["rays"])
         return {
-            "boxes": what, "rays_inside_boxes": rays_run, "rays_per_job": round(rays_run / n_jobs, 1),
+            "boxes": what, "jobs": n_jobs, "super_clusters": len(sc_boxes), "rays_inside_boxes": rays_run, "rays_per_job": round(rays_run / n_jobs, 1),
             "rectangle_pixels": int(run.stats["slots"]), "batches": len(run.batches),
             "batched": {"seconds": round(t_b, 4), "jobs_per_sec": round(n_jobs / t_b, 1), "ms_per_job": round(t_b / n_jobs * 1e3, 4),
                         "with_png_tree": {"seconds": round(t_bf, 4), "jobs_per_sec": round(n_jobs / t_bf, 1),
@@ -822,21 +859,21 @@ def subsystem_timings(args, params, device):
 
     # boll-sized boxes: a 3DCotton boll is 3-5 cm of a plant that fills the +-1 scene box (0.03-0.05 units: ~55 pixels across
     # at 800 x 800 from the 0.8 orbit); the analytic plant of tools/pipeline.py has 0.13-0.17-wide bolls (~200 pixels across)
-    small = projection_case(boll_boxes(0.03, 0.05, 5), "0.03-0.05 wide (3DCotton boll scale)")
-    large = projection_case(boll_boxes(0.13, 0.17, 6), "0.13-0.17 wide (the analytic plant's bolls)")
+    small = projection_case(boll_boxes(0.03, 0.05, 5, 32), "0.03-0.05 wide (3DCotton boll scale)")
+    large = projection_case(boll_boxes(0.13, 0.17, 6, 8), "0.13-0.17 wide (the analytic plant's bolls)")
     # fixed cost per job: boxes nobody sees (no ray hits: planning, tests and bookkeeping only)
     far = [{"aabb": np.tile(np.array([[[5.0, 5, 5], [5.1, 5.1, 5.1]]], np.float32), (2, 1, 1))} for _ in range(8)]
     with background_color_override_context(torch.zeros(3)):
         t_fb, _ = wall(lambda: m.get_outputs_for_projections(_DS, None, pcd_data=far, save=False, return_run=True))
         t_fp, _ = wall(lambda: m.get_outputs_for_projections(_DS, None, pcd_data=far[:2], save=False, batched=False))
     out["projection_run"] = {
-        "jobs": n_jobs, "super_clusters": 8, "cameras": 16, "sub_clusters": 2, "image": [H, W],
+        "cameras": 16, "sub_clusters": 2, "image": [H, W],
         **small, "analytic_plant_boxes": large,
-        "fixed_cost_ms_per_job": {"batched": round(t_fb / n_jobs * 1e3, 4), "per_job_loop": round(t_fp / n_sub * 1e3, 4),
+        "fixed_cost_ms_per_job": {"batched": round(t_fb / (8 * 16 * 2) * 1e3, 4), "per_job_loop": round(t_fp / n_sub * 1e3, 4),
                                   "note": "boxes outside every frame: no ray is rendered"},
-        "workload": "get_outputs_for_projections: 8 super-clusters x 16 cameras x 2 sub-cluster boxes at 800 x 800, both passes per "
-                    "job, batched (projection.project_all) against the per-job loop that mirrors the reference call for call (timed "
-                    "on 2 of the 8 super-clusters); with_png_tree also writes the reference's file tree (2 PNGs per job); reference: "
+        "workload": "get_outputs_for_projections: 32 (boll scale) / 8 (analytic-plant scale) super-clusters x 16 cameras x 2 "
+                    "sub-cluster boxes at 800 x 800, both passes per job, batched (projection.project_all) against the per-job loop "
+                    "that mirrors the reference call for call (timed on 2 of the super-clusters); with_png_tree also writes the reference's file tree (2 PNGs per job); reference: "
                     "fruit_nerf.py:254-318, scripts/semantic_projection.py:132-170"}
     # ---- one whole 800 x 800 eval image of the default method (fruit_nerf.py:377-404: chunks of eval_num_rays_per_chunk) ------------
     # exact fp32 on the torch-layout model above, and a model as an imported reference checkpoint is -- tcnn layout, fp16 tables --
@@ -860,6 +897,43 @@ def subsystem_timings(args, params, device):
                                    "ray is empty (a quarter of the matrix work)"),
         "workload": "get_outputs_for_camera_ray_bundle, default method ((256, 96) proposal + 48 field samples), ray generation "
                     "included; reference: fruit_nerf.py:377-404"}
+    # ---- the same at the resolution and from the poses of the reference's one real capture (fruit_nerf/utils/transforms.json:
+    # 147 frames, 1920 x 1440, f = 1442.48; camera data = tests/golden/capture_3dcotton.npz, parsed by the dataparser mirror) ---
+    cap_path = os.path.join(ROOT, "tests", "golden", "capture_3dcotton.npz")
+    if os.path.exists(cap_path):
+        from cropnerf_amd.fruit_nerf.data.cotton_nerf_dataparser import CottonNerfDataParserConfig
+
+        fxt = np.load(cap_path)
+        cap_dir = tempfile.mkdtemp(prefix="cn_capture_")
+        try:
+            synthetic.write_transforms_json(cap_dir, fxt["frame_number"], fxt["transform_matrix"], fxt["intrinsics"], fxt["size_hw"],
+                                            orientation_override="none", auto_scale_poses_override=False)
+            dpo = CottonNerfDataParserConfig(data=cap_dir, downscale_factor=1).setup().get_dataparser_outputs("train")
+        finally:
+            shutil.rmtree(cap_dir, ignore_errors=True)
+        cap_cams = dpo.cameras.to(device)
+        Hc, Wc = cap_cams.height, cap_cams.width
+        # the capture's 140 training cameras index an appearance / pose table of their own size
+        m_cap = FruitModel(cfg, dpo.scene_box, len(cap_cams), {"semantics": Semantics()}, device=device, test_mode="test")
+
+        def cap_image_ms(model):
+            model.get_outputs_for_camera_ray_bundle(cap_cams.generate_rays(0, keep_shape=True))
+            ts_ = []
+            for i in range(1, 6):
+                ti_, _ = wall(lambda: model.get_outputs_for_camera_ray_bundle(cap_cams.generate_rays(20 * i, keep_shape=True)))
+                ts_.append(ti_)
+            ts_.sort()
+            return ts_[len(ts_) // 2], ts_
+
+        tc, tsc = cap_image_ms(m_cap)
+        out["eval_image_1920x1440"] = {
+            "ms_per_image": round(tc * 1e3, 3), "spread_ms": {"min": round(tsc[0] * 1e3, 3), "max": round(tsc[-1] * 1e3, 3), "images": len(tsc)},
+            "rays_per_sec": Hc * Wc / tc, "image": [Hc, Wc], "cameras": len(cap_cams),
+            "roofline": mixed_roofline(Hc * Wc, tc, "proposal_sample_kernel + render_split_kernel per 32 768-ray chunk",
+                                       "as eval_image_800 (the sampler + a 48-sample field pass), 4.3 x the rays"),
+            "workload": "get_outputs_for_camera_ray_bundle at the resolution and from the (centred, unit-box-scaled) poses of the "
+                        "reference's real capture file, default method, random-init model; reference: fruit_nerf.py:377-404, "
+                        "fruit_nerf/utils/transforms.json"}
     cfg16 = PC.FruitNerfModelConfig(implementation="tcnn", hash_table_dtype="float16", matrix_precision="f16")
     m16 = FruitModel(cfg16, box, NUM_CAMERAS, {"semantics": Semantics()}, device=device, test_mode="test")
     t16, ts16 = image_ms(m16)

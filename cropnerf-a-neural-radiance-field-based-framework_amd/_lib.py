@@ -110,6 +110,7 @@ SIGNATURES = {
     "cn_projection_test": (C.c_int, [_P, _I32, _I64, _I32, _I32, _P, _P, _P, _P]),
     "cn_projection_gather": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cn_projection_scatter": (C.c_int, [_P, _P, _P, _I64, _F, _P, _P, _P, _P, _P]),
+    "cn_png_write_gray_rects": (C.c_int, [_I32, C.POINTER(C.c_char_p), _P, _P, _P, _I32, _I32, _I32]),
     "cn_projection_paste": (C.c_int, [_P, _P, _P, _I64, _P, _I32, _I32, _I32, _P, _P]),
     "cn_sample_spaced": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _I32, _P, _P, _P, _P, _P]),
     "cn_sample_pdf": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _F, _I32, _P, _I32, _P, _P, _P]),
@@ -134,6 +135,8 @@ SIGNATURES = {
                                            _P]),
     "cn_export_compact": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _I64, C.POINTER(_P), C.POINTER(_P), _P, _P]),
     "cn_pointcloud_compact": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
+    "cn_pixel_sample": (C.c_int, [C.c_uint64, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),
+    "cn_pointcloud_compact_calls": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "cn_embedding_mean": (C.c_int, [_P, _I32, _I32, _P, _P]),
     "cn_train_render_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F, _P, _P, _P, _P, _P, _P, _P, _P,
                                            _P]),

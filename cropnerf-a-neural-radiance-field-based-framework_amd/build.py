@@ -22,7 +22,7 @@ BUILD = HERE / "build"
 ARCH = "gfx950"
 
 SOURCES = ["api_common.cpp", "raygen.hip", "sampler.hip", "field_simple.hip", "composite.hip", "render_fused.hip",
-           "proposal.hip", "export.hip", "train_render.hip", "train_field.hip", "zbuffer.hip", "knn.hip", "cluster.hip", "tcnn_grid.hip", "contour.hip", "projection.hip"]
+           "proposal.hip", "export.hip", "train_render.hip", "train_field.hip", "zbuffer.hip", "knn.hip", "cluster.hip", "tcnn_grid.hip", "contour.hip", "projection.hip", "png_writer.cpp"]
 
 
 def _headers():
@@ -70,7 +70,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(OUT, objs):
-        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(OUT), *map(str, objs)])
+        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(OUT), *map(str, objs), "-lz"])  # zlib: png_writer.cpp
     return OUT
 
 

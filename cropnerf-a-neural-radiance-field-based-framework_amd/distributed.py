@@ -131,3 +131,76 @@ def all_reduce_mean(value: Tensor, group=None) -> Tensor:
     else:
         dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
     return v / ws
+
+
+class _Finished:
+    """Handle of an exchange that needed no communication."""
+
+    def wait(self) -> None:
+        return None
+
+
+class _Then:
+    """A collective's work handle plus what has to follow it on the host (gloo: the division, the copy back to the device)."""
+
+    def __init__(self, work, after):
+        self.work, self.after = work, after
+
+    def wait(self) -> None:
+        self.work.wait()
+        if self.after is not None:
+            self.after()
+            self.after = None
+
+
+def all_reduce_mean_(buf: Tensor, group=None, force: bool = False):
+    """IN-PLACE mean of ``buf`` over the ranks, asynchronous: returns a handle whose ``wait()`` orders the caller after the
+    result (RCCL: the collective runs on the process group's own stream behind everything enqueued on the current stream so
+    far, and ``wait()`` is a stream-side dependency -- the host never blocks; gloo: a host wait).  No clone, no separate
+    divide pass, no copy back on RCCL (``ReduceOp.AVG``); gloo has no AVG: SUM, then one in-place division -- the same
+    arithmetic as ``all_reduce_mean``.  ``force``: run the collective also in a one-rank group (tests of the call pattern)."""
+    rank, ws = world(group)
+    if not (dist.is_available() and dist.is_initialized()) or (ws == 1 and not force):
+        return _Finished()
+    if dist.get_backend(group) == "gloo":
+        if buf.is_cuda:  # rehearsal on a one-GPU box: gloo moves host memory
+            host = buf.cpu()
+            work = dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group, async_op=True)
+            return _Then(work, lambda: buf.copy_(host.div_(ws)))
+        work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        return _Then(work, lambda: buf.div_(ws))
+    return dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=group, async_op=True)
+
+
+class GroupedGradientExchange:
+    """Data-parallel gradient averaging per OPTIMISER GROUP, overlapped with the rest of the backward pass -- the reference's
+    DDP (``crop_nerf/fruit_nerf/fruit_pipeline.py:119-121``: bucketed all-reduce hooked into autograd) for a backward that is
+    a fixed sequence of kernels: the ``fields`` slice of the flat gradient buffer (67 of its 78 MB) is final when the field
+    backward has been enqueued, ~0.7 ms of proposal-backward / pose kernels before the optimiser needs it, so its all-reduce
+    is issued right there (``start``) and each group is stepped behind its own reduce (``wait``).  One in-place collective
+    per group; nothing is exchanged for a group that has no gradient this iteration."""
+
+    def __init__(self, flat_grads: Tensor, group_range: Dict[str, Tuple[int, int]], group=None, force: bool = False):
+        self.flat, self.ranges, self.group, self.force = flat_grads, dict(group_range), group, force
+        self.pending: Dict[str, object] = {}
+        self.started: List[str] = []  # order of the last iteration's collectives (every rank must agree on it)
+
+    def begin_iteration(self) -> None:
+        if self.pending:
+            raise RuntimeError(f"gradient exchange of {sorted(self.pending)} was started and never waited for")
+        self.started = []
+
+    def start(self, name: str) -> None:
+        lo, hi = self.ranges[name]
+        if hi > lo and name not in self.pending:
+            self.pending[name] = all_reduce_mean_(self.flat[lo:hi], self.group, self.force)
+            self.started.append(name)
+
+    def wait(self, name: str) -> None:
+        h = self.pending.pop(name, None)
+        if h is not None:
+            h.wait()
+
+    def wait_all(self) -> None:
+        for name in list(self.pending):
+            self.wait(name)

@@ -20,7 +20,9 @@ this package's first format (round 1; still read):
 from __future__ import annotations
 
 import json
+import os
 import pathlib
+import sys
 from dataclasses import asdict
 from typing import Dict, Optional, Tuple
 
@@ -108,7 +110,12 @@ def save_run(run_dir, model_config: FruitNerfModelConfig, cameras: Cameras, scen
 
 
 def eval_setup(load_config, eval_num_rays_per_chunk: Optional[int] = None, test_mode: str = "test",
-               device: str = "cuda") -> Tuple[RunConfig, FruitPipeline, pathlib.Path, int]:
+               device: str = "cuda", matrix_precision: Optional[str] = None
+               ) -> Tuple[RunConfig, FruitPipeline, pathlib.Path, int]:
+    """``matrix_precision`` (extension): ``None`` = automatic -- a run whose checkpoint is tcnn-packed and whose config says
+    ``mixed_precision: true`` (every reference run: ``fruit_field.py:95``, ``fruit_nerf_config.py:35``) is evaluated in the
+    arithmetic it was trained in, ``"f16"`` (fp16 weights and layer inputs, fp32 accumulation; 1.9x the exact-fp32 mode on
+    such a table); pass ``"fp32"`` (or set ``CROPNERF_MATRIX_PRECISION=fp32``) for exact fp32 on the same fp16 values."""
     from ..distributed import init_from_env
 
     rank, world_size, dist_device = init_from_env()  # under torch.distributed.run: one rank per GPU
@@ -116,7 +123,8 @@ def eval_setup(load_config, eval_num_rays_per_chunk: Optional[int] = None, test_
         device = dist_device
     load_config = pathlib.Path(load_config)
     if load_config.suffix in (".yml", ".yaml"):
-        return _eval_setup_nerfstudio(load_config, eval_num_rays_per_chunk, test_mode, device, rank, world_size)
+        return _eval_setup_nerfstudio(load_config, eval_num_rays_per_chunk, test_mode, device, rank, world_size,
+                                      matrix_precision)
     raw = json.loads(load_config.read_text())
     cfg = RunConfig(load_config, raw)
     m = dict(raw["model"])
@@ -124,6 +132,8 @@ def eval_setup(load_config, eval_num_rays_per_chunk: Optional[int] = None, test_
     if isinstance(m.get("background_color"), list):
         m["background_color"] = tuple(m["background_color"])
     model_cfg = FruitNerfModelConfig(**m)
+    if matrix_precision or os.environ.get("CROPNERF_MATRIX_PRECISION"):
+        model_cfg.matrix_precision = matrix_precision or os.environ["CROPNERF_MATRIX_PRECISION"]
     if eval_num_rays_per_chunk is not None:
         model_cfg.eval_num_rays_per_chunk = eval_num_rays_per_chunk
         cfg.eval_num_rays_per_chunk = eval_num_rays_per_chunk
@@ -139,7 +149,8 @@ def eval_setup(load_config, eval_num_rays_per_chunk: Optional[int] = None, test_
     return cfg, pipe, ckpts[-1], int(state["step"])
 
 
-def _eval_setup_nerfstudio(load_config: pathlib.Path, eval_num_rays_per_chunk, test_mode, device, rank, world_size):
+def _eval_setup_nerfstudio(load_config: pathlib.Path, eval_num_rays_per_chunk, test_mode, device, rank, world_size,
+                           matrix_precision: Optional[str] = None):
     """``eval_setup`` on a nerfstudio run directory (config.yml + step-*.ckpt)."""
     from . import nerfstudio_io as NIO
     from .tcnn_params import from_tcnn_state_dict, is_tcnn_state_dict
@@ -182,6 +193,13 @@ def _eval_setup_nerfstudio(load_config: pathlib.Path, eval_num_rays_per_chunk, t
         model_cfg.implementation, model_cfg.hash_table_dtype = "tcnn", "float16"
         params = from_tcnn_state_dict(state, model_cfg.field_spec(num_images), model_cfg.proposal_specs(), device,
                                       torch.float16)
+        # ... and in the arithmetic tcnn runs under mixed precision, unless the caller / the run's own config says otherwise
+        explicit = matrix_precision or os.environ.get("CROPNERF_MATRIX_PRECISION")
+        if not explicit and "matrix_precision" not in tree["pipeline"]["model"] and bool(tree.get("mixed_precision", False)):
+            model_cfg.matrix_precision = "f16"
+            print(f"[cropnerf_amd] {load_config}: tcnn-packed checkpoint of a mixed-precision run -> matrix_precision='f16' "
+                  "(tiny-cuda-nn's own arithmetic class); eval_setup(..., matrix_precision='fp32') or "
+                  "CROPNERF_MATRIX_PRECISION=fp32 selects exact fp32", file=sys.stderr)
     else:
         model_cfg.implementation = "torch"
         from ..config import param_shapes
@@ -193,6 +211,8 @@ def _eval_setup_nerfstudio(load_config: pathlib.Path, eval_num_rays_per_chunk, t
         missing = sorted(set(want) - set(params))
         if missing:
             raise KeyError(f"{ckpt}: parameters missing from the checkpoint: {missing[:4]}{' ...' if len(missing) > 4 else ''}")
+    if matrix_precision or os.environ.get("CROPNERF_MATRIX_PRECISION"):
+        model_cfg.matrix_precision = matrix_precision or os.environ["CROPNERF_MATRIX_PRECISION"]
     pipe = FruitPipeline(FruitPipelineConfig(FruitDataManagerConfig(), model_cfg), device=device, cameras=cams,
                          scene_box=scene_box, test_mode=test_mode, params=params, world_size=world_size,
                          local_rank=rank, semantics=semantics)

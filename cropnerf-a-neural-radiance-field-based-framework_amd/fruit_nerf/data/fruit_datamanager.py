@@ -129,6 +129,11 @@ class FruitDataManager:
                            torch.randint(0, w, (num_rays,), device=dev, generator=g)], dim=-1)
         return self.cameras.generate_rays(idx), {"indices": idx}
 
+    @property
+    def export_seed(self) -> int:
+        """Seed of the point-cloud exporter's counter-based pixel stream (``cn_pixel_sample``), one stream per rank."""
+        return self._seed
+
     def next_eval(self, step: int) -> Tuple[RayBundle, Dict]:
         self.eval_count += 1
         return self._sample(self.config.eval_num_rays_per_batch)

@@ -2,7 +2,8 @@
 (``crop_nerf/fruit_nerf/export/exporter_utils_nerfacto.py:83-227``): random train rays -> model forward ->
 ``point = o + d * depth`` kept where ``semantics_colormap[:, 0] > 0`` (``:156-166``) and inside the optional oriented
 box (``:168-174``, folded into the same mask) -> accumulate
-until ``num_points``.  Mask, point computation and compaction run in ``cn_pointcloud_compact``; kept points leave the
+until ``num_points``.  Pixel draws (``cn_pixel_sample``), mask, point computation and compaction
+(``cn_pointcloud_compact_calls``) run on the device, several of the reference's calls per launch; kept points leave the
 device once.  The statistical outlier removal (``:194-199``, open3d ``remove_statistical_outlier(nb_neighbors=20,
 std_ratio)``, on by default) runs on the device too (``ops.statistical_outlier_mask``: uniform-grid k-nearest search,
 ``cn_knn_mean_distance``).  Normal estimation / re-orientation (``:200-225``) stays open3d CPU post-processing and is
@@ -19,11 +20,22 @@ import torch
 from ... import ops
 
 
+DEFAULT_LAUNCH_RAYS = 1 << 16  # one C2-sized batch per launch sequence
+
+
 def generate_point_cloud(pipeline, num_points: int = 1000000, remove_outliers: bool = True,
                          estimate_normals: bool = False, reorient_normals: bool = False, rgb_output_name: str = "rgb",
                          depth_output_name: str = "depth", normal_output_name: Optional[str] = None, crop_obb=None,
                          std_ratio: float = 10.0, only_semantics: bool = True, max_batches: Optional[int] = None,
-                         use_graph: bool = True) -> Dict[str, np.ndarray]:
+                         use_graph: bool = True, launch_rays: Optional[int] = DEFAULT_LAUNCH_RAYS,
+                         stats: Optional[dict] = None) -> Dict[str, np.ndarray]:
+    """``launch_rays`` (extension): the reference's call size (``train_num_rays_per_batch``: 2 048 in its own exporter, 32 768
+    upstream) bounds ITS memory and fixes its stopping rule -- the cloud is every kept point of calls 0 .. c*, c* = the first
+    call at which the count reaches ``num_points``.  Here K = ``launch_rays // rays_per_call`` calls' pixel draws go through ONE
+    sampler + render + compaction launch sequence; the draws come from a counter-based stream (``cn_pixel_sample``) and the
+    append stops at the same call boundary (``cn_pointcloud_compact_calls``), so the cloud does not depend on K (tested).
+    ``launch_rays=None`` (or below the call size): one call per launch, as the reference loops.  ``stats``: filled with the
+    calls / rays rendered."""
     model, dm = pipeline.model, pipeline.datamanager
     # several ranks (one per GPU): every rank collects its share of the target from its own random rays; the shares are
     # concatenated with one variable-length all-gather (counts, then padded rows) before the outlier pass
@@ -32,17 +44,24 @@ def generate_point_cloud(pipeline, num_points: int = 1000000, remove_outliers: b
     rank, world_size = _world()
     if world_size > 1:
         num_points = -(-num_points // world_size)
-    # The reference reads the kept-point count back after every 2048-ray call (``while num_points < total``).  Here up to
-    # ``lookahead`` calls are enqueued before one read-back of their running counts; the cloud is then cut at the count of
-    # the first call that reached ``num_points``, so the result is exactly the reference's (calls append in order), without
-    # a host round trip per call.
-    lookahead = 16
-    rays_per_call = dm.config.train_num_rays_per_batch
-    cap = int(num_points + (lookahead + 4) * rays_per_call)
+    rays_per_call = int(dm.config.train_num_rays_per_batch)
+    K = max(1, int(launch_rays) // rays_per_call) if launch_rays else 1
+    if max_batches is not None:
+        K = max(1, min(K, int(max_batches)))
+    # The reference reads the kept-point count back after every call (``while num_points < total``).  Here up to ``lookahead``
+    # launches are enqueued before one read-back of the running count; a launch issued after the target was reached appends
+    # nothing (its ray limit is 0), so the result is exactly the reference's, without a host round trip per call.
+    lookahead = max(1, 16 // K) if K > 1 else 16
+    cap = int(num_points + rays_per_call + 64)
+    cams = dm.cameras
+    n_cam, H, W = len(cams), int(cams.height), int(cams.width)
+    dev = model.device
+    call_no = torch.zeros(1, dtype=torch.int64, device=dev)  # first call of the next launch (device: a graph advances it)
     state = {"buffers": None}
 
-    def one_call(next_rays):
-        ray_bundle, _ = next_rays(0)
+    def one_launch():
+        idx = ops.pixel_sample(dm.export_seed, call_no, K, rays_per_call, n_cam, H, W)
+        ray_bundle = cams.generate_rays(idx)  # data/fruit_datamanager.py:188-197 -> train_ray_generator(ray_indices)
         outputs = model(ray_bundle)
         for name in (rgb_output_name, depth_output_name):
             if name not in outputs:  # :133-142
@@ -52,59 +71,55 @@ def generate_point_cloud(pipeline, num_points: int = 1000000, remove_outliers: b
         if crop_obb is not None:  # :168-174: cropped points do not count towards num_points
             inside = crop_obb.within(ray_bundle.origins + ray_bundle.directions * outputs[depth_output_name])
             cmap = cmap * inside[:, None].to(cmap.dtype)
-        state["buffers"] = ops.pointcloud_compact(ray_bundle.origins, ray_bundle.directions, outputs[depth_output_name],
-                                                  outputs[rgb_output_name], cmap.contiguous(), cap, state["buffers"])
+        state["buffers"] = ops.pointcloud_compact_calls(ray_bundle.origins, ray_bundle.directions, outputs[depth_output_name],
+                                                        outputs[rgb_output_name], cmap.contiguous(), rays_per_call, num_points,
+                                                        cap, state["buffers"])
+        call_no.add_(K)
 
     kept = 0
-    batches = 0
+    launches = 0
     with torch.no_grad():
-        history = torch.zeros(lookahead, dtype=torch.int64, device=model.device)
-        # One call is ~15 small launches for 2048 rays: the loop is bound by the host.  After three eager calls (they
-        # count, and they run every first-call initialisation) the call is captured into a HIP graph -- pixel indices from
-        # the device generator, every intermediate in the graph's memory pool -- and replayed.
+        # A 2 048-ray call is ~15 small launches: that loop is bound by the host.  After three eager launches (they count, and
+        # they run every first-call initialisation) the launch sequence is captured into a HIP graph -- the call counter is
+        # device memory, every intermediate lives in the graph's memory pool -- and replayed.
         graph = None
         replay = None
         if use_graph and max_batches is None:
             for j in range(3):
-                one_call(dm.next_train_device)
-                history[j].copy_(state["buffers"][3].reshape(()))
-            batches = 3
-            try:
-                graph = torch.cuda.CUDAGraph()
-                graph.register_generator_state(dm.device_generator)  # the pixel sampler's own (per-rank) random stream
-                with torch.cuda.graph(graph):
-                    one_call(dm.next_train_device)
-                replay = graph.replay
-                dm.train_count -= 1  # the capture pass enqueued nothing
-            except Exception as e:  # capture is an optimisation: fall back to eager launches, loudly
-                print(f"[generate_point_cloud] HIP graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-                graph, replay = None, None
-                torch.cuda.synchronize()
-            counts = history[:3].tolist()
-            kept = next((c for c in counts if c >= num_points), counts[-1])
+                one_launch()
+            launches = 3
+            kept = int(state["buffers"][3].item())
+            if kept < num_points:
+                try:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):  # records, runs nothing: counters and buffers keep their values
+                        one_launch()
+                    replay = graph.replay
+                except Exception as e:  # capture is an optimisation: fall back to eager launches, loudly
+                    print(f"[generate_point_cloud] HIP graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+                    graph, replay = None, None
+                    torch.cuda.synchronize()
         done = kept >= num_points
         while not done:
-            group = lookahead if max_batches is None else min(lookahead, max_batches - batches)
+            group = lookahead
+            if max_batches is not None:
+                group = min(lookahead, -(-(max_batches - launches * K) // K))
             for j in range(group):
                 if replay is not None:
                     replay()
-                    dm.train_count += 1
                 else:
-                    one_call(dm.next_train)
-                history[j].copy_(state["buffers"][3].reshape(()))
-            counts = history[:group].tolist()  # the one synchronisation per group
-            batches += group
-            kept = counts[-1]
-            for c in counts:
-                if c >= num_points:
-                    kept, done = c, True
-                    break
-            if max_batches is not None and batches >= max_batches:
-                done = True
+                    one_launch()
+            launches += group
+            kept = int(state["buffers"][3].item())  # the one synchronisation per group
+            done = kept >= num_points or (max_batches is not None and launches * K >= max_batches)
+    dm.train_count += launches * K
     buffers = state["buffers"]
-    pts, cols, dirs, count = buffers
+    pts, cols, dirs = buffers[0], buffers[1], buffers[2]
     n = min(kept, cap)
     pts, cols, dirs = pts[:n], cols[:n], dirs[:n]
+    if stats is not None:
+        stats.update(calls=launches * K, rays=launches * K * rays_per_call, launches=launches, calls_per_launch=K,
+                     rays_per_call=rays_per_call, graph=replay is not None, kept=n)
     if world_size > 1:
         rows = all_gather_points(torch.cat([pts, cols, dirs], dim=-1).contiguous())
         pts, cols, dirs = rows[:, 0:3].contiguous(), rows[:, 3:6].contiguous(), rows[:, 6:9].contiguous()

@@ -203,10 +203,17 @@ class FruitModel:
             return L.BG_COLOR, _BACKGROUND_COLOR_OVERRIDE
         bg = self.config.background_color
         if isinstance(bg, str):
-            if bg != "last_sample":
-                raise NotImplementedError(f"background_color={bg!r} (eval path supports 'last_sample' or an RGB triple)")
-            return L.BG_LAST_SAMPLE, (0.0, 0.0, 0.0)
-        return L.BG_COLOR, tuple(bg)
+            if bg == "last_sample":
+                return L.BG_LAST_SAMPLE, (0.0, 0.0, 0.0)
+            # NerfactoModelConfig.background_color (inherited at fruit_nerf.py:60) also admits the named colours of
+            # nerfstudio's RGBRenderer.  "random": combine_rgb returns the composited colour WITHOUT blending a background,
+            # "as if the background color was black" -- and the reference's get_loss_dict (:601-615) does not blend the target
+            # either, so for this model it IS black, in training and in eval.
+            named = {"black": (0.0, 0.0, 0.0), "white": (1.0, 1.0, 1.0), "random": (0.0, 0.0, 0.0)}
+            if bg not in named:
+                raise ValueError(f"background_color={bg!r}: 'last_sample', 'black', 'white', 'random' or an RGB triple")
+            return L.BG_COLOR, named[bg]
+        return L.BG_COLOR, tuple(float(c) for c in bg)
 
     def _app_mode(self) -> int:
         if self.test_mode in ("inference", "export"):
@@ -237,8 +244,9 @@ class FruitModel:
 
     def _matrix_precision(self) -> int:
         mode = getattr(self.config, "matrix_precision", "fp32")
+        mode = {"fp16": "f16", "bf16": "split_bf16"}.get(mode, mode)  # the spellings a user of 'fp32' tries first
         if mode not in ("fp32", "split_bf16", "f16"):
-            raise ValueError(f"matrix_precision {mode!r}: 'fp32', 'split_bf16' or 'f16'")
+            raise ValueError(f"matrix_precision {mode!r}: 'fp32', 'split_bf16' or 'f16' (alias 'fp16')")
         if self.training or mode == "fp32":
             return L.MATRIX_FP32
         return L.MATRIX_SPLIT_BF16 if mode == "split_bf16" else L.MATRIX_F16

@@ -48,8 +48,8 @@ def box_screen_rects(c2w: np.ndarray, fx: float, fy: float, cx: float, cy: float
     """[J,2,3] boxes seen by one pinhole camera (``c2w`` 3x4, OpenGL frame: -z forward, +y up, pixel centres at +0.5 as
     ``Cameras.generate_rays`` has them) -> [J,4] int32 (x0, y0, w, h): a rectangle, clipped to the frame, that contains every
     pixel whose centre ray can hit the box -- the bounding box of the 8 projected corners, ``margin`` pixels wider on every
-    side (the rays are float32, this is float64).  A box with a corner at or behind the camera plane gets the whole frame;
-    a box that projects outside the frame gets an empty rectangle (w = h = 0 never happens partially: both are 0)."""
+    side (the rays are float32, this is float64).  A box that straddles the camera plane gets the whole frame; a box that
+    projects outside the frame, or lies wholly behind the camera, gets an empty rectangle (w and h are 0 together)."""
     aabbs = np.asarray(aabbs, dtype=np.float64).reshape(-1, 2, 3)
     J = aabbs.shape[0]
     m = np.asarray(c2w, dtype=np.float64).reshape(3, 4)
@@ -78,6 +78,8 @@ def box_screen_rects(c2w: np.ndarray, fx: float, fy: float, cx: float, cy: float
     rects[:, 0], rects[:, 1] = np.where(empty, 0, x0), np.where(empty, 0, y0)
     rects[:, 2], rects[:, 3] = np.where(empty, 0, w), np.where(empty, 0, h)
     rects[~front] = (0, 0, width, height)
+    # every corner behind the camera plane: the (convex) box is behind it, t > 0 never reaches it -- no pixel can hit
+    rects[(depth < -1e-6 * scale).all(axis=1)] = (0, 0, 0, 0)
     return rects
 
 
@@ -96,11 +98,16 @@ def _deflate_piece(data, level: int = 1) -> bytes:
 
 
 def _zero_band(row_bytes: int, rows: int) -> bytes:
-    key = (row_bytes, rows)
-    piece = _zero_bands.get(key)
-    if piece is None:
-        piece = _zero_bands[key] = _deflate_piece(bytes(row_bytes * rows))
-    return piece
+    """``rows`` all-zero rows as cached pieces of 2^k rows, largest first (log2(height) distinct pieces per row length)."""
+    out = []
+    for k in range(30, -1, -1):
+        n = 1 << k
+        if rows & n:
+            piece = _zero_bands.get((row_bytes, n))
+            if piece is None:
+                piece = _zero_bands[(row_bytes, n)] = _deflate_piece(bytes(row_bytes * n))
+            out.append(piece)
+    return b"".join(out)
 
 
 def _adler32_zeros(adler: int, n: int) -> int:
@@ -116,9 +123,11 @@ def encode_png_gray_rect(crop: np.ndarray, x0: int, y0: int, height: int, width:
     """An 8-bit RGB PNG of a ``height`` x ``width`` frame that is black except for the gray rectangle ``crop`` [h,w] uint8 at
     (x0, y0), all three channels equal -- the file ``torchvision.utils.save_image`` writes for such an image
     (``fruit_nerf.py:304,315``) up to the compressed byte stream, which decodes to the same pixels.  The rows above and
-    below the rectangle are all zero: their deflate streams are cached per (row length, row count) and spliced in (pieces end
-    with a full flush), so a file costs the rectangle's rows, not the frame's (0.6 ms instead of 9 ms at 800 x 800)."""
+    below the rectangle are all zero: their deflate streams are assembled from cached pieces of 2^k rows and spliced in (pieces
+    end with a full flush), so a file costs the rectangle's rows, not the frame's (0.6 ms instead of 9 ms at 800 x 800)."""
     h, w = (int(crop.shape[0]), int(crop.shape[1])) if crop.size else (0, 0)
+    if h == 0:
+        x0 = y0 = 0  # an empty rectangle: one band of `height` zero rows
     row_bytes = 1 + 3 * width  # filter type 0 + RGB
     below = height - y0 - h
     mid = np.zeros((h, row_bytes), np.uint8)
@@ -149,36 +158,47 @@ def _worker_count() -> int:
 
 
 class PngWriter:
-    """Worker threads that turn rectangle crops into the reference's PNG files (zlib and file I/O release the GIL).  ``submit``
-    never blocks on the GPU: it is handed host arrays.  ``close`` waits for every file and re-raises the first failure."""
+    """Worker threads that turn rectangle crops into the reference's PNG files through ``cn_png_write_gray_rects`` (native:
+    the GIL is released for the whole call, so the threads really run side by side; the Python encoder above is the readable
+    statement of the same stream and the test's cross-check).  ``submit_rects`` never blocks on the GPU: it is handed host
+    arrays.  ``close`` waits for every file and re-raises the first failure."""
+
+    FILES_PER_TASK = 32
 
     def __init__(self, workers: Optional[int] = None):
         self.pool = ThreadPoolExecutor(max_workers=workers or _worker_count(), thread_name_prefix="cn-png")
         self.futures: List = []
         self.files = 0
-        self._dirs = set()
-        self._lock = threading.Lock()
+        self._lib = L.load()
 
-    def _mkdir(self, d: str) -> None:
-        if d in self._dirs:
-            return
-        with self._lock:  # the directory exists before any thread sees it in the set
-            os.makedirs(d, exist_ok=True)
-            self._dirs.add(d)
-
-    def _write(self, path: str, crop: np.ndarray, x0: int, y0: int, height: int, width: int) -> None:
-        data = encode_png_gray_rect(crop, x0, y0, height, width)
-        self._mkdir(os.path.dirname(path))
-        with open(path, "wb") as f:
-            f.write(data)
+    def _write(self, paths: List[str], values: np.ndarray, offsets: np.ndarray, rects: np.ndarray, height: int, width: int) -> None:
+        n = len(paths)
+        arr = (C.c_char_p * n)(*[os.fsencode(p) for p in paths])
+        offsets = np.ascontiguousarray(offsets, np.int64)
+        rects = np.ascontiguousarray(rects, np.int32)
+        L.check(self._lib.cn_png_write_gray_rects(n, arr, C.c_void_p(values.ctypes.data), C.c_void_p(offsets.ctypes.data),
+                                                  C.c_void_p(rects.ctypes.data), height, width, 1))
 
     def _copy(self, src: str, dst_dir: str) -> None:
-        self._mkdir(dst_dir)
+        os.makedirs(dst_dir, exist_ok=True)
         shutil.copy(src, dst_dir)
 
+    def submit_rects(self, paths: Sequence[str], values: np.ndarray, offsets: np.ndarray, rects: np.ndarray, height: int,
+                     width: int) -> None:
+        """One file per path: the frame that is black but for ``rects[i]`` = (x0, y0, w, h), filled row-major from the uint8
+        array ``values`` starting at ``offsets[i]`` (``values`` must stay alive and unchanged until ``close``)."""
+        if values.dtype != np.uint8 or not values.flags["C_CONTIGUOUS"]:
+            raise TypeError("values: a contiguous uint8 array")
+        for lo in range(0, len(paths), self.FILES_PER_TASK):
+            hi = lo + self.FILES_PER_TASK
+            self.futures.append(self.pool.submit(self._write, list(paths[lo:hi]), values, offsets[lo:hi], rects[lo:hi],
+                                                 height, width))
+        self.files += len(paths)
+
     def submit(self, path: str, crop: np.ndarray, x0: int, y0: int, height: int, width: int) -> None:
-        self.futures.append(self.pool.submit(self._write, path, crop, x0, y0, height, width))
-        self.files += 1
+        crop = np.ascontiguousarray(crop, np.uint8)
+        h, w = (crop.shape if crop.size else (0, 0))
+        self.submit_rects([path], crop.reshape(-1), np.zeros(1, np.int64), np.array([[x0, y0, w, h]], np.int32), height, width)
 
     def submit_copy(self, src: str, dst_dir: str) -> None:
         self.futures.append(self.pool.submit(self._copy, src, dst_dir))
@@ -369,14 +389,14 @@ class _PngStage:
         self.pending = keep
 
     def _emit(self, batch: ProjectionBatch, host: Optional[np.ndarray]) -> None:
-        for j, (i_sc, cam, i) in enumerate(batch.keys):
-            t = batch.table[j]
-            x0, y0, w, h, off = int(t["x0"]), int(t["y0"]), int(t["w"]), int(t["h"]), int(t["slot_offset"])
-            cam_dir = os.path.join(self.root, f"super_cluster_{i_sc}", f"cam_{cam}")
-            for kind, name in ((0, "wo_occ_cluster"), (1, "visible_cluster")):
-                crop = (host[kind, off:off + w * h].reshape(h, w) if host is not None and w and h
-                        else np.zeros((0, 0), np.uint8))
-                self.writer.submit(os.path.join(cam_dir, f"{name}_{i}.png"), crop, x0, y0, self.H, self.W)
+        t = batch.table
+        rects = np.stack([t["x0"], t["y0"], t["w"], t["h"]], axis=1).astype(np.int32)
+        offsets = t["slot_offset"].astype(np.int64)
+        dirs = [os.path.join(self.root, f"super_cluster_{i_sc}", f"cam_{cam}") for i_sc, cam, _ in batch.keys]
+        empty = np.zeros(0, np.uint8)
+        for kind, name in ((0, "wo_occ_cluster"), (1, "visible_cluster")):
+            paths = [os.path.join(d, f"{name}_{i}.png") for d, (_, _, i) in zip(dirs, batch.keys)]
+            self.writer.submit_rects(paths, host[kind] if host is not None else empty, offsets, rects, self.H, self.W)
 
 
 def project_all(model, cameras: Cameras, pcd_data, output_root: Optional[str] = None, segmentation_files: Sequence[str] = (),

@@ -66,6 +66,11 @@ def groups_from_spec(optimizers) -> Dict[str, "OptimGroup"]:
 class FruitTrainer:
     def __init__(self, model: FruitModel, groups: Optional[Dict[str, OptimGroup]] = None, seed: int = 0):
         self.model = model
+        if model.config.background_color != "last_sample":
+            # cn_train_render_backward is RGBRenderer("last_sample") -- the nerfacto default every reference config keeps
+            # (fruit_nerf_config.py never sets background_color); the eval renders take any named colour or triple
+            raise NotImplementedError(f"training with background_color={model.config.background_color!r}: the training kernels "
+                                      "implement 'last_sample' (the reference's setting); other backgrounds are eval-only")
         # fruit_nerf_method_big / _huge field shapes train through the shape-generic kernels (cn_field_eval +
         # cn_field_backward_general)
         self.general = not model._fused_shape
@@ -80,6 +85,8 @@ class FruitTrainer:
         self.groups = groups or {"proposal_networks": OptimGroup(), "fields": OptimGroup(),
                                  "camera_opt": OptimGroup(1e-3, 1e-15, 1e-4, 5000)}
         self._general_ws = None
+        self._exchange = None
+        self.force_exchange = False  # run the data-parallel exchange also in a one-rank process group (tests)
         dev = model.device
         # a group that is not listed is frozen (its gradients are still computed for "fields"/"proposal_networks")
         self.train_pose = "camera_opt" in self.groups
@@ -161,10 +168,15 @@ class FruitTrainer:
         return self._steps_since_update > sched or step < 10
 
     def forward_backward(self, ray_bundle: RayBundle, batch: Dict[str, Tensor],
-                         jitter: Optional[List[Tensor]] = None, update_proposals: bool = True) -> Dict[str, Tensor]:
+                         jitter: Optional[List[Tensor]] = None, update_proposals: bool = True,
+                         on_group_ready=None) -> Dict[str, Tensor]:
         """One training forward + backward; gradients are ACCUMULATED into ``self.grads``.  ``jitter`` = the three
         [R,1] uniform randoms of the proposal sampler (drawn here when None).  ``update_proposals`` False = the
-        reference's ``no_grad`` proposal evaluation (interlevel loss reported, no proposal gradients)."""
+        reference's ``no_grad`` proposal evaluation (interlevel loss reported, no proposal gradients).
+        ``on_group_ready(name)`` is called as soon as every kernel that writes the gradients of an optimiser group has been
+        enqueued (``fields`` after the field backward, ``proposal_networks`` after both proposal passes, ``camera_opt`` at the
+        end): the data-parallel exchange of that group starts there, under the kernels that follow."""
+        ready = on_group_ready or (lambda name: None)
         m, cfg = self.model, self.model.config
         dev = m.device
         rb = ray_bundle.flatten().to(dev)._map(lambda t: t.contiguous())
@@ -280,14 +292,21 @@ class FruitTrainer:
                 if self.train_pose:
                     d_o += acc[0]
                     d_d += acc[1]
+            ready("fields")
+            if update_proposals:
+                ready("proposal_networks")
         else:
             field_pass(d_o if self.train_pose else None, d_d if self.train_pose else None)
+            ready("fields")
             for lvl in range(len(levels)):
                 proposal_pass(lvl, d_o if self.train_pose else None, d_d if self.train_pose else None)
+            if update_proposals:
+                ready("proposal_networks")
         if self.train_pose:
             gp = self.grads["camera_optimizer.pose_adjustment"]
             ops.pose_adjustment_backward(pose, cam, d_raw, d_o, d_d, gp)
             ops.pose_regularizer(pose, gp, self.loss_sums[3:4], self.trans_l2_penalty, self.rot_l2_penalty)
+            ready("camera_opt")
         self._last_bins, self._last_weights = bins, rb_out["weights"]
         sums = self.loss_sums
         loss_dict = {"rgb_loss": sums[0] / (3.0 * R), "semantics_loss": cfg.semantic_loss_weight * sums[1] / R,
@@ -298,15 +317,27 @@ class FruitTrainer:
                 "accumulation": rb_out["accumulation"]}
 
     def all_reduce_gradients(self, group=None) -> None:
-        """Data-parallel step: average the gradients of all ranks (each rank trained on its own ray batch)."""
-        from ..distributed import all_reduce_mean
+        """Data-parallel step, blocking form: average the whole flat gradient buffer over the ranks in place (each rank
+        trained on its own ray batch).  ``train_iteration`` uses the overlapped per-group form (``gradient_exchange``)."""
+        from ..distributed import all_reduce_mean_
 
-        self.flat_grads.copy_(all_reduce_mean(self.flat_grads, group))
+        all_reduce_mean_(self.flat_grads, group).wait()
 
-    def optimizer_step(self, proposals_updated: bool = True) -> None:
+    def gradient_exchange(self, group=None, force: bool = False):
+        """The per-group, overlapped exchange over this trainer's flat gradient buffer (created on first use)."""
+        from ..distributed import GroupedGradientExchange
+
+        if self._exchange is None or self._exchange.group is not group or self._exchange.force != force:
+            self._exchange = GroupedGradientExchange(self.flat_grads, self.group_range, group, force)
+        return self._exchange
+
+    def optimizer_step(self, proposals_updated: bool = True, exchange=None) -> None:
         """One optimiser step of every group that has a gradient.  ``proposals_updated`` False: the proposal networks
-        were evaluated without gradient this iteration (``grad is None`` in the reference): their group is not stepped."""
+        were evaluated without gradient this iteration (``grad is None`` in the reference): their group is not stepped.
+        ``exchange``: a ``GroupedGradientExchange`` with collectives in flight -- every group is stepped behind its own."""
         self.step += 1
+        if self.tcnn and exchange is not None:
+            exchange.wait_all()  # the alias folds below read whole tables of several groups
         if self.tcnn:
             for spec, key in self._tcnn_tables:
                 ops.tcnn_grid_tie_gradients(spec, self.grads[key])
@@ -318,10 +349,14 @@ class FruitTrainer:
                 continue
             grp = self.groups[g]
             self.group_steps[g] += 1
+            if exchange is not None:
+                exchange.wait(g)
             step_fn = {"adam": ops.adam_step, "radam": ops.radam_step}[grp.optimizer]
             step_fn(self.flat_params[lo:hi], self.flat_grads[lo:hi], self.flat_exp_avg[lo:hi],
                     self.flat_exp_avg_sq[lo:hi], self.group_steps[g], grp.lr_at(self.step - 1), eps=grp.eps,
                     zero_grad=True)
+        if exchange is not None:
+            exchange.wait_all()  # a group that was exchanged but is frozen here
         if self.tcnn:
             for spec, key in self._tcnn_tables:
                 ops.tcnn_grid_tie_parameters(spec, self.model.params[key])
@@ -351,14 +386,24 @@ class FruitTrainer:
         self.set_anneal(self.step)
         it = self.step
         updated = self.proposal_update_due(self._sampler_step)
-        out = self.forward_backward(ray_bundle, batch, update_proposals=updated)
-        if updated:
-            self._steps_since_update = 0
         import torch.distributed as dist
 
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            self.all_reduce_gradients()
-        self.optimizer_step(proposals_updated=updated)
+        exchange = None
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_exchange):
+            # data-parallel training: each group's gradients are averaged under the kernels that follow their last writer
+            # (CN_DP_EXCHANGE=blocking: one all-reduce of the whole buffer after the backward, the round-3 form, for A/B runs)
+            if os.environ.get("CN_DP_EXCHANGE", "overlap") == "blocking":
+                out = self.forward_backward(ray_bundle, batch, update_proposals=updated)
+                self.all_reduce_gradients()
+            else:
+                exchange = self.gradient_exchange(force=self.force_exchange)
+                exchange.begin_iteration()
+                out = self.forward_backward(ray_bundle, batch, update_proposals=updated, on_group_ready=exchange.start)
+        else:
+            out = self.forward_backward(ray_bundle, batch, update_proposals=updated)
+        if updated:
+            self._steps_since_update = 0
+        self.optimizer_step(proposals_updated=updated, exchange=exchange)
         self._sampler_step = it  # step_cb, an AFTER_TRAIN_ITERATION callback
         self._steps_since_update += 1
         out["metrics_dict"] = self.get_metrics_dict(out)

@@ -140,6 +140,19 @@ def _attach_scatter_scratch(grid: L.Grid, device, max_samples: Optional[int] = N
     return buf
 
 
+def _scratch_too_small(handle, max_samples: Optional[int]) -> bool:
+    """Whether a gradient handle's scatter scratch has to be (re-)allocated for backward calls of up to ``max_samples`` samples.
+    A scratch sized for ANY batch (``_scratch_samples`` None) is the largest there is and is kept for every later request."""
+    if os.environ.get("CN_SCATTER_SCRATCH", "1") == "0":
+        return False
+    if handle._scatter_scratch is None:
+        return True
+    have = getattr(handle, "_scratch_samples", None)
+    if have is None:
+        return False
+    return max_samples is None or have < max_samples
+
+
 class FieldHandle:
     """cn_field_params for a parameter dict (keeps the tensors alive)."""
 
@@ -167,9 +180,7 @@ class FieldHandle:
     def enable_scatter_scratch(self, max_samples: Optional[int] = None) -> "FieldHandle":
         """For a handle over GRADIENT buffers: ``cn_grid.scatter_scratch``, sized for backward calls of at most ``max_samples``
         samples (None: any size).  Called again with a larger size it re-allocates."""
-        if os.environ.get("CN_SCATTER_SCRATCH", "1") != "0" and (
-                self._scatter_scratch is None or (getattr(self, "_scratch_samples", 0) or 0) < (max_samples or 0) or
-                (max_samples is None and getattr(self, "_scratch_samples", None) is not None)):
+        if _scratch_too_small(self, max_samples):
             self._scatter_scratch = _attach_scatter_scratch(self.struct.grid, self.device, max_samples)
             self._scratch_samples = max_samples
         return self
@@ -193,9 +204,7 @@ class DensityHandle:
 
     def enable_scatter_scratch(self, max_samples: Optional[int] = None) -> "DensityHandle":
         """For a handle over GRADIENT buffers (see ``FieldHandle.enable_scatter_scratch``)."""
-        if os.environ.get("CN_SCATTER_SCRATCH", "1") != "0" and (
-                self._scatter_scratch is None or (getattr(self, "_scratch_samples", 0) or 0) < (max_samples or 0) or
-                (max_samples is None and getattr(self, "_scratch_samples", None) is not None)):
+        if _scratch_too_small(self, max_samples):
             self._scatter_scratch = _attach_scatter_scratch(
                 self.struct.grid, self.params[next(k for k in self.params if k.endswith("hash_table"))].device, max_samples)
             self._scratch_samples = max_samples
@@ -647,6 +656,41 @@ def pointcloud_compact(origins: Tensor, directions: Tensor, depth: Tensor, rgb: 
                                       _p(_f32(semantics_colormap, "semantics_colormap")), R, capacity, _p(pts),
                                       _p(cols), _p(dirs), _p(count), _stream(origins)))
     return pts, cols, dirs, count
+
+
+def pixel_sample(seed: int, first_call: Tensor, num_calls: int, rays_per_call: int, num_cameras: int, height: int,
+                 width: int) -> Tensor:
+    """``cn_pixel_sample``: the (camera, row, col) draws of calls ``first_call`` .. ``first_call + num_calls - 1`` of the point-cloud
+    exporter's pixel stream, [num_calls * rays_per_call, 3] int64.  ``first_call``: device int64 tensor of one element."""
+    lib = L.load()
+    first_call = _i64(first_call, "first_call")
+    out = torch.empty(num_calls * rays_per_call, 3, dtype=torch.int64, device=first_call.device)
+    L.check(lib.cn_pixel_sample(int(seed) & 0xFFFFFFFFFFFFFFFF, _p(first_call), num_calls, rays_per_call, num_cameras, height,
+                                width, _p(out), _stream(first_call)))
+    return out
+
+
+def pointcloud_compact_calls(origins: Tensor, directions: Tensor, depth: Tensor, rgb: Tensor, semantics_colormap: Tensor,
+                             rays_per_call: int, target_points: int, capacity: int,
+                             buffers: Optional[Tuple[Tensor, ...]] = None) -> Tuple[Tensor, ...]:
+    """``cn_pointcloud_compact_calls``: buffers = (points, colors, dirs, count, call_counts, ray_limit)."""
+    lib = L.load()
+    dev = origins.device
+    R = origins.shape[0]
+    calls = -(-R // rays_per_call)
+    if buffers is None:
+        buffers = (torch.empty(capacity, 3, device=dev), torch.empty(capacity, 3, device=dev), torch.empty(capacity, 3, device=dev),
+                   torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(max(calls, 1), dtype=torch.int64, device=dev),
+                   torch.zeros(1, dtype=torch.int64, device=dev))
+    pts, cols, dirs, count, call_counts, ray_limit = buffers
+    if call_counts.numel() < calls:
+        raise ValueError(f"call_counts holds {call_counts.numel()} calls, the launch has {calls}")
+    L.check(lib.cn_pointcloud_compact_calls(_p(_f32(origins, "origins")), _p(_f32(directions, "directions")),
+                                            _p(_f32(depth, "depth")), _p(_f32(rgb, "rgb")),
+                                            _p(_f32(semantics_colormap, "semantics_colormap")), R, rays_per_call,
+                                            target_points, capacity, _p(pts), _p(cols), _p(dirs), _p(count), _p(call_counts),
+                                            _p(ray_limit), _stream(origins)))
+    return buffers
 
 
 # --------------------------------------------------------------------------------------------------------------

@@ -173,3 +173,28 @@ def write_capture(path, num: int = 24, res: int = 64, radius: float = 0.8, world
     with open(os.path.join(path, "transforms.json"), "w", encoding="UTF-8") as f:
         json.dump(meta, f)
     return str(path)
+
+
+def write_transforms_json(path, frame_numbers, transform_matrices, intrinsics, size_hw, orientation_override=None,
+                          auto_scale_poses_override=None) -> str:
+    """A nerfstudio-format ``transforms.json`` (shared intrinsics, ``images/frame_%05d.jpg`` names, no distortion) from
+    arrays -- e.g. the camera data of the reference's real capture file kept in ``tests/golden/capture_3dcotton.npz``
+    (``fruit_nerf/utils/transforms.json``: 147 frames, 1920 x 1440).  Only the description is written, no images: parse it
+    with ``downscale_factor=1`` (the automatic choice opens the first image)."""
+    import json
+    import os
+
+    fx, fy, cx, cy = (float(v) for v in intrinsics)
+    meta = {"fl_x": fx, "fl_y": fy, "cx": cx, "cy": cy, "h": int(size_hw[0]), "w": int(size_hw[1]),
+            "k1": 0, "k2": 0, "p1": 0, "p2": 0}
+    if orientation_override is not None:
+        meta["orientation_override"] = orientation_override
+    if auto_scale_poses_override is not None:
+        meta["auto_scale_poses_override"] = bool(auto_scale_poses_override)
+    meta["frames"] = [{"file_path": f"images/frame_{int(n):05d}.jpg", "transform_matrix": [[float(v) for v in row] for row in m]}
+                      for n, m in zip(frame_numbers, transform_matrices)]
+    os.makedirs(path, exist_ok=True)
+    out = os.path.join(path, "transforms.json")
+    with open(out, "w", encoding="UTF-8") as f:
+        json.dump(meta, f)
+    return out

@@ -320,6 +320,15 @@ int cn_projection_paste(const cn_projection_job* jobs, const int32_t* job_of_slo
                         int64_t num_slots, const int32_t* image_of_job, int32_t num_images, int32_t image_height,
                         int32_t image_width, uint8_t* images, cn_stream_t stream);
 
+/* The projection stage's files: for each of `count` jobs an 8-bit RGB PNG of an image_height x image_width frame that is
+ * black except for the gray rectangle rects[i] = (x0, y0, w, h) filled, row-major, from values[value_offsets[i] ...] (HOST
+ * memory: the slot values of cn_projection_scatter copied back) -- the file torchvision.utils.save_image writes at
+ * fruit_nerf/fruit_nerf.py:304,315 up to the compressed byte stream (same decoded pixels).  make_dirs != 0 creates missing
+ * parent directories.  Pure host code, thread-safe, no stream: meant to be called from worker threads behind the GPU. */
+int cn_png_write_gray_rects(int32_t count, const char* const* paths, const uint8_t* values, const int64_t* value_offsets,
+                            const int32_t* rects /*[count,4]*/, int32_t image_height, int32_t image_width,
+                            int32_t make_dirs);
+
 /* ---------------------------------------------------------------------------------------------
  * Samplers
  * ------------------------------------------------------------------------------------------- */
@@ -461,6 +470,25 @@ int cn_export_compact(const float* positions, const float* rgb, const float* sem
 int cn_pointcloud_compact(const float* origins, const float* directions, const float* depth, const float* rgb,
                           const float* semantics_colormap, int64_t num_rays, int64_t capacity, float* points,
                           float* colors, float* view_dirs, int64_t* count, cn_stream_t stream);
+
+/* generate_point_cloud with SEVERAL of the reference's calls per launch (exporter_utils_nerfacto.py:125-183: a call =
+ * rays_per_call random pixels -> render -> append -> `while not finished` check; 2 048 rays at debug/exporter_nerfacto.py:91,
+ * 32 768 upstream).  The cloud the loop produces is the union of the kept points of calls 0 .. c*, c* = the first call at
+ * which the running count reaches the target -- however the calls are grouped into launches, provided that
+ *   cn_pixel_sample            draws call c's pixels from a counter-based stream: ray_indices[(c - first) * rays_per_call + r]
+ *                              = floor(u * (num_cameras, H, W)), u = hash(seed, c, r, component) -- nerfstudio's PixelSampler
+ *                              formula on a stream that does not depend on the grouping (first_call: DEVICE int64, so a HIP
+ *                              graph can advance it);
+ *   cn_pointcloud_compact_calls  counts the kept rays per call (call_counts [ceil(num_rays / rays_per_call)], written), finds
+ *                              on the device the call at which *count reaches target_points, writes the number of rays up
+ *                              to the end of that call to *ray_limit (0 when *count had reached the target before) and
+ *                              appends exactly those rays' points as cn_pointcloud_compact does. */
+int cn_pixel_sample(uint64_t seed, const int64_t* first_call, int32_t num_calls, int32_t rays_per_call, int32_t num_cameras,
+                    int32_t height, int32_t width, int64_t* ray_indices /*[num_calls*rays_per_call,3]*/, cn_stream_t stream);
+int cn_pointcloud_compact_calls(const float* origins, const float* directions, const float* depth, const float* rgb,
+                                const float* semantics_colormap, int64_t num_rays, int64_t rays_per_call,
+                                int64_t target_points, int64_t capacity, float* points, float* colors, float* view_dirs,
+                                int64_t* count, int64_t* call_counts, int64_t* ray_limit, cn_stream_t stream);
 
 /* Embedding.mean(dim=0) (fruit_nerf/fruit_field.py:220,257): [num_images, dim] -> [dim]. */
 int cn_embedding_mean(const float* embedding, int32_t num_images, int32_t dim, float* mean, cn_stream_t stream);

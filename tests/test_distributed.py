@@ -85,6 +85,116 @@ def _case_grad_allreduce(rank, world):
     return out.tolist()
 
 
+def _case_grouped_exchange(rank, world):
+    """Three data-parallel optimiser steps on a flat buffer with the trainer's group layout: the overlapped per-group exchange
+    (collectives started group by group in backward order, each group stepped behind its own) against the blocking whole-buffer
+    all-reduce -- same parameters, bit for bit; a group without a gradient (the proposal networks, two iterations in three here)
+    exchanges nothing and keeps its values."""
+    from cropnerf_amd import distributed as D
+
+    ranges = {"fields": (0, 4000), "proposal_networks": (4000, 5200), "camera_opt": (5200, 5236)}
+    lr = {"fields": 1e-2, "proposal_networks": 1e-2, "camera_opt": 1e-3}
+
+    def grads(step):
+        g = torch.Generator().manual_seed(1000 * step + rank)
+        return torch.randn(5236, generator=g)
+
+    def run(overlap):
+        params = torch.linspace(-1, 1, 5236)
+        flat = torch.zeros(5236)
+        ex = D.GroupedGradientExchange(flat, ranges)
+        order = []
+        for step in range(3):
+            updated = step % 3 == 0
+            flat.copy_(grads(step))
+            if overlap:
+                ex.begin_iteration()
+                ex.start("fields")  # ... proposal backward kernels would run here ...
+                if updated:
+                    ex.start("proposal_networks")
+                ex.start("camera_opt")
+                order.append(list(ex.started))
+            else:
+                flat.copy_(D.all_reduce_mean(flat))
+            for name, (lo, hi) in ranges.items():
+                if name == "proposal_networks" and not updated:
+                    continue
+                if overlap:
+                    ex.wait(name)
+                params[lo:hi] -= lr[name] * flat[lo:hi]
+            if overlap:
+                ex.wait_all()
+        return params, order
+
+    a, order = run(True)
+    b, _ = run(False)
+    # an exchange that was started and never waited for is an error at the next iteration
+    ex = D.GroupedGradientExchange(torch.zeros(8), {"fields": (0, 8)})
+    ex.begin_iteration()
+    ex.start("fields")
+    try:
+        ex.begin_iteration()
+        leak = False
+    except RuntimeError:
+        leak = True
+    ex.wait_all()
+    return {"equal": bool(torch.equal(a, b)), "order": order, "sum": float(a.double().sum()), "leak_detected": leak}
+
+
+def test_grouped_gradient_exchange_equals_the_blocking_all_reduce():
+    res = _run("_case_grouped_exchange", 2)
+    assert all(r["equal"] and r["leak_detected"] for r in res.values())
+    assert res[0]["sum"] == res[1]["sum"]  # both ranks hold the same parameters
+    assert res[0]["order"] == [["fields", "proposal_networks", "camera_opt"], ["fields", "camera_opt"], ["fields", "camera_opt"]]
+    assert res[0]["order"] == res[1]["order"]  # every rank issues the same collectives in the same order
+
+
+@pytest.mark.gpu
+def test_trainer_overlapped_exchange_on_one_rank_rccl():
+    """``FruitTrainer.train_iteration`` with the data-parallel exchange forced on in a ONE-rank RCCL group: the per-group
+    in-place ``ReduceOp.AVG`` collectives on RCCL's stream between the backward kernels and the optimiser step -- the call
+    pattern (async issue behind the group's last writer, stream-side wait before the group's Adam step) is valid on this box,
+    a mean over one rank changes nothing (losses fall as without it), and the blocking form (``CN_DP_EXCHANGE=blocking``) runs
+    too.  The multi-rank arithmetic is the gloo test above."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_train import _hip_model, _hip_rays, _setup
+    from cropnerf_amd.fruit_nerf.trainer import FruitTrainer
+
+    def _trainer_setup():
+        sc, idx, _, image, mask = _setup(seed=6, R=128)
+        model = _hip_model(sc)
+        model.training = True
+        return FruitTrainer(model, seed=3), _hip_rays(sc, idx), {"image": image, "fruit_mask": mask}
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        losses = {}
+        for mode in ("overlap", "blocking", "none"):
+            os.environ["CN_DP_EXCHANGE"] = mode if mode != "none" else "overlap"
+            tr, rb, batch = _trainer_setup()
+            tr.force_exchange = mode != "none"
+            hist = []
+            for _ in range(6):
+                out = tr.train_iteration(rb, batch)
+                hist.append(float(out["loss_dict"]["rgb_loss"]))
+            torch.cuda.synchronize()
+            if mode == "overlap":
+                assert tr._exchange is not None and tr._exchange.started == ["fields", "proposal_networks", "camera_opt"]
+                assert not tr._exchange.pending
+            losses[mode] = hist
+        for mode in ("overlap", "blocking"):
+            assert losses[mode][-1] < losses[mode][0]
+            for a, b in zip(losses[mode], losses["none"]):  # the same trajectory up to the order of the atomic sums
+                assert abs(a - b) <= 2e-2 * abs(b) + 1e-5, (mode, losses)
+    finally:
+        os.environ.pop("CN_DP_EXCHANGE", None)
+        dist.destroy_process_group()
+
+
 def test_gradient_all_reduce_mean():
     res = _run("_case_grad_allreduce", 2)
     expect = [1.5 * i for i in range(10)]
@@ -230,14 +340,14 @@ def test_bench_self_launch_relays_the_exit_code_without_touching_the_gpu(monkeyp
     import subprocess
     import sys
 
+    import torch
+
+    if torch.cuda.is_available():  # before anything is started: on a GPU box two real ranks would come up and be torn down
+        pytest.skip("CPU-tier check of the failure path")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=env, capture_output=True, text=True, timeout=600, cwd=root)
-    import torch
-
-    if torch.cuda.is_available():
-        pytest.skip("CPU-tier check of the failure path")
     assert p.returncode != 0
     assert "launching -m torch.distributed.run --nnodes=1 --nproc-per-node=2" in p.stderr
     assert "needs an MI355X" in p.stderr  # every rank refused for the same reason the N = 1 run does

@@ -214,3 +214,44 @@ def test_proposal_sampler_in_fp16_mode(ops, L, second_prop):
     assert torch.equal(a["euclidean_bins"], b["euclidean_bins"])
     with pytest.raises(L.CropNerfHipError, match="matrix_precision"):
         ops.proposal_sample(dh, sc, o, d, nears, fars, (256, 96), 48, matrix_precision=9)
+
+
+@pytest.mark.parametrize("mode", ["f16", "split_bf16"])
+def test_early_stop_in_the_team_gather_path_is_bounded(mode, monkeypatch):
+    """Early termination (an extension, off by default) in the producer/consumer kernel's TEAM gather -- the path of the fp16
+    and split-bf16 matrix modes, where two or four gather waves share a half-step and read each other's stop flags: on a
+    batch that fills the device (8 rays per workgroup x 256 CUs and more) every output stays within the threshold of the same
+    mode without early stop, and most rays really stop."""
+    from cropnerf_amd import _lib as L
+    from cropnerf_amd import ops
+
+    sc = make_tcnn_scene(seed=3) if mode == "f16" else make_scene(seed=3)  # half tcnn table / float torch table
+    monkeypatch.setenv("CN_FUSED_SPLIT", "2")  # the split kernel also for split-bf16 with early stop (default: single-wave kernel)
+    fspec, _ = product_specs(sc)
+    dp = {k: v.clone() for k, v in dev_params(sc).items()}
+    dp["field.mlp_base_mlp.layers.1.bias"][0] += 4.0  # an opaque medium: rays stop within the first chunks
+    fh = ops.FieldHandle(dp, fspec)
+    rbs = [rays_with_box(sc, c) for c in range(3)]
+    o, d, n, f = (to_dev(torch.cat([getattr(rb, k) for rb in rbs])) for k in ("origins", "directions", "nears", "fars"))
+    assert o.shape[0] >= 4096
+    scene = ops.scene_struct(sc.aabb, True)
+    mp = {"f16": L.MATRIX_F16, "split_bf16": L.MATRIX_SPLIT_BF16}[mode]
+    S, eps = 256, 1e-3
+    full = ops.render_rays(fh, scene, ops.render_opts(S, matrix_precision=mp), o, d, n, f, want_weights=True)
+    again = ops.render_rays(fh, scene, ops.render_opts(S, matrix_precision=mp, early_stop_transmittance=0.0), o, d, n, f,
+                            want_weights=True)
+    for k in full:
+        assert torch.equal(full[k], again[k]), k
+    cut = ops.render_rays(fh, scene, ops.render_opts(S, matrix_precision=mp, early_stop_transmittance=eps), o, d, n, f,
+                          want_weights=True)
+    torch.cuda.synchronize()
+    stopped = (cut["weights"][:, 192:] == 0).all(dim=1) & (full["weights"][:, 192:] != 0).any(dim=1)
+    assert stopped.float().mean() > 0.5, "the medium was meant to be opaque enough to stop most rays"
+    assert_close(cut["rgb"], full["rgb"], 0, 1.01 * eps, f"{mode} early-stop rgb")
+    assert_close(cut["accumulation"], full["accumulation"], 0, 1.01 * eps, f"{mode} early-stop accumulation")
+    sem_scale = float(full["semantics"].abs().max()) + 1.0
+    assert_close(cut["semantics"], full["semantics"], 0, 4 * eps * sem_scale, f"{mode} early-stop semantics")
+    assert torch.equal(cut["depth"], full["depth"])
+    # the evaluated part of a stopped ray is the same arithmetic: weights in front of the cut are bit-identical
+    front = cut["weights"] != 0
+    assert torch.equal(cut["weights"][front], full["weights"][front])

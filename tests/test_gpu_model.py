@@ -401,10 +401,40 @@ def test_model_matrix_precision_option(scene):
         m.config.matrix_precision = "fp32"
     for k in ("rgb", "accumulation", "semantics"):
         assert_close(fast[k], exact[k], 2e-4, 5e-5, k)
-    m.config.matrix_precision = "fp16"
+    m.config.matrix_precision = "fp8"
     with pytest.raises(ValueError):
         m.get_outputs_for_camera_ray_bundle(rb)
-    m.config.matrix_precision = "fp32"
+    m.config.matrix_precision = "fp16"  # alias of "f16" (fp32 tables here: the fp16 products on float entries)
+    try:
+        half = m.get_outputs_for_camera_ray_bundle(rb)
+    finally:
+        m.config.matrix_precision = "fp32"
+    assert_close(half["rgb"], exact["rgb"], 0.0, 2e-3, "rgb in fp16 matrix mode")
+
+
+def test_named_background_colours(scene):
+    """NerfactoModelConfig.background_color (inherited at fruit_nerf.py:60): 'black' / 'white' / 'random' beside 'last_sample'
+    and RGB triples.  rgb = sum w c + bg (1 - sum w), clamped in eval; 'random' blends nothing (= black) in nerfstudio's
+    combine_rgb, and the reference's loss does not blend the target either."""
+    rb = _cameras(scene).to("cuda").generate_rays(1, keep_shape=False)
+    outs = {}
+    for bg in ("last_sample", "black", "white", "random", (0.25, 0.5, 0.75)):
+        m = _model(scene, background_color=bg)
+        outs[bg] = m(rb)
+    acc = outs["black"]["accumulation"]
+    assert torch.equal(outs["random"]["rgb"], outs["black"]["rgb"])
+    assert_close(outs["white"]["rgb"], (outs["black"]["rgb"] + (1 - acc)).clamp(0, 1), 1e-5, 1e-6, "white background")
+    tri = torch.tensor([0.25, 0.5, 0.75], device="cuda")
+    assert_close(outs[(0.25, 0.5, 0.75)]["rgb"], (outs["black"]["rgb"] + tri * (1 - acc)).clamp(0, 1), 1e-5, 1e-6, "triple")
+    assert not torch.equal(outs["last_sample"]["rgb"], outs["black"]["rgb"])
+    for k in ("accumulation", "semantics", "depth"):
+        assert torch.equal(outs["white"][k], outs["last_sample"][k])
+    with pytest.raises(ValueError, match="background_color"):
+        _model(scene, background_color="green")(rb)
+    from cropnerf_amd.fruit_nerf.trainer import FruitTrainer
+
+    with pytest.raises(NotImplementedError, match="last_sample"):
+        FruitTrainer(_model(scene, background_color="white"))
 
 
 def test_bench_line_contract():
@@ -498,3 +528,54 @@ def test_pipeline_replicas_one_plant_per_rank():
         for k in ("train_s", "export_s", "segment_s", "projection_s", "depth_projection_s", "fruit_count", "export_kept"):
             assert k in d, k
         assert d["export_samples"] == 160 ** 3
+
+
+def test_point_cloud_export_does_not_depend_on_calls_per_launch():
+    """generate_point_cloud with K of the reference's calls per launch (``launch_rays``): the pixel stream is counter-based and
+    the append stops at the call that reaches the target, so K = 1 (the reference's loop, eager or graph-replayed), K = 4 and
+    K = 64 give the SAME cloud -- compared as sorted rows (the append order inside a call is atomic, as before) -- on a scene
+    where only part of the rays are kept."""
+    from cropnerf_amd.fruit_nerf.export.exporter_utils_nerfacto import generate_point_cloud
+
+    sc = make_scene(seed=4, log2_T=16, num_images=5, height=24, width=24, focal=33.0, prop_log2_T=13)
+    sc.params["field.field_head_semantics.net.bias"] += 2.5  # ~ a fifth of the rays end up above the 0.9 threshold
+    sc.params["field.mlp_base_mlp.layers.1.bias"][0] += 4.0
+    pipe = _pipeline(sc, "test")  # 512 rays per call
+    clouds, stats = [], []
+    for launch_rays, use_graph in ((None, False), (None, True), (2048, True), (1 << 15, False)):
+        st = {}
+        pcd = generate_point_cloud(pipe, num_points=3000, remove_outliers=False, use_graph=use_graph, launch_rays=launch_rays,
+                                   stats=st)
+        rows = np.concatenate([pcd["points"], pcd["colors"], pcd["view_directions"]], axis=1)
+        clouds.append(rows[np.lexsort(rows.T[::-1])])
+        stats.append(st)
+    assert [s["calls_per_launch"] for s in stats] == [1, 1, 4, 64] and stats[1]["graph"] and not stats[0]["graph"]
+    n = clouds[0].shape[0]
+    assert 3000 <= n < 3000 + 512
+    frac = n / (stats[0]["calls"] * 512)
+    assert 0.02 < frac < 0.9, f"kept fraction {frac}: the scene was meant to reject part of the rays"
+    for c in clouds[1:]:
+        assert c.shape == clouds[0].shape and np.array_equal(c, clouds[0])
+
+
+def test_pixel_stream_is_counter_based():
+    """cn_pixel_sample: the draws of call c are the same whether it is sampled alone or inside a multi-call launch, lie inside
+    (cameras, H, W) and are uniform."""
+    from cropnerf_amd import ops
+
+    first = torch.tensor([5], dtype=torch.int64, device="cuda")
+    many = ops.pixel_sample(11, first, 7, 1000, 140, 1440, 1920)
+    assert many.shape == (7000, 3) and many.dtype == torch.int64
+    for c in range(7):
+        one = ops.pixel_sample(11, torch.tensor([5 + c], dtype=torch.int64, device="cuda"), 1, 1000, 140, 1440, 1920)
+        assert torch.equal(one, many[1000 * c:1000 * (c + 1)])
+    assert not torch.equal(ops.pixel_sample(12, first, 1, 1000, 140, 1440, 1920), many[:1000])
+    big = ops.pixel_sample(3, torch.zeros(1, dtype=torch.int64, device="cuda"), 64, 4096, 7, 50, 30)
+    for k, n in enumerate((7, 50, 30)):
+        col = big[:, k]
+        assert int(col.min()) == 0 and int(col.max()) == n - 1
+        counts = torch.bincount(col, minlength=n).double()
+        expect = col.numel() / n
+        chi2 = float(((counts - expect) ** 2 / expect).sum())
+        assert chi2 < 3.0 * n, (k, chi2)  # dof = n - 1; far below any suspicious value
+    assert len(torch.unique(big[:, 0] * 1500 + big[:, 1] * 30 + big[:, 2])) > 7 * 50 * 30 * 0.99  # every pixel is reachable

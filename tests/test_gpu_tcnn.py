@@ -362,6 +362,10 @@ def test_eval_setup_and_exporter_cli_load_a_tcnn_run_directory(tmp_path, ops):
     assert step == 29999 and ck.name == "step-000029999.ckpt"
     assert m.config.implementation == "tcnn" and m.params["field.mlp_base_grid.hash_table"].dtype == torch.float16
     assert m.field_spec.grid.layout == "tcnn" and m.num_train_data == 3
+    # a tcnn-packed checkpoint of a mixed_precision run renders in tiny-cuda-nn's arithmetic class unless told otherwise
+    assert m.config.matrix_precision == "f16"
+    _, pipe32, _, _ = eval_setup(run / "config.yml", test_mode="inference", matrix_precision="fp32")
+    assert pipe32.model.config.matrix_precision == "fp32"
     # full-image render of camera 1 against the tcnn oracle (inference mode: proposal sampler + 48 field samples)
     rb = ORY.image_rays(sc.c2w, sc.intr, 1, sc.height, sc.width)
     ref = oracle_model(sc, "inference").render_rays(rb)
@@ -370,6 +374,9 @@ def test_eval_setup_and_exporter_cli_load_a_tcnn_run_directory(tmp_path, ops):
     out = m.get_outputs_for_camera_ray_bundle(pipe.datamanager.cameras.to("cuda").generate_rays(1, keep_shape=True))
     assert_close(out["rgb"].reshape(-1, 3), ref["rgb"], 2e-3, 2e-3, "rgb of a loaded tcnn run", frac_ok=0.99)
     assert_close(out["accumulation"].reshape(-1, 1), ref["accumulation"], 2e-3, 2e-3, "accumulation", frac_ok=0.99)
+    out32 = pipe32.model.get_outputs_for_camera_ray_bundle(pipe32.datamanager.cameras.to("cuda").generate_rays(1, keep_shape=True))
+    assert_close(out32["rgb"].reshape(-1, 3), ref["rgb"], 2e-3, 2e-3, "rgb of the same run in exact fp32", frac_ok=0.99)
+    assert not torch.equal(out32["rgb"], out["rgb"])
     # the dense exporter CLI on the same run
     outdir = tmp_path / "export"
     exporter.entrypoint(["semantic-pointcloud", "--load-config", str(run / "config.yml"), "--output-dir", str(outdir),

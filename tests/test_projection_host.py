@@ -50,8 +50,8 @@ def test_screen_rectangle_contains_every_pixel_that_hits_the_box():
                 ys, xs = np.nonzero(hit)
                 assert x0 >= xs.min() - 4 and x0 + w <= xs.max() + 5 and y0 >= ys.min() - 4 and y0 + h <= ys.max() + 5
             cases += 1
-        # the box around the camera keeps the whole frame
-        assert tuple(rects[-2]) == (0, 0, W, H)
+        # the box around the camera keeps the whole frame; the one behind it can be hit by no pixel
+        assert tuple(rects[-2]) == (0, 0, W, H) and tuple(rects[-1]) == (0, 0, 0, 0)
     assert cases == 5 * 42
 
 
@@ -114,14 +114,46 @@ def test_png_writer_decodes_to_the_image_save_image_would_write(rect, tmp_path):
     save_image(frame[..., None].repeat(1, 1, 3), str(ref_path))
     ref = np.asarray(Image.open(ref_path))
     assert (got == ref).all()
-    # and through the worker pool, into a directory that does not exist yet
+    # and through the worker pool (the native writer, cn_png_write_gray_rects), into directories that do not exist yet:
+    # the same pixels, and -- same zlib, same parameters -- the same bytes as the Python statement of the stream
     wr = PngWriter(workers=2)
     for i in range(4):
-        wr.submit(str(tmp_path / "a" / f"cam_{i}" / "x.png"), crop, x0, y0, H, W)
+        wr.submit(str(tmp_path / "a" / f"cam_{i}" / "deep" / "x.png"), crop, x0, y0, H, W)
     wr.close()
     assert wr.files == 4
     for i in range(4):
-        assert (np.asarray(Image.open(tmp_path / "a" / f"cam_{i}" / "x.png")) == ref).all()
+        f = tmp_path / "a" / f"cam_{i}" / "deep" / "x.png"
+        assert (np.asarray(Image.open(f)) == ref).all()
+        assert f.read_bytes() == data
+
+
+def test_png_writer_batches_of_rectangles(tmp_path):
+    """``submit_rects``: many files from one slot-ordered value array (how a projection batch arrives), more than one task."""
+    from PIL import Image
+
+    from cropnerf_amd.fruit_nerf.projection import PngWriter
+
+    H, W = 40, 50
+    rng = np.random.default_rng(3)
+    rects = np.array([[rng.integers(0, 30), rng.integers(0, 20), rng.integers(1, 20), rng.integers(1, 20)] for _ in range(70)]
+                     + [[0, 0, 0, 0]], np.int32)
+    sizes = rects[:, 2].astype(np.int64) * rects[:, 3]
+    offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    values = rng.integers(0, 256, int(sizes.sum()), dtype=np.uint8)
+    paths = [str(tmp_path / f"d{i % 5}" / f"f{i}.png") for i in range(len(rects))]
+    wr = PngWriter(workers=3)
+    wr.submit_rects(paths, values, offsets, rects, H, W)
+    wr.close()
+    assert wr.files == 71
+    for p, (x0, y0, w, h), off in zip(paths, rects, offsets):
+        ref = np.zeros((H, W), np.uint8)
+        ref[y0:y0 + h, x0:x0 + w] = values[off:off + w * h].reshape(h, w)
+        im = np.asarray(Image.open(p))
+        assert im.shape == (H, W, 3) and (im == ref[..., None]).all()
+    with pytest.raises(Exception, match="outside"):
+        wr2 = PngWriter(workers=1)
+        wr2.submit_rects([str(tmp_path / "bad.png")], values, np.zeros(1, np.int64), np.array([[45, 0, 10, 5]], np.int32), H, W)
+        wr2.close()
 
 
 def test_png_writer_reports_a_failed_file(tmp_path):
@@ -130,5 +162,5 @@ def test_png_writer_reports_a_failed_file(tmp_path):
     (tmp_path / "blocker").write_text("a file where a directory should be")
     wr = PngWriter(workers=1)
     wr.submit(str(tmp_path / "blocker" / "x.png"), np.zeros((2, 2), np.uint8), 0, 0, 8, 8)
-    with pytest.raises(OSError):
+    with pytest.raises(Exception, match="cannot create the directory|cannot open"):
         wr.close()
