@@ -708,8 +708,17 @@ static hipError_t split_attr() {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<PS, MM, H, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<PS, MM, H, true>),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<PS, MM, H, true>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if constexpr (MM == MM_FP32) {  // the packed schedule of 48-sample rays (render_split.hpp: PACK)
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<PS, MM, H, false, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS_BYTES_PACK);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(render_split_kernel<PS, MM, H, true, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)SPLIT_LDS_BYTES_PACK);
+  }
+  return e;
 }
 
 static hipError_t fused_device_init(int dev, FusedDevice& d) {
@@ -883,6 +892,9 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
   const unsigned blocks = (unsigned)(want < cap ? want : cap);
   if (split_blocks) {
     const size_t lds_bytes = bf16 ? SPLIT_LDS_BYTES_BF16 : SPLIT_LDS_BYTES;
+    const char* pack_env = getenv("CN_SPLIT_PACK");
+    const bool pack = mm == MM_FP32 && opts->num_samples > 32 && opts->num_samples <= 48 && early_stop == 0.f &&
+                      !(pack_env && atoi(pack_env) == 0);
 #define CN_SPLIT_LAUNCH(MM, H)                                                                                       \
   do {                                                                                                               \
     if (generic)                                                                                                     \
@@ -896,6 +908,18 @@ static int launch_fused(const cn_field_params* params, const cn_scene* scene, co
     else if (mm == MM_F16) CN_SPLIT_LAUNCH(MM_F16, false);
     else if (bf16 && half) CN_SPLIT_LAUNCH(MM_BF16, true);
     else if (bf16) CN_SPLIT_LAUNCH(MM_BF16, false);
+    else if (pack) {
+      // 32 < S <= 48 in exact fp32 -- the default method's 48 field samples per ray --: two rays in three half-steps instead of
+      // four (render_split.hpp: PACK).  CN_SPLIT_PACK=0 keeps the one-ray schedule (A/B runs, the bit-identity test).
+#define CN_SPLIT_LAUNCH_PACK(H, G)                                                                                  \
+  hipLaunchKernelGGL((render_split_kernel<PER_SAMPLE, MM_FP32, H, G, true>), dim3(split_blocks), dim3(SPLIT_THREADS), \
+                     SPLIT_LDS_BYTES_PACK, s, A)
+      if (half && generic) CN_SPLIT_LAUNCH_PACK(true, true);
+      else if (half) CN_SPLIT_LAUNCH_PACK(true, false);
+      else if (generic) CN_SPLIT_LAUNCH_PACK(false, true);
+      else CN_SPLIT_LAUNCH_PACK(false, false);
+#undef CN_SPLIT_LAUNCH_PACK
+    }
     else if (half) CN_SPLIT_LAUNCH(MM_FP32, true);
     else CN_SPLIT_LAUNCH(MM_FP32, false);
 #undef CN_SPLIT_LAUNCH

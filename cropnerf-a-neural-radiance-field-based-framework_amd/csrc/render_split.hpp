@@ -83,6 +83,10 @@ constexpr int PAIR_SCRATCH = 2 * XCH_FLOATS + 64 + 68 + 68 + 4;  // ring | per-r
 constexpr int PAIR_FLAGS = 2 * XCH_FLOATS + 64 + 68 + 68;
 constexpr size_t SPLIT_LDS_BYTES = (size_t)(BLOB_FLOATS + SPLIT_PAIRS * PAIR_SCRATCH) * sizeof(float);
 constexpr size_t SPLIT_LDS_BYTES_BF16 = SPLIT_LDS_BYTES + (size_t)BF16_EXT_FLOATS * sizeof(float);
+// PACK (two 48-sample rays in three half-steps, below): per pair the second ray's colour bias, matrix-side and gather-side
+// bin edges, behind the pair scratch
+constexpr int PACK_SCRATCH = 64 + 68 + 68;
+constexpr size_t SPLIT_LDS_BYTES_PACK = SPLIT_LDS_BYTES + (size_t)(SPLIT_PAIRS * PACK_SCRATCH) * sizeof(float);
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -209,14 +213,24 @@ __device__ __forceinline__ void split_fill_edges(const FusedArgs& A, const Split
 // products (v_mfma_f32_16x16x32_f16, fp32 accumulation; tcnn's FullyFusedMLP arithmetic): the gather waves hand over fp16
 // features (16 bytes per lane and sample instead of 32), blended on packed fp16 pairs when the table is a half table.
 // HALF: half2 table entries (CN_TABLE_F16).  GENERIC: per-level index records (tcnn layout), see lane_level_rec.
-template <bool PER_SAMPLE, int MM = MM_FP32, bool HALF = false, bool GENERIC = false>
+// PACK (exact-fp32 products, 32 < S <= 48 -- the default method's 48 field samples per ray, nerfacto's
+// num_nerf_samples_per_ray inherited at fruit_nerf.py:59-68): a ray is THREE 16-sample column tiles and a half-step is two, so a
+// ray per two half-steps leaves every fourth tile empty -- a quarter of the matrix waves' MFMAs and of the gather waves' table
+// reads spent on samples past the end of the ray.  Here a pair walks its schedule slots two rays at a time, A and B, in three
+// half-steps: (A0, A1), (A2, B0), (B1, B2).  The two-tile MLP chain is the same code (a copy of it for one tile next to it
+// makes hipcc spill ~50 of the 128 registers a 1024-thread workgroup leaves per lane: built three ways, 0.96 vs 0.91 ms per
+// 65 536 rays, removed); what changes is which ray a tile belongs to -- its sample positions on the gather side, its per-ray
+// colour bias, its lanes in the 64-lane compositing row (tile B0 is computed in A's last half-step and moved from lanes 48..63
+// to lanes 0..15 when B's row starts) on the matrix side.  Per ray the arithmetic, hence every output bit, is unchanged.
+template <bool PER_SAMPLE, int MM = MM_FP32, bool HALF = false, bool GENERIC = false, bool PACK = false>
 __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A) {
+  static_assert(!PACK || MM == MM_FP32, "the packed schedule exists for the exact-fp32 kernel (the other modes gather in teams)");
   constexpr bool BF16 = MM == MM_BF16, F16 = MM == MM_F16;
   // TEAM (fp16 or split-bf16 products): the gather waves of neighbouring pairs work as a team -- see the gather role
   // rays (= pairs = gather waves) per team: 2 or 4 (1 = no team).  Per-sample outputs (the exporters' parallel rays, whose
   // neighbouring SAMPLES are as close as neighbouring rays) keep 16 consecutive samples of one ray per lane row: no team
   constexpr int TR = PER_SAMPLE ? CN_TEAM_RAYS_PS : CN_TEAM_RAYS;
-  constexpr bool TEAM = (CN_TEAM_ALL || MM != MM_FP32) && TR > 1 && (SPLIT_MPG == 1) && (SPLIT_G % TR == 0) && !CN_ABLATE_GATHER;
+  constexpr bool TEAM = !PACK && (CN_TEAM_ALL || MM != MM_FP32) && TR > 1 && (SPLIT_MPG == 1) && (SPLIT_G % TR == 0) && !CN_ABLATE_GATHER;
   constexpr bool QUAD = TEAM && TR == 4 && !CN_TEAM_ROW_WALK;  // stripes walked in 2 x 2 pixel blocks (split_ray_setup)
   extern __shared__ __align__(16) float lds[];
   constexpr int OFF_EXT = BLOB_FLOATS + SPLIT_PAIRS * PAIR_SCRATCH;  // BF16 only
@@ -242,6 +256,8 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
   float* ring = ps;
   float* scratch = ps + 2 * XCH_FLOATS;  // per-ray colour bias (written and read by the matrix wave only)
   float* tb_m = scratch + 64;
+  // PACK: ray B's colour bias | matrix-side edges | gather-side edges
+  float* packs = lds + BLOB_FLOATS + SPLIT_PAIRS * PAIR_SCRATCH + pair * PACK_SCRATCH;
   const int S = A.S;
 
   const int xcd = blockIdx.x & 7;
@@ -267,11 +283,15 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
   // of pair 0, the longest list; a slot without a ray (past the end, outside the image) is an idle step
   const long long q_first = (long long)slot * SPLIT_PAIRS;
   const long long n_q = q_first < items ? (items - q_first + stride - 1) / stride : 0;
-  const int nhalf = PER_SAMPLE ? 2 : 2 * nchunks;
-  const long long total = n_q * nhalf;
+  const int nhalf = PACK ? 3 : (PER_SAMPLE ? 2 : 2 * nchunks);
+  const long long total = PACK ? ((n_q + 1) >> 1) * 3 : n_q * nhalf;  // PACK: three half-steps per two schedule slots
 
   SplitRay ray;
   ray.valid = false;
+  SplitRay ray_b;  // PACK: the second ray of the duo (matrix wave) ...
+  ray_b.valid = false;
+  SplitRay gray_b;  // ... and of the gather wave
+  gray_b.valid = false;
   SplitRay gray[SPLIT_MPG];  // gather wave: the rays of the matrix waves it feeds
 
 #pragma unroll
@@ -440,25 +460,56 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
           SplitRay& gr = gray[m];
           float* gring = ring + m * PAIR_SCRATCH;
           float* tb_g = gring + 2 * XCH_FLOATS + 64 + 68;
+          if constexpr (PACK) {
+            // duo qi = schedule slots 2 qi (ray A) and 2 qi + 1 (ray B): A is set up in the duo's first half-step, B in its second
+            // (under the striped schedule a slot in the middle of a pair's list can be empty: either ray may be missing)
+            if (k == 0) {
+              split_ray_setup<QUAD>(A, q_first + pair + m + 2 * qi * stride, items, xcd, striped, rows, cw, first_row, per_xcd, chunks_per_item_ray, gr);
+              if (gr.valid) split_fill_edges(A, gr, (PER_SAMPLE ? gr.chunk : 0) * 64, tb_g, lane);
+              gray_b.valid = false;
+            }
+            if (k == 1) {
+              split_ray_setup<QUAD>(A, q_first + pair + m + (2 * qi + 1) * stride, items, xcd, striped, rows, cw, first_row, per_xcd, chunks_per_item_ray, gray_b);
+              if (gray_b.valid) split_fill_edges(A, gray_b, (PER_SAMPLE ? gray_b.chunk : 0) * 64, packs + 64 + 68, lane);
+            }
+          } else {
           if (k == 0)
             split_ray_setup<QUAD>(A, q_first + pair + m + qi * stride, items, xcd, striped, rows, cw, first_row, per_xcd, chunks_per_item_ray, gr);
+          }
           // early termination: the matrix wave publishes the schedule slot of a ray it has finished early; the rest of
           // that ray's half-steps are then idle for the pair (the workgroup still runs them in lock-step: the time is
           // saved when the 8 rays in flight -- neighbouring pixels -- go opaque at about the same depth)
-          const bool stopped_g = !PER_SAMPLE && A.early_stop > 0.f &&
+          const bool stopped_g = !PACK && !PER_SAMPLE && A.early_stop > 0.f &&
                                  reinterpret_cast<volatile int*>(gring + PAIR_FLAGS)[2] == (int)qi;
-          if (gr.valid && !stopped_g) {
+          // PACK: the half-step is live when a ray that owns one of its tiles exists
+          const bool live_g = PACK ? (k == 0 ? gr.valid : (k == 1 ? (gr.valid || gray_b.valid) : gray_b.valid)) : gr.valid;
+          if (live_g && !stopped_g) {
             const int chunk = PER_SAMPLE ? gr.chunk : (k >> 1), half = k & 1;
-            if (half == 0) split_fill_edges(A, gr, chunk * 64, tb_g, lane);
+            if constexpr (!PACK) {
+              if (half == 0) split_fill_edges(A, gr, chunk * 64, tb_g, lane);
+            }
             float px[2], py[2], pz[2];
             bool sel[2];
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
+              if constexpr (PACK) {
+                // tile c of half-step k: (A0, A1), (A2, B0), (B1, B2); the tile of a missing ray is computed on the other (unused)
+                const bool owner_b = c == 0 ? k == 2 : k >= 1;
+                const bool of_b = owner_b ? gray_b.valid : !gr.valid;
+                const int t16 = c == 0 ? (k == 0 ? 0 : (k == 1 ? 32 : 16)) : (k == 0 ? 16 : (k == 1 ? 0 : 32));
+                const float* tb = of_b ? packs + 64 + 68 : tb_g;
+                const int kk = t16 + j;
+                const float mid = (tb[kk] + tb[kk + 1]) / 2.f;
+                px[c] = (of_b ? gray_b.ox : gr.ox) + (of_b ? gray_b.dx : gr.dx) * mid;
+                py[c] = (of_b ? gray_b.oy : gr.oy) + (of_b ? gray_b.dy : gr.dy) * mid;
+                pz[c] = (of_b ? gray_b.oz : gr.oz) + (of_b ? gray_b.dz : gr.dz) * mid;
+              } else {
               const int kk = 32 * half + 16 * c + j;
               const float mid = (tb_g[kk] + tb_g[kk + 1]) / 2.f;
               px[c] = gr.ox + gr.dx * mid;
               py[c] = gr.oy + gr.dy * mid;
               pz[c] = gr.oz + gr.dz * mid;
+              }
               sel[c] = normalize_position(A.scene, px[c], py[c], pz[c]);
             }
             f32x4 feat[2][2];
@@ -543,13 +594,27 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
       const long long hs = step - 1;
       const long long qi = hs / nhalf;
       const int k = (int)(hs - qi * nhalf);
-      if (k == 0) {
-        split_ray_setup<QUAD>(A, q_first + pair + qi * stride, items, xcd, striped, rows, cw, first_row, per_xcd, chunks_per_item_ray, ray);
-        st = CompositeState();
-        ray_stopped = false;
-        if (ray.valid) {
+      if (PACK ? k <= 1 : k == 0) {
+        // PACK: k = 0 sets up ray A of the duo (schedule slot 2 qi), k = 1 ray B (slot 2 qi + 1) -- one copy of the code,
+        // the ray record and the LDS areas picked by k
+        SplitRay cur;
+        split_ray_setup<QUAD>(A, q_first + pair + (PACK ? 2 * qi + k : qi) * stride, items, xcd, striped, rows, cw, first_row, per_xcd, chunks_per_item_ray, cur);
+        if (!PACK || k == 0) {
+          ray = cur;
+          st = CompositeState();
+          ray_stopped = false;
+          ray_b.valid = false;
+        } else {
+          ray_b = cur;
+        }
+        float* scratch_k = (PACK && k == 1) ? packs : scratch;
+        if constexpr (PACK) {
+          if (cur.valid) split_fill_edges(A, cur, (PER_SAMPLE ? cur.chunk : 0) * 64, k == 1 ? packs + 64 : tb_m, lane);
+          if (k == 0) my_dlogit = my_sel = my_sem = my_r = my_g = my_b = 0.f;
+        }
+        if (cur.valid) {
           // per-ray colour bias: bc0 + Wc0[:, sh].SH(d) + Wc0[:, app].app  (lane n = neuron n)
-          float sx = ray.dx, sy = ray.dy, sz = ray.dz;
+          float sx = cur.dx, sy = cur.dy, sz = cur.dz;
           if (!A.sh_unit) {
             sx = (sx + 1.f) / 2.f;
             sy = (sy + 1.f) / 2.f;
@@ -561,7 +626,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
 #pragma unroll
             for (int q = 0; q < 16; ++q) sh[q] = (float)(_Float16)sh[q];
           }
-          const long long row = A.app_per_camera ? A.cam_idx[ray.r] : 0;
+          const long long row = A.app_per_camera ? A.cam_idx[cur.r] : 0;
           float bias = A.app_bias[row * 64 + lane];
           const f32x4* wsh = reinterpret_cast<const f32x4*>(lds + OFF_WSH + lane * 16);
 #pragma unroll
@@ -573,18 +638,27 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
             bias = fmaf(w.w, sh[4 * q + 3], bias);
           }
           __builtin_amdgcn_wave_barrier();
-          scratch[lane] = bias;
+          scratch_k[lane] = bias;
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
         }
       }
-      if (ray.valid && !ray_stopped) {
-        const int chunk = PER_SAMPLE ? ray.chunk : (k >> 1), half = k & 1;
+      const bool live_m = PACK ? (k == 0 ? ray.valid : (k == 1 ? (ray.valid || ray_b.valid) : ray_b.valid)) : ray.valid;
+      if (live_m && !ray_stopped) {
+        const int chunk = PACK ? 0 : (PER_SAMPLE ? ray.chunk : (k >> 1)), half = PACK ? (k >= 1 ? 1 : 0) : (k & 1);
         const int c0 = chunk * 64;
-        if (half == 0) {
-          split_fill_edges(A, ray, c0, tb_m, lane);
-          my_dlogit = my_sel = my_sem = my_r = my_g = my_b = 0.f;
+        if constexpr (!PACK) {
+          if (half == 0) {
+            split_fill_edges(A, ray, c0, tb_m, lane);
+            my_dlogit = my_sel = my_sem = my_r = my_g = my_b = 0.f;
+          }
         }
+        // lane group of tile c: gb + c.  Unpacked: tiles (0, 1) of half-step `half` are lane rows 2 half, 2 half + 1.  PACK:
+        // (A0, A1) -> rows 0, 1; (A2, B0) -> rows 2, 3 (B0 moves to row 0 when A's row is done); (B1, B2) -> rows 1, 2
+        const int gb = PACK ? (k == 0 ? 0 : (k == 1 ? 2 : 1)) : 2 * half;
+        // per-ray colour bias of tile c (PACK: tile 1 of the middle half-step and both tiles of the last belong to ray B)
+        const float* cbias0 = (PACK && k == 2) ? packs : scratch;
+        const float* cbias1 = (PACK && k >= 1) ? packs : scratch;
         const float* xs = ring + (int)(hs & 1) * XCH_FLOATS;
         const f32x4* xv = reinterpret_cast<const f32x4*>(xs);
         f32x4 feat[2][2];
@@ -685,8 +759,8 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        const bool mine = (g >> 1) == half;
-        const bool odd = (g & 1) != 0;
+        const bool mine = PACK ? (g == gb || g == gb + 1) : ((g >> 1) == half);
+        const bool odd = PACK ? (g == gb + 1) : ((g & 1) != 0);
         {
           const float d0 = row0_broadcast(o16[0].x), d1 = row0_broadcast(o16[1].x);
           const float dsel = odd ? d1 : d0;
@@ -735,8 +809,9 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
         f32x4 c1[4][2];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-          const f32x4 cb = *reinterpret_cast<const f32x4*>(scratch + 16 * mt + 4 * g);
-          f32x4 acc[2] = {cb, cb};
+          const f32x4 cb = *reinterpret_cast<const f32x4*>(cbias0 + 16 * mt + 4 * g);
+          const f32x4 cb_1 = PACK ? *reinterpret_cast<const f32x4*>(cbias1 + 16 * mt + 4 * g) : cb;
+          f32x4 acc[2] = {cb, cb_1};
           if constexpr (F16) {
             const f16x8 a = blkh(10 + mt);
 #pragma unroll
@@ -822,7 +897,11 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
           const float b0 = group_sum(rgb_part[0][2]), b1 = group_sum(rgb_part[1][2]);
           my_b = mine ? (odd ? b1 : b0) : my_b;
         }
-        if (half == 1) {
+        // PACK: the middle half-step completes ray A (lanes 0..47 of the row), the last one ray B
+        const bool of_b = PACK && k == 2;
+        const SplitRay fr = of_b ? ray_b : ray;
+        const float* tb_f = of_b ? packs + 64 : tb_m;
+        if (half == 1 && fr.valid) {
           // ---- lane l holds sample c0 + l: composite the chunk -----------------------------------------------------------
           const float density = expf(my_dlogit) * my_sel;
           const float sem = my_sem + lds[OFF_MISC + 0];
@@ -831,11 +910,11 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
           const float cb = sigmoidf(my_b + lds[OFF_MISC + 3]);
           const int i = c0 + lane;
           const bool valid = i < S;
-          const float e0 = tb_m[lane], e1 = tb_m[lane + 1];
+          const float e0 = tb_f[lane], e1 = tb_f[lane + 1];
           const float mid = (e0 + e1) / 2.f;
           if (PER_SAMPLE) {
             if (valid) {
-              const long long o = ray.r * (long long)S + i;
+              const long long o = fr.r * (long long)S + i;
               if (A.s_density) A.s_density[o] = density;
               if (A.s_sem) A.s_sem[o] = sem;
               if (A.s_label) A.s_label[o] = (int64_t)semantics_label(sem);
@@ -845,15 +924,15 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
                 A.s_rgb[3 * o + 2] = cb;
               }
               if (A.s_pos) {
-                A.s_pos[3 * o + 0] = ray.ox + ray.dx * mid;
-                A.s_pos[3 * o + 1] = ray.oy + ray.dy * mid;
-                A.s_pos[3 * o + 2] = ray.oz + ray.dz * mid;
+                A.s_pos[3 * o + 0] = fr.ox + fr.dx * mid;
+                A.s_pos[3 * o + 1] = fr.oy + fr.dy * mid;
+                A.s_pos[3 * o + 2] = fr.oz + fr.dz * mid;
               }
             }
           } else {
           const float w = composite_chunk(st, valid, i == S - 1, e1 - e0, density, mid, cr, cg, cb, sem, A.eval_clamp != 0);
-          if (A.out_w && valid) A.out_w[ray.r * (long long)S + i] = w;
-          bool finish = k == nhalf - 1;
+          if (A.out_w && valid) A.out_w[fr.r * (long long)S + i] = w;
+          bool finish = PACK || k == nhalf - 1;
           if (!finish && A.early_stop > 0.f && __expf(-st.carry_dd) < A.early_stop) {  // wave-uniform
             // the samples behind this chunk carry less than the threshold in total weight: drop them (same rule and same
             // "last sample" stand-in as render_fused_kernel)
@@ -862,7 +941,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
             st.last_b = wave_read(A.eval_clamp ? nan_to_num(cb) : cb, 63);
             st.last_mid = wave_read(mid, 63);
             if (A.out_w)
-              for (int kk = c0 + 64 + lane; kk < S; kk += 64) A.out_w[ray.r * (long long)S + kk] = 0.f;
+              for (int kk = c0 + 64 + lane; kk < S; kk += 64) A.out_w[fr.r * (long long)S + kk] = 0.f;
             if (lane == 0) reinterpret_cast<volatile int*>(ring + PAIR_FLAGS)[2] = (int)qi;
             ray_stopped = true;
             finish = true;
@@ -870,7 +949,7 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
           if (finish) {
             const CompositeOut o = composite_finish(st, A.bg_mode, A.bg[0], A.bg[1], A.bg[2], A.eval_clamp != 0);
             if (lane == 0) {
-              const long long r = ray.r;
+              const long long r = fr.r;
               if (A.out_acc) A.out_acc[r] = o.acc;
               if (A.out_depth) A.out_depth[r] = o.depth;
               if (A.out_rgb) {
@@ -888,6 +967,19 @@ __global__ void __launch_bounds__(SPLIT_THREADS) render_split_kernel(FusedArgs A
             }
           }
           }  // !PER_SAMPLE
+        }
+        if constexpr (PACK) {
+          if (k == 1) {
+            // ray A's row is done: tile B0 sits in lane row 3 (lanes 48..63) and starts ray B's row at lanes 0..15
+            const int src = (lane + 48) & 63;
+            my_dlogit = __shfl(my_dlogit, src);
+            my_sel = __shfl(my_sel, src);
+            my_sem = __shfl(my_sem, src);
+            my_r = __shfl(my_r, src);
+            my_g = __shfl(my_g, src);
+            my_b = __shfl(my_b, src);
+            st = CompositeState();
+          }
         }
       }
     }

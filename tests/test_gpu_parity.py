@@ -746,6 +746,38 @@ def test_split_kernel_matches_fused(scene, ops, handles, S, width, monkeypatch):
     assert torch.isfinite(outs["1"]["rgb"]).all()
 
 
+@pytest.mark.parametrize("S", [48, 47, 33])
+@pytest.mark.parametrize("n,width", [(1600, 40), (1237, 0), (1, 0), (2, 0), (333, 37)])
+def test_packed_schedule_of_48_sample_rays_changes_no_bit(scene, ops, handles, S, n, width, monkeypatch):
+    """32 < S <= 48 in exact fp32 (the default method's 48 field samples per ray): render_split_kernel<..., PACK> walks a
+    pair's rays two at a time in three half-steps -- (A0, A1), (A2, B0), (B1, B2) -- instead of leaving every fourth 16-sample
+    tile empty.  Same arithmetic per ray: every output of the composited render (weights included, per-camera appearance,
+    proposal bins, with and without the image hint, whose striped schedule has empty slots in the middle of a pair's list) and
+    of the per-sample render is bit-identical to the one-ray-per-two-half-steps schedule (CN_SPLIT_PACK=0)."""
+    dp, fh, dh = handles
+    monkeypatch.setenv("CN_FUSED_SPLIT", "2")  # the producer/consumer kernel also for these small batches
+    rb = rays_with_box(scene, 1)
+    g = torch.Generator().manual_seed(S + n)
+    idx = torch.arange(n) if width else torch.randint(0, len(rb), (n,), generator=g)
+    o, d, ne, f = (to_dev(t[idx]) for t in (rb.origins, rb.directions, rb.nears, rb.fars))
+    cam = torch.randint(0, scene.c2w.shape[0], (n,), generator=g).cuda()
+    sc = ops.scene_struct(scene.aabb, True)
+    bins = ops.proposal_sample(dh, sc, o, d, ne, f, (64, 32), S)["euclidean_bins"] if n % 2 else None
+    opts = ops.render_opts(S, app_mode=2, image_width=width, pixel_start=0)
+    outs, samples = {}, {}
+    for pack in ("0", "1"):
+        monkeypatch.setenv("CN_SPLIT_PACK", pack)
+        outs[pack] = ops.render_rays(fh, sc, opts, o, d, ne, f, camera_indices=cam, bins=bins, want_weights=True)
+        samples[pack] = ops.render_samples(fh, sc, ops.render_opts(S, app_mode=2, eval_clamp=False), o, d, ne, f,
+                                           camera_indices=cam, bins=bins)
+    torch.cuda.synchronize()
+    for k in outs["0"]:
+        assert torch.equal(outs["0"][k], outs["1"][k]), f"composited {k}"
+    for k in samples["0"]:
+        assert torch.equal(samples["0"][k], samples["1"][k]), f"per-sample {k}"
+    assert torch.isfinite(outs["1"]["rgb"]).all() and float(outs["1"]["weights"].abs().sum()) > 0
+
+
 @pytest.mark.parametrize("S,contraction", [(192, False), (64, True), (100, False)])
 def test_split_bf16_matrix_option_meets_the_parity_bar(scene, ops, handles, S, contraction, monkeypatch):
     """cn_render_opts.matrix_precision = CN_MATRIX_SPLIT_BF16: the MLP products on v_mfma_f32_16x16x32_bf16 with operands
