@@ -48,42 +48,55 @@ L2_GATHER_PEAK_GBPS = 16800.0  # MI355X_MICROARCH.md, "Indexed rows": rows serve
 MFMA_F16_PEAK_TFLOPS = 2516.6  # v_mfma_f32_16x16x32_f16: 1024 FLOP/clk/SIMD x 4 SIMD x 256 CU x 2.4 GHz (dense; ~2.5 PF)
 L1_LOOKUPS_PER_SEC = 256 * 2.4e9  # per-lane-addressed loads: one L1 line lookup per clock and CU (tools/gather_rate_microbench.hip)
 ATOMIC_REQUESTS_PER_SEC = 21.07e9  # float-atomic requests the memory side takes (tools/atomic_microbench.hip)
-# float-atomic requests per iteration, MEASURED with the TCC atomic counters on tools/train_probe.py (default method, 48 field
-# samples per ray) at the two batch sizes bench.py times -- the set of cell-major levels depends on the batch size -- read
-# from the newest profiles/r*_pmc_train_atomics.json (TCC_ATOMIC == TCC_EA0_ATOMIC); fallback: the round-1 figures.
-FIELD_PART = {}  # {rays: requests of the field backward alone (48 field samples per ray)}, filled below
+# float-atomic requests per iteration, MEASURED with the TCC atomic counters (TCC_ATOMIC == TCC_EA0_ATOMIC) on the default method at
+# every (rays, field samples per ray) bench.py times -- the set of cell-major levels depends on the batch size -- read from the
+# newest profiles/r*_pmc_train_atomics.json; nothing is scaled or estimated any more (round 3 scaled the 192-sample figure).
 
 
 def _measured_atomic_requests():
-    """{rays: requests per iteration} for the iterations bench.py times (every one updates both proposal networks: one field
-    backward, two proposal backwards and their fold kernels), from the newest profiles/r*_pmc_train_atomics.json."""
+    """({"<rays>x<samples>": requests per iteration}, source).  The timed iterations all update both proposal networks (one field
+    backward, two proposal backwards, their fold kernels): so do the profiled ones (tools/pmc_workloads.py train)."""
     import glob
     import json as _json
 
-    per_ray_r1 = 48 * 72.94 + 2 * 5.372e6 / 4096  # round-1 figures (profiles/r01_v7_pmc_train_atomics.json), per ray
-    table = {4096: 4096 * per_ray_r1, 65536: 65536 * per_ray_r1}
-    src = "profiles/r01_v7_pmc_train_atomics.json (TCC_ATOMIC per launch, 4096 rays)"
     here = os.path.dirname(os.path.abspath(__file__))
-    files = sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_train_atomics.json")))
-    if files:
+    for f in sorted(glob.glob(os.path.join(here, "profiles", "r*_pmc_train_atomics.json")), reverse=True):
         try:
-            d = _json.load(open(files[-1]))
-            got = {}
-            for rays, k in d["rays"].items():
-                def avg(part):
-                    return next((v["TCC_ATOMIC_sum"]["avg_per_launch"] for n, v in k.items() if part in n), 0.0)
-                # one field backward + two proposal backwards + three folds of the cell-major records per iteration
-                got[int(rays)] = avg("field_backward_mfma_kernel") + 2 * avg("proposal_backward_kernel") + \
-                    3 * (avg("cell_scatter_fold_kernel") + avg("coarse_scatter_reduce_kernel"))
-                FIELD_PART[int(rays)] = avg("field_backward_mfma_kernel")
+            d = _json.load(open(f))
+            if "configs" in d:  # round 4 format: per iteration, every kernel of the process
+                got = {k: float(v["requests_per_iteration"]) for k, v in d["configs"].items()}
+            else:  # rounds 1-3: per launch of the named kernels at 48 field samples per ray
+                got = {}
+                for rays, k in d["rays"].items():
+                    avg = lambda part: next((v["TCC_ATOMIC_sum"]["avg_per_launch"] for n, v in k.items() if part in n), 0.0)
+                    got[f"{rays}x48"] = avg("field_backward_mfma_kernel") + 2 * avg("proposal_backward_kernel") + \
+                        3 * (avg("cell_scatter_fold_kernel") + avg("coarse_scatter_reduce_kernel"))
             if got:
-                table, src = got, f"profiles/{os.path.basename(files[-1])} @ {d.get('commit', '?')} (TCC_ATOMIC per launch at each batch size)"
+                return got, f"profiles/{os.path.basename(f)} @ {d.get('commit', '?')} (TCC_ATOMIC per iteration at each batch size, measured)"
         except (KeyError, StopIteration, ValueError, OSError):
-            pass
-    return table, src
+            continue
+    return {}, "no profiles/r*_pmc_train_atomics.json"
 
 
 ATOMIC_REQUESTS_PER_ITERATION, ATOMIC_REQUESTS_SOURCE = _measured_atomic_requests()
+
+
+def workload_traffic(name: str, units: float):
+    """(memory-side bytes for `units` of a secondary workload, source) from the newest profiles/r*_pmc_workloads.json
+    (tools/collect_pmc_workloads.sh: FETCH_SIZE + WRITE_SIZE of this library's kernels over a whole run of the workload, separate
+    rocprofv3 --pmc passes, divided by the units it processed).  Counters cannot be read inside this process: the figure is the
+    profiled bytes per unit times the units of THIS run, labelled with its source.  Raw counter values (no x2 on FETCH_SIZE: the
+    guide calibrates that for 16-byte streaming reads; these are 8-byte gathers and 4-byte atomics); Infinity-Cache hits count."""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_workloads.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            e = d["workloads"][name]
+            return int(e["bytes_per_unit"] * units), f"profiles/{os.path.basename(f)} @ {d.get('commit', '?')}: {e['bytes_per_unit']:.1f} B per {e['unit']}"
+        except (KeyError, ValueError, OSError):
+            continue
+    return None, "no profiles/r*_pmc_workloads.json entry"
 
 
 
@@ -556,8 +569,8 @@ def secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, o
     # chip-wide, its lower figure), not against HBM, whose 8 TB/s this kernel's algorithmic rate exceeds.
     out["proposal_mode"]["roofline"] = {
         "bound": "l2", "kernel": "proposal_sample_kernel", "achieved": round(alg / tp / 1e9, 1), "peak": L2_GATHER_PEAK_GBPS,
-        "unit": "GB/s", "frac": round(alg / tp / 1e9 / L2_GATHER_PEAK_GBPS, 4), "traffic": None,
-        "algorithmic_bytes_per_launch": alg, "bytes_per_sample": BYTES_PER_PROPOSAL_SAMPLE, "avg_launch_ms": round(tp * 1e3, 4),
+        "unit": "GB/s", "frac": round(alg / tp / 1e9 / L2_GATHER_PEAK_GBPS, 4), "traffic": workload_traffic("proposal", R)[0],
+        "traffic_source": workload_traffic("proposal", R)[1], "algorithmic_bytes_per_launch": alg, "bytes_per_sample": BYTES_PER_PROPOSAL_SAMPLE, "avg_launch_ms": round(tp * 1e3, 4),
         "limited_by": "one dependent chain per ray (gathers -> MLP on the matrix cores -> compositing scan -> cdf -> inverse cdf, "
                       "twice) at four waves per SIMD; ablation builds: 0.21 ms without the networks, 0.58 ms with the hash encoding"}
 
@@ -610,20 +623,16 @@ def secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, o
             train[key] = {"ms_per_iter": round(t * 1e3, 3), "rays_per_sec": nrays / t, "field_samples_per_ray": spp,
                           "field_samples_per_sec": nrays * spp / t}
             # The iteration's bound is the rate at which the memory side takes float-atomic requests (hash-grid gradient
-            # scatter), not HBM bytes or MFMA.  Requests per iteration are MEASURED (TCC_ATOMIC) at 48 field
-            # samples per ray for both batch sizes; at 192 the field backward's share is scaled by 4 (same requests per field
-            # sample, an upper bound: more samples per cell merge more) and labelled as an estimate.
-            req = ATOMIC_REQUESTS_PER_ITERATION.get(nrays, nrays / 4096.0 * ATOMIC_REQUESTS_PER_ITERATION.get(4096, 0.0))
+            # scatter), not HBM bytes or MFMA.  Requests per iteration are MEASURED (TCC_ATOMIC) for each of the
+            # three configurations.
+            req = ATOMIC_REQUESTS_PER_ITERATION.get(f"{nrays}x{spp}", 0.0)
             src = ATOMIC_REQUESTS_SOURCE
-            if spp != 48:
-                fld = FIELD_PART.get(nrays, 0.6 * req)
-                req = req + fld * (spp / 48.0 - 1.0)
-                src += f"; field-backward share scaled x{spp // 48} from the 48-sample measurement (estimate)"
+            t_bytes, t_src = workload_traffic(f"train_{nrays}x{spp}", 1)
             train[key]["roofline"] = {
                 "bound": "hbm", "kernel": "train_iteration (field_backward_mfma_kernel + 2 x proposal_backward_kernel scatter)",
                 "achieved": round(req / t / 1e9, 3), "peak": round(ATOMIC_REQUESTS_PER_SEC / 1e9, 2),
                 "unit": "G atomic requests/s (memory side; 64-byte read-modify-writes)", "frac": round(req / t / ATOMIC_REQUESTS_PER_SEC, 4),
-                "traffic": None, "atomic_requests_per_iteration": int(req),
+                "traffic": t_bytes, "traffic_source": t_src, "atomic_requests_per_iteration": int(req),
                 "requests_source": src,
                 "hbm_equivalent_GBps": round(req * 64 / t / 1e9, 1),
                 "limited_by": "the field backward (about half the iteration): 17 barrier-separated matrix phases per 32-sample tile "
@@ -672,12 +681,18 @@ def subsystem_timings(args, params, device):
     field_bytes_per_ray = cfg.num_nerf_samples_per_ray * BYTES_PER_SAMPLE
     prop_bytes_per_ray = n_prop * BYTES_PER_PROPOSAL_SAMPLE
 
-    def mixed_roofline(rays_, t_, kernel, limited_by):
+    def mixed_roofline(rays_, t_, kernel, limited_by, pmc=None):
+        """`pmc`: the workload of tools/pmc_workloads.py whose profiled memory-side bytes per ray price `traffic`."""
         bound_t = rays_ * (field_bytes_per_ray / (HBM_PEAK_GBPS * 1e9) + prop_bytes_per_ray / (L2_GATHER_PEAK_GBPS * 1e9))
-        return {"bound": "hbm+l2", "kernel": kernel, "achieved": round(rays_ * bytes_per_ray_default / t_ / 1e9, 1), "unit": "GB/s",
-                "peak": {"field_bytes_hbm": HBM_PEAK_GBPS, "proposal_bytes_l2": L2_GATHER_PEAK_GBPS},
-                "frac": round(bound_t / t_, 4), "traffic": None, "bytes_per_ray": bytes_per_ray_default,
-                "field_bytes_per_ray": field_bytes_per_ray, "proposal_bytes_per_ray": prop_bytes_per_ray, "limited_by": limited_by}
+        traffic, tsrc = workload_traffic(pmc, rays_) if pmc else (None, None)
+        r = {"bound": "hbm+l2", "kernel": kernel, "achieved": round(rays_ * bytes_per_ray_default / t_ / 1e9, 1), "unit": "GB/s",
+             "peak": {"field_bytes_hbm": HBM_PEAK_GBPS, "proposal_bytes_l2": L2_GATHER_PEAK_GBPS},
+             "frac": round(bound_t / t_, 4), "traffic": traffic, "bytes_per_ray": bytes_per_ray_default,
+             "field_bytes_per_ray": field_bytes_per_ray, "proposal_bytes_per_ray": prop_bytes_per_ray, "limited_by": limited_by}
+        if traffic is not None:
+            r["traffic_source"] = tsrc
+            r["memory_side_GBps"] = round(traffic / t_ / 1e9, 1)
+        return r
 
     # ---- ns-export pointcloud (BASELINE.json configs[3]): random training rays until 10 M points are kept ---------------------
     # exporter_utils_nerfacto.py:125-183.  Call sizes: 2 048 rays (the reference's copy, debug/exporter_nerfacto.py:91) and
@@ -720,7 +735,10 @@ def subsystem_timings(args, params, device):
                 "roofline": mixed_roofline(st["rays"], t_, "pixel_sample + raygen + proposal_sample_kernel + render kernel + "
                                            "pointcloud_compact_calls per launch",
                                            f"{st['calls_per_launch']} call(s) of {rays_per_call} rays per launch sequence"
-                                           + (" (HIP-graph replay)" if st.get("graph") else ""))}
+                                           + (" (HIP-graph replay)" if st.get("graph") else "") + "; RANDOM pixels of random cameras: "
+                                           "the field's gathers miss the L2 (profiled: ~108 KB of memory-side traffic per ray against "
+                                           "3 KB for the coherent rays of an image), i.e. the rate at which the memory side serves "
+                                           "scattered 64-byte requests bounds it, as it bounds the training forward", pmc="export_c4")}
 
     c4 = export_case(2048, 1 << 16, 10_000_000)
     c4["call_size_32768"] = export_case(32768, 1 << 16, 10_000_000)
@@ -764,7 +782,8 @@ def subsystem_timings(args, params, device):
                                    "float64 arrays inside the timed region, as sample_volume returns them"},
         "roofline": {"bound": "hbm", "kernel": "render_split_kernel<per-sample> + export_compact", "achieved": round(ns * BYTES_PER_SAMPLE / t / 1e9, 1),
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ns * BYTES_PER_SAMPLE / t / 1e9 / HBM_PEAK_GBPS, 4),
-                     "traffic": None, "bytes_per_sample": BYTES_PER_SAMPLE,
+                     "traffic": workload_traffic("dense_export", ns)[0], "traffic_source": workload_traffic("dense_export", ns)[1],
+                     "bytes_per_sample": BYTES_PER_SAMPLE,
                      "limited_by": "SIMD issue of the render kernel (as the headline) + 28 B per sample of per-sample outputs"},
         "workload": f"exporter.py semantic-pointcloud: {side} x {side} surface rays (reference: 3000 x 3000) x 3000 samples, 512 rays per "
                     "call; reference: scripts/exporter.py:75-77, export/exporter_utils.py:93-172"}
@@ -788,7 +807,7 @@ def subsystem_timings(args, params, device):
         "image": [H, W], "rays_inside_aabb": int(vr), "passes": 2, "rays_per_sec": 2 * vr / tj,
         "roofline": mixed_roofline(2 * vr, tj, "proposal_sample_kernel + render kernels (full pass, density-only occlusion pass)",
                                    "ray generation + AABB test for all 640 000 pixels, one index list of the rays inside the box, "
-                                   "then the two renders of those rays (sampler and 48-sample field pass each)"),
+                                   "then the two renders of those rays (sampler and 48-sample field pass each)", pmc="projection"),
         "workload": "get_outputs_for_projections, one camera x one sub-cluster AABB (0.3-wide box at the origin), 800 x 800: the "
                     "AABB-restricted render and the occlusion pass; reference: fruit_nerf.py:283-315"}
     # ---- the projection stage as the reference RUNS it (fruit_nerf.py:254-318, scripts/semantic_projection.py:132-170): every
@@ -855,7 +874,7 @@ def subsystem_timings(args, params, device):
                         "with_png_tree": round((n_jobs / t_bf) / (n_sub / t_pf), 2)},
             "roofline": mixed_roofline(2 * rays_run, t_b, "projection_test/gather/scatter + proposal_sample_kernel + render kernels",
                                        "two passes over the rays inside the boxes (sampler + 48-sample field pass; sampler + "
-                                       "density-only pass), one host synchronisation per batch")}
+                                       "density-only pass), one host synchronisation per batch", pmc="projection")}
 
     # boll-sized boxes: a 3DCotton boll is 3-5 cm of a plant that fills the +-1 scene box (0.03-0.05 units: ~55 pixels across
     # at 800 x 800 from the 0.8 orbit); the analytic plant of tools/pipeline.py has 0.13-0.17-wide bolls (~200 pixels across)
@@ -893,8 +912,8 @@ def subsystem_timings(args, params, device):
         "ms_per_image": round(ti * 1e3, 3), "spread_ms": {"min": round(ts_[0] * 1e3, 3), "max": round(ts_[-1] * 1e3, 3), "images": len(ts_)},
         "rays_per_sec": H * W / ti, "chunk_rays": int(cfg.eval_num_rays_per_chunk),
         "roofline": mixed_roofline(H * W, ti, "proposal_sample_kernel + render_split_kernel per 32 768-ray chunk",
-                                   "the sampler (0.6 ms per 65 536 rays) and a 48-sample field pass whose last 16-column tile of every "
-                                   "ray is empty (a quarter of the matrix work)"),
+                                   "the sampler (0.6 ms per 65 536 rays) and the 48-sample field pass (two rays per three half-steps since "
+                                   "round 4: no empty column tiles), both at SIMD issue", pmc="eval_image"),
         "workload": "get_outputs_for_camera_ray_bundle, default method ((256, 96) proposal + 48 field samples), ray generation "
                     "included; reference: fruit_nerf.py:377-404"}
     # ---- the same at the resolution and from the poses of the reference's one real capture (fruit_nerf/utils/transforms.json:
@@ -930,7 +949,7 @@ def subsystem_timings(args, params, device):
             "ms_per_image": round(tc * 1e3, 3), "spread_ms": {"min": round(tsc[0] * 1e3, 3), "max": round(tsc[-1] * 1e3, 3), "images": len(tsc)},
             "rays_per_sec": Hc * Wc / tc, "image": [Hc, Wc], "cameras": len(cap_cams),
             "roofline": mixed_roofline(Hc * Wc, tc, "proposal_sample_kernel + render_split_kernel per 32 768-ray chunk",
-                                       "as eval_image_800 (the sampler + a 48-sample field pass), 4.3 x the rays"),
+                                       "as eval_image_800 (the sampler + a 48-sample field pass), 4.3 x the rays", pmc="eval_image"),
             "workload": "get_outputs_for_camera_ray_bundle at the resolution and from the (centred, unit-box-scaled) poses of the "
                         "reference's real capture file, default method, random-init model; reference: fruit_nerf.py:377-404, "
                         "fruit_nerf/utils/transforms.json"}

@@ -107,6 +107,8 @@ SIGNATURES = {
     "cn_raygen_ortho": (C.c_int, [_P, C.POINTER(_F), _I64, _I64, _P, _P, _P, _P, _P, _P]),
     "cn_surface_grid": (C.c_int, [_F, _F, _I32, _F, _F, _I32, _F, _P, _P]),
     "cn_apply_pose_adjustment": (C.c_int, [_P, _P, _I64, _P, _P, _P]),
+    "cn_apply_pose_adjustment_to": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P, _P]),
+    "cn_train_epilogue": (C.c_int, [_P, _I64, _I32, _F, _F, _P, _I32, _P, _P]),
     "cn_projection_test": (C.c_int, [_P, _I32, _I64, _I32, _I32, _P, _P, _P, _P]),
     "cn_projection_gather": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cn_projection_scatter": (C.c_int, [_P, _P, _P, _I64, _F, _P, _P, _P, _P, _P]),

@@ -109,8 +109,8 @@ surface_grid_kernel(float x0, float x1, int nx, float y0, float y1, int ny, floa
 }
 
 __global__ void __launch_bounds__(256)
-pose_adjust_kernel(const float* __restrict__ adj, const int64_t* __restrict__ cam, long long n, float* __restrict__ o,
-                   float* __restrict__ d) {
+pose_adjust_kernel(const float* __restrict__ adj, const int64_t* __restrict__ cam, long long n, const float* o_in,
+                   const float* d_in, float* o, float* d) {  // o_in / d_in may alias o / d (the in-place form)
   for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < n; r += (long long)gridDim.x * blockDim.x) {
     const float* a = adj + 6 * cam[r];
     float tx = a[0], ty = a[1], tz = a[2], wx = a[3], wy = a[4], wz = a[5];
@@ -127,10 +127,10 @@ pose_adjust_kernel(const float* __restrict__ adj, const int64_t* __restrict__ ca
     float r00 = f2 * s00 + 1.f, r01 = f1 * k01 + f2 * s01, r02 = f1 * k02 + f2 * s02;
     float r10 = f1 * k10 + f2 * s10, r11 = f2 * s11 + 1.f, r12 = f1 * k12 + f2 * s12;
     float r20 = f1 * k20 + f2 * s20, r21 = f1 * k21 + f2 * s21, r22 = f2 * s22 + 1.f;
-    float dx = d[3 * r], dy = d[3 * r + 1], dz = d[3 * r + 2];
-    o[3 * r + 0] += tx;
-    o[3 * r + 1] += ty;
-    o[3 * r + 2] += tz;
+    float dx = d_in[3 * r], dy = d_in[3 * r + 1], dz = d_in[3 * r + 2];
+    o[3 * r + 0] = o_in[3 * r + 0] + tx;
+    o[3 * r + 1] = o_in[3 * r + 1] + ty;
+    o[3 * r + 2] = o_in[3 * r + 2] + tz;
     d[3 * r + 0] = r00 * dx + r01 * dy + r02 * dz;
     d[3 * r + 1] = r10 * dx + r11 * dy + r12 * dz;
     d[3 * r + 2] = r20 * dx + r21 * dy + r22 * dz;
@@ -208,8 +208,21 @@ extern "C" int cn_apply_pose_adjustment(const float* pose_adjustment, const int6
              "cn_apply_pose_adjustment: null argument");
   if (num_rays <= 0) return CN_OK;
   hipLaunchKernelGGL(cn::pose_adjust_kernel, dim3(cn::grid_for(num_rays, 256, 8192)), dim3(256), 0,
-                     cn::as_stream(stream), pose_adjustment, camera_indices, (long long)num_rays, origins, directions);
+                     cn::as_stream(stream), pose_adjustment, camera_indices, (long long)num_rays, origins, directions, origins,
+                     directions);
   return cn::check_launch("cn_apply_pose_adjustment");
+}
+
+extern "C" int cn_apply_pose_adjustment_to(const float* pose_adjustment, const int64_t* camera_indices, int64_t num_rays,
+                                           const float* origins, const float* directions, float* out_origins,
+                                           float* out_directions, cn_stream_t stream) {
+  CN_REQUIRE(pose_adjustment && camera_indices && origins && directions && out_origins && out_directions, CN_ERR_INVALID,
+             "cn_apply_pose_adjustment_to: null argument");
+  if (num_rays <= 0) return CN_OK;
+  hipLaunchKernelGGL(cn::pose_adjust_kernel, dim3(cn::grid_for(num_rays, 256, 8192)), dim3(256), 0,
+                     cn::as_stream(stream), pose_adjustment, camera_indices, (long long)num_rays, origins, directions,
+                     out_origins, out_directions);
+  return cn::check_launch("cn_apply_pose_adjustment_to");
 }
 
 extern "C" int cn_embedding_mean(const float* embedding, int32_t num_images, int32_t dim, float* mean,

@@ -390,6 +390,36 @@ pose_regularizer_kernel(const float* __restrict__ adj, int C, float trans, float
   if (lane_id() == 0 && local != 0.f) atomicAdd(loss_out, local);
 }
 
+// get_loss_dict (fruit_nerf.py:601-615) and the scalar part of get_metrics_dict (:639-645) from the kernels' loss sums, in ONE
+// launch (the host composed them from ~12 one-element ATen kernels per iteration): out[0] rgb_loss = sum / (3 R); [1]
+// semantics_loss = weight * sum / R; [2] interlevel_loss = mult * sum / (R S); [3] camera_opt_regularizer (already a mean);
+// [4] psnr = -10 log10(rgb_loss); [5] / [6] the Frobenius norms of the translation / rotation halves of pose_adjustment
+// (CameraOptimizer.get_metrics_dict); [7] unused.
+__global__ void __launch_bounds__(64)
+train_epilogue_kernel(const float* __restrict__ sums, double inv_3r, double sem_over_r, double inter_over_rs,
+                      const float* __restrict__ pose, int C, float* __restrict__ out) {
+  float t2 = 0.f, r2 = 0.f;
+  if (pose)
+    for (int c = threadIdx.x; c < C; c += 64) {
+      const float* v = pose + 6 * c;
+      t2 += v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+      r2 += v[3] * v[3] + v[4] * v[4] + v[5] * v[5];
+    }
+  t2 = wave_sum(t2);
+  r2 = wave_sum(r2);
+  if (threadIdx.x == 0) {
+    const float rgb = (float)((double)sums[0] * inv_3r);
+    out[0] = rgb;
+    out[1] = (float)((double)sums[1] * sem_over_r);
+    out[2] = (float)((double)sums[2] * inter_over_rs);
+    out[3] = sums[3];
+    out[4] = -10.f * log10f(rgb);
+    out[5] = sqrtf(t2);
+    out[6] = sqrtf(r2);
+    out[7] = 0.f;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 adam_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                  long long n, float step_size, float beta1, float beta2, float omb1, float omb2, float inv_sqrt_bc2,
@@ -529,6 +559,17 @@ extern "C" int cn_pose_adjustment_backward(const float* pose_adjustment, const i
                      cn::as_stream(stream), pose_adjustment, camera_indices, directions_raw, d_origins, d_directions,
                      (long long)num_rays, grad_pose);
   return cn::check_launch("cn_pose_adjustment_backward");
+}
+
+extern "C" int cn_train_epilogue(const float* loss_sums, int64_t num_rays, int32_t num_samples, float semantic_loss_weight,
+                                 float interlevel_loss_mult, const float* pose_adjustment, int32_t num_cameras, float* out,
+                                 cn_stream_t stream) {
+  CN_REQUIRE(loss_sums && out && num_rays > 0 && num_samples > 0, CN_ERR_INVALID, "cn_train_epilogue: bad argument");
+  const double r = (double)num_rays;
+  hipLaunchKernelGGL(cn::train_epilogue_kernel, dim3(1), dim3(64), 0, cn::as_stream(stream), loss_sums, 1.0 / (3.0 * r),
+                     (double)semantic_loss_weight / r, (double)interlevel_loss_mult / (r * (double)num_samples),
+                     pose_adjustment, pose_adjustment ? num_cameras : 0, out);
+  return cn::check_launch("cn_train_epilogue");
 }
 
 extern "C" int cn_pose_regularizer(const float* pose_adjustment, int32_t num_cameras, float trans_l2_penalty,

@@ -149,6 +149,8 @@ class FruitTrainer:
         self._sampler_step = 0
         self._gen = torch.Generator(device="cpu").manual_seed(seed)
         self.loss_sums = torch.zeros(4, device=dev)
+        self._zeroed = None    # [6 R + 8]: ray-gradient accumulators | loss sums, one fill per iteration (forward_backward)
+        self._epilogue = None  # cn_train_epilogue's output of the last forward_backward
 
     # ------------------------------------------------------------------------------------------------------
     def set_anneal(self, step: int) -> None:
@@ -185,11 +187,16 @@ class FruitTrainer:
             raise AttributeError("Camera indices are not provided.")
         cam = rb.camera_indices.reshape(-1).to(torch.int64).contiguous()
         d_raw = rb.directions
-        o, d = rb.origins.clone(), rb.directions.clone()
         pose = m.params["camera_optimizer.pose_adjustment"]
-        ops.apply_pose_adjustment(pose, cam, o, d)
+        o, d = torch.empty_like(rb.origins), torch.empty_like(rb.directions)
+        ops.apply_pose_adjustment_to(pose, cam, rb.origins, rb.directions, o, d)  # (out of place: no clones of the raw rays)
+        # one zeroed buffer per iteration: the ray-gradient accumulators and the four loss sums (one fill instead of three)
+        if self._zeroed is None or self._zeroed.numel() != 6 * R + 8:
+            self._zeroed = torch.empty(6 * R + 8, device=dev)
+            self.loss_sums = self._zeroed[6 * R:6 * R + 4]
+        self._zeroed.zero_()
         if self.train_pose:
-            d_o, d_d = torch.zeros(R, 3, device=dev), torch.zeros(R, 3, device=dev)
+            d_o, d_d = self._zeroed[:3 * R].view(R, 3), self._zeroed[3 * R:6 * R].view(R, 3)
         nears = rb.nears if rb.nears is not None else torch.full((R, 1), float(cfg.near_plane), device=dev)
         fars = rb.fars if rb.fars is not None else torch.full((R, 1), float(cfg.far_plane), device=dev)
         n_lvl = len(m.proposal_networks)
@@ -237,7 +244,6 @@ class FruitTrainer:
             opts = ops.render_opts(S, app_mode=L.APP_PER_CAMERA, sh_unit_dir=cfg.sh_input == "unit", eval_clamp=False)
             fo = ops.render_samples(m.field, scene, opts, o, d, nears, fars, camera_indices=cam, bins=eu.contiguous())
         # ---- renderer + losses + their backward ------------------------------------------------------------------------
-        self.loss_sums.zero_()
         image = batch["image"].to(dev)[:, :3].to(torch.float32).contiguous()
         mask = batch["fruit_mask"].to(dev).to(torch.float32).reshape(R, 1).contiguous()
         rb_out = ops.train_render_backward(starts, ends, fo["density"], fo["rgb"], fo["semantics"], image, mask,
@@ -308,11 +314,12 @@ class FruitTrainer:
             ops.pose_regularizer(pose, gp, self.loss_sums[3:4], self.trans_l2_penalty, self.rot_l2_penalty)
             ready("camera_opt")
         self._last_bins, self._last_weights = bins, rb_out["weights"]
-        sums = self.loss_sums
-        loss_dict = {"rgb_loss": sums[0] / (3.0 * R), "semantics_loss": cfg.semantic_loss_weight * sums[1] / R,
-                     "interlevel_loss": cfg.interlevel_loss_mult * sums[2] / (R * S)}
+        # get_loss_dict + the scalar metrics in one launch (cn_train_epilogue); the dictionary holds views of its output
+        ep = self._epilogue = ops.train_epilogue(self.loss_sums, R, S, cfg.semantic_loss_weight, cfg.interlevel_loss_mult,
+                                                 pose if self.train_pose else None)
+        loss_dict = {"rgb_loss": ep[0], "semantics_loss": ep[1], "interlevel_loss": ep[2]}
         if self.train_pose:
-            loss_dict["camera_opt_regularizer"] = sums[3]
+            loss_dict["camera_opt_regularizer"] = ep[3]
         return {"loss_dict": loss_dict, "rgb": rb_out["rgb"], "semantics": rb_out["semantics"],
                 "accumulation": rb_out["accumulation"]}
 
@@ -411,11 +418,10 @@ class FruitTrainer:
 
     def get_metrics_dict(self, out) -> Dict[str, Tensor]:
         """``get_metrics_dict`` (``fruit_nerf.py:639-645``): PSNR and the distortion metric of the last batch."""
-        mse = out["loss_dict"]["rgb_loss"]
-        md = {"psnr": -10.0 * torch.log10(mse),
+        ep = self._epilogue  # of the forward_backward that produced `out` (the pose norms are those BEFORE the optimiser step,
+        md = {"psnr": ep[4],  # as nerfstudio's get_train_loss_dict computes its metrics before the step)
               "distortion": ops.distortion_metric(self._last_bins, self._last_weights)}
         if self.train_pose:  # CameraOptimizer.get_metrics_dict (fruit_nerf.py:644)
-            pose = self.model.params["camera_optimizer.pose_adjustment"]
-            md["camera_opt_translation"] = pose[:, :3].norm()
-            md["camera_opt_rotation"] = pose[:, 3:].norm()
+            md["camera_opt_translation"] = ep[5]
+            md["camera_opt_rotation"] = ep[6]
         return md

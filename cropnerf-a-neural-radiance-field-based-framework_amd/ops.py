@@ -407,6 +407,30 @@ def projection_paste(jobs: Tensor, job_of_slot: Tensor, slot_values: Tensor, ima
     return images
 
 
+def apply_pose_adjustment_to(pose_adjustment: Tensor, camera_indices: Tensor, origins: Tensor, directions: Tensor,
+                             out_origins: Tensor, out_directions: Tensor) -> None:
+    """``cn_apply_pose_adjustment_to``: the tweak written to separate outputs (the inputs stay as they are)."""
+    lib = L.load()
+    L.check(lib.cn_apply_pose_adjustment_to(_p(_f32(pose_adjustment, "pose_adjustment")),
+                                            _p(_i64(camera_indices, "camera_indices")), origins.shape[0],
+                                            _p(_f32(origins, "origins")), _p(_f32(directions, "directions")),
+                                            _p(_f32(out_origins, "out_origins")), _p(_f32(out_directions, "out_directions")),
+                                            _stream(origins)))
+
+
+def train_epilogue(loss_sums: Tensor, num_rays: int, num_samples: int, semantic_loss_weight: float,
+                   interlevel_loss_mult: float, pose_adjustment: Optional[Tensor], out: Optional[Tensor] = None) -> Tensor:
+    """``cn_train_epilogue``: [rgb_loss, semantics_loss, interlevel_loss, camera_opt_regularizer, psnr, |t|, |w|, 0]."""
+    lib = L.load()
+    if out is None:
+        out = torch.empty(8, device=loss_sums.device)
+    C_ = 0 if pose_adjustment is None else pose_adjustment.shape[0]
+    L.check(lib.cn_train_epilogue(_p(_f32(loss_sums, "loss_sums")), num_rays, num_samples, semantic_loss_weight,
+                                  interlevel_loss_mult, _p(_f32(pose_adjustment, "pose_adjustment")), C_, _p(_f32(out, "out")),
+                                  _stream(loss_sums)))
+    return out
+
+
 def embedding_mean(embedding: Tensor) -> Tensor:
     lib = L.load()
     out = torch.empty(embedding.shape[1], device=embedding.device)

@@ -259,6 +259,10 @@ int cn_surface_grid(float x0, float x1, int32_t nx, float y0, float y1, int32_t 
  * origins/directions are updated in place. */
 int cn_apply_pose_adjustment(const float* pose_adjustment /*[C,6]*/, const int64_t* camera_indices,
                              int64_t num_rays, float* origins, float* directions, cn_stream_t stream);
+/* The same out of place (the training step keeps the raw rays for the pose gradient: no clone before the tweak). */
+int cn_apply_pose_adjustment_to(const float* pose_adjustment, const int64_t* camera_indices, int64_t num_rays,
+                                const float* origins, const float* directions, float* out_origins,
+                                float* out_directions, cn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Batched semantic projection (FruitModel.get_outputs_for_projections, fruit_nerf/fruit_nerf.py:254-318)
@@ -566,6 +570,14 @@ int cn_ray_backward(const float* d_positions /*[R,S,3]*/, const float* d_dir_sam
 int cn_pose_adjustment_backward(const float* pose_adjustment /*[C,6]*/, const int64_t* camera_indices,
                                 const float* directions_raw /*[R,3]*/, const float* d_origins,
                                 const float* d_directions, int64_t num_rays, float* grad_pose, cn_stream_t stream);
+
+/* get_loss_dict (fruit_nerf/fruit_nerf.py:601-615) + the scalar metrics of get_metrics_dict (:639-645) from the loss sums
+ * the training kernels left in loss_sums[4] = {sum (rgb - image)^2, sum BCE, sum interlevel terms, camera regulariser}:
+ * out[8] = {rgb_loss, semantics_loss, interlevel_loss, camera_opt_regularizer, psnr, |translations|, |rotations|, 0}
+ * (pose_adjustment NULL: the two norms are 0).  One launch instead of a dozen one-element host-composed kernels. */
+int cn_train_epilogue(const float* loss_sums, int64_t num_rays, int32_t num_samples, float semantic_loss_weight,
+                      float interlevel_loss_mult, const float* pose_adjustment /*[C,6] or NULL*/, int32_t num_cameras,
+                      float* out, cn_stream_t stream);
 
 /* camera_opt_regularizer of CameraOptimizer.get_loss_dict (fruit_nerf/fruit_nerf.py:614):
  * mean_c |t_c| * trans_l2_penalty + mean_c |w_c| * rot_l2_penalty; adds the loss to *loss_out and, when grad_pose

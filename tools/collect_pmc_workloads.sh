@@ -16,11 +16,11 @@ pass() {  # name, counter group, program arguments / environment come from the c
   timeout -k 10 300 rocprofv3 --pmc $group --output-format csv -d $d -- python3 $ROOT/tools/pmc_workloads.py "$@" > $d/run.log 2>&1
   echo "$name [$group]: rc=$? $(grep PMC_UNITS $d/run.log | tail -1)"
 }
-for W in eval_image projection export_c4 dense_export; do
+for W in ${PMC_WORKLOADS:-eval_image projection export_c4 dense_export proposal}; do
   pass $W "FETCH_SIZE" $W
   pass $W "WRITE_SIZE" $W
 done
-for CFG in "4096 48" "65536 48" "65536 192"; do
+[ -n "$PMC_SKIP_TRAIN" ] || for CFG in "4096 48" "65536 48" "65536 192"; do
   set -- $CFG
   export TRAIN_RAYS=$1 TRAIN_FIELD_SAMPLES=$2
   N=train_${1}x${2}
