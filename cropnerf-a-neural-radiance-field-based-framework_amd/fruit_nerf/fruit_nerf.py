@@ -167,10 +167,10 @@ class FruitModel:
             N = cfg.proposal_weights_anneal_max_num_iters
 
             def set_anneal(step):
+                from .schedules import proposal_weights_anneal
+
                 self.step = step
-                train_frac = float(np.clip(step / N, 0, 1))
-                b = cfg.proposal_weights_anneal_slope
-                self.set_anneal(b * train_frac / ((b - 1) * train_frac + 1))
+                self.set_anneal(proposal_weights_anneal(step, N, cfg.proposal_weights_anneal_slope))
 
             def step_cb(step):  # ProposalNetworkSampler.step_cb
                 self._sampler_step = step

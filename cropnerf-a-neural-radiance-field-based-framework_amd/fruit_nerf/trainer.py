@@ -40,6 +40,7 @@ from .. import _lib as L
 from .. import ops
 from ..rays import RayBundle
 from .fruit_nerf import FruitModel
+from .schedules import proposal_update_schedule, proposal_weights_anneal
 
 
 @dataclass
@@ -158,15 +159,13 @@ class FruitTrainer:
         cfg = self.model.config
         if not cfg.use_proposal_weight_anneal:
             return
-        frac = float(np.clip(step / cfg.proposal_weights_anneal_max_num_iters, 0, 1))
-        b = cfg.proposal_weights_anneal_slope
-        self.model.set_anneal(b * frac / ((b - 1) * frac + 1))
+        self.model.set_anneal(proposal_weights_anneal(step, cfg.proposal_weights_anneal_max_num_iters,
+                                                      cfg.proposal_weights_anneal_slope))
 
     def proposal_update_due(self, step: int) -> bool:
         """``ProposalNetworkSampler``: proposal densities carry gradient only when this is true."""
         cfg = self.model.config
-        sched = float(np.clip(np.interp(step, [0, cfg.proposal_warmup], [0, cfg.proposal_update_every]), 1,
-                              cfg.proposal_update_every))
+        sched = proposal_update_schedule(step, cfg.proposal_warmup, cfg.proposal_update_every)
         return self._steps_since_update > sched or step < 10
 
     def forward_backward(self, ray_bundle: RayBundle, batch: Dict[str, Tensor],

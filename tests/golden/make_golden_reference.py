@@ -22,6 +22,10 @@ that holds only the libraries they use, and runs them on seeded inputs:
     fruit_nerf/components/ray_generators.py                 class OrthographicRayGenerator :22-66 (round 3): the class definition,
                                                             on torch's real nn.Module, with RayBundle a record of its keywords
 
+    fruit_nerf/fruit_nerf.py                                update_schedule :144-149 and set_anneal / bias :206-216 (round 4): the two
+                                                            nested closures of the hot path that are the reference's own code, executed
+                                                            on an object that holds the config fields they read
+
 Nothing of the reference is copied into the repository: the fixture holds inputs and outputs only.  The oracle
 (``oracle/zbuffer.py``, ``oracle/rays.py``), the host mirrors (``cropnerf_amd/segmentation/merger.py``,
 ``fruit_nerf/data/fruit_datamanager.py``) and the HIP kernels (``cn_depth_project``, ``cn_zbuffer_update*``,
@@ -252,6 +256,50 @@ def ortho_cases(out):
     out["num_og"] = np.array(case)
 
 
+def extract_nested(path, class_name, method, inner, namespace):
+    """exec the FunctionDef `inner` that is nested (at any depth) inside `class_name.method` of the module at `path`, as a
+    module-level function of `namespace` -- the names it closes over (`self`, `N`, `np`) are then looked up there."""
+    with open(path, encoding="utf-8") as f:
+        tree = ast.parse(f.read(), filename=path)
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == class_name:
+            for sub in node.body:
+                if isinstance(sub, ast.FunctionDef) and sub.name == method:
+                    for n in ast.walk(sub):
+                        if isinstance(n, ast.FunctionDef) and n.name == inner:
+                            exec(compile(ast.Module(body=[n], type_ignores=[]), path, "exec"), namespace)
+                            return namespace
+    raise RuntimeError(f"{path}: {class_name}.{method}.{inner} not found")
+
+
+def schedule_cases(out):
+    """The two closures of the hot path that are the reference's own code (fruit_nerf/fruit_nerf.py): `update_schedule`
+    (:144-149, nested in populate_modules: after how many steps the proposal networks get a gradient) and `set_anneal` with its
+    inner `bias` (:206-216, nested in get_training_callbacks: the proposal-weight annealing exponent, arXiv 2111.12077 eq. 18).
+    Executed unchanged on an object that holds the config fields they read (nerfacto's defaults) and a sampler that records
+    what `set_anneal` hands it."""
+    path = f"{REF}/fruit_nerf/fruit_nerf.py"
+    cfg = Record(proposal_warmup=5000, proposal_update_every=5, proposal_weights_anneal_slope=10.0,
+                 proposal_weights_anneal_max_num_iters=1000)
+    seen = []
+    fake = Record(config=cfg, proposal_sampler=Record(set_anneal=lambda a: seen.append(float(a))), step=0)
+    ns = {"np": np, "self": fake}
+    extract_nested(path, "FruitModel", "populate_modules", "update_schedule", ns)
+    steps = np.array([0, 1, 9, 10, 999, 1000, 1001, 2499, 2500, 4999, 5000, 5001, 39999], dtype=np.int64)
+    out["sched_steps"] = steps
+    out["sched_values"] = np.array([float(ns["update_schedule"](int(s))) for s in steps], dtype=np.float64)
+    out["sched_config"] = np.array([cfg.proposal_warmup, cfg.proposal_update_every], dtype=np.float64)
+    ns2 = {"np": np, "self": fake, "N": cfg.proposal_weights_anneal_max_num_iters}
+    extract_nested(path, "FruitModel", "get_training_callbacks", "set_anneal", ns2)
+    asteps = np.array([0, 1, 2, 10, 100, 250, 500, 999, 1000, 1001, 5000], dtype=np.int64)
+    for s in asteps:
+        ns2["set_anneal"](int(s))
+    assert len(seen) == len(asteps)
+    out["anneal_steps"] = asteps
+    out["anneal_values"] = np.array(seen, dtype=np.float64)
+    out["anneal_config"] = np.array([cfg.proposal_weights_anneal_slope, cfg.proposal_weights_anneal_max_num_iters], dtype=np.float64)
+
+
 def main():
     out = {}
     projection_cases(out)
@@ -259,6 +307,7 @@ def main():
     merger_cases(out)
     sampler_cases(out)
     ortho_cases(out)
+    schedule_cases(out)
     path = os.path.join(HERE, "reference_functions.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path), "bytes", len(out), "arrays")

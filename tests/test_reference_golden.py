@@ -209,3 +209,70 @@ def test_hip_ortho_raygen_reproduces_the_reference(gold):
         for name in ("directions", "fars"):
             err = np.abs(out[name].cpu().numpy() - gold[f"{k}/{name}"]).max()
             assert err <= 2.4e-7, f"{k} {name}: {err:.3e}"  # normalize / norm: one fp32 ulp of a value <= 2
+
+
+def test_schedule_mirrors_reproduce_the_references_closures(gold):
+    """``update_schedule`` (``fruit_nerf.py:144-149``) and ``set_anneal`` / ``bias`` (``:206-216``), the two closures of the hot
+    path that are the reference's own code, executed from source by ``make_golden_reference.py``: the mirrors in
+    ``fruit_nerf/schedules.py`` (used by ``FruitTrainer`` and ``FruitModel.get_training_callbacks``) give the same numbers."""
+    from cropnerf_amd.fruit_nerf.schedules import proposal_update_schedule, proposal_weights_anneal
+
+    warmup, every = (int(v) for v in gold["sched_config"])
+    got = [proposal_update_schedule(int(s), warmup, every) for s in gold["sched_steps"]]
+    assert np.array_equal(np.array(got), gold["sched_values"])
+    slope, n_iters = float(gold["anneal_config"][0]), int(gold["anneal_config"][1])
+    got = [proposal_weights_anneal(int(s), n_iters, slope) for s in gold["anneal_steps"]]
+    assert np.array_equal(np.array(got), gold["anneal_values"])
+    # the defaults the vectors were made with are the model config's
+    from cropnerf_amd.config import FruitNerfModelConfig
+
+    c = FruitNerfModelConfig()
+    assert (c.proposal_warmup, c.proposal_update_every) == (warmup, every)
+    assert (c.proposal_weights_anneal_slope, c.proposal_weights_anneal_max_num_iters) == (slope, n_iters)
+
+
+@pytest.mark.gpu
+def test_trainer_and_sampler_follow_the_references_schedules(gold):
+    """The same vectors through the product: ``FruitTrainer.set_anneal`` / ``FruitModel.get_training_callbacks`` set the
+    reference's annealing exponents, ``proposal_update_due`` follows ``update_schedule``, and ``cn_proposal_sample``'s ``anneal``
+    input resamples on ``weights ** anneal`` as the oracle does for each of those exponents."""
+    from _helpers import assert_close, dev_params, make_scene, product_specs, rays_with_box, to_dev
+    from cropnerf_amd import ops
+    from cropnerf_amd.config import FruitNerfModelConfig
+    from cropnerf_amd.fruit_nerf.fruit_nerf import FruitModel, Semantics
+    from cropnerf_amd.fruit_nerf.trainer import FruitTrainer
+    from cropnerf_amd.rays import SceneBox
+    from oracle import samplers as OSM
+
+    sc = make_scene(seed=2, log2_T=14, num_images=3, height=16, width=16, focal=22.0, prop_log2_T=12)
+    pl = [{"hidden_dim": 16, "log2_hashmap_size": p.grid.log2_hashmap_size, "num_levels": 5, "max_res": p.grid.max_res}
+          for p in sc.pspecs]
+    model = FruitModel(FruitNerfModelConfig(log2_hashmap_size=14, proposal_net_args_list=pl), SceneBox(sc.aabb), 3,
+                       {"semantics": Semantics()}, device="cuda", params=sc.params)
+    tr = FruitTrainer(model)
+    for s, a in zip(gold["anneal_steps"], gold["anneal_values"]):
+        tr.set_anneal(int(s))
+        assert model._anneal == float(a)
+    cb = model.get_training_callbacks()[0]
+    for s, a in zip(gold["anneal_steps"], gold["anneal_values"]):
+        cb.run_callback(int(s))
+        assert model._anneal == float(a)
+    for s, v in zip(gold["sched_steps"], gold["sched_values"]):
+        for since in (1, 2, 3, 5, 6):
+            tr._steps_since_update = since
+            assert tr.proposal_update_due(int(s)) == (since > float(v) or int(s) < 10), (int(s), since)
+    # the sampler's anneal input, at three of the reference's exponents
+    from oracle import field as OF
+
+    fspec, pspecs = product_specs(sc)
+    dp = dev_params(sc)
+    dh = [ops.DensityHandle(dp, i, ps) for i, ps in enumerate(pspecs)]
+    rb = rays_with_box(sc, 1, 200)
+    scene = ops.scene_struct(sc.aabb, True)
+    dens = [lambda pos, i=i: OF.proposal_density(pos, sc.params, i, sc.pspecs[i], sc.aabb, True) for i in range(2)]
+    for a in (float(gold["anneal_values"][1]), float(gold["anneal_values"][4]), 1.0):
+        ref = OSM.proposal_sampler(rb, dens, (64, 32), 24, anneal=a)
+        got = ops.proposal_sample(dh, scene, to_dev(rb.origins), to_dev(rb.directions), to_dev(rb.nears), to_dev(rb.fars),
+                                  (64, 32), 24, anneal=a)
+        ref_eu = torch.cat([ref[0].starts[..., 0], ref[0].ends[:, -1:, 0]], -1)
+        assert_close(got["euclidean_bins"], ref_eu, 2e-3, 2e-4, f"final bins at anneal {a:.4f}", frac_ok=0.99)

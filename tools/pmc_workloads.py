@@ -3,7 +3,7 @@ divide cleanly by the units it processed (tools/collect_pmc_workloads.sh runs it
 tools/summarise_pmc_workloads.py folds the CSVs into profiles/<tag>_pmc_workloads.json, which bench.py reads for the
 `roofline.traffic` of its secondary lines).
 
-    python3 tools/pmc_workloads.py eval_image | projection | export_c4 | dense_export | proposal | train   [env TRAIN_RAYS, TRAIN_FIELD_SAMPLES]
+    python3 tools/pmc_workloads.py eval_image | projection | export_c4 | dense_export | proposal | render48 | train   [env TRAIN_RAYS, TRAIN_FIELD_SAMPLES]
 
 Prints ONE line `PMC_UNITS {"workload": ..., "units": N, "unit": "..."}`.  Same scene, cameras and call shapes as bench.py."""
 import json
@@ -88,6 +88,16 @@ elif what == "dense_export":
     n_rays = pipe.datamanager.setup_inference(((-1, -1, -1 + .318), (1, 1, 1 + .318)), 128)
     sample_volume(pipe, n_rays, transform_json={"scale": 1.0, "transform": None}, capacity=1 << 24)
     units, unit = n_rays * 3000, "field samples"
+elif what == "render48":
+    # the default method's field pass on image-coherent C2 batches at 48 samples per ray (proposal bins), composited: the kernel
+    # whose schedule CN_SPLIT_PACK switches (two rays per three half-steps / one ray per two)
+    cfgb, fspec, pspecs, params, fh, dh, c2w_b, intr_b = bench.build_scene(dev)
+    batches = bench.make_batches(ops, c2w_b, intr_b, 0, 1)
+    scene_c = ops.scene_struct(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), contraction=True)
+    for b in batches:
+        bins = ops.proposal_sample(dh, scene_c, *b[:4], cfgb.num_proposal_samples_per_ray, 48)["euclidean_bins"]
+        ops.render_rays(fh, scene_c, ops.render_opts(48, image_width=W, pixel_start=b[5]), *b[:4], bins=bins)
+    units, unit = len(batches) * bench.R, "rays"
 elif what == "proposal":
     cfgb, fspec, pspecs, params, fh, dh, c2w_b, intr_b = bench.build_scene(dev)
     batches = bench.make_batches(ops, c2w_b, intr_b, 0, 1)
