@@ -135,6 +135,11 @@ SIGNATURES = {
     "cn_proposal_sample_train": (C.c_int, [C.POINTER(C.POINTER(DensityParams)), _I32, C.POINTER(Scene), _P, _P, _P, _P,
                                            _I64, C.POINTER(_I32), _I32, _F, _P, C.POINTER(ProposalLevelOut), _P, _P, _P, _P,
                                            _P]),
+    "cn_proposal_sample_train_dev": (C.c_int, [C.POINTER(C.POINTER(DensityParams)), _I32, C.POINTER(Scene), _P, _P, _P, _P,
+                                               _I64, C.POINTER(_I32), _I32, _P, _P, C.POINTER(ProposalLevelOut), _P, _P, _P, _P,
+                                               _P]),
+    "cn_adam_hyper": (C.c_int, [_I32, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
+    "cn_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I32, _P]),
     "cn_export_compact": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _I64, C.POINTER(_P), C.POINTER(_P), _P, _P]),
     "cn_pointcloud_compact": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
     "cn_pixel_sample": (C.c_int, [C.c_uint64, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),

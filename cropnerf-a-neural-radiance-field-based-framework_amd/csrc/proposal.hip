@@ -55,6 +55,7 @@ struct PropArgs {
   int smax;
   int enc_rows;  // rows of a wave's encoding block (prop_mlp_mfma): 2 L rounded up to a multiple of 4, of the largest net
   float anneal;
+  const float* anneal_dev;  // when not NULL the exponent is read from device memory (a captured HIP graph replays with new values)
   SceneDev scene;
   const float* origins;
   const float* directions;
@@ -349,7 +350,7 @@ __global__ void __launch_bounds__(256, CN_PROP_SAMPLE_WAVES) proposal_sample_ker
       if (A.out_depth && lane == 0) A.out_depth[lvl * A.num_rays + r] = st.found ? st.depth : st.last_mid;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      wave_cdf_from_weights(wts, S, A.anneal, cdf);
+      wave_cdf_from_weights(wts, S, A.anneal_dev ? *A.anneal_dev : A.anneal, cdf);
       const int s_next = lvl + 1 < A.num_levels ? A.s_prop[lvl + 1] : A.s_final;
       const int nb = s_next + 1;
       const bool last = lvl + 1 == A.num_levels;
@@ -388,7 +389,7 @@ static int proposal_sample_launch(const char* who, const cn_density_params* cons
                                   int32_t s_final, float anneal, const float* jitter,
                                   const cn_proposal_level_out* levels, float* euclidean_bins, float* spacing_bins,
                                   float* prop_depth, float* final_starts, float* final_ends, cn_stream_t stream,
-                                  int matrix_precision = CN_MATRIX_FP32) {
+                                  int matrix_precision = CN_MATRIX_FP32, const float* anneal_dev = nullptr) {
   CN_REQUIRE(props && scene && origins && directions && nears && fars && s_prop && euclidean_bins, CN_ERR_INVALID,
              "%s: null argument", who);
   CN_REQUIRE(matrix_precision == CN_MATRIX_FP32 || matrix_precision == CN_MATRIX_SPLIT_BF16 || matrix_precision == CN_MATRIX_F16,
@@ -436,6 +437,7 @@ static int proposal_sample_launch(const char* who, const cn_density_params* cons
   A.num_levels = num_levels;
   A.s_final = s_final;
   A.anneal = anneal;
+  A.anneal_dev = anneal_dev;
   A.scene = make_scene_dev(*scene);
   A.origins = origins;
   A.directions = directions;
@@ -499,4 +501,16 @@ extern "C" int cn_proposal_sample_train(const cn_density_params* const* props, i
   return cn::proposal_sample_launch("cn_proposal_sample_train", props, num_levels, scene, origins, directions, nears,
                                     fars, num_rays, s_prop, s_final, anneal, jitter, levels, euclidean_bins,
                                     spacing_bins, nullptr, final_starts, final_ends, stream);
+}
+
+extern "C" int cn_proposal_sample_train_dev(const cn_density_params* const* props, int32_t num_levels,
+                                            const cn_scene* scene, const float* origins, const float* directions,
+                                            const float* nears, const float* fars, int64_t num_rays, const int32_t* s_prop,
+                                            int32_t s_final, const float* anneal_dev, const float* jitter,
+                                            const cn_proposal_level_out* levels, float* euclidean_bins, float* spacing_bins,
+                                            float* final_starts, float* final_ends, cn_stream_t stream) {
+  CN_REQUIRE(jitter && anneal_dev, CN_ERR_INVALID, "cn_proposal_sample_train_dev: null jitter / anneal");
+  return cn::proposal_sample_launch("cn_proposal_sample_train_dev", props, num_levels, scene, origins, directions, nears,
+                                    fars, num_rays, s_prop, s_final, 1.f, jitter, levels, euclidean_bins, spacing_bins,
+                                    nullptr, final_starts, final_ends, stream, CN_MATRIX_FP32, anneal_dev);
 }

@@ -453,6 +453,24 @@ radam_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restric
   }
 }
 
+// the same update with its per-step scalars in device memory (hyper = {step_size, beta1, beta2, 1 - beta1, 1 - beta2,
+// 1 / sqrt(bias correction 2), eps}): a captured HIP graph of the training iteration replays with the schedule's new values
+__global__ void __launch_bounds__(256)
+adam_step_dev_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long long n,
+                     const float* __restrict__ hyper, int zero_grad) {
+  const float step_size = hyper[0], beta1 = hyper[1], beta2 = hyper[2], omb1 = hyper[3], omb2 = hyper[4],
+              inv_sqrt_bc2 = hyper[5], eps = hyper[6];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = beta1 * m[i] + omb1 * gi;
+    const float vi = beta2 * v[i] + omb2 * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    if (zero_grad) g[i] = 0.f;
+  }
+}
+
 }  // namespace cn
 
 extern "C" int cn_train_render_backward(const float* starts, const float* ends, const float* density,
@@ -504,6 +522,29 @@ extern "C" int cn_adam_step(float* param, float* grad, float* exp_avg, float* ex
                      grad, exp_avg, exp_avg_sq, (long long)n, (float)(lr / bc1), (float)beta1, (float)beta2,
                      (float)(1.0 - beta1), (float)(1.0 - beta2), (float)(1.0 / sqrt(bc2)), (float)eps, zero_grad);
   return cn::check_launch("cn_adam_step");
+}
+
+extern "C" int cn_adam_hyper(int32_t step, double lr, double beta1, double beta2, double eps, float* hyper_host) {
+  CN_REQUIRE(hyper_host && step >= 1, CN_ERR_INVALID, "cn_adam_hyper: bad argument (step is 1-based)");
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  hyper_host[0] = (float)(lr / bc1);
+  hyper_host[1] = (float)beta1;
+  hyper_host[2] = (float)beta2;
+  hyper_host[3] = (float)(1.0 - beta1);
+  hyper_host[4] = (float)(1.0 - beta2);
+  hyper_host[5] = (float)(1.0 / sqrt(bc2));
+  hyper_host[6] = (float)eps;
+  hyper_host[7] = 0.f;
+  return CN_OK;
+}
+
+extern "C" int cn_adam_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper,
+                                int32_t zero_grad, cn_stream_t stream) {
+  CN_REQUIRE(param && grad && exp_avg && exp_avg_sq && hyper, CN_ERR_INVALID, "cn_adam_step_dev: null argument");
+  if (n <= 0) return CN_OK;
+  hipLaunchKernelGGL(cn::adam_step_dev_kernel, dim3(cn::grid_for(n, 256, 4096)), dim3(256), 0, cn::as_stream(stream), param,
+                     grad, exp_avg, exp_avg_sq, (long long)n, hyper, zero_grad);
+  return cn::check_launch("cn_adam_step_dev");
 }
 
 extern "C" int cn_radam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,

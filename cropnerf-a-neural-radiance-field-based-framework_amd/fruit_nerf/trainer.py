@@ -88,6 +88,12 @@ class FruitTrainer:
         self._general_ws = None
         self._exchange = None
         self.force_exchange = False  # run the data-parallel exchange also in a one-rank process group (tests)
+        # CN_TRAIN_GRAPH=0: every iteration as eager launches (A/B; default: replay a captured HIP graph where it applies)
+        self.use_graph = os.environ.get("CN_TRAIN_GRAPH", "1") != "0"
+        self._graphs: Dict[tuple, dict] = {}
+        self._g_dev = None
+        self._g_ring: List[dict] = []
+        self._g_ring_next = 0
         dev = model.device
         # a group that is not listed is frozen (its gradients are still computed for "fields"/"proposal_networks")
         self.train_pose = "camera_opt" in self.groups
@@ -150,7 +156,7 @@ class FruitTrainer:
         self._sampler_step = 0
         self._gen = torch.Generator(device="cpu").manual_seed(seed)
         self.loss_sums = torch.zeros(4, device=dev)
-        self._zeroed = None    # [6 R + 8]: ray-gradient accumulators | loss sums, one fill per iteration (forward_backward)
+        self._zeroed: Dict[int, Tensor] = {}  # per batch size R, [6 R + 8]: ray-gradient accumulators | loss sums, one fill per iteration
         self._epilogue = None  # cn_train_epilogue's output of the last forward_backward
 
     # ------------------------------------------------------------------------------------------------------
@@ -170,7 +176,8 @@ class FruitTrainer:
 
     def forward_backward(self, ray_bundle: RayBundle, batch: Dict[str, Tensor],
                          jitter: Optional[List[Tensor]] = None, update_proposals: bool = True,
-                         on_group_ready=None) -> Dict[str, Tensor]:
+                         on_group_ready=None, anneal_dev: Optional[Tensor] = None,
+                         jitter_rows: Optional[Tensor] = None) -> Dict[str, Tensor]:
         """One training forward + backward; gradients are ACCUMULATED into ``self.grads``.  ``jitter`` = the three
         [R,1] uniform randoms of the proposal sampler (drawn here when None).  ``update_proposals`` False = the
         reference's ``no_grad`` proposal evaluation (interlevel loss reported, no proposal gradients).
@@ -190,20 +197,22 @@ class FruitTrainer:
         o, d = torch.empty_like(rb.origins), torch.empty_like(rb.directions)
         ops.apply_pose_adjustment_to(pose, cam, rb.origins, rb.directions, o, d)  # (out of place: no clones of the raw rays)
         # one zeroed buffer per iteration: the ray-gradient accumulators and the four loss sums (one fill instead of three)
-        if self._zeroed is None or self._zeroed.numel() != 6 * R + 8:
-            self._zeroed = torch.empty(6 * R + 8, device=dev)
-            self.loss_sums = self._zeroed[6 * R:6 * R + 4]
-        self._zeroed.zero_()
+        zeroed = self._zeroed.get(R)  # (kept per batch size: a captured iteration of another size still reads its own)
+        if zeroed is None:
+            zeroed = self._zeroed[R] = torch.empty(6 * R + 8, device=dev)
+        self.loss_sums = zeroed[6 * R:6 * R + 4]
+        zeroed.zero_()
         if self.train_pose:
-            d_o, d_d = self._zeroed[:3 * R].view(R, 3), self._zeroed[3 * R:6 * R].view(R, 3)
+            d_o, d_d = zeroed[:3 * R].view(R, 3), zeroed[3 * R:6 * R].view(R, 3)
         nears = rb.nears if rb.nears is not None else torch.full((R, 1), float(cfg.near_plane), device=dev)
         fars = rb.fars if rb.fars is not None else torch.full((R, 1), float(cfg.far_plane), device=dev)
         n_lvl = len(m.proposal_networks)
         self.grad_field.enable_scatter_scratch(R * int(cfg.num_nerf_samples_per_ray))
         for i, gp in enumerate(self.grad_props):
             gp.enable_scatter_scratch(R * int(cfg.num_proposal_samples_per_ray[i]))
-        jitter_rows = None
-        if jitter is None:
+        if jitter_rows is not None:  # [levels + 1, R] on the device already (the graph-replayed iteration's static buffer)
+            jitter = [jitter_rows[i].reshape(R, 1) for i in range(n_lvl + 1)]
+        elif jitter is None:
             # one draw, one host-to-device copy: rows = the samplers' per-ray uniforms, level by level
             jitter_rows = torch.rand(n_lvl + 1, R, generator=self._gen).to(dev)
             jitter = [jitter_rows[i].reshape(R, 1) for i in range(n_lvl + 1)]
@@ -215,7 +224,7 @@ class FruitTrainer:
         if self.fused_sampler and ops.proposal_sample_fused_supported(m.proposal_networks, s_prop, cfg.num_nerf_samples_per_ray):
             # one launch: cn_proposal_sample_train
             ps = ops.proposal_sample_train(m.proposal_networks, scene, o, d, nears, fars, s_prop,
-                                           cfg.num_nerf_samples_per_ray, m._anneal,
+                                           cfg.num_nerf_samples_per_ray, m._anneal if anneal_dev is None else anneal_dev,
                                            jitter_rows if jitter_rows is not None else
                                            torch.cat([j.reshape(1, R) for j in jitter], 0).contiguous())
             levels = ps["levels"]
@@ -337,6 +346,24 @@ class FruitTrainer:
             self._exchange = GroupedGradientExchange(self.flat_grads, self.group_range, group, force)
         return self._exchange
 
+    def _optimizer_step_dev(self, proposals_updated: bool, hyper: Tensor) -> None:
+        """``optimizer_step`` for the captured iteration: the same launches with every per-step scalar read from ``hyper``
+        ([groups, 8] on the device, one row per optimiser group in ``group_range`` order); counters are kept by the caller."""
+        if self.tcnn:
+            for spec, key in self._tcnn_tables:
+                ops.tcnn_grid_tie_gradients(spec, self.grads[key])
+            for k in self._frozen:
+                self.grads[k].zero_()
+        for gi, (g, (lo, hi)) in enumerate(self.group_range.items()):
+            if g not in self.groups or (g == "proposal_networks" and not proposals_updated):
+                self.flat_grads[lo:hi].zero_()
+                continue
+            ops.adam_step_dev(self.flat_params[lo:hi], self.flat_grads[lo:hi], self.flat_exp_avg[lo:hi],
+                              self.flat_exp_avg_sq[lo:hi], hyper[gi], zero_grad=True)
+        if self.tcnn:
+            for spec, key in self._tcnn_tables:
+                ops.tcnn_grid_tie_parameters(spec, self.model.params[key])
+
     def optimizer_step(self, proposals_updated: bool = True, exchange=None) -> None:
         """One optimiser step of every group that has a gradient.  ``proposals_updated`` False: the proposal networks
         were evaluated without gradient this iteration (``grad is None`` in the reference): their group is not stepped.
@@ -388,7 +415,126 @@ class FruitTrainer:
         if load_generator:
             self._gen.set_state(state["generator"])
 
+    # ---- the iteration as a replayed HIP graph -----------------------------------------------------------------------------------
+    def _graph_eligible(self) -> bool:
+        import torch.distributed as dist
+
+        return (self.use_graph and not self.general and not self.concurrent_backward and self.model.device.type == "cuda"
+                and all(g.optimizer == "adam" for g in self.groups.values())
+                and not (dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_exchange))
+                and self.fused_sampler)
+
+    def _train_iteration_graph(self, ray_bundle: RayBundle, batch: Dict[str, Tensor]) -> Optional[Dict[str, Tensor]]:
+        """At the reference's batch size (4 096 rays) an iteration is ~45 launches of 5-700 us: the gaps between them are a tenth
+        of it.  The whole iteration -- pose tweak, sampler, field forward, losses, the three backward passes, folds, epilogue,
+        the optimiser steps, the distortion metric -- is captured ONCE per (batch geometry, proposal-update yes / no) into a
+        HIP graph and replayed; what changes from step to step enters through device memory: the annealing exponent and the
+        Adam scalars of every group (one 100-byte host-to-device copy), the sampler's jitter (one copy), and the batch itself
+        (read in place when the caller hands over the same tensors as at capture time, e.g. a resident dataset's views;
+        otherwise copied into the captured buffers).  Returns None when the iteration has to run eagerly (first two
+        occurrences of a variant: warm-up, then capture)."""
+        m, cfg, dev = self.model, self.model.config, self.model.device
+        rb = ray_bundle.flatten()
+        R = rb.origins.shape[0]
+        if rb.camera_indices is None or not rb.origins.is_cuda:
+            return None
+        n_lvl = len(m.proposal_networks)
+        updated = self.proposal_update_due(self._sampler_step)
+        key = (R, bool(updated), rb.nears is None)
+        st = self._graphs.get(key)
+        if st is None:
+            self._graphs[key] = {"seen": 1}
+            return None  # first occurrence: eager (runs every first-call initialisation)
+        # ---- per-step scalars and randoms -> device --------------------------------------------------------------------------------
+        # (pinned staging in a ring of four slots, each guarded by an event: the host runs ahead of the GPU, and a slot must not
+        #  be rewritten before the copy that reads it has executed)
+        ngrp = len(self.group_range)
+        if self._g_dev is None:
+            self._g_dev = torch.zeros(1 + ngrp, 8, device=dev)
+        slot = self._g_ring[self._g_ring_next % len(self._g_ring)] if self._g_ring else None
+        if not self._g_ring or slot["jitter"].shape[1] != R:
+            self._g_ring = [{"scalars": torch.zeros(1 + ngrp, 8).pin_memory(), "jitter": torch.empty(n_lvl + 1, R).pin_memory(),
+                             "event": None} for _ in range(4)]
+            slot = self._g_ring[0]
+        self._g_ring_next += 1
+        if slot["event"] is not None:
+            slot["event"].synchronize()
+        self.set_anneal(self.step)
+        slot["scalars"][0, 0] = float(m._anneal)
+        steps = dict(self.group_steps)
+        for gi, g in enumerate(self.group_range):
+            if g in self.groups and not (g == "proposal_networks" and not updated):
+                steps[g] += 1
+                grp = self.groups[g]
+                ops.adam_hyper(steps[g], grp.lr_at(self.step), eps=grp.eps, out=slot["scalars"][1 + gi])
+        torch.rand(n_lvl + 1, R, generator=self._gen, out=slot["jitter"])
+        given = {"origins": rb.origins, "directions": rb.directions, "cam": rb.camera_indices, "nears": rb.nears, "fars": rb.fars,
+                 "image": batch["image"], "mask": batch["fruit_mask"]}
+
+        def stage_inputs():
+            # the captured launches read the trainer's own copies of the batch; a tensor the caller hands over again unchanged
+            # (same storage, same version counter: a resident batch) is not copied again
+            for name, t in given.items():
+                if t is None:
+                    continue
+                tag = (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+                if st["seen_inputs"].get(name) != tag:
+                    st["inputs"][name].copy_(t.to(dev).reshape(st["inputs"][name].shape), non_blocking=True)
+                    st["seen_inputs"][name] = tag
+            st["jitter"].copy_(slot["jitter"], non_blocking=True)
+            self._g_dev.copy_(slot["scalars"], non_blocking=True)
+            slot["event"] = torch.cuda.Event()
+            slot["event"].record()
+
+        if "graph" not in st:
+            # second occurrence: capture
+            st["jitter"] = torch.empty(n_lvl + 1, R, device=dev)
+            st["inputs"] = {k: (None if t is None else torch.empty_like(t.to(dev))) for k, t in given.items()}
+            st["seen_inputs"] = {}
+            stage_inputs()
+            ins = st["inputs"]
+            srb = RayBundle(ins["origins"], ins["directions"], None, ins["cam"], ins["nears"], ins["fars"])
+            sbatch = {"image": ins["image"], "fruit_mask": ins["mask"]}
+
+            def body():
+                out = self.forward_backward(srb, sbatch, update_proposals=updated, anneal_dev=self._g_dev[0, 0:1],
+                                            jitter_rows=st["jitter"])
+                self._optimizer_step_dev(updated, self._g_dev[1:])
+                out["metrics_dict"] = self.get_metrics_dict(out)
+                return out
+
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph):
+                    st["out"] = body()
+            except Exception as e:  # capture is an optimisation: fall back to eager launches, loudly, for good
+                import sys
+
+                print(f"[FruitTrainer] HIP graph capture of the training iteration failed ({type(e).__name__}: {e}); running eagerly",
+                      file=sys.stderr)
+                self.use_graph = False
+                torch.cuda.synchronize()
+                return None
+            st["graph"] = graph
+        else:
+            stage_inputs()
+        st["graph"].replay()
+        # ---- the host-side counters of optimizer_step / train_iteration ------------------------------------------------------------
+        it = self.step
+        self.step += 1
+        self.group_steps = steps
+        if updated:
+            self._steps_since_update = 0
+        self._sampler_step = it
+        self._steps_since_update += 1
+        return st["out"]
+
     def train_iteration(self, ray_bundle: RayBundle, batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        if self._graph_eligible():
+            out = self._train_iteration_graph(ray_bundle, batch)
+            if out is not None:
+                return out
         self.set_anneal(self.step)
         it = self.step
         updated = self.proposal_update_due(self._sampler_step)

@@ -505,10 +505,11 @@ def proposal_sample_fused_supported(props: Sequence[DensityHandle], s_prop: Sequ
 
 
 def proposal_sample_train(props: Sequence[DensityHandle], scene: L.Scene, origins: Tensor, directions: Tensor,
-                          nears: Tensor, fars: Tensor, s_prop: Sequence[int], s_final: int, anneal: float,
+                          nears: Tensor, fars: Tensor, s_prop: Sequence[int], s_final: int, anneal,
                           jitter: Tensor) -> Dict[str, object]:
     """``cn_proposal_sample_train``: the proposal sampler of the training forward in one launch.  ``jitter`` [n + 1, R].
-    Returns the final bins and, per level, what the interlevel loss and the proposal backward read."""
+    Returns the final bins and, per level, what the interlevel loss and the proposal backward read.  ``anneal``: a float, or a
+    one-element device tensor (``cn_proposal_sample_train_dev``: the exponent is read at run time -- captured HIP graphs)."""
     lib = L.load()
     R = origins.shape[0]
     dev = origins.device
@@ -525,10 +526,17 @@ def proposal_sample_train(props: Sequence[DensityHandle], scene: L.Scene, origin
                                                          lv["ends"].data_ptr(), lv["density"].data_ptr())
                                       for lv in levels])
     starts, ends = torch.empty(R, s_final, device=dev), torch.empty(R, s_final, device=dev)
-    L.check(lib.cn_proposal_sample_train(arr, n, C.byref(scene), _p(_f32(origins, "origins")),
-                                         _p(_f32(directions, "directions")), _p(_f32(nears, "nears")),
-                                         _p(_f32(fars, "fars")), R, sp_arr, s_final, anneal, _p(_f32(jitter, "jitter")),
-                                         outs, _p(eu), _p(sp), _p(starts), _p(ends), _stream(origins)))
+    if isinstance(anneal, Tensor):
+        L.check(lib.cn_proposal_sample_train_dev(arr, n, C.byref(scene), _p(_f32(origins, "origins")),
+                                                 _p(_f32(directions, "directions")), _p(_f32(nears, "nears")),
+                                                 _p(_f32(fars, "fars")), R, sp_arr, s_final, _p(_f32(anneal, "anneal")),
+                                                 _p(_f32(jitter, "jitter")), outs, _p(eu), _p(sp), _p(starts), _p(ends),
+                                                 _stream(origins)))
+    else:
+        L.check(lib.cn_proposal_sample_train(arr, n, C.byref(scene), _p(_f32(origins, "origins")),
+                                             _p(_f32(directions, "directions")), _p(_f32(nears, "nears")),
+                                             _p(_f32(fars, "fars")), R, sp_arr, s_final, anneal, _p(_f32(jitter, "jitter")),
+                                             outs, _p(eu), _p(sp), _p(starts), _p(ends), _stream(origins)))
     return {"euclidean_bins": eu, "spacing_bins": sp, "starts": starts, "ends": ends, "levels": levels}
 
 
@@ -853,6 +861,26 @@ def adam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, 
     L.check(lib.cn_adam_step(_p(_f32(param, "param")), _p(_f32(grad, "grad")), _p(_f32(exp_avg, "exp_avg")),
                              _p(_f32(exp_avg_sq, "exp_avg_sq")), param.numel(), int(step), float(lr), beta1, beta2,
                              eps, 1 if zero_grad else 0, _stream(param)))
+
+
+def adam_hyper(step: int, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-15, out: Optional[Tensor] = None
+               ) -> Tensor:
+    """``cn_adam_hyper``: the eight per-step floats ``cn_adam_step_dev`` reads, into a HOST tensor (pinned by the caller)."""
+    lib = L.load()
+    if out is None:
+        out = torch.empty(8)
+    if out.is_cuda or out.dtype != torch.float32 or out.numel() < 8 or not out.is_contiguous():
+        raise TypeError("adam_hyper: out must be a contiguous float32 host tensor of 8 elements")
+    L.check(lib.cn_adam_hyper(int(step), float(lr), beta1, beta2, eps, C.c_void_p(out.data_ptr())))
+    return out
+
+
+def adam_step_dev(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, hyper: Tensor, zero_grad: bool = True) -> None:
+    """``cn_adam_step_dev``: ``adam_step`` with its per-step scalars in device memory (``hyper`` [8], see ``adam_hyper``)."""
+    lib = L.load()
+    L.check(lib.cn_adam_step_dev(_p(_f32(param, "param")), _p(_f32(grad, "grad")), _p(_f32(exp_avg, "exp_avg")),
+                                 _p(_f32(exp_avg_sq, "exp_avg_sq")), param.numel(), _p(_f32(hyper, "hyper")),
+                                 1 if zero_grad else 0, _stream(param)))
 
 
 def radam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step: int, lr: float,

@@ -452,6 +452,12 @@ int cn_proposal_sample_train(const cn_density_params* const* props_host, int32_t
                              const float* jitter, const cn_proposal_level_out* levels_host, float* euclidean_bins,
                              float* spacing_bins, float* final_starts /*[R,s_final] or NULL*/,
                              float* final_ends /*[R,s_final] or NULL*/, cn_stream_t stream);
+/* The same with the annealing exponent in device memory (anneal_dev [1]): for a captured HIP graph of the training iteration. */
+int cn_proposal_sample_train_dev(const cn_density_params* const* props, int32_t num_levels, const cn_scene* scene,
+                                 const float* origins, const float* directions, const float* nears, const float* fars,
+                                 int64_t num_rays, const int32_t* s_prop, int32_t s_final, const float* anneal_dev,
+                                 const float* jitter, const cn_proposal_level_out* levels, float* euclidean_bins,
+                                 float* spacing_bins, float* final_starts, float* final_ends, cn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Exporters
@@ -599,6 +605,13 @@ int cn_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, i
  * decay), same arguments as cn_adam_step. */
 int cn_radam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step, double lr,
                  double beta1, double beta2, double eps, int32_t zero_grad, cn_stream_t stream);
+
+/* The per-step scalars of cn_adam_step as a host computation (hyper_host [8] = {lr / bias correction 1, beta1, beta2, 1 - beta1,
+ * 1 - beta2, 1 / sqrt(bias correction 2), eps, 0}) and the update reading them from DEVICE memory: a HIP graph that captured a
+ * whole training iteration replays with the schedules' new values after one small host-to-device copy. */
+int cn_adam_hyper(int32_t step, double lr, double beta1, double beta2, double eps, float* hyper_host);
+int cn_adam_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper /*device [8]*/,
+                     int32_t zero_grad, cn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Depth-based semantic projection (the alternative to the NeRF projection:
