@@ -108,7 +108,7 @@ SIGNATURES = {
     "cn_surface_grid": (C.c_int, [_F, _F, _I32, _F, _F, _I32, _F, _P, _P]),
     "cn_apply_pose_adjustment": (C.c_int, [_P, _P, _I64, _P, _P, _P]),
     "cn_apply_pose_adjustment_to": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P, _P]),
-    "cn_train_epilogue": (C.c_int, [_P, _I64, _I32, _F, _F, _P, _I32, _P, _P]),
+    "cn_train_epilogue": (C.c_int, [_P, _I32, _I64, _I32, _F, _F, _P, _I32, _P, _P]),
     "cn_projection_test": (C.c_int, [_P, _I32, _I64, _I32, _I32, _P, _P, _P, _P]),
     "cn_projection_gather": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cn_projection_scatter": (C.c_int, [_P, _P, _P, _I64, _F, _P, _P, _P, _P, _P]),
@@ -140,6 +140,7 @@ SIGNATURES = {
                                                _P]),
     "cn_adam_hyper": (C.c_int, [_I32, C.c_double, C.c_double, C.c_double, C.c_double, _P]),
     "cn_adam_step_dev": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I32, _P]),
+    "cn_adam_step_groups_dev": (C.c_int, [_P, _P, _P, _P, _P, _I32, _P, _P]),
     "cn_export_compact": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _I64, C.POINTER(_P), C.POINTER(_P), _P, _P]),
     "cn_pointcloud_compact": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
     "cn_pixel_sample": (C.c_int, [C.c_uint64, _P, _I32, _I32, _I32, _I32, _I32, _P, _P]),

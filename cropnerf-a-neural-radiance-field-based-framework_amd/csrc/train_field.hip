@@ -349,6 +349,53 @@ __device__ __forceinline__ void hash_level_backward_cells(float* __restrict__ re
                              dpz);
 }
 
+// hash_level_backward_cells with the run-length reduction done AFTER the transpose: every lane writes its 16 weighted values
+// and its cell to the wave-private buffer unreduced; then the 16 lanes of a row walk the row's 16 samples in order, each lane
+// summing one of the 16 record entries, and add the sum to the cell's record whenever the next sample lies in another cell.
+// Same requests as the DPP form (one per run of samples in a cell), a third of its instructions: no segmented scans -- 16
+// values x 4 steps of cross-lane moves -- only a running sum.  The sums of a run are taken in sample order instead of as a
+// tree, so the last bit may differ from the first form's.  All 64 lanes must call; gradient only (no position gradient).
+__device__ __forceinline__ void hash_level_backward_cells_rows(float* __restrict__ rec, unsigned n, float* __restrict__ tb,
+                                                               float* __restrict__ gtab, const float* __restrict__ table,
+                                                               const Lvl& lv, float pos_offset, float px, float py, float pz,
+                                                               float g0, float g1, int lane) {
+  const Cell cell = hash_cell(lv, pos_offset, px, py, pz);
+  const float ox = cell.ox, oy = cell.oy, oz = cell.oz;
+  const unsigned ix = cell.hx0;
+  const unsigned iy = (unsigned)(int)floorf(fmaf(py, lv.scale, pos_offset));
+  const unsigned iz = (unsigned)(int)floorf(fmaf(pz, lv.scale, pos_offset));
+  const bool inside = ix < n && iy < n && iz < n;  // unsigned: negative coordinates are huge
+  const float h0 = inside ? g0 : 0.f, h1 = inside ? g1 : 0.f;
+  const float wx[2] = {1.f - ox, ox}, wy[2] = {1.f - oy, oy}, wz[2] = {1.f - oz, oz};
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float w = wx[c & 1] * wy[(c >> 1) & 1] * wz[c >> 2];
+    tb[lane * 17 + 2 * c] = w * h0;
+    tb[lane * 17 + 2 * c + 1] = w * h1;
+  }
+  tb[lane * 17 + 16] = __builtin_bit_cast(float, inside ? ix + n * (iy + n * iz) : 0xffffffffu);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int row0 = lane & 48, row_lane = lane & 15;
+  float acc = 0.f;
+  unsigned cur = __builtin_bit_cast(unsigned, tb[row0 * 17 + 16]);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    acc += tb[(row0 + k) * 17 + row_lane];
+    const unsigned next = k < 15 ? __builtin_bit_cast(unsigned, tb[(row0 + k + 1) * 17 + 16]) : 0xfffffffdu;
+    if (next != cur) {  // (uniform within the row)
+      if (cur != 0xffffffffu && acc != 0.f) atomicAdd(rec + (size_t)cur * 16 + row_lane, acc);
+      acc = 0.f;
+    }
+    cur = next;
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (__builtin_amdgcn_ballot_w64(!inside && (g0 != 0.f || g1 != 0.f)) != 0ull) {
+    float ux = 0.f, uy = 0.f, uz = 0.f;
+    hash_level_backward<false>(gtab, table, lv, pos_offset, px, py, pz, inside ? 0.f : g0, inside ? 0.f : g1, lane, ux, uy, uz);
+  }
+}
+
 // fold the cell-major levels into the gradient table and zero their touched records: one thread per (copy, cell) record,
 // all levels in one launch (workgroups [first_block[l], first_block[l + 1]) belong to level l)
 struct CellFoldArgs {
@@ -928,6 +975,10 @@ __global__ void __launch_bounds__(TB, 4) proposal_backward_kernel(PropBwdArgs A)
   if (tid < 1) atomicAdd(A.g_b1 + tid, gb1);
 }
 
+}  // namespace cn
+#include "train_proposal_wave.hpp"
+namespace cn {
+
 int validate_field(const cn_field_params& p);  // field_simple.hip
 int validate_grid(const cn_grid& g, const char* name);
 
@@ -1092,11 +1143,21 @@ extern "C" int cn_proposal_backward(const cn_density_params* params, const cn_de
     if (A.cells.num_levels > 0 && A.coarse.base) A.coarse.base = nullptr;  // level 0 is cell-major then
   }
   long long ntiles = (num_rays * (long long)num_samples + cn::TS - 1) / cn::TS;
-  dim3 grid(cn::grid_for(ntiles, 1, 1024));
-  if (L == 5)
-    hipLaunchKernelGGL(cn::proposal_backward_kernel<5>, grid, dim3(cn::TB), 0, cn::as_stream(stream), A);
-  else
-    hipLaunchKernelGGL(cn::proposal_backward_kernel<7>, grid, dim3(cn::TB), 0, cn::as_stream(stream), A);
+  // one wave per tile (train_proposal_wave.hpp); CN_PROP_BWD=tile: the first form, four waves per tile (A/B runs, cross-check)
+  const char* form = getenv("CN_PROP_BWD");
+  if (form && strcmp(form, "tile") == 0) {
+    dim3 grid(cn::grid_for(ntiles, 1, 1024));
+    if (L == 5)
+      hipLaunchKernelGGL(cn::proposal_backward_kernel<5>, grid, dim3(cn::TB), 0, cn::as_stream(stream), A);
+    else
+      hipLaunchKernelGGL(cn::proposal_backward_kernel<7>, grid, dim3(cn::TB), 0, cn::as_stream(stream), A);
+  } else {
+    dim3 grid(cn::grid_for((ntiles + 3) / 4, 1, 1024));
+    if (L == 5)
+      hipLaunchKernelGGL(cn::pw::proposal_backward_wave_kernel<5>, grid, dim3(256), 0, cn::as_stream(stream), A);
+    else
+      hipLaunchKernelGGL(cn::pw::proposal_backward_wave_kernel<7>, grid, dim3(256), 0, cn::as_stream(stream), A);
+  }
   cn::launch_coarse_reduce(A.coarse, A.grid, A.g_table, cn::as_stream(stream));
   cn::launch_cell_fold(A.cells, A.grid, A.g_table, cn::as_stream(stream));
   return cn::check_launch("cn_proposal_backward");

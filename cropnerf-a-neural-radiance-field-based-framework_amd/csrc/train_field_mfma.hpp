@@ -326,8 +326,8 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
         const unsigned nl = cell_n_of(A.cells, lvl);
         float* rec = A.cells.base + cell_offset_of(A.cells, lvl) +
                      (size_t)(blockIdx.x % cell_copies_of(A.cells, lvl)) * ((size_t)nl * nl * nl * 16);
-        hash_level_backward_cells<false>(rec, nl, tb, A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py, p_pz, p_g0,
-                                         p_g1, lane, gpx, gpy, gpz);
+        hash_level_backward_cells_rows(rec, nl, tb, A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py, p_pz, p_g0, p_g1,
+                                       lane);
       } else if (lvl == 0 && A.coarse.base) {
         float* mine = A.coarse.base + (size_t)(blockIdx.x % A.coarse.copies) * (2u * A.coarse.n1 * A.coarse.n1 * A.coarse.n1);
         hash_level_backward_private<false>(mine, A.coarse.n1, A.g.table, A.p.table, my_lv, A.grid.pos_offset, p_px, p_py,

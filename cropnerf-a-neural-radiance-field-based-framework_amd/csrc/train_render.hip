@@ -394,10 +394,11 @@ pose_regularizer_kernel(const float* __restrict__ adj, int C, float trans, float
 // launch (the host composed them from ~12 one-element ATen kernels per iteration): out[0] rgb_loss = sum / (3 R); [1]
 // semantics_loss = weight * sum / R; [2] interlevel_loss = mult * sum / (R S); [3] camera_opt_regularizer (already a mean);
 // [4] psnr = -10 log10(rgb_loss); [5] / [6] the Frobenius norms of the translation / rotation halves of pose_adjustment
-// (CameraOptimizer.get_metrics_dict); [7] unused.
+// (CameraOptimizer.get_metrics_dict); [7] the distortion metric = sums[4] / R when the caller accumulated cn_distortion_metric's
+// sum there (five sums), else 0.
 __global__ void __launch_bounds__(64)
-train_epilogue_kernel(const float* __restrict__ sums, double inv_3r, double sem_over_r, double inter_over_rs,
-                      const float* __restrict__ pose, int C, float* __restrict__ out) {
+train_epilogue_kernel(const float* __restrict__ sums, double inv_3r, double sem_over_r, double inter_over_rs, double inv_r,
+                      int with_distortion, const float* __restrict__ pose, int C, float* __restrict__ out) {
   float t2 = 0.f, r2 = 0.f;
   if (pose)
     for (int c = threadIdx.x; c < C; c += 64) {
@@ -416,8 +417,21 @@ train_epilogue_kernel(const float* __restrict__ sums, double inv_3r, double sem_
     out[4] = -10.f * log10f(rgb);
     out[5] = sqrtf(t2);
     out[6] = sqrtf(r2);
-    out[7] = 0.f;
+    out[7] = with_distortion ? (float)((double)sums[4] * inv_r) : 0.f;
   }
+}
+
+// One Adam update, every rounding spelled out: the three kernels below (scalars as arguments, scalars in device memory, several
+// groups per launch) must produce the same bits, and the compiler's choice of which product to contract into an FMA differs
+// with where the scalars live.  (1 - beta arrives rounded from double on the host, like torch's.)
+__device__ __forceinline__ void adam_update(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, long long i,
+                                            float gi, float step_size, float beta1, float beta2, float omb1, float omb2,
+                                            float inv_sqrt_bc2, float eps) {
+  const float mi = __fmaf_rn(beta1, m[i], __fmul_rn(omb1, gi));
+  const float vi = __fmaf_rn(beta2, v[i], __fmul_rn(__fmul_rn(omb2, gi), gi));
+  m[i] = mi;
+  v[i] = vi;
+  p[i] = __fsub_rn(p[i], __fdiv_rn(__fmul_rn(step_size, mi), __fmaf_rn(__fsqrt_rn(vi), inv_sqrt_bc2, eps)));
 }
 
 __global__ void __launch_bounds__(256)
@@ -425,12 +439,7 @@ adam_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict
                  long long n, float step_size, float beta1, float beta2, float omb1, float omb2, float inv_sqrt_bc2,
                  float eps, int zero_grad) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const float gi = g[i];
-    const float mi = beta1 * m[i] + omb1 * gi;  // 1 - beta rounded from double on the host, like torch
-    const float vi = beta2 * v[i] + omb2 * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    adam_update(p, m, v, i, g[i], step_size, beta1, beta2, omb1, omb2, inv_sqrt_bc2, eps);
     if (zero_grad) g[i] = 0.f;
   }
 }
@@ -461,13 +470,30 @@ adam_step_dev_kernel(float* __restrict__ p, float* __restrict__ g, float* __rest
   const float step_size = hyper[0], beta1 = hyper[1], beta2 = hyper[2], omb1 = hyper[3], omb2 = hyper[4],
               inv_sqrt_bc2 = hyper[5], eps = hyper[6];
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const float gi = g[i];
-    const float mi = beta1 * m[i] + omb1 * gi;
-    const float vi = beta2 * v[i] + omb2 * gi * gi;
-    m[i] = mi;
-    v[i] = vi;
-    p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    adam_update(p, m, v, i, g[i], step_size, beta1, beta2, omb1, omb2, inv_sqrt_bc2, eps);
     if (zero_grad) g[i] = 0.f;
+  }
+}
+
+// every optimiser group of a flat parameter buffer in ONE launch: group k owns [bounds[k], bounds[k + 1]); hyper row k as in
+// adam_step_dev_kernel, hyper[k][7] != 0 marks a group WITHOUT a step this iteration (frozen, or the proposal networks between
+// their updates): its gradients are only zeroed
+constexpr int ADAM_MAX_GROUPS = 8;
+struct AdamGroups {
+  long long bounds[ADAM_MAX_GROUPS + 1];
+  int num;
+};
+__global__ void __launch_bounds__(256)
+adam_step_groups_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, AdamGroups G,
+                        const float* __restrict__ hyper) {
+  const long long n = G.bounds[G.num];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < ADAM_MAX_GROUPS; ++j) k += (j < G.num && i >= G.bounds[j]) ? 1 : 0;
+    const float* h = hyper + 8 * k;
+    if (h[7] == 0.f) adam_update(p, m, v, i, g[i], h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
+    g[i] = 0.f;
   }
 }
 
@@ -547,6 +573,26 @@ extern "C" int cn_adam_step_dev(float* param, float* grad, float* exp_avg, float
   return cn::check_launch("cn_adam_step_dev");
 }
 
+extern "C" int cn_adam_step_groups_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const int64_t* bounds_host,
+                                       int32_t num_groups, const float* hyper, cn_stream_t stream) {
+  CN_REQUIRE(param && grad && exp_avg && exp_avg_sq && bounds_host && hyper, CN_ERR_INVALID,
+             "cn_adam_step_groups_dev: null argument");
+  CN_REQUIRE(num_groups >= 1 && num_groups <= cn::ADAM_MAX_GROUPS, CN_ERR_UNSUPPORTED,
+             "cn_adam_step_groups_dev: %d groups (max %d)", num_groups, cn::ADAM_MAX_GROUPS);
+  cn::AdamGroups G{};
+  G.num = num_groups;
+  for (int k = 0; k <= num_groups; ++k) {
+    CN_REQUIRE(k == 0 ? bounds_host[0] == 0 : bounds_host[k] >= bounds_host[k - 1], CN_ERR_INVALID,
+               "cn_adam_step_groups_dev: group bounds must start at 0 and ascend");
+    G.bounds[k] = bounds_host[k];
+  }
+  const long long n = G.bounds[num_groups];
+  if (n <= 0) return CN_OK;
+  hipLaunchKernelGGL(cn::adam_step_groups_kernel, dim3(cn::grid_for(n, 256, 4096)), dim3(256), 0, cn::as_stream(stream), param,
+                     grad, exp_avg, exp_avg_sq, G, hyper);
+  return cn::check_launch("cn_adam_step_groups_dev");
+}
+
 extern "C" int cn_radam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
                              double lr, double beta1, double beta2, double eps, int32_t zero_grad, cn_stream_t stream) {
   CN_REQUIRE(param && grad && exp_avg && exp_avg_sq, CN_ERR_INVALID, "cn_radam_step: null argument");
@@ -602,14 +648,15 @@ extern "C" int cn_pose_adjustment_backward(const float* pose_adjustment, const i
   return cn::check_launch("cn_pose_adjustment_backward");
 }
 
-extern "C" int cn_train_epilogue(const float* loss_sums, int64_t num_rays, int32_t num_samples, float semantic_loss_weight,
-                                 float interlevel_loss_mult, const float* pose_adjustment, int32_t num_cameras, float* out,
-                                 cn_stream_t stream) {
-  CN_REQUIRE(loss_sums && out && num_rays > 0 && num_samples > 0, CN_ERR_INVALID, "cn_train_epilogue: bad argument");
+extern "C" int cn_train_epilogue(const float* loss_sums, int32_t num_sums, int64_t num_rays, int32_t num_samples,
+                                 float semantic_loss_weight, float interlevel_loss_mult, const float* pose_adjustment,
+                                 int32_t num_cameras, float* out, cn_stream_t stream) {
+  CN_REQUIRE(loss_sums && out && num_rays > 0 && num_samples > 0 && (num_sums == 4 || num_sums == 5), CN_ERR_INVALID,
+             "cn_train_epilogue: bad argument (loss_sums holds 4 sums, or 5 with the distortion sum)");
   const double r = (double)num_rays;
   hipLaunchKernelGGL(cn::train_epilogue_kernel, dim3(1), dim3(64), 0, cn::as_stream(stream), loss_sums, 1.0 / (3.0 * r),
-                     (double)semantic_loss_weight / r, (double)interlevel_loss_mult / (r * (double)num_samples),
-                     pose_adjustment, pose_adjustment ? num_cameras : 0, out);
+                     (double)semantic_loss_weight / r, (double)interlevel_loss_mult / (r * (double)num_samples), 1.0 / r,
+                     num_sums == 5 ? 1 : 0, pose_adjustment, pose_adjustment ? num_cameras : 0, out);
   return cn::check_launch("cn_train_epilogue");
 }
 

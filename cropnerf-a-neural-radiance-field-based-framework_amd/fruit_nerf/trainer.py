@@ -91,9 +91,10 @@ class FruitTrainer:
         # CN_TRAIN_GRAPH=0: every iteration as eager launches (A/B; default: replay a captured HIP graph where it applies)
         self.use_graph = os.environ.get("CN_TRAIN_GRAPH", "1") != "0"
         self._graphs: Dict[tuple, dict] = {}
-        self._g_dev = None
-        self._g_ring: List[dict] = []
+        self._g_dev: Dict[int, Tensor] = {}  # per batch size R: Adam scalars of every group | the sampler's jitter, one buffer
+        self._g_ring: Dict[int, List[dict]] = {}  # its pinned staging slots
         self._g_ring_next = 0
+        self._planes: Dict[tuple, Tensor] = {}  # constant [R, 1] near / far columns of bundles that carry none
         dev = model.device
         # a group that is not listed is frozen (its gradients are still computed for "fields"/"proposal_networks")
         self.train_pose = "camera_opt" in self.groups
@@ -155,7 +156,7 @@ class FruitTrainer:
         self._steps_since_update = 0  # ProposalNetworkSampler state (_steps_since_update, _step)
         self._sampler_step = 0
         self._gen = torch.Generator(device="cpu").manual_seed(seed)
-        self.loss_sums = torch.zeros(4, device=dev)
+        self.loss_sums = torch.zeros(5, device=dev)
         self._zeroed: Dict[int, Tensor] = {}  # per batch size R, [6 R + 8]: ray-gradient accumulators | loss sums, one fill per iteration
         self._epilogue = None  # cn_train_epilogue's output of the last forward_backward
 
@@ -196,16 +197,17 @@ class FruitTrainer:
         pose = m.params["camera_optimizer.pose_adjustment"]
         o, d = torch.empty_like(rb.origins), torch.empty_like(rb.directions)
         ops.apply_pose_adjustment_to(pose, cam, rb.origins, rb.directions, o, d)  # (out of place: no clones of the raw rays)
-        # one zeroed buffer per iteration: the ray-gradient accumulators and the four loss sums (one fill instead of three)
+        # one zeroed buffer per iteration: the ray-gradient accumulators, the four loss sums and the distortion metric's sum (one
+        # fill instead of four)
         zeroed = self._zeroed.get(R)  # (kept per batch size: a captured iteration of another size still reads its own)
         if zeroed is None:
             zeroed = self._zeroed[R] = torch.empty(6 * R + 8, device=dev)
-        self.loss_sums = zeroed[6 * R:6 * R + 4]
+        self.loss_sums = zeroed[6 * R:6 * R + 5]
         zeroed.zero_()
         if self.train_pose:
             d_o, d_d = zeroed[:3 * R].view(R, 3), zeroed[3 * R:6 * R].view(R, 3)
-        nears = rb.nears if rb.nears is not None else torch.full((R, 1), float(cfg.near_plane), device=dev)
-        fars = rb.fars if rb.fars is not None else torch.full((R, 1), float(cfg.far_plane), device=dev)
+        nears = rb.nears if rb.nears is not None else self._plane(R, cfg.near_plane)
+        fars = rb.fars if rb.fars is not None else self._plane(R, cfg.far_plane)
         n_lvl = len(m.proposal_networks)
         self.grad_field.enable_scatter_scratch(R * int(cfg.num_nerf_samples_per_ray))
         for i, gp in enumerate(self.grad_props):
@@ -255,7 +257,9 @@ class FruitTrainer:
         image = batch["image"].to(dev)[:, :3].to(torch.float32).contiguous()
         mask = batch["fruit_mask"].to(dev).to(torch.float32).reshape(R, 1).contiguous()
         rb_out = ops.train_render_backward(starts, ends, fo["density"], fo["rgb"], fo["semantics"], image, mask,
-                                           cfg.semantic_loss_weight, self.loss_sums)
+                                           cfg.semantic_loss_weight, self.loss_sums[:4])
+        # get_metrics_dict's distortion (fruit_nerf.py:642): its sum over rays goes to loss_sums[4], the epilogue divides
+        ops.distortion_metric(bins, rb_out["weights"], self.loss_sums[4:5])
         # The three backward passes (field, proposal network 0, proposal network 1) only share read-only inputs, so they run
         # on three streams when self.concurrent_backward: each is bound by the float-atomic request rate of its scatter for
         # part of its time and by matrix / gather work for the rest, and the parts of different kernels overlap on a CU.
@@ -331,6 +335,13 @@ class FruitTrainer:
         return {"loss_dict": loss_dict, "rgb": rb_out["rgb"], "semantics": rb_out["semantics"],
                 "accumulation": rb_out["accumulation"]}
 
+    def _plane(self, R: int, value: float) -> Tensor:
+        key = (R, float(value))
+        t = self._planes.get(key)
+        if t is None:
+            t = self._planes[key] = torch.full((R, 1), float(value), device=self.model.device)
+        return t
+
     def all_reduce_gradients(self, group=None) -> None:
         """Data-parallel step, blocking form: average the whole flat gradient buffer over the ranks in place (each rank
         trained on its own ray batch).  ``train_iteration`` uses the overlapped per-group form (``gradient_exchange``)."""
@@ -346,20 +357,38 @@ class FruitTrainer:
             self._exchange = GroupedGradientExchange(self.flat_grads, self.group_range, group, force)
         return self._exchange
 
+    def _group_stepped(self, g: str, proposals_updated: bool) -> bool:
+        return g in self.groups and not (g == "proposal_networks" and not proposals_updated)
+
+    def _adam_group_dev(self, g: str, proposals_updated: bool, hyper_row: Tensor) -> None:
+        lo, hi = self.group_range[g]
+        if not self._group_stepped(g, proposals_updated):
+            self.flat_grads[lo:hi].zero_()
+            return
+        ops.adam_step_dev(self.flat_params[lo:hi], self.flat_grads[lo:hi], self.flat_exp_avg[lo:hi],
+                          self.flat_exp_avg_sq[lo:hi], hyper_row, zero_grad=True)
+
     def _optimizer_step_dev(self, proposals_updated: bool, hyper: Tensor) -> None:
-        """``optimizer_step`` for the captured iteration: the same launches with every per-step scalar read from ``hyper``
-        ([groups, 8] on the device, one row per optimiser group in ``group_range`` order); counters are kept by the caller."""
+        """``optimizer_step`` for the captured iteration: every per-step scalar is read from ``hyper`` ([groups, 8] on the
+        device, one row per optimiser group in ``group_range`` order, ``hyper[k][7] != 0`` = no step for group k); counters are
+        kept by the caller.  The first group (the field, 67 of the 78 MB) keeps its own launch with its scalars in registers;
+        the small ones after it (proposal networks, camera poses) share ONE launch."""
         if self.tcnn:
             for spec, key in self._tcnn_tables:
                 ops.tcnn_grid_tie_gradients(spec, self.grads[key])
             for k in self._frozen:
                 self.grads[k].zero_()
-        for gi, (g, (lo, hi)) in enumerate(self.group_range.items()):
-            if g not in self.groups or (g == "proposal_networks" and not proposals_updated):
-                self.flat_grads[lo:hi].zero_()
-                continue
-            ops.adam_step_dev(self.flat_params[lo:hi], self.flat_grads[lo:hi], self.flat_exp_avg[lo:hi],
-                              self.flat_exp_avg_sq[lo:hi], hyper[gi], zero_grad=True)
+        names = list(self.group_range)
+        self._adam_group_dev(names[0], proposals_updated, hyper[0])
+        rest = names[1:]
+        if len(rest) == 1:
+            self._adam_group_dev(rest[0], proposals_updated, hyper[len(names) - 1])
+        elif rest:
+            lo = self.group_range[rest[0]][0]
+            bounds = [0] + [self.group_range[g][1] - lo for g in rest]
+            hi = lo + bounds[-1]
+            ops.adam_step_groups_dev(self.flat_params[lo:hi], self.flat_grads[lo:hi], self.flat_exp_avg[lo:hi],
+                                     self.flat_exp_avg_sq[lo:hi], bounds, hyper[len(names) - len(rest):])
         if self.tcnn:
             for spec, key in self._tcnn_tables:
                 ops.tcnn_grid_tie_parameters(spec, self.model.params[key])
@@ -428,11 +457,14 @@ class FruitTrainer:
         """At the reference's batch size (4 096 rays) an iteration is ~45 launches of 5-700 us: the gaps between them are a tenth
         of it.  The whole iteration -- pose tweak, sampler, field forward, losses, the three backward passes, folds, epilogue,
         the optimiser steps, the distortion metric -- is captured ONCE per (batch geometry, proposal-update yes / no) into a
-        HIP graph and replayed; what changes from step to step enters through device memory: the annealing exponent and the
-        Adam scalars of every group (one 100-byte host-to-device copy), the sampler's jitter (one copy), and the batch itself
+        HIP graph and replayed; what changes from step to step enters through device memory: the annealing exponent, the Adam
+        scalars of every group and the sampler's jitter (ONE host-to-device copy from a pinned slot), and the batch itself
         (read in place when the caller hands over the same tensors as at capture time, e.g. a resident dataset's views;
-        otherwise copied into the captured buffers).  Returns None when the iteration has to run eagerly (first two
-        occurrences of a variant: warm-up, then capture)."""
+        otherwise copied into the captured buffers).  The graph is one chain: a branch for the work nothing downstream waits
+        for (the distortion metric beside the field backward, the field group's HBM-bound Adam step beside the atomic-bound
+        proposal backward) was built and measured -- 1.84-1.87 ms with it, 1.86-1.87 without at 4 096 rays, and the same on two
+        streams without a graph -- and removed.  Returns None when the iteration has to run eagerly (first two occurrences of
+        a variant: warm-up, then capture)."""
         m, cfg, dev = self.model, self.model.config, self.model.device
         rb = ray_bundle.flatten()
         R = rb.origins.shape[0]
@@ -449,13 +481,17 @@ class FruitTrainer:
         # (pinned staging in a ring of four slots, each guarded by an event: the host runs ahead of the GPU, and a slot must not
         #  be rewritten before the copy that reads it has executed)
         ngrp = len(self.group_range)
-        if self._g_dev is None:
-            self._g_dev = torch.zeros(1 + ngrp, 8, device=dev)
-        slot = self._g_ring[self._g_ring_next % len(self._g_ring)] if self._g_ring else None
-        if not self._g_ring or slot["jitter"].shape[1] != R:
-            self._g_ring = [{"scalars": torch.zeros(1 + ngrp, 8).pin_memory(), "jitter": torch.empty(n_lvl + 1, R).pin_memory(),
-                             "event": None} for _ in range(4)]
-            slot = self._g_ring[0]
+        nsc = (1 + ngrp) * 8
+        if R not in self._g_dev:
+            self._g_dev[R] = torch.zeros(nsc + (n_lvl + 1) * R, device=dev)
+            self._g_ring[R] = []
+            for _ in range(4):
+                buf = torch.zeros(nsc + (n_lvl + 1) * R).pin_memory()
+                self._g_ring[R].append({"buf": buf, "scalars": buf[:nsc].view(1 + ngrp, 8), "jitter": buf[nsc:].view(n_lvl + 1, R),
+                                        "event": None})
+        g_dev = self._g_dev[R]
+        g_scalars, g_jitter = g_dev[:nsc].view(1 + ngrp, 8), g_dev[nsc:].view(n_lvl + 1, R)
+        slot = self._g_ring[R][self._g_ring_next % 4]
         self._g_ring_next += 1
         if slot["event"] is not None:
             slot["event"].synchronize()
@@ -463,32 +499,35 @@ class FruitTrainer:
         slot["scalars"][0, 0] = float(m._anneal)
         steps = dict(self.group_steps)
         for gi, g in enumerate(self.group_range):
-            if g in self.groups and not (g == "proposal_networks" and not updated):
+            if self._group_stepped(g, updated):
                 steps[g] += 1
                 grp = self.groups[g]
                 ops.adam_hyper(steps[g], grp.lr_at(self.step), eps=grp.eps, out=slot["scalars"][1 + gi])
+            else:
+                slot["scalars"][1 + gi, 7] = 1.0  # no step for this group: cn_adam_step_groups_dev only zeroes its gradients
         torch.rand(n_lvl + 1, R, generator=self._gen, out=slot["jitter"])
         given = {"origins": rb.origins, "directions": rb.directions, "cam": rb.camera_indices, "nears": rb.nears, "fars": rb.fars,
                  "image": batch["image"], "mask": batch["fruit_mask"]}
 
         def stage_inputs():
             # the captured launches read the trainer's own copies of the batch; a tensor the caller hands over again unchanged
-            # (same storage, same version counter: a resident batch) is not copied again
+            # (same storage, same version counter: a resident batch) is not copied again.  The STORAGE object is part of the
+            # tag and thereby kept alive: a freshly allocated batch can land on the address of a freed one with the same shape
+            # and version 0, and an address alone would then pass stale rays for new ones.
             for name, t in given.items():
                 if t is None:
                     continue
-                tag = (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
-                if st["seen_inputs"].get(name) != tag:
+                tag = (t.untyped_storage(), t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype)
+                old = st["seen_inputs"].get(name)
+                if old is None or old[0] is not tag[0] or old[1:] != tag[1:]:
                     st["inputs"][name].copy_(t.to(dev).reshape(st["inputs"][name].shape), non_blocking=True)
                     st["seen_inputs"][name] = tag
-            st["jitter"].copy_(slot["jitter"], non_blocking=True)
-            self._g_dev.copy_(slot["scalars"], non_blocking=True)
+            g_dev.copy_(slot["buf"], non_blocking=True)
             slot["event"] = torch.cuda.Event()
             slot["event"].record()
 
         if "graph" not in st:
             # second occurrence: capture
-            st["jitter"] = torch.empty(n_lvl + 1, R, device=dev)
             st["inputs"] = {k: (None if t is None else torch.empty_like(t.to(dev))) for k, t in given.items()}
             st["seen_inputs"] = {}
             stage_inputs()
@@ -497,9 +536,9 @@ class FruitTrainer:
             sbatch = {"image": ins["image"], "fruit_mask": ins["mask"]}
 
             def body():
-                out = self.forward_backward(srb, sbatch, update_proposals=updated, anneal_dev=self._g_dev[0, 0:1],
-                                            jitter_rows=st["jitter"])
-                self._optimizer_step_dev(updated, self._g_dev[1:])
+                out = self.forward_backward(srb, sbatch, update_proposals=updated, anneal_dev=g_scalars[0, 0:1],
+                                            jitter_rows=g_jitter)
+                self._optimizer_step_dev(updated, g_scalars[1:])
                 out["metrics_dict"] = self.get_metrics_dict(out)
                 return out
 
@@ -565,7 +604,7 @@ class FruitTrainer:
         """``get_metrics_dict`` (``fruit_nerf.py:639-645``): PSNR and the distortion metric of the last batch."""
         ep = self._epilogue  # of the forward_backward that produced `out` (the pose norms are those BEFORE the optimiser step,
         md = {"psnr": ep[4],  # as nerfstudio's get_train_loss_dict computes its metrics before the step)
-              "distortion": ops.distortion_metric(self._last_bins, self._last_weights)}
+              "distortion": ep[7]}
         if self.train_pose:  # CameraOptimizer.get_metrics_dict (fruit_nerf.py:644)
             md["camera_opt_translation"] = ep[5]
             md["camera_opt_rotation"] = ep[6]

@@ -420,12 +420,13 @@ def apply_pose_adjustment_to(pose_adjustment: Tensor, camera_indices: Tensor, or
 
 def train_epilogue(loss_sums: Tensor, num_rays: int, num_samples: int, semantic_loss_weight: float,
                    interlevel_loss_mult: float, pose_adjustment: Optional[Tensor], out: Optional[Tensor] = None) -> Tensor:
-    """``cn_train_epilogue``: [rgb_loss, semantics_loss, interlevel_loss, camera_opt_regularizer, psnr, |t|, |w|, 0]."""
+    """``cn_train_epilogue``: [rgb_loss, semantics_loss, interlevel_loss, camera_opt_regularizer, psnr, |t|, |w|, distortion]
+    (``loss_sums`` of five elements: the fifth is the sum ``distortion_metric(..., acc=)`` left there; of four: distortion = 0)."""
     lib = L.load()
     if out is None:
         out = torch.empty(8, device=loss_sums.device)
     C_ = 0 if pose_adjustment is None else pose_adjustment.shape[0]
-    L.check(lib.cn_train_epilogue(_p(_f32(loss_sums, "loss_sums")), num_rays, num_samples, semantic_loss_weight,
+    L.check(lib.cn_train_epilogue(_p(_f32(loss_sums, "loss_sums")), loss_sums.numel(), num_rays, num_samples, semantic_loss_weight,
                                   interlevel_loss_mult, _p(_f32(pose_adjustment, "pose_adjustment")), C_, _p(_f32(out, "out")),
                                   _stream(loss_sums)))
     return out
@@ -883,6 +884,24 @@ def adam_step_dev(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tens
                                  1 if zero_grad else 0, _stream(param)))
 
 
+def adam_step_groups_dev(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, bounds: Sequence[int],
+                         hyper: Tensor) -> None:
+    """``cn_adam_step_groups_dev``: several optimiser groups of a flat buffer in one launch (``bounds``: ascending element offsets
+    from 0, one more than groups; ``hyper`` [groups, 8] on the device, ``hyper[k][7] != 0``: group k takes no step, its gradients
+    are only zeroed)."""
+    lib = L.load()
+    n = len(bounds) - 1
+    if n < 1 or param.numel() < int(bounds[-1]) or tuple(hyper.shape) != (n, 8) or not hyper.is_contiguous():
+        raise ValueError("adam_step_groups_dev: bounds exceed the buffer, or hyper is not a contiguous [groups, 8]")
+    for t in (grad, exp_avg, exp_avg_sq):
+        if t.numel() != param.numel():
+            raise ValueError("adam_step_groups_dev: param / grad / moments differ in length")
+    arr = (C.c_int64 * (n + 1))(*[int(b) for b in bounds])
+    L.check(lib.cn_adam_step_groups_dev(_p(_f32(param, "param")), _p(_f32(grad, "grad")), _p(_f32(exp_avg, "exp_avg")),
+                                        _p(_f32(exp_avg_sq, "exp_avg_sq")), C.cast(arr, C.c_void_p), n, _p(_f32(hyper, "hyper")),
+                                        _stream(param)))
+
+
 def radam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor, step: int, lr: float,
                beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-15, zero_grad: bool = True) -> None:
     """``torch.optim.RAdam`` (the ``_big`` / ``_huge`` methods' optimiser)."""
@@ -892,14 +911,19 @@ def radam_step(param: Tensor, grad: Tensor, exp_avg: Tensor, exp_avg_sq: Tensor,
                               eps, 1 if zero_grad else 0, _stream(param)))
 
 
-def distortion_metric(spacing_bins: Tensor, weights: Tensor) -> Tensor:
-    """mean over rays of nerfstudio's distortion loss (get_metrics_dict "distortion")."""
+def distortion_metric(spacing_bins: Tensor, weights: Tensor, acc: Optional[Tensor] = None) -> Optional[Tensor]:
+    """mean over rays of nerfstudio's distortion loss (get_metrics_dict "distortion").  With ``acc`` (one zeroed device float)
+    only the SUM over rays is added there and None is returned: the training step divides it in ``cn_train_epilogue``."""
     lib = L.load()
     R, S = weights.shape
-    acc = torch.zeros(1, device=weights.device)
-    L.check(lib.cn_distortion_metric(_p(_f32(spacing_bins, "spacing_bins")), _p(_f32(weights, "weights")), R, S, _p(acc),
-                                     _stream(weights)))
-    return acc[0] / R
+    own = acc is None
+    if own:
+        acc = torch.zeros(1, device=weights.device)
+    elif acc.numel() != 1:
+        raise ValueError("distortion_metric: acc is one float")
+    L.check(lib.cn_distortion_metric(_p(_f32(spacing_bins, "spacing_bins")), _p(_f32(weights, "weights")), R, S,
+                                     _p(_f32(acc, "acc")), _stream(weights)))
+    return acc[0] / R if own else None
 
 
 # --------------------------------------------------------------------------------------------------------------

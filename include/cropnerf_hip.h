@@ -578,12 +578,14 @@ int cn_pose_adjustment_backward(const float* pose_adjustment /*[C,6]*/, const in
                                 const float* d_directions, int64_t num_rays, float* grad_pose, cn_stream_t stream);
 
 /* get_loss_dict (fruit_nerf/fruit_nerf.py:601-615) + the scalar metrics of get_metrics_dict (:639-645) from the loss sums
- * the training kernels left in loss_sums[4] = {sum (rgb - image)^2, sum BCE, sum interlevel terms, camera regulariser}:
- * out[8] = {rgb_loss, semantics_loss, interlevel_loss, camera_opt_regularizer, psnr, |translations|, |rotations|, 0}
- * (pose_adjustment NULL: the two norms are 0).  One launch instead of a dozen one-element host-composed kernels. */
-int cn_train_epilogue(const float* loss_sums, int64_t num_rays, int32_t num_samples, float semantic_loss_weight,
-                      float interlevel_loss_mult, const float* pose_adjustment /*[C,6] or NULL*/, int32_t num_cameras,
-                      float* out, cn_stream_t stream);
+ * the training kernels left in loss_sums = {sum (rgb - image)^2, sum BCE, sum interlevel terms, camera regulariser} and, when
+ * num_sums = 5, the sum cn_distortion_metric accumulated:
+ * out[8] = {rgb_loss, semantics_loss, interlevel_loss, camera_opt_regularizer, psnr, |translations|, |rotations|, distortion}
+ * (pose_adjustment NULL: the two norms are 0; distortion = loss_sums[4] / R, the "distortion" entry of get_metrics_dict, or 0
+ * when num_sums = 4).  One launch instead of a dozen one-element host-composed kernels. */
+int cn_train_epilogue(const float* loss_sums, int32_t num_sums /*4 or 5*/, int64_t num_rays, int32_t num_samples,
+                      float semantic_loss_weight, float interlevel_loss_mult, const float* pose_adjustment /*[C,6] or NULL*/,
+                      int32_t num_cameras, float* out, cn_stream_t stream);
 
 /* camera_opt_regularizer of CameraOptimizer.get_loss_dict (fruit_nerf/fruit_nerf.py:614):
  * mean_c |t_c| * trans_l2_penalty + mean_c |w_c| * rot_l2_penalty; adds the loss to *loss_out and, when grad_pose
@@ -612,6 +614,11 @@ int cn_radam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
 int cn_adam_hyper(int32_t step, double lr, double beta1, double beta2, double eps, float* hyper_host);
 int cn_adam_step_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper /*device [8]*/,
                      int32_t zero_grad, cn_stream_t stream);
+/* Several optimiser groups of one flat buffer in ONE launch: group k owns elements [bounds_host[k], bounds_host[k + 1]) (a HOST
+ * array of num_groups + 1 ascending offsets from 0, at most 8 groups), hyper [num_groups, 8] on the device as above, with
+ * hyper[k][7] != 0 marking a group that takes no step this iteration.  Gradients are zeroed everywhere. */
+int cn_adam_step_groups_dev(float* param, float* grad, float* exp_avg, float* exp_avg_sq, const int64_t* bounds_host,
+                            int32_t num_groups, const float* hyper /*device [num_groups, 8]*/, cn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Depth-based semantic projection (the alternative to the NeRF projection:

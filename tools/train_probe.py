@@ -20,7 +20,8 @@ R = int(os.environ.get("TRAIN_RAYS", "4096"))
 idx = torch.stack([torch.randint(0,100,(R,),generator=g), torch.randint(0,800,(R,),generator=g), torch.randint(0,800,(R,),generator=g)],-1)
 rb = cams.generate_rays(idx.to(dev))
 batch = {"image": torch.rand(R,3,generator=g).to(dev), "fruit_mask": (torch.rand(R,1,generator=g)>0.5).float().to(dev)}
-for i in range(2): tr.train_iteration(rb, batch)
+WARM, ITERS = int(os.environ.get("WARM", "2")), int(os.environ.get("ITERS", "20"))
+for i in range(WARM): tr.train_iteration(rb, batch)
 torch.cuda.synchronize(); t=time.perf_counter()
-for i in range(20): tr.train_iteration(rb, batch)
-torch.cuda.synchronize(); print("CN_DEBUG_SKIP", os.environ.get("CN_DEBUG_SKIP"), "ms/iter", (time.perf_counter()-t)/20*1e3)
+for i in range(ITERS): tr.train_iteration(rb, batch)
+torch.cuda.synchronize(); print("CN_DEBUG_SKIP", os.environ.get("CN_DEBUG_SKIP"), "rays", R, "ms/iter", (time.perf_counter()-t)/ITERS*1e3)
