@@ -448,8 +448,104 @@ __global__ void __launch_bounds__(256) cell_scatter_fold_kernel(CellFoldArgs F, 
     atomicAdd(gtab + 2 * (size_t)e + 1, v[2 * c + 1]);
   }
 }
+// The same fold by BLOCKS of 8 x 8 x 8 cells (round 4).  The kernel above adds every touched record's 16 values to the table
+// one float per atomic instruction: up to 16 requests per record and copy, 4.3e6 per call at 65 536 rays -- the fold was bound
+// by its own atomics (0.27 ms per call, three calls per iteration).  Here a workgroup owns a block of cells in up to four of
+// the level's copies, sums their records into the block's 9 x 9 x 9 vertices in LDS (ds_add_f32), and then adds every non-zero
+// vertex to the table ONCE, two lanes per vertex (its two features) and vertices in x order: the index function xors x into
+// the low bits, so the eight vertices of an aligned x-row of the block lie on one 64-byte line and travel as one request.
+// Requests per block: ~2 per (y, z) row of vertices instead of up to 16 per record.
+struct CellFoldBlocksArgs {
+  CellScatter c;
+  unsigned first_block[CN_CELL_LEVELS + 1];
+  unsigned nb[CN_CELL_LEVELS];      // blocks per axis
+  unsigned groups[CN_CELL_LEVELS];  // workgroups per block: the level's copies are dealt out over them
+  Lvl lv[CN_CELL_LEVELS];
+};
+__global__ void __launch_bounds__(256) cell_scatter_fold_blocks_kernel(CellFoldBlocksArgs F, float* __restrict__ gtab) {
+  __shared__ float acc[2 * 729];
+  int l = 0;
+#pragma unroll
+  for (int k = 1; k < CN_CELL_LEVELS; ++k) l = (k < F.c.num_levels && blockIdx.x >= F.first_block[k]) ? k : l;  // block-uniform
+  unsigned n = F.c.n[0], copies = F.c.copies[0], first = F.first_block[0], nb = F.nb[0], groups = F.groups[0];
+  unsigned long long off = F.c.offset[0];
+  Lvl lv = F.lv[0];
+#pragma unroll
+  for (int k = 1; k < CN_CELL_LEVELS; ++k) {
+    const bool m = l == k;
+    n = m ? F.c.n[k] : n;
+    copies = m ? F.c.copies[k] : copies;
+    first = m ? F.first_block[k] : first;
+    nb = m ? F.nb[k] : nb;
+    groups = m ? F.groups[k] : groups;
+    off = m ? F.c.offset[k] : off;
+    lv.off = m ? F.lv[k].off : lv.off;
+    lv.mask = m ? F.lv[k].mask : lv.mask;
+    lv.m1 = m ? F.lv[k].m1 : lv.m1;
+    lv.m2 = m ? F.lv[k].m2 : lv.m2;
+  }
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 2 * 729; i += 256) acc[i] = 0.f;
+  __syncthreads();
+  const unsigned local = blockIdx.x - first, grp = local % groups, b = local / groups;
+  const unsigned bx = b % nb, by = (b / nb) % nb, bz = b / (nb * nb);
+  const unsigned long long cells = (unsigned long long)n * n * n;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const unsigned cl = tid + 256 * h, lx = cl & 7u, ly = (cl >> 3) & 7u, lz = cl >> 6;
+    const unsigned x = bx * 8 + lx, y = by * 8 + ly, z = bz * 8 + lz;
+    if (x >= n || y >= n || z >= n) continue;
+    const unsigned long long cidx = x + (unsigned long long)n * (y + (unsigned long long)n * z);
+    for (unsigned k = grp; k < copies; k += groups) {
+      f32x4* p = reinterpret_cast<f32x4*>(F.c.base + off + ((unsigned long long)k * cells + cidx) * 16);
+      const f32x4 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
+      const float v[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) any = any || v[j] != 0.f;
+      if (!any) continue;
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      p[0] = zero;
+      p[1] = zero;
+      p[2] = zero;
+      p[3] = zero;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const unsigned vi = ((lz + (c >> 2)) * 9 + (ly + ((c >> 1) & 1))) * 9 + (lx + (c & 1));
+        if (v[2 * c] != 0.f) atomicAdd(&acc[2 * vi], v[2 * c]);
+        if (v[2 * c + 1] != 0.f) atomicAdd(&acc[2 * vi + 1], v[2 * c + 1]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * 729; i += 256) {
+    const float val = acc[i];
+    if (val == 0.f) continue;
+    const unsigned vtx = (unsigned)i >> 1, vx = vtx % 9, vy = (vtx / 9) % 9, vz = vtx / 81;
+    const unsigned e = (((bx * 8 + vx) ^ ((by * 8 + vy) * lv.m1) ^ ((bz * 8 + vz) * lv.m2)) & lv.mask) + lv.off;
+    atomicAdd(gtab + 2 * (size_t)e + (i & 1), val);
+  }
+}
 inline void launch_cell_fold(const CellScatter& c, const GridDev& grid, float* gtab, hipStream_t stream) {
   if (!c.base || c.num_levels <= 0) return;
+  const char* form = getenv("CN_CELL_FOLD");  // "records": the first form, one thread per record (A/B runs)
+  if (!form || strcmp(form, "records") != 0) {
+    CellFoldBlocksArgs B{};
+    B.c = c;
+    unsigned blocks = 0;
+    for (int l = 0; l < c.num_levels; ++l) {
+      B.first_block[l] = blocks;
+      B.lv[l] = grid.level(l);
+      B.nb[l] = (c.n[l] + 7) / 8;
+      B.groups[l] = (c.copies[l] + 3) / 4;
+      blocks += B.nb[l] * B.nb[l] * B.nb[l] * B.groups[l];
+    }
+    for (int l = c.num_levels; l <= CN_CELL_LEVELS; ++l) B.first_block[l] = blocks;
+    for (int l = c.num_levels; l < CN_CELL_LEVELS; ++l) B.nb[l] = B.groups[l] = 1;
+    hipLaunchKernelGGL(cell_scatter_fold_blocks_kernel, dim3(blocks), dim3(256), 0, stream, B, gtab);
+    return;
+  }
   CellFoldArgs F{};
   F.c = c;
   unsigned blocks = 0;
