@@ -639,6 +639,25 @@ def secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, o
                               "(5.5 ms at 65 536 rays with the memory operations switched off) plus its gathers and scatter, which "
                               "add to them; the atomic-request rate priced here is a floor of the iteration, not its cost "
                               "(DESIGN.md 4.10: a store-based scatter that removed most requests did not shorten it)"}
+            if spp == 48:
+                # The iterations above are the first seven of a run, where the reference updates the proposal networks every
+                # time.  The schedule (fruit_nerf.py:144-149: update_every = 5 once step >= proposal_warmup = 5 000) makes that
+                # one iteration in five for most of a run: the same trainer moved to step 5 000, 25 iterations (five schedule
+                # periods) on the wall clock with no wait between them.
+                tr.step = tr._sampler_step = 5000
+                tr._steps_since_update = 0
+                for i in range(15):
+                    tr.train_iteration(rb, batch)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(25):
+                    tr.train_iteration(rb, batch)
+                torch.cuda.synchronize()
+                ts = (time.perf_counter() - t0) / 25
+                train[key]["steady_state"] = {
+                    "ms_per_iter": round(ts * 1e3, 3), "rays_per_sec": nrays / ts,
+                    "schedule": "step >= proposal_warmup (5 000): the proposal networks take a gradient every 5th iteration",
+                    "timing": "wall clock over 25 consecutive iterations"}
             del tr, model
         out["train_iteration"] = train
     return out

@@ -17,14 +17,17 @@ except Exception:  # noqa: BLE001
 
 def short(name):
     name = name.replace("void ", "")
-    m = re.match(r"(?:cn::(?:mf::)?)?([A-Za-z0-9_]+)", name)
+    m = re.match(r"(?:cn::(?:mf::|pw::)?)?([A-Za-z0-9_]+)", name)
     return m.group(1) if m else name[:40]
 
 
 def fold(d):
     """{counter: {kernel: (total, launches)}} for the cn:: kernels of one pass, and the units line of its log"""
     acc = {}
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    # (gpurun merges a call's files INTO gpurun_out/: an earlier collection's CSVs of the same pass stay beside the new one --
+    #  only the newest file of a pass is that pass)
+    files = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:
         for row in csv.DictReader(open(f)):
             if "cn::" not in row["Kernel_Name"]:
                 continue
