@@ -89,6 +89,12 @@ class ProjectionJob(C.Structure):
                 ("camera_index", C.c_int32), ("reserved", C.c_int32), ("slot_offset", C.c_int64)]
 
 
+class InterlevelLevel(C.Structure):
+    """``cn_interlevel_level`` (a host array read by ``cn_interlevel_backward_levels`` at call time)"""
+    _fields_ = [("spacing_bins", C.c_void_p), ("starts", C.c_void_p), ("ends", C.c_void_p), ("density", C.c_void_p),
+                ("d_density", C.c_void_p), ("num_samples", C.c_int32), ("reserved", C.c_int32)]
+
+
 _P = C.c_void_p
 _I32, _I64, _F = C.c_int32, C.c_int64, C.c_float
 
@@ -147,8 +153,9 @@ SIGNATURES = {
     "cn_pointcloud_compact_calls": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "cn_embedding_mean": (C.c_int, [_P, _I32, _I32, _P, _P]),
     "cn_train_render_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F, _P, _P, _P, _P, _P, _P, _P, _P,
-                                           _P]),
+                                           _P, _P]),
     "cn_interlevel_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _F, _P, _P, _P]),
+    "cn_interlevel_backward_levels": (C.c_int, [_P, _P, C.POINTER(InterlevelLevel), _I32, _I64, _I32, _F, _P, _P]),
     "cn_field_backward": (C.c_int, [C.POINTER(FieldParams), C.POINTER(FieldParams), C.POINTER(Scene), _I32, _I32, _P,
                                     _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P]),
     "cn_proposal_backward": (C.c_int, [C.POINTER(DensityParams), C.POINTER(DensityParams), C.POINTER(Scene), _P, _P,

@@ -24,7 +24,8 @@ train_render_backward_kernel(const float* __restrict__ starts, const float* __re
                              const float* __restrict__ mask, long long R, int S, float sem_weight,
                              float* __restrict__ out_rgb, float* __restrict__ out_sem, float* __restrict__ out_acc,
                              float* __restrict__ out_w, float* __restrict__ d_density, float* __restrict__ d_rgb,
-                             float* __restrict__ d_sem, float* __restrict__ loss_sums) {
+                             float* __restrict__ d_sem, float* __restrict__ loss_sums,
+                             const float* __restrict__ spacing_bins) {
   extern __shared__ __align__(16) float lds[];
   const int wave = threadIdx.x >> 6, lane = lane_id();
   float* wbuf = lds + wave * 2 * S;
@@ -32,10 +33,17 @@ train_render_backward_kernel(const float* __restrict__ starts, const float* __re
   const long long waves = (long long)gridDim.x * 4;
   const float inv_3r = 1.f / (3.f * (float)R), inv_r = 1.f / (float)R;
   float mse_sum = 0.f, bce_sum = 0.f;  // this wave's rays (lane 0): one atomic per wave at the end, not one per ray on one address
+  float dist_sum = 0.f;
   for (long long r = blockIdx.x * 4LL + wave; r < R; r += waves) {
     const long long base = r * (long long)S;
     // ---- forward: weights, rgb / accumulation / semantics ------------------------------------------------------
     float carry = 0.f, ar = 0.f, ag = 0.f, ab = 0.f, aw = 0.f, as = 0.f;
+    // nerfstudio's distortion_loss of this ray (the "distortion" metric, fruit_nerf.py:643) rides along when the caller hands
+    // over the spacing bins: sum_ij w_i w_j |u_i - u_j| = 2 sum_i w_i (u_i W_<i - (w u)_<i) for ascending mid-points u -- two
+    // more prefix sums of the scan that is here anyway, O(S) instead of the S^2 products of cn_distortion_metric; u is taken
+    // relative to the ray's first bin edge, so the difference of the two prefix terms does not cancel at the far end of [0, 1]
+    float dW = 0.f, dWU = 0.f, dterm = 0.f;
+    const float u_ref = spacing_bins ? spacing_bins[r * (S + 1)] : 0.f;
     for (int c0 = 0; c0 < S; c0 += 64) {
       const int i = c0 + lane;
       const bool valid = i < S;
@@ -45,6 +53,14 @@ train_render_backward_kernel(const float* __restrict__ starts, const float* __re
       float P = carry + (incl - dd);
       float w = valid ? nan_to_num((1.f - expf(-dd)) * expf(-P)) : 0.f;
       carry += wave_read(incl, 63);
+      if (spacing_bins) {  // (wave-uniform)
+        const float b0 = spacing_bins[r * (S + 1) + ic], b1 = spacing_bins[r * (S + 1) + ic + 1];
+        const float u = (b0 + b1) / 2.f - u_ref, wu = w * u;
+        const float sw = wave_inclusive_scan(w), swu = wave_inclusive_scan(wu);
+        dterm += 2.f * w * (u * (dW + sw - w) - (dWU + swu - wu)) + w * w * (b1 - b0) / 3.f;
+        dW += wave_read(sw, 63);
+        dWU += wave_read(swu, 63);
+      }
       if (valid) {
         wbuf[i] = w;
         pbuf[i] = P;
@@ -62,6 +78,10 @@ train_render_backward_kernel(const float* __restrict__ starts, const float* __re
     const float cg = wave_sum(ag) + lg_ * (1.f - acc);
     const float cb = wave_sum(ab) + lb_ * (1.f - acc);
     const float so = wave_sum(as);
+    if (spacing_bins) {
+      const float t = wave_sum(dterm);
+      if (lane == 0) dist_sum += t;
+    }
     // ---- losses and their derivatives w.r.t. the rendered values ----------------------------------------------------
     const float e0 = cr - image[3 * r + 0], e1 = cg - image[3 * r + 1], e2 = cb - image[3 * r + 2];
     const float y = mask[r];
@@ -108,10 +128,11 @@ train_render_backward_kernel(const float* __restrict__ starts, const float* __re
   }
   // one atomic pair per workgroup (every ray's own atomic on these two addresses is served one after the other: at
   // 4096 rays that alone was a third of this kernel)
-  __shared__ float red[4][2];
+  __shared__ float red[4][3];
   if (lane == 0) {
     red[wave][0] = mse_sum;
     red[wave][1] = bce_sum;
+    red[wave][2] = dist_sum;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -120,6 +141,8 @@ train_render_backward_kernel(const float* __restrict__ starts, const float* __re
       atomicAdd(loss_sums + 0, a);
       atomicAdd(loss_sums + 1, b);
     }
+    const float c = red[0][2] + red[1][2] + red[2][2] + red[3][2];
+    if (spacing_bins && c != 0.f) atomicAdd(loss_sums + 4, c);
   }
 }
 
@@ -134,12 +157,11 @@ __device__ __forceinline__ int upper_bound(const float* a, int n, float v) {
 }
 
 // one wave per ray.  LDS per wave: cp[Sp+1] | wp[Sp] | P[Sp] | cy[Sp+1] | diff[Sp+1]
-__global__ void __launch_bounds__(256)
-interlevel_backward_kernel(const float* __restrict__ c_bins, const float* __restrict__ w_final,
-                           const float* __restrict__ cp_bins, const float* __restrict__ starts_p,
-                           const float* __restrict__ ends_p, const float* __restrict__ density_p, long long R, int Sf,
-                           int Sp, float mult, float* __restrict__ d_density_p, float* __restrict__ loss_sum) {
-  extern __shared__ __align__(16) float lds[];
+__device__ __forceinline__ void
+interlevel_backward_rays(float* lds, const float* __restrict__ c_bins, const float* __restrict__ w_final,
+                         const float* __restrict__ cp_bins, const float* __restrict__ starts_p,
+                         const float* __restrict__ ends_p, const float* __restrict__ density_p, long long R, int Sf,
+                         int Sp, float mult, float* __restrict__ d_density_p, float* __restrict__ loss_sum) {
   const int wave = threadIdx.x >> 6, lane = lane_id();
   const int stride = 5 * Sp + 3;
   float* cp = lds + wave * stride;
@@ -236,6 +258,42 @@ interlevel_backward_kernel(const float* __restrict__ c_bins, const float* __rest
     const float a = red[0] + red[1] + red[2] + red[3];
     if (a != 0.f) atomicAdd(loss_sum, a);
   }
+}
+__global__ void __launch_bounds__(256)
+interlevel_backward_kernel(const float* __restrict__ c_bins, const float* __restrict__ w_final,
+                           const float* __restrict__ cp_bins, const float* __restrict__ starts_p,
+                           const float* __restrict__ ends_p, const float* __restrict__ density_p, long long R, int Sf,
+                           int Sp, float mult, float* __restrict__ d_density_p, float* __restrict__ loss_sum) {
+  extern __shared__ __align__(16) float lds[];
+  interlevel_backward_rays(lds, c_bins, w_final, cp_bins, starts_p, ends_p, density_p, R, Sf, Sp, mult, d_density_p, loss_sum);
+}
+// every proposal level of an iteration in ONE launch (blockIdx.y = level): the levels only share read-only inputs, and at the
+// reference's 4 096-ray batches each of them is a launch-latency-sized kernel
+constexpr int INTERLEVEL_MAX_LEVELS = 4;
+struct InterlevelLevels {
+  const float *cp_bins[INTERLEVEL_MAX_LEVELS], *starts[INTERLEVEL_MAX_LEVELS], *ends[INTERLEVEL_MAX_LEVELS],
+      *density[INTERLEVEL_MAX_LEVELS];
+  float* d_density[INTERLEVEL_MAX_LEVELS];
+  int Sp[INTERLEVEL_MAX_LEVELS];
+};
+__global__ void __launch_bounds__(256)
+interlevel_backward_levels_kernel(const float* __restrict__ c_bins, const float* __restrict__ w_final, InterlevelLevels L,
+                                  long long R, int Sf, float mult, float* __restrict__ loss_sum) {
+  extern __shared__ __align__(16) float lds[];
+  const float *cp = L.cp_bins[0], *st = L.starts[0], *en = L.ends[0], *de = L.density[0];
+  float* dd = L.d_density[0];
+  int Sp = L.Sp[0];
+#pragma unroll
+  for (int k = 1; k < INTERLEVEL_MAX_LEVELS; ++k) {  // (block-uniform selects: no run-time index into the kernel arguments)
+    const bool m = (int)blockIdx.y == k;
+    cp = m ? L.cp_bins[k] : cp;
+    st = m ? L.starts[k] : st;
+    en = m ? L.ends[k] : en;
+    de = m ? L.density[k] : de;
+    dd = m ? L.d_density[k] : dd;
+    Sp = m ? L.Sp[k] : Sp;
+  }
+  interlevel_backward_rays(lds, c_bins, w_final, cp, st, en, de, R, Sf, Sp, mult, dd, loss_sum);
 }
 
 // nerfstudio distortion_loss on the final level (a metric in the reference, fruit_nerf.py:643):
@@ -504,7 +562,8 @@ extern "C" int cn_train_render_backward(const float* starts, const float* ends, 
                                         const float* fruit_mask, int64_t num_rays, int32_t num_samples,
                                         float semantic_loss_weight, float* out_rgb, float* out_semantics,
                                         float* out_accumulation, float* out_weights, float* d_density, float* d_rgb,
-                                        float* d_semantics, float* loss_sums, cn_stream_t stream) {
+                                        float* d_semantics, float* loss_sums, const float* spacing_bins,
+                                        cn_stream_t stream) {
   CN_REQUIRE(starts && ends && density && rgb && semantics && image && fruit_mask && d_density && d_rgb &&
                  d_semantics && loss_sums,
              CN_ERR_INVALID, "cn_train_render_backward: null argument");
@@ -515,7 +574,7 @@ extern "C" int cn_train_render_backward(const float* starts, const float* ends, 
   hipLaunchKernelGGL(cn::train_render_backward_kernel, dim3(cn::grid_for(num_rays, 4, 4096)), dim3(256), lds,
                      cn::as_stream(stream), starts, ends, density, rgb, semantics, image, fruit_mask,
                      (long long)num_rays, num_samples, semantic_loss_weight, out_rgb, out_semantics, out_accumulation,
-                     out_weights, d_density, d_rgb, d_semantics, loss_sums);
+                     out_weights, d_density, d_rgb, d_semantics, loss_sums, spacing_bins);
   return cn::check_launch("cn_train_render_backward");
 }
 
@@ -535,6 +594,45 @@ extern "C" int cn_interlevel_backward(const float* final_spacing_bins, const flo
                      cn::as_stream(stream), final_spacing_bins, final_weights, prop_spacing_bins, prop_starts, prop_ends,
                      prop_density, (long long)num_rays, s_final, s_prop, mult, d_prop_density, loss_sum);
   return cn::check_launch("cn_interlevel_backward");
+}
+
+extern "C" int cn_interlevel_backward_levels(const float* final_spacing_bins, const float* final_weights,
+                                             const cn_interlevel_level* levels, int32_t num_levels, int64_t num_rays,
+                                             int32_t s_final, float loss_mult, float* loss_sum, cn_stream_t stream) {
+  CN_REQUIRE(final_spacing_bins && final_weights && levels && loss_sum, CN_ERR_INVALID, "cn_interlevel_backward_levels: null argument");
+  CN_REQUIRE(num_levels >= 1 && num_levels <= cn::INTERLEVEL_MAX_LEVELS, CN_ERR_UNSUPPORTED,
+             "cn_interlevel_backward_levels: %d levels (max %d)", num_levels, cn::INTERLEVEL_MAX_LEVELS);
+  CN_REQUIRE(s_final >= 1, CN_ERR_UNSUPPORTED, "cn_interlevel_backward_levels: %d final samples", s_final);
+  cn::InterlevelLevels L{};
+  int smax = 0;
+  for (int k = 0; k < num_levels; ++k) {
+    const cn_interlevel_level& v = levels[k];
+    CN_REQUIRE(v.spacing_bins && v.starts && v.ends && v.density && v.d_density, CN_ERR_INVALID,
+               "cn_interlevel_backward_levels: null buffer in level %d", k);
+    CN_REQUIRE(v.num_samples >= 1 && v.num_samples <= cn::TRAIN_MAX_S, CN_ERR_UNSUPPORTED,
+               "cn_interlevel_backward_levels: level %d has %d samples per ray (max %d)", k, v.num_samples, cn::TRAIN_MAX_S);
+    L.cp_bins[k] = v.spacing_bins;
+    L.starts[k] = v.starts;
+    L.ends[k] = v.ends;
+    L.density[k] = v.density;
+    L.d_density[k] = v.d_density;
+    L.Sp[k] = v.num_samples;
+    smax = std::max(smax, (int)v.num_samples);
+  }
+  for (int k = num_levels; k < cn::INTERLEVEL_MAX_LEVELS; ++k) {  // (never selected: blockIdx.y < num_levels)
+    L.cp_bins[k] = L.cp_bins[0];
+    L.starts[k] = L.starts[0];
+    L.ends[k] = L.ends[0];
+    L.density[k] = L.density[0];
+    L.d_density[k] = L.d_density[0];
+    L.Sp[k] = L.Sp[0];
+  }
+  if (num_rays <= 0) return CN_OK;
+  const size_t lds = (size_t)4 * (5 * smax + 3) * sizeof(float);
+  const float mult = loss_mult / ((float)num_rays * (float)s_final);
+  hipLaunchKernelGGL(cn::interlevel_backward_levels_kernel, dim3(cn::grid_for(num_rays, 4, 4096), num_levels), dim3(256), lds,
+                     cn::as_stream(stream), final_spacing_bins, final_weights, L, (long long)num_rays, s_final, mult, loss_sum);
+  return cn::check_launch("cn_interlevel_backward_levels");
 }
 
 extern "C" int cn_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,

@@ -256,10 +256,10 @@ class FruitTrainer:
         # ---- renderer + losses + their backward ------------------------------------------------------------------------
         image = batch["image"].to(dev)[:, :3].to(torch.float32).contiguous()
         mask = batch["fruit_mask"].to(dev).to(torch.float32).reshape(R, 1).contiguous()
+        # (with the final level's spacing bins: get_metrics_dict's distortion, fruit_nerf.py:643, rides in the same kernel -- its
+        #  sum over rays goes to loss_sums[4], the epilogue divides)
         rb_out = ops.train_render_backward(starts, ends, fo["density"], fo["rgb"], fo["semantics"], image, mask,
-                                           cfg.semantic_loss_weight, self.loss_sums[:4])
-        # get_metrics_dict's distortion (fruit_nerf.py:642): its sum over rays goes to loss_sums[4], the epilogue divides
-        ops.distortion_metric(bins, rb_out["weights"], self.loss_sums[4:5])
+                                           cfg.semantic_loss_weight, self.loss_sums, spacing_bins=bins)
         # The three backward passes (field, proposal network 0, proposal network 1) only share read-only inputs, so they run
         # on three streams when self.concurrent_backward: each is bound by the float-atomic request rate of its scatter for
         # part of its time and by matrix / gather work for the rest, and the parts of different kernels overlap on a CU.
@@ -278,10 +278,13 @@ class FruitTrainer:
             if self.train_pose:
                 ops.ray_backward(dpos, ddir, starts, ends, d_o_acc, d_d_acc)
 
+        dd_levels = None  # every level's interlevel term in one launch (they share the final bins / weights and one loss sum)
+
         def proposal_pass(lvl, d_o_acc, d_d_acc):
             lv = levels[lvl]
-            dd = ops.interlevel_backward(bins, rb_out["weights"], lv["bins"], lv["starts"], lv["ends"], lv["density"],
-                                         cfg.interlevel_loss_mult, self.loss_sums[2:3])
+            dd = dd_levels[lvl] if dd_levels is not None else ops.interlevel_backward(
+                bins, rb_out["weights"], lv["bins"], lv["starts"], lv["ends"], lv["density"], cfg.interlevel_loss_mult,
+                self.loss_sums[2:3])
             if not update_proposals:
                 return
             dpos = torch.empty(R, lv["starts"].shape[1], 3, device=dev) if self.train_pose else None
@@ -314,6 +317,9 @@ class FruitTrainer:
             if update_proposals:
                 ready("proposal_networks")
         else:
+            if 1 <= len(levels) <= 4:
+                dd_levels = ops.interlevel_backward_levels(bins, rb_out["weights"], levels, cfg.interlevel_loss_mult,
+                                                           self.loss_sums[2:3])
             field_pass(d_o if self.train_pose else None, d_d if self.train_pose else None)
             ready("fields")
             for lvl in range(len(levels)):

@@ -731,12 +731,15 @@ def pointcloud_compact_calls(origins: Tensor, directions: Tensor, depth: Tensor,
 # --------------------------------------------------------------------------------------------------------------
 
 def train_render_backward(starts: Tensor, ends: Tensor, density: Tensor, rgb: Tensor, semantics: Tensor,
-                          image: Tensor, fruit_mask: Tensor, semantic_loss_weight: float, loss_sums: Tensor
-                          ) -> Dict[str, Tensor]:
-    """cn_train_render_backward: rendered values, per-sample gradients of rgb_loss + semantics_loss."""
+                          image: Tensor, fruit_mask: Tensor, semantic_loss_weight: float, loss_sums: Tensor,
+                          spacing_bins: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """cn_train_render_backward: rendered values, per-sample gradients of rgb_loss + semantics_loss.  ``spacing_bins`` [R, S+1]:
+    the distortion metric's sum over rays is added to ``loss_sums[4]`` as well (``loss_sums`` has five slots then)."""
     lib = L.load()
     R, S = starts.shape
     dev = starts.device
+    if spacing_bins is not None and (tuple(spacing_bins.shape) != (R, S + 1) or loss_sums.numel() < 5):
+        raise ValueError(f"train_render_backward: spacing_bins must be [{R},{S + 1}] and loss_sums hold five sums")
     out = {"rgb": torch.empty(R, 3, device=dev), "semantics": torch.empty(R, 1, device=dev),
            "accumulation": torch.empty(R, 1, device=dev), "weights": torch.empty(R, S, device=dev),
            "d_density": torch.empty(R, S, device=dev), "d_rgb": torch.empty(R, S, 3, device=dev),
@@ -746,7 +749,7 @@ def train_render_backward(starts: Tensor, ends: Tensor, density: Tensor, rgb: Te
         _p(_f32(semantics, "semantics")), _p(_f32(image, "image")), _p(_f32(fruit_mask, "fruit_mask")), R, S,
         float(semantic_loss_weight), _p(out["rgb"]), _p(out["semantics"]), _p(out["accumulation"]), _p(out["weights"]),
         _p(out["d_density"]), _p(out["d_rgb"]), _p(out["d_semantics"]), _p(_f32(loss_sums, "loss_sums")),
-        _stream(starts)))
+        _p(_f32(spacing_bins, "spacing_bins")), _stream(starts)))
     return out
 
 
@@ -763,6 +766,30 @@ def interlevel_backward(final_spacing_bins: Tensor, final_weights: Tensor, prop_
         _p(_f32(prop_ends, "prop_ends")), _p(_f32(prop_density, "prop_density")), R, Sf, Sp, float(loss_mult), _p(d),
         _p(_f32(loss_sum, "loss_sum")), _stream(prop_density)))
     return d
+
+
+def interlevel_backward_levels(final_spacing_bins: Tensor, final_weights: Tensor, levels: Sequence[Dict[str, Tensor]],
+                               loss_mult: float, loss_sum: Tensor) -> List[Tensor]:
+    """``cn_interlevel_backward_levels``: ``interlevel_backward`` for every proposal level (dicts with "bins", "starts", "ends",
+    "density") in one launch; returns the levels' d loss / d density."""
+    lib = L.load()
+    R, Sf = final_weights.shape
+    arr = (L.InterlevelLevel * len(levels))()
+    outs, keep = [], []
+    for k, lv in enumerate(levels):
+        Sp = lv["density"].shape[1]
+        if tuple(lv["bins"].shape) != (R, Sp + 1) or tuple(lv["starts"].shape) != (R, Sp) or tuple(lv["ends"].shape) != (R, Sp):
+            raise ValueError(f"interlevel_backward_levels: level {k} has inconsistent shapes")
+        d = torch.empty(R, Sp, device=final_weights.device)
+        ts = [_f32(lv["bins"], "bins"), _f32(lv["starts"], "starts"), _f32(lv["ends"], "ends"), _f32(lv["density"], "density")]
+        keep.append(ts)
+        arr[k].spacing_bins, arr[k].starts, arr[k].ends, arr[k].density = (t.data_ptr() for t in ts)
+        arr[k].d_density, arr[k].num_samples, arr[k].reserved = d.data_ptr(), Sp, 0
+        outs.append(d)
+    L.check(lib.cn_interlevel_backward_levels(_p(_f32(final_spacing_bins, "final_spacing_bins")),
+                                              _p(_f32(final_weights, "final_weights")), arr, len(levels), R, Sf,
+                                              float(loss_mult), _p(_f32(loss_sum, "loss_sum")), _stream(final_weights)))
+    return outs
 
 
 def field_backward(fh: FieldHandle, gh: FieldHandle, scene: L.Scene, origins: Tensor, directions: Tensor,

@@ -516,13 +516,16 @@ int cn_embedding_mean(const float* embedding, int32_t num_images, int32_t dim, f
  * starts, ends, density, rgb [R,S,3], semantics.  Outputs: rendered rgb [R,3] / semantics [R,1] /
  * accumulation [R,1] / weights [R,S] (any NULL skips), gradients d_density [R,S], d_rgb [R,S,3],
  * d_semantics [R,S] of (rgb_loss + semantics_loss), and loss_sums[0] += sum (rgb-image)^2,
- * loss_sums[1] += sum BCE terms (divide by 3R / R on the host). */
+ * loss_sums[1] += sum BCE terms (divide by 3R / R on the host).
+ * spacing_bins (may be NULL) [R,S+1]: the sampler's bins in the spacing domain; when given, loss_sums has FIVE slots and
+ * loss_sums[4] += the sum over rays of nerfstudio's distortion_loss of these weights (the "distortion" entry of
+ * get_metrics_dict, fruit_nerf.py:643; what cn_distortion_metric computes pair by pair, here from two more prefix sums). */
 int cn_train_render_backward(const float* starts, const float* ends, const float* density, const float* rgb,
                              const float* semantics, const float* image /*[R,3]*/,
                              const float* fruit_mask /*[R,1]*/, int64_t num_rays, int32_t num_samples,
                              float semantic_loss_weight, float* out_rgb, float* out_semantics,
                              float* out_accumulation, float* out_weights, float* d_density, float* d_rgb,
-                             float* d_semantics, float* loss_sums, cn_stream_t stream);
+                             float* d_semantics, float* loss_sums, const float* spacing_bins, cn_stream_t stream);
 
 /* nerfstudio interlevel_loss term of ONE proposal level (fruit_nerf.py:609-612): final spacing bins
  * [R,Sf+1] and (detached) final weights [R,Sf] against the level's spacing bins [R,Sp+1] and density
@@ -532,6 +535,20 @@ int cn_interlevel_backward(const float* final_spacing_bins, const float* final_w
                            const float* prop_spacing_bins, const float* prop_starts, const float* prop_ends,
                            const float* prop_density, int64_t num_rays, int32_t s_final, int32_t s_prop,
                            float loss_mult, float* d_prop_density, float* loss_sum, cn_stream_t stream);
+/* The same for every proposal level of an iteration (1..4) in ONE launch: the levels share the final bins / weights and
+ * *loss_sum (the reference sums the levels' terms into one "interlevel_loss", fruit_nerf.py:609-612). */
+typedef struct cn_interlevel_level {
+  const float* spacing_bins; /* [R,Sp+1] */
+  const float* starts;       /* [R,Sp] euclidean */
+  const float* ends;
+  const float* density;      /* [R,Sp] */
+  float* d_density;          /* [R,Sp] out */
+  int32_t num_samples;       /* Sp */
+  int32_t reserved;
+} cn_interlevel_level;
+int cn_interlevel_backward_levels(const float* final_spacing_bins, const float* final_weights,
+                                  const cn_interlevel_level* levels, int32_t num_levels, int64_t num_rays, int32_t s_final,
+                                  float loss_mult, float* loss_sum, cn_stream_t stream);
 
 /* Parameter gradients of FruitField (training branch: per-camera appearance, semantic MLP on detached geo
  * features, fruit_nerf/fruit_field.py:235-282) from per-sample upstream gradients; the forward is recomputed

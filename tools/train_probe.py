@@ -21,6 +21,13 @@ idx = torch.stack([torch.randint(0,100,(R,),generator=g), torch.randint(0,800,(R
 rb = cams.generate_rays(idx.to(dev))
 batch = {"image": torch.rand(R,3,generator=g).to(dev), "fruit_mask": (torch.rand(R,1,generator=g)>0.5).float().to(dev)}
 WARM, ITERS = int(os.environ.get("WARM", "2")), int(os.environ.get("ITERS", "20"))
+if os.environ.get("PER_ITER") == "1":  # one line per iteration, each waited for (which variant ran, and how long it took)
+    for i in range(WARM + ITERS):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        upd = tr.proposal_update_due(tr._sampler_step)
+        tr.train_iteration(rb, batch)
+        torch.cuda.synchronize(); print(f"it {i:3d} proposals_updated {int(upd)} ms {(time.perf_counter() - t) * 1e3:7.3f}")
+    sys.exit(0)
 for i in range(WARM): tr.train_iteration(rb, batch)
 torch.cuda.synchronize(); t=time.perf_counter()
 for i in range(ITERS): tr.train_iteration(rb, batch)
