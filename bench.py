@@ -913,7 +913,7 @@ def subsystem_timings(args, params, device):
                     "sub-cluster boxes at 800 x 800, both passes per job, batched (projection.project_all) against the per-job loop "
                     "that mirrors the reference call for call (timed on 2 of the super-clusters); with_png_tree also writes the reference's file tree (2 PNGs per job); reference: "
                     "fruit_nerf.py:254-318, scripts/semantic_projection.py:132-170"}
-    # ---- one whole 800 x 800 eval image of the default method (fruit_nerf.py:377-404: chunks of eval_num_rays_per_chunk) ------------
+    # ---- one whole 800 x 800 eval image of the default method (fruit_nerf.py:377-404; chunks of max(eval_num_rays_per_chunk, 2^18)) ---
     # exact fp32 on the torch-layout model above, and a model as an imported reference checkpoint is -- tcnn layout, fp16 tables --
     # in tcnn's own arithmetic class (matrix_precision = "f16")
     from cropnerf_amd.fruit_nerf.fruit_nerf import FruitModel, Semantics
@@ -929,8 +929,8 @@ def subsystem_timings(args, params, device):
     ti, ts_ = image_ms(m)
     out["eval_image_800"] = {
         "ms_per_image": round(ti * 1e3, 3), "spread_ms": {"min": round(ts_[0] * 1e3, 3), "max": round(ts_[-1] * 1e3, 3), "images": len(ts_)},
-        "rays_per_sec": H * W / ti, "chunk_rays": int(cfg.eval_num_rays_per_chunk),
-        "roofline": mixed_roofline(H * W, ti, "proposal_sample_kernel + render_split_kernel per 32 768-ray chunk",
+        "rays_per_sec": H * W / ti, "chunk_rays": max(int(cfg.eval_num_rays_per_chunk), int(m.EVAL_CHUNK)),
+        "roofline": mixed_roofline(H * W, ti, "proposal_sample_kernel + render_split_kernel per 262 144-ray chunk",
                                    "the sampler (0.6 ms per 65 536 rays) and the 48-sample field pass (two rays per three half-steps since "
                                    "round 4: no empty column tiles), both at SIMD issue", pmc="eval_image"),
         "workload": "get_outputs_for_camera_ray_bundle, default method ((256, 96) proposal + 48 field samples), ray generation "
@@ -967,7 +967,7 @@ def subsystem_timings(args, params, device):
         out["eval_image_1920x1440"] = {
             "ms_per_image": round(tc * 1e3, 3), "spread_ms": {"min": round(tsc[0] * 1e3, 3), "max": round(tsc[-1] * 1e3, 3), "images": len(tsc)},
             "rays_per_sec": Hc * Wc / tc, "image": [Hc, Wc], "cameras": len(cap_cams),
-            "roofline": mixed_roofline(Hc * Wc, tc, "proposal_sample_kernel + render_split_kernel per 32 768-ray chunk",
+            "roofline": mixed_roofline(Hc * Wc, tc, "proposal_sample_kernel + render_split_kernel per 262 144-ray chunk",
                                        "as eval_image_800 (the sampler + a 48-sample field pass), 4.3 x the rays", pmc="eval_image"),
             "workload": "get_outputs_for_camera_ray_bundle at the resolution and from the (centred, unit-box-scaled) poses of the "
                         "reference's real capture file, default method, random-init model; reference: fruit_nerf.py:377-404, "

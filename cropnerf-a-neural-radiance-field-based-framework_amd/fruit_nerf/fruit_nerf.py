@@ -451,13 +451,17 @@ class FruitModel:
                 "density": out["density"], "semantics_colormap": out["semantics_colormap"]}
 
     # ------------------------------------------------------------------------------------------ chunked renders
+    # The reference's chunk size (eval_num_rays_per_chunk = 32 768; the projection CLI asks for 4 096) bounds ITS memory --
+    # materialised [R, S, .] tensors.  Rays are independent, so any size gives the same image here, and small chunks cost twice:
+    # two launches each, and a 32 768-ray launch of the sampler fills half of the 256 CUs.  800 x 800: 13.95 ms per image in
+    # chunks of 2^15 rays, 13.22 in 2^16, 12.68 in 2^18 (tools/image_probe.py) -- every render works in chunks of at least 2^18.
+    EVAL_CHUNK = 1 << 18
+
     def _chunked(self, camera_ray_bundle: RayBundle, fn, image_width: int = 0, keys: Optional[Sequence[str]] = None,
-                 min_chunk: int = 1 << 15) -> Dict[str, Tensor]:
+                 min_chunk: Optional[int] = None) -> Dict[str, Tensor]:
         """``image_width`` > 0: the bundle is a whole row-major image, so every chunk is a pixel run -- passed to the
         renderer as a scheduling hint (cn_render_opts.image_width / pixel_start).  ``keys``: keep only these outputs."""
-        # the reference's chunk size bounds ITS memory (materialised [R,S,.] tensors); rays are independent, so any size
-        # gives the same image here and chunks below 32 768 rays (the projection CLI asks for 4096) only add launches
-        chunk = max(int(self.config.eval_num_rays_per_chunk), int(min_chunk))
+        chunk = max(int(self.config.eval_num_rays_per_chunk), int(self.EVAL_CHUNK if min_chunk is None else min_chunk))
         flat = camera_ray_bundle.flatten()
         n = len(flat)
         lists: Dict[str, List[Tensor]] = {}
@@ -479,8 +483,7 @@ class FruitModel:
         out = self._chunked(camera_ray_bundle, self.forward, image_width=image_width)
         return {k: v.view(image_height, image_width, -1) for k, v in out.items()}
 
-    # a jagged bundle has no image to stripe: larger chunks only save launches (one C2-sized batch at a time)
-    JAGGED_CHUNK = 1 << 17
+    JAGGED_CHUNK = EVAL_CHUNK  # (a jagged bundle has no image to stripe; same reasoning)
 
     @torch.no_grad()
     def get_outputs_for_camera_jagged_ray_bundle(self, camera_ray_bundle: RayBundle,

@@ -89,7 +89,7 @@ def test_forward_test_mode_matches_oracle(scene):
         m(rb)
 
 
-def test_full_image_render_and_chunking(scene):
+def test_full_image_render_and_chunking(scene, monkeypatch):
     m = _model(scene, "inference", eval_num_rays_per_chunk=100)
     m.setup_inference(True, 40)
     cams = _cameras(scene)
@@ -98,6 +98,17 @@ def test_full_image_render_and_chunking(scene):
     rays = cams.generate_rays(camera_indices=1, keep_shape=True, aabb_box=SceneBox(scene.aabb))
     out = m.get_outputs_for_camera_ray_bundle(rays)
     assert out["rgb"].shape == (scene.height, scene.width, 3) and out["depth"].shape == (scene.height, scene.width, 1)
+    # renders work in chunks of max(eval_num_rays_per_chunk, EVAL_CHUNK = 2^18) rays: the image above was one chunk; in the
+    # configuration's 100-ray chunks (one kernel form for every size, so that the comparison is bit for bit) it is the same image
+    monkeypatch.setenv("CN_FUSED_SPLIT", "0")
+    whole = m.get_outputs_for_camera_ray_bundle(rays)
+    m.EVAL_CHUNK = 64
+    assert scene.height * scene.width > 3 * 100
+    parts = m.get_outputs_for_camera_ray_bundle(rays)
+    del m.EVAL_CHUNK
+    monkeypatch.delenv("CN_FUSED_SPLIT")
+    for k in whole:
+        assert torch.equal(whole[k], parts[k]), k
     om = oracle_model(scene, "inference", eval_num_rays_per_chunk=100)
     om.setup_inference(True, 40)
     ref = om.render_rays(rays_with_box(scene, 1))

@@ -1,5 +1,7 @@
 """Whole-image render of the default fruit_nerf_method in eval (proposal sampler (256, 96) + 48 field samples per ray,
-chunks of eval_num_rays_per_chunk = 32768, fruit_nerf.py:377-404) at 800 x 800.  Profiling aid:  python tools/image_probe.py"""
+fruit_nerf.py:377-404) at 800 x 800, at three values of eval_num_rays_per_chunk.  The model works in chunks of
+max(eval_num_rays_per_chunk, FruitModel.EVAL_CHUNK = 2^18) rays; EVAL_CHUNK=<n> in the environment lowers that floor (13.95 /
+13.22 / 12.68 ms per image in chunks of 2^15 / 2^16 / 2^18 rays is how the floor was chosen).  python tools/image_probe.py"""
 import json, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cropnerf_amd import config as PC, synthetic
@@ -15,6 +17,8 @@ params = synthetic.p_rand(cfg.field_spec(100), cfg.proposal_specs(), seed=0, dev
 c2w, intr = synthetic.orbit_cameras(100)
 cams = Cameras(c2w, intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], 800, 800).to("cuda")
 res = {}
+if os.environ.get("EVAL_CHUNK"):
+    FruitModel.EVAL_CHUNK = FruitModel.JAGGED_CHUNK = int(os.environ["EVAL_CHUNK"])
 for chunk in (1 << 15, 1 << 16, 1 << 18):
     cfg.eval_num_rays_per_chunk = chunk
     m = FruitModel(cfg, SceneBox(torch.tensor(synthetic.SCENE_AABB)), 100, {"semantics": Semantics()}, device="cuda",
