@@ -464,6 +464,9 @@ class FruitModel:
         chunk = max(int(self.config.eval_num_rays_per_chunk), int(self.EVAL_CHUNK if min_chunk is None else min_chunk))
         flat = camera_ray_bundle.flatten()
         n = len(flat)
+        if n > chunk:  # equal chunks instead of full ones and a short tail (640 000 rays: 3 x 213 376, not 2 x 262 144 + 115 712)
+            pieces = -(-n // chunk)
+            chunk = min(chunk, -(-(-(-n // pieces)) // 64) * 64)
         lists: Dict[str, List[Tensor]] = {}
         for i in range(0, n, chunk):
             self._image_hint = (image_width, i)
