@@ -70,6 +70,7 @@ class FruitDataManager:
         self._device_generator: Optional[torch.Generator] = None
         self._seed = seed + 1000 * local_rank
         self.orthographic_ray_generator: Optional[OrthographicRayGenerator] = None
+        self._idx_ring: Dict[tuple, dict] = {}  # pinned staging of next_train / next_eval's pixel indices, per batch shape
 
     @classmethod
     def from_dataset(cls, config: FruitDataManagerConfig, dataset, device="cuda", **kwargs) -> "FruitDataManager":
@@ -91,17 +92,41 @@ class FruitDataManager:
         return dm
 
     # PixelSampler.sample + train_ray_generator (:188-197)
+    def _indices_to_device(self, idx: Tensor) -> Tensor:
+        """The batch's pixel indices on the device through ONE asynchronous copy from a pinned staging slot (a ring of four,
+        each guarded by an event: the host may run four batches ahead of the GPU).  Indexing resident images with host index
+        tensors made three synchronous pageable copies per image tensor -- at 4 096 rays per batch the host side of
+        ``next_train`` was longer than half a training iteration."""
+        if self.device.type != "cuda":
+            return idx.to(self.device)
+        ring = self._idx_ring.get(tuple(idx.shape))
+        if ring is None:
+            ring = self._idx_ring[tuple(idx.shape)] = {"slots": [torch.empty_like(idx).pin_memory() for _ in range(4)],
+                                                       "events": [None] * 4, "next": 0}
+        k = ring["next"] % 4
+        ring["next"] += 1
+        if ring["events"][k] is not None:
+            ring["events"][k].synchronize()
+        ring["slots"][k].copy_(idx)
+        dev = ring["slots"][k].to(self.device, non_blocking=True)
+        ring["events"][k] = torch.cuda.Event()
+        ring["events"][k].record()
+        return dev
+
     def _sample(self, num_rays: int) -> Tuple[RayBundle, Dict]:
         n, h, w = len(self.cameras), self.cameras.height, self.cameras.width
         idx = torch.stack([torch.randint(0, n, (num_rays,), generator=self._gen),
                            torch.randint(0, h, (num_rays,), generator=self._gen),
                            torch.randint(0, w, (num_rays,), generator=self._gen)], dim=-1)
         batch: Dict[str, Tensor] = {"indices": idx}
+        idx_d = self._indices_to_device(idx)
         if self.images is not None:
-            batch["image"] = self.images[idx[:, 0], idx[:, 1], idx[:, 2]]
+            ii = idx_d if self.images.device == idx_d.device else idx
+            batch["image"] = self.images[ii[:, 0], ii[:, 1], ii[:, 2]]
         if self.fruit_masks is not None:
-            batch["fruit_mask"] = self.fruit_masks[idx[:, 0], idx[:, 1], idx[:, 2]]
-        return self.cameras.generate_rays(idx.to(self.device)), batch
+            ii = idx_d if self.fruit_masks.device == idx_d.device else idx
+            batch["fruit_mask"] = self.fruit_masks[ii[:, 0], ii[:, 1], ii[:, 2]]
+        return self.cameras.generate_rays(idx_d), batch
 
     def next_train(self, step: int) -> Tuple[RayBundle, Dict]:
         self.train_count += 1
