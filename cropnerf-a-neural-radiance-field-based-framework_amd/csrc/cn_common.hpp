@@ -456,8 +456,15 @@ inline CoarseScatter make_coarse_scatter(const cn_grid& grads_grid) {
 // floats 2c, 2c + 1 -- so that a sample adds its whole cell in ONE 64-byte request (the hash table takes 4.5: one per x-edge),
 // and consecutive samples of a ray in the same cell merge into one.  A fold kernel adds the touched records to the table and
 // zeroes them.  Worth it where samples outnumber cells: the launch picks the levels by batch size.
-constexpr int CN_CELL_LEVELS = 8;
-constexpr unsigned long long CELL_MAX_CELLS = 2200000ull;  // 129^3 fits
+constexpr int CN_CELL_LEVELS = 10;
+// A level goes through cell-major records when it has at most (ratio x samples of the call) cells.  Since the fold works by
+// blocks (cell_scatter_fold_blocks_kernel: ~0.4 requests per cell and a streaming pass over the records) a level pays as long as
+// one request per run of samples plus that pass is cheaper than 4.5 requests per sample: measured optimum (tools/train_probe.py,
+// 4 096 / 65 536 rays) at ~2-3 cells per sample for the field (48 samples per ray: few samples share a cell at the
+// fine levels; 3.03 -- 9.5e6 cells, 610 MB of records at 65 536 rays -- already costs 0.6 ms) and 3-8 for the proposal networks
+// (256 / 96 samples per ray: runs merge).  CELL_RATIO_MAX bounds what cn_grid_scatter_scratch_bytes_for sizes the scratch for.
+constexpr double CELL_RATIO_FIELD = 2.85, CELL_RATIO_PROPOSAL = 6.0, CELL_RATIO_MAX = 8.0;
+constexpr unsigned long long CELL_MAX_CELLS = 17500000ull;  // 259^3 fits
 struct CellScatter {
   float* base;  // nullptr: off
   int num_levels;
@@ -493,9 +500,9 @@ inline size_t cell_scratch_layout(const cn_grid& g, CellScatter* out) {
   if (out) *out = c;
   return (size_t)floats * sizeof(float);
 }
-// levels 0 .. k-1 with at most max_cells cells each (the launch passes ~ samples / 2).  Of a small level's copies only as
-// many are used as the batch needs to keep the requests per record in the low hundreds (a copy in use costs the fold kernel
-// 16 atomics per touched cell): ~ samples / (48 cells), rounded up to a power of two.
+// levels 0 .. k-1 with at most max_cells cells each (the launch passes ratio x samples).  Of a small level's copies only as
+// many are used as the batch needs to keep the requests per record in the low hundreds: ~ samples / (48 cells), rounded up
+// to a power of two.
 inline CellScatter make_cell_scatter(const cn_grid& grads_grid, unsigned long long max_cells, unsigned long long samples) {
   CellScatter c{};
   if (!grads_grid.scatter_scratch) return c;

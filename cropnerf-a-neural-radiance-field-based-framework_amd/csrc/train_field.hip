@@ -1075,6 +1075,7 @@ __global__ void __launch_bounds__(TB, 4) proposal_backward_kernel(PropBwdArgs A)
 #include "train_proposal_wave.hpp"
 namespace cn {
 
+static double cell_scatter_ratio(bool proposal, double dflt);
 int validate_field(const cn_field_params& p);  // field_simple.hip
 int validate_grid(const cn_grid& g, const char* name);
 
@@ -1174,9 +1175,9 @@ extern "C" int cn_field_backward(const cn_field_params* params, const cn_field_p
   } else {
     long long ntiles = (nsamp + cn::mf::TSM - 1) / cn::mf::TSM;
     A.coarse = cn::make_coarse_scatter(grads->grid);
-    {  // cell-major records where samples outnumber cells two to one (CN_CELL_SCATTER=0: off)
-      const char* cs = getenv("CN_CELL_SCATTER");
-      if (!cs || atof(cs) != 0.0) A.cells = cn::make_cell_scatter(grads->grid, (unsigned long long)(nsamp * (cs ? atof(cs) : 0.5)), (unsigned long long)nsamp);
+    {  // cell-major records for the levels with at most CELL_RATIO_FIELD cells per sample (CN_CELL_SCATTER=<ratio>, 0: off)
+      const double ratio = cn::cell_scatter_ratio(false, cn::CELL_RATIO_FIELD);
+      if (ratio != 0.0) A.cells = cn::make_cell_scatter(grads->grid, (unsigned long long)(nsamp * ratio), (unsigned long long)nsamp);
       if (A.cells.num_levels > 0) A.coarse.base = nullptr;  // level 0 is cell-major then
     }
     hipLaunchKernelGGL(cn::mf::field_backward_mfma_kernel, dim3(cn::grid_for(ntiles, 1, 256)), dim3(cn::mf::NT),
@@ -1186,6 +1187,17 @@ extern "C" int cn_field_backward(const cn_field_params* params, const cn_field_p
   }
   return cn::check_launch("cn_field_backward");
 }
+
+namespace cn {
+// cells-per-sample ratio up to which a level's gradient goes through cell-major records:
+// CN_CELL_SCATTER sets it for every backward kernel (0 = off), CN_CELL_SCATTER_PROP for the proposal networks alone.
+static double cell_scatter_ratio(bool proposal, double dflt) {
+  const char* cs = getenv("CN_CELL_SCATTER");
+  const char* cp = proposal ? getenv("CN_CELL_SCATTER_PROP") : nullptr;
+  if (cp) return atof(cp);
+  return cs ? atof(cs) : dflt;
+}
+}  // namespace cn
 
 extern "C" int cn_proposal_backward(const cn_density_params* params, const cn_density_params* grads,
                                     const cn_scene* scene, const float* origins, const float* directions,
@@ -1230,12 +1242,12 @@ extern "C" int cn_proposal_backward(const cn_density_params* params, const cn_de
     A.debug_skip = dbg ? atoi(dbg) : 0;
   }
   A.coarse = cn::make_coarse_scatter(grads->grid);
-  // cell-major records for the levels that hold at most half as many cells as there are samples (merging pays there);
-  // CN_CELL_SCATTER=0 keeps every level on the table path
+  // cell-major records for the levels with at most CELL_RATIO_PROPOSAL cells per sample (runs of a ray's samples merge there);
+  // CN_CELL_SCATTER_PROP / CN_CELL_SCATTER = 0 keeps every level on the table path
   {
-    const char* cs = getenv("CN_CELL_SCATTER");
+    const double ratio = cn::cell_scatter_ratio(true, cn::CELL_RATIO_PROPOSAL);
     const unsigned long long nsamp = (unsigned long long)num_rays * (unsigned long long)num_samples;
-    if (!cs || atof(cs) != 0.0) A.cells = cn::make_cell_scatter(grads->grid, (unsigned long long)(nsamp * (cs ? atof(cs) : 0.5)), nsamp);
+    if (ratio != 0.0) A.cells = cn::make_cell_scatter(grads->grid, (unsigned long long)(nsamp * ratio), nsamp);
     if (A.cells.num_levels > 0 && A.coarse.base) A.coarse.base = nullptr;  // level 0 is cell-major then
   }
   long long ntiles = (num_rays * (long long)num_samples + cn::TS - 1) / cn::TS;
@@ -1266,9 +1278,9 @@ extern "C" size_t cn_grid_scatter_scratch_bytes(const cn_grid* grid) {
 }
 
 // The same, sized for batches of at most `max_samples` samples per backward call: a level is kept cell-major only when it
-// has at most (CN_CELL_SCATTER, default 0.5, at most 2) x samples cells, so the records of levels with more than
-// 2 x max_samples cells would never be touched -- at the reference's 4 096-ray batches that is most of the 160-180 MB per
-// gradient grid.  max_samples <= 0: every level (= cn_grid_scatter_scratch_bytes).
+// has at most (CN_CELL_SCATTER / CN_CELL_SCATTER_PROP; defaults CELL_RATIO_FIELD / CELL_RATIO_PROPOSAL, at most
+// CELL_RATIO_MAX) x samples cells, so the records of levels with more than CELL_RATIO_MAX x max_samples cells would never be
+// touched.  max_samples <= 0: every level up to CELL_MAX_CELLS cells (= cn_grid_scatter_scratch_bytes).
 extern "C" size_t cn_grid_scatter_scratch_bytes_for(const cn_grid* grid, int64_t max_samples) {
   if (!grid || grid->num_levels < 1) return 0;
   const size_t head = cn::coarse_scratch_bytes(*grid);
@@ -1279,7 +1291,7 @@ extern "C" size_t cn_grid_scatter_scratch_bytes_for(const cn_grid* grid, int64_t
   size_t bytes = 0;
   for (int l = 0; l < c.num_levels; ++l) {
     const unsigned long long cells = (unsigned long long)c.n[l] * c.n[l] * c.n[l];
-    if (cells > 2ull * (unsigned long long)max_samples) break;
+    if ((double)cells > cn::CELL_RATIO_MAX * (double)max_samples) break;
     bytes = (size_t)(c.offset[l] + c.copies[l] * cells * 16ull) * sizeof(float);
   }
   return head + bytes;
@@ -1434,11 +1446,10 @@ extern "C" int cn_field_backward_general(const cn_field_params* params, const cn
   const int grid = (int)std::min<long long>(ntiles, nblk);
   A.coarse = cn::make_coarse_scatter(grads->grid);
   {  // cell-major records (as in cn_field_backward) when the four LDS buffers that carry the hand-over hold two waves each
-    const char* cs = getenv("CN_CELL_SCATTER");
+    const double ratio = cn::cell_scatter_ratio(false, cn::CELL_RATIO_FIELD);
     const int small = std::min(std::min(p16(params->color.dims[1]), p16(params->color.dims[2])), p16(cin));
-    if ((!cs || atof(cs) != 0.0) && small * cn::gb::LDG >= 2 * 64 * 17 && A.num_levels <= 16)
-      A.cells = cn::make_cell_scatter(grads->grid,
-                                      (unsigned long long)(num_rays * (double)num_samples * (cs ? atof(cs) : 0.5)),
+    if (ratio != 0.0 && small * cn::gb::LDG >= 2 * 64 * 17 && A.num_levels <= 16)
+      A.cells = cn::make_cell_scatter(grads->grid, (unsigned long long)(num_rays * (double)num_samples * ratio),
                                       (unsigned long long)num_rays * (unsigned long long)num_samples);
     if (A.cells.num_levels > 0) A.coarse.base = nullptr;
   }

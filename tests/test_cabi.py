@@ -121,8 +121,8 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
 
 def test_scatter_scratch_size_is_a_host_computation(lib):
     """cn_grid_scatter_scratch_bytes: 64 private dense copies of level 0 (n + 1 = floor(scale_0 + offset) + 2 vertices per axis)
-    + cell-major records (16 floats per cell) of the consecutive coarse levels with at most 2.2e6 cells, the small ones
-    replicated (16 copies up to 8192 cells, 4 up to 65536)."""
+    + cell-major records (16 floats per cell) of the consecutive coarse levels (at most ten) with at most 1.75e7 cells, the
+    small ones replicated (16 copies up to 8192 cells, 4 up to 65536)."""
     import ctypes as C
     import math
 
@@ -132,9 +132,9 @@ def test_scatter_scratch_size_is_a_host_computation(lib):
     def expected(scalings, offset):
         head = 64 * (math.floor(scalings[0] + offset) + 2) ** 3 * 2 * 4
         floats = 0
-        for sc in scalings[:8]:
+        for sc in scalings[:10]:
             cells = (math.floor(sc + offset) + 1) ** 3
-            if cells > 2_200_000:
+            if cells > 17_500_000:
                 break
             floats += (16 if cells <= 8192 else 4 if cells <= 65536 else 1) * cells * 16
         return head + 4 * floats
@@ -150,13 +150,13 @@ def test_scatter_scratch_size_is_a_host_computation(lib):
     g.layout = _lib.GRID_TCNN  # tcnn: scale_0 = 15, positions shifted by half a cell -> cells 0..15, vertices 0..16
     g.scalings[0] = 15.0
     assert lib.cn_grid_scatter_scratch_bytes(C.byref(g)) == expected([15.0] + list(sc[1:]), 0.5)
-    # sized for a maximum batch: only the consecutive levels with at most 2 x max_samples cells (a prefix of the layout)
+    # sized for a maximum batch: only the consecutive levels with at most 8 x max_samples cells (a prefix of the layout)
     def expected_for(scalings, offset, max_samples):
         head = 64 * (math.floor(scalings[0] + offset) + 2) ** 3 * 2 * 4
         floats = 0
-        for s_ in scalings[:8]:
+        for s_ in scalings[:10]:
             cells = (math.floor(s_ + offset) + 1) ** 3
-            if cells > 2_200_000 or cells > 2 * max_samples:
+            if cells > 17_500_000 or cells > 8 * max_samples:
                 break
             floats += (16 if cells <= 8192 else 4 if cells <= 65536 else 1) * cells * 16
         return head + 4 * floats

@@ -155,9 +155,13 @@ def test_train_cli_two_ranks_rehearsal(tmp_path):
     import sys
 
     cap = synthetic.write_capture(tmp_path / "plant", num=12, res=40)
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+
+    def free_port():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            return s.getsockname()[1]
+
+    port = free_port()
     root = Path(__file__).resolve().parents[1]
     script = root / "cropnerf-a-neural-radiance-field-based-framework_amd" / "fruit_nerf" / "scripts" / "train.py"
     env = dict(os.environ, CROPNERF_REHEARSE_ON_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -165,7 +169,7 @@ def test_train_cli_two_ranks_rehearsal(tmp_path):
            "--master-port", str(port), str(script), "fruit_nerf", "--data", cap, "--output-dir", str(tmp_path / "out"),
            "--max-num-iterations", "30", "--log-every", "10", "--timestamp", "t", "--train-split-fraction", "0.8"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-8000:]
     last = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     res = json.loads(last)
     assert res["ranks"] == 2 and math.isfinite(res["eval_psnr"])
@@ -178,17 +182,19 @@ def test_train_cli_two_ranks_rehearsal(tmp_path):
     assert not torch.equal(rs[0]["datamanager_generator"], rs[1]["datamanager_generator"])
     # ... and the exporter CLI under the same launcher: batches dealt over the ranks, rank 0 writes the gathered clouds
     exp = root / "cropnerf-a-neural-radiance-field-based-framework_amd" / "fruit_nerf" / "scripts" / "exporter.py"
+    cmd[9] = str(free_port())  # (the launcher that just exited may still hold the first port)
     cmd = cmd[:10] + [str(exp), "semantic-pointcloud", "--load-config", str(run / "config.yml"), "--output-dir",
                       str(tmp_path / "pcd"), "--num-points-per-side", "30", "--num-rays-per-batch", "128"]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-8000:]
     assert (tmp_path / "pcd" / "fruit_nerf" / "density.ply").exists() and p.stdout.count("Saving Point Cloud: done") == 1
     # two-rank RESUME: every rank continues its own random streams -- the two ranks keep drawing different pixels
+    cmd[9] = str(free_port())
     cmd = cmd[:10] + [str(script), "fruit_nerf", "--data", cap, "--output-dir", str(tmp_path / "out2"),
                       "--max-num-iterations", "40", "--log-every", "10", "--timestamp", "t", "--train-split-fraction", "0.8",
                       "--load-dir", str(run / "nerfstudio_models")]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-8000:]
     res2 = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert res2["resumed_at"] == 30 and res2["ranks"] == 2
     rs2 = torch.load(tmp_path / "out2" / "plant" / "fruit_nerf" / "t" / "nerfstudio_models" / "step-000000039.ckpt",

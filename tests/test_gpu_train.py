@@ -509,8 +509,9 @@ def test_private_copies_of_the_coarsest_level_change_nothing(monkeypatch):
 
 def test_cell_major_records_at_a_training_batch_size(monkeypatch):
     """The default method (2^19-entry levels, (256, 96) + 48 samples) on 8192 random rays: with the default level selection
-    -- field levels 0-4, every proposal level but the finest of the second network, the small levels in several copies --
-    the gradients equal the plain scatter's up to the order of additions, and the scratch is left zeroed."""
+    (field levels 0-6, every proposal level but the finest of the second network, the small levels in several copies) and
+    with round 2's (half a cell per sample: field levels 0-4) the gradients equal the plain scatter's up to the order of
+    additions, and the scratch is left zeroed."""
     from cropnerf_amd import config as PC, synthetic
     from cropnerf_amd.fruit_nerf.fruit_nerf import FruitModel, Semantics
     from cropnerf_amd.fruit_nerf.trainer import FruitTrainer
@@ -530,8 +531,11 @@ def test_cell_major_records_at_a_training_batch_size(monkeypatch):
     tables = ["field.mlp_base_grid.hash_table", "proposal_networks.0.encoding.hash_table",
               "proposal_networks.1.encoding.hash_table", "camera_optimizer.pose_adjustment"]
     got = {}
-    for flag in ("0.5", "0"):
-        monkeypatch.setenv("CN_CELL_SCATTER", flag)
+    for flag in ("default", "0.5", "0"):
+        if flag == "default":  # field levels with at most 2.85 cells per sample, proposal levels with at most 6
+            monkeypatch.delenv("CN_CELL_SCATTER", raising=False)
+        else:
+            monkeypatch.setenv("CN_CELL_SCATTER", flag)
         model = FruitModel(cfg, SceneBox(torch.tensor([[-1.0, -1, -1], [1, 1, 1]])), 20, {"semantics": Semantics()},
                            device="cuda", params={k: v.clone() for k, v in params.items()})
         model.training = True
@@ -542,8 +546,9 @@ def test_cell_major_records_at_a_training_batch_size(monkeypatch):
     for k in tables:
         ref = got["0"][k]
         assert float(ref.abs().sum()) > 0, k
-        err = float((got["0.5"][k] - ref).norm() / ref.norm())
-        assert err < 1e-5, f"{k}: {err}"
+        for flag in ("default", "0.5"):
+            err = float((got[flag][k] - ref).norm() / ref.norm())
+            assert err < 1e-5, f"{flag} {k}: {err}"
 
 
 def test_proposal_backward_one_wave_per_tile_equals_four_waves_per_tile(monkeypatch):
