@@ -629,16 +629,16 @@ def secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, o
             src = ATOMIC_REQUESTS_SOURCE
             t_bytes, t_src = workload_traffic(f"train_{nrays}x{spp}", 1)
             train[key]["roofline"] = {
-                "bound": "hbm", "kernel": "train_iteration (field_backward_mfma_kernel + 2 x proposal_backward_kernel scatter)",
+                "bound": "hbm", "kernel": "train_iteration (field_backward_mfma_kernel + 2 x proposal_backward_wave_kernel + 3 x cell_scatter_fold_blocks_kernel)",
                 "achieved": round(req / t / 1e9, 3), "peak": round(ATOMIC_REQUESTS_PER_SEC / 1e9, 2),
                 "unit": "G atomic requests/s (memory side; 64-byte read-modify-writes)", "frac": round(req / t / ATOMIC_REQUESTS_PER_SEC, 4),
                 "traffic": t_bytes, "traffic_source": t_src, "atomic_requests_per_iteration": int(req),
                 "requests_source": src,
                 "hbm_equivalent_GBps": round(req * 64 / t / 1e9, 1),
-                "limited_by": "the field backward (about half the iteration): 17 barrier-separated matrix phases per 32-sample tile "
-                              "(5.5 ms at 65 536 rays with the memory operations switched off) plus its gathers and scatter, which "
-                              "add to them; the atomic-request rate priced here is a floor of the iteration, not its cost "
-                              "(DESIGN.md 4.10: a store-based scatter that removed most requests did not shorten it)"}
+                "limited_by": "the field backward (half of the iteration): its float-atomic requests share one port per XCD "
+                              "(~1 request per clock for 32 CUs) and its tile is a chain of 17 barrier-separated matrix phases at two "
+                              "waves per SIMD -- 74-80 % of its own request floor at 48 samples per ray, the phase chain alone at 192; "
+                              "the fraction priced here falls when requests are removed faster than time (DESIGN.md 4.17, 7)"}
             if spp == 48:
                 # The iterations above are the first seven of a run, where the reference updates the proposal networks every
                 # time.  The schedule (fruit_nerf.py:144-149: update_every = 5 once step >= proposal_warmup = 5 000) makes that
