@@ -164,7 +164,7 @@ SIGNATURES = {
     "cn_field_backward_general": (C.c_int, [C.POINTER(FieldParams), C.POINTER(FieldParams), C.POINTER(Scene), _I32, _I32,
                                             _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, C.c_size_t, _P]),
     "cn_ray_backward": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _P]),
-    "cn_pose_adjustment_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P]),
+    "cn_pose_adjustment_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P, _P]),
     "cn_pose_regularizer": (C.c_int, [_P, _I32, _F, _F, _P, _P, _P]),
     "cn_distortion_metric": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "cn_depth_project": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P, _P, _P]),

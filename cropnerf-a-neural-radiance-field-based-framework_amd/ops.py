@@ -871,7 +871,8 @@ def pose_adjustment_backward(pose_adjustment: Tensor, camera_indices: Tensor, di
     L.check(lib.cn_pose_adjustment_backward(
         _p(_f32(pose_adjustment, "pose_adjustment")), _p(_i64(camera_indices, "camera_indices")),
         _p(_f32(directions_raw, "directions_raw")), _p(_f32(d_origins, "d_origins")),
-        _p(_f32(d_directions, "d_directions")), R, _p(_f32(grad_pose, "grad_pose")), _stream(directions_raw)))
+        _p(_f32(d_directions, "d_directions")), R, int(pose_adjustment.shape[0]), _p(_f32(grad_pose, "grad_pose")),
+        _stream(directions_raw)))
 
 
 def pose_regularizer(pose_adjustment: Tensor, grad_pose: Optional[Tensor], loss_out: Tensor,

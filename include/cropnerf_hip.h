@@ -589,10 +589,13 @@ int cn_ray_backward(const float* d_positions /*[R,S,3]*/, const float* d_dir_sam
                     float* d_origins /*[R,3]*/, float* d_directions /*[R,3]*/, cn_stream_t stream);
 
 /* Step 2: chain through exp_map_SO3xR3 (o' = o + t, d' = R(w) d): ACCUMULATE into grad_pose [C,6].
- * directions_raw = the ray directions BEFORE cn_apply_pose_adjustment. */
+ * directions_raw = the ray directions BEFORE cn_apply_pose_adjustment.  num_cameras = C (every camera index must lie in
+ * [0, C)): up to 2048 cameras the rays of a workgroup are summed per camera on chip before they reach grad_pose; 0 = not
+ * given (one atomic per ray and entry). */
 int cn_pose_adjustment_backward(const float* pose_adjustment /*[C,6]*/, const int64_t* camera_indices,
                                 const float* directions_raw /*[R,3]*/, const float* d_origins,
-                                const float* d_directions, int64_t num_rays, float* grad_pose, cn_stream_t stream);
+                                const float* d_directions, int64_t num_rays, int32_t num_cameras, float* grad_pose,
+                                cn_stream_t stream);
 
 /* get_loss_dict (fruit_nerf/fruit_nerf.py:601-615) + the scalar metrics of get_metrics_dict (:639-645) from the loss sums
  * the training kernels left in loss_sums = {sum (rgb - image)^2, sum BCE, sum interlevel terms, camera regulariser} and, when
