@@ -165,6 +165,14 @@ def test_pose_backward_kernels_match_autograd():
     ops.pose_regularizer(to_dev(pose), gpose, reg, 0.7, 0.3)
     assert_close(gpose, p.grad, 2e-4, 2e-4, "pose gradient")
     assert_close(reg, OL.camera_opt_regularizer(pose, 0.7, 0.3).reshape(1), 1e-5, 1e-6, "regularizer")
+    # a pose table of more than 2048 cameras does not fit the per-workgroup LDS sums: one atomic per ray and entry, same values
+    big = torch.zeros(2100, 6)
+    big[:C] = pose
+    g_big, g_small = torch.zeros(2100, 6, device="cuda"), torch.zeros(C, 6, device="cuda")
+    ops.pose_adjustment_backward(to_dev(big), to_dev(cam), to_dev(d_raw), d_o, d_d, g_big)
+    ops.pose_adjustment_backward(to_dev(pose), to_dev(cam), to_dev(d_raw), d_o, d_d, g_small)
+    assert_close(g_big[:C], g_small, 1e-5, 1e-5, "pose gradient, table path")
+    assert float(g_big[C:].abs().sum()) == 0.0
 
 
 def test_adam_step_matches_torch_semantics():
