@@ -360,10 +360,107 @@ def main():
         }
         if gather_check is not None:
             line["gather_check"] = gather_check
-        line.update(extra)
-        print(json.dumps(line), flush=True)
+        emit(line, extra)
     if world > 1:
         dist.destroy_process_group()
+
+
+MAX_LINE_BYTES = 4096  # the driver reads the LAST stdout line; round 4's 20.6 KB line was not parsed (12.0 KB still was)
+
+
+def _num(x, digits=4):
+    """A bare number for the flat `secondary` object: 4 significant digits are what the timings carry."""
+    if x is None or isinstance(x, (bool, str)):
+        return x
+    return float(f"{float(x):.{digits}g}")
+
+
+def flat_secondary(extra: dict) -> dict:
+    """Bare numbers of the secondary workloads (the full records, with their rooflines, workload strings and spreads, are in
+    bench_secondary.json next to this file)."""
+    f = {}
+
+    def put(key, *path, scale=1.0):
+        d = extra
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return
+            d = d[k]
+        if isinstance(d, (int, float)):
+            f[key] = _num(d * scale)
+
+    put("mfma_fp32_tflops", "roofline_mfma", "achieved")
+    put("split_bf16_ms", "uniform_mode_split_bf16_matrix", "ms_per_batch")
+    put("tcnn_f16_table_ms", "uniform_mode_tcnn_f16_table", "ms_per_batch")
+    put("f16_mode_ms", "uniform_mode_tcnn_f16_mfma", "ms_per_batch")
+    put("f16_mode_samples_per_s", "uniform_mode_tcnn_f16_mfma", "samples_per_sec")
+    put("f16_mode_frac", "uniform_mode_tcnn_f16_mfma", "roofline", "frac")
+    put("proposal_mode_ms", "proposal_mode", "ms_per_batch")
+    put("proposal_sampler_frac_l2", "proposal_mode", "roofline", "frac")
+    for key in ("4096", "65536", "65536x192"):
+        put(f"train_{key}_ms", "train_iteration", key, "ms_per_iter")
+        put(f"train_{key}_fresh_batches_ms", "train_iteration", key, "fresh_batches", "ms_per_iter")
+        put(f"train_{key}_frac_atomic", "train_iteration", key, "roofline", "frac")
+        put(f"train_{key}_f16_ms", "train_iteration", key, "mixed_precision", "ms_per_iter")
+    put("train_4096_steady_ms", "train_iteration", "4096", "steady_state", "ms_per_iter")
+    put("c4_seconds", "export_pointcloud_c4", "seconds_to_10M_points")
+    put("c4_rays_per_s", "export_pointcloud_c4", "rays_per_sec")
+    put("c4_frac", "export_pointcloud_c4", "roofline", "frac")
+    put("c4_normals_seconds", "export_pointcloud_c4", "normals", "seconds")
+    put("dense_export_samples_per_s", "dense_export", "field_samples_per_sec")
+    put("dense_export_frac", "dense_export", "roofline", "frac")
+    put("projection_job_ms", "projection_job", "ms_per_job")
+    put("projection_jobs_per_s", "projection_run", "batched", "jobs_per_sec")
+    put("projection_jobs_per_s_png", "projection_run", "batched", "with_png_tree", "jobs_per_sec")
+    put("projection_loop_jobs_per_s", "projection_run", "per_job_loop", "jobs_per_sec")
+    put("eval_image_800_ms", "eval_image_800", "ms_per_image")
+    put("eval_image_800_f16_ms", "eval_image_800", "tcnn_f16_mode", "ms_per_image")
+    put("eval_image_800_frac", "eval_image_800", "roofline", "frac")
+    put("eval_image_1920x1440_ms", "eval_image_1920x1440", "ms_per_image")
+    put("big_render_65536_ms", "generic_shapes", "big_render_ms")
+    put("big_train_8192_ms", "generic_shapes", "big_train_ms")
+    return f
+
+
+def compact_line(line: dict, extra: dict) -> dict:
+    """The ONE stdout line: contract keys, `config`, a trimmed `roofline` and `cpu_baseline`, a flat `secondary` of bare numbers."""
+    out = dict(line)
+    rf = line.get("roofline")
+    if rf:
+        out["roofline"] = {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel",
+                                              "avg_launch_ms", "mfma_frac", "hbm_measured_frac") if k in rf}
+        out["roofline"]["limited_by"] = "SIMD issue (fp32 MFMA + VALU), not HBM: the table is cache-resident"
+    cb = line.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {"value": _num(cb["value"], 6), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                               "sample": cb["sample_short"], "rays_per_sec": _num(cb["rays_per_sec"]),
+                               "c1": {"value": _num(cb["c1"]["value"], 6), "unit": "samples/s", "sample": cb["c1"]["sample_short"]}}
+    sec = flat_secondary(extra)
+    if sec:
+        out["secondary"] = sec
+        out["secondary_file"] = "bench_secondary.json"
+    return out
+
+
+def emit(line: dict, extra: dict):
+    """Full record -> bench_secondary.json (next to this file); the compact line -> stdout, LAST, under 4 KB."""
+    full = dict(line)
+    full.update(extra)
+    text = json.dumps(full)
+    try:
+        with open(os.path.join(ROOT, "bench_secondary.json"), "w") as fh_:
+            fh_.write(text + "\n")
+    except OSError as e:
+        print(f"bench.py: could not write bench_secondary.json: {e}", file=sys.stderr)
+    # stderr stays short too: the driver's captured tail holds stdout THEN stderr, cut to its last few KB
+    print(f"bench.py: full record ({len(text)} B) written to bench_secondary.json", file=sys.stderr, flush=True)
+    short = json.dumps(compact_line(line, extra))
+    if len(short) >= MAX_LINE_BYTES:  # never let the driver's line grow past what it reads: drop the secondaries first
+        c = compact_line(line, extra)
+        c.pop("secondary", None)
+        short = json.dumps(c)
+    assert len(short) < MAX_LINE_BYTES, len(short)
+    print(short, flush=True)
 
 
 def tcnn_f16_field(params, device):
@@ -1052,10 +1149,12 @@ def run_cpu_baseline(args, params, fspec, pspecs, batches, ops, fh, scene_u, opt
     chunk1, n1 = 1024, 20
     med1, tot1, _, _ = timed_chunks(model1, rays1, chunk1, n1)
     base = {"value": chunk2 * S / med2, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample_short": f"C2: {n2} chunks x {chunk2} rays x {S} spp, median {med2 * 1e3:.0f} ms ({tot2:.1f} s timed), {torch.get_num_threads()} threads",
             "sample": f"C2: {n2} timed chunks of {chunk2} rays x {S} samples of batch 0 after 3 warm-ups, median chunk time "
                       f"{med2 * 1e3:.1f} ms ({tot2:.1f} s timed), torch {torch.get_num_threads()} threads, fp32, eval mode",
             "rays_per_sec": chunk2 / med2,
             "c1": {"value": chunk1 * 64 / med1, "unit": "samples/s", "rays_per_sec": chunk1 / med1,
+                   "sample_short": f"C1: 400x400, 64 spp, {n1} chunks x {chunk1} rays, median {med1 * 1e3:.0f} ms",
                    "sample": f"C1 (BASELINE.json configs[0]): 400x400 camera, 64 samples/ray, {n1} timed chunks of {chunk1} rays "
                              f"after 3 warm-ups, median chunk time {med1 * 1e3:.1f} ms ({tot1:.1f} s timed)"}}
     return base, round(psnr, 2)

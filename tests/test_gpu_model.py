@@ -449,20 +449,28 @@ def test_named_background_colours(scene):
 
 
 def test_bench_line_contract():
-    """bench.py prints ONE JSON line with the driver's keys plus ``roofline`` and ``cpu_baseline`` (a short run here: few
-    steps, the minimum CPU-baseline chunk count, no secondary timings)."""
+    """bench.py as the driver runs it (DEFAULT flags: every secondary workload, the CPU baseline; fewer steps only) prints ONE
+    stdout line, under 4 KB, that round-trips through json with the driver's keys plus ``roofline`` and ``cpu_baseline``; the full
+    record goes to bench_secondary.json.  (Round 4's line had grown to 20.6 KB and the driver could not read it -- this test ran
+    with --no-secondary and never saw the line the driver gets.)"""
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    side = os.path.join(root, "bench_secondary.json")
+    if os.path.exists(side):
+        os.remove(side)
     # (10 steps after 5 warm-ups: with 3 + 1 the whole timed region is 8 ms and fell inside the clock ramp of an idle device
     #  once -- 16 ms per step on a fresh box)
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "5", "--no-secondary",
-                        "--cpu-baseline-chunks", "10"], capture_output=True, text=True, timeout=600, cwd=root)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "10", "--warmup", "5"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]
+    assert len(p.stderr) < 4096, len(p.stderr)  # the driver's captured tail is stdout THEN stderr: keep both short
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
+    assert len(lines[0]) < 4096, len(lines[0])
     d = json.loads(lines[0])
+    assert json.loads(json.dumps(d)) == d
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -471,13 +479,23 @@ def test_bench_line_contract():
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and 0 < r["frac"] <= 1.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["peak"] == 8000.0
-    assert "limited_by" in r and "traffic_source" in r and r["bytes_per_sample"] == 1024
-    m = d["roofline_mfma"]
-    assert m["bound"] == "mfma" and m["unit"] == "TFLOP/s" and abs(m["frac"] - m["achieved"] / m["peak"]) < 1e-3
+    assert "limited_by" in r and "traffic_source" in r and "traffic" in r
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and "sample" in c
     assert "median" in c["sample"] and c["c1"]["value"] > 0 and "400x400" in c["c1"]["sample"]
     assert d["value"] > 1e9 and abs(d["ms_per_step"] * 1e-3 * d["value"] - 65536 * 192) / (65536 * 192) < 1e-6
+    # the flat secondaries: bare numbers only, every workload of the default run present
+    sec = d["secondary"]
+    assert all(isinstance(v, (int, float)) for v in sec.values()), sec
+    for k in ("f16_mode_ms", "proposal_mode_ms", "train_4096_ms", "train_65536_ms", "train_65536x192_ms", "c4_seconds",
+              "dense_export_samples_per_s", "projection_jobs_per_s", "eval_image_800_ms", "eval_image_1920x1440_ms"):
+        assert sec.get(k, 0) > 0, k
+    # the full record, with the per-workload rooflines
+    full = json.load(open(side))
+    assert full["roofline"]["bytes_per_sample"] == 1024 and full["value"] == d["value"]
+    m = full["roofline_mfma"]
+    assert m["bound"] == "mfma" and m["unit"] == "TFLOP/s" and abs(m["frac"] - m["achieved"] / m["peak"]) < 1e-3
+    assert "roofline" in full["train_iteration"]["4096"] and "roofline" in full["export_pointcloud_c4"]
 
 
 def test_pointcloud_export_at_c4_size():

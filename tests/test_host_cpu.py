@@ -1,6 +1,7 @@
 """CPU-side checks of host logic that needs no GPU: plugin config objects, PLY I/O, run-directory config."""
 
 import math
+import os
 
 import numpy as np
 import pytest
@@ -186,3 +187,33 @@ def test_semantic_field_head_names_shapes_and_the_separate_op():
         SemanticFieldHead(64, 2)
     with pytest.raises(ValueError, match="activation"):
         SemanticFieldHead(64, 1, activation=torch.nn.ReLU())
+
+
+def test_bench_compact_line_fits_the_driver():
+    """bench.py's stdout line built from a FULL record (round 4's, 20.6 KB, which the driver could not read) stays under 4 KB,
+    keeps the contract keys, `roofline` and `cpu_baseline`, and carries the secondaries as bare numbers."""
+    import importlib.util
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_bench_for_test", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    full = json.load(open(os.path.join(root, "profiles", "r04_bench.json")))
+    assert len(json.dumps(full)) > 16000
+    contract = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "rays_per_sec", "psnr_vs_oracle_db", "roofline", "cpu_baseline")
+    line = {k: full[k] for k in contract}
+    line["cpu_baseline"]["sample_short"] = "C2: 10 chunks x 4096 rays x 192 spp, median 2894 ms"
+    line["cpu_baseline"]["c1"]["sample_short"] = "C1: 400x400, 64 spp, 20 chunks x 1024 rays, median 72 ms"
+    extra = {k: v for k, v in full.items() if k not in contract}
+    c = b.compact_line(line, extra)
+    text = json.dumps(c)
+    assert len(text) < b.MAX_LINE_BYTES == 4096
+    assert json.loads(text) == c
+    for k in contract:
+        assert k in c
+    assert c["value"] == full["value"] and c["roofline"]["frac"] == full["roofline"]["frac"]
+    assert c["roofline"]["traffic"] == full["roofline"]["traffic"] and c["cpu_baseline"]["cores"] == 16
+    assert all(isinstance(v, (int, float)) for v in c["secondary"].values())
+    assert c["secondary"]["train_65536_ms"] == 15.56 and c["secondary"]["c4_seconds"] == 12.77
