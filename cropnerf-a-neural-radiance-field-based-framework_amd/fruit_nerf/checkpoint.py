@@ -48,6 +48,17 @@ def _cameras_dict(cameras: Cameras) -> dict:
             "height": cameras.height, "width": cameras.width}
 
 
+def _attach_datasets(pipe, side: dict) -> None:
+    """The train / eval datasets the exporters walk (``collect_camera_poses``), from a run's ``cameras.json``."""
+    from .data.fruit_datamanager import CameraDataset
+
+    dm = pipe.datamanager
+    if side.get("image_filenames"):
+        dm.train_dataset = CameraDataset(dm.cameras, side["image_filenames"])
+    if side.get("eval"):
+        dm.eval_dataset = CameraDataset(_cameras_from_dict(side["eval"]), side["eval"].get("image_filenames"))
+
+
 def _cameras_from_dict(c: dict) -> Cameras:
     return Cameras(torch.tensor(c["camera_to_worlds"], dtype=torch.float32), torch.tensor(c["fx"]), torch.tensor(c["fy"]),
                    torch.tensor(c["cx"]), torch.tensor(c["cy"]), int(c["height"]), int(c["width"]))
@@ -57,7 +68,8 @@ def save_run(run_dir, model_config: FruitNerfModelConfig, cameras: Cameras, scen
              params: Dict[str, torch.Tensor], step: int = 0, transform=None, scale: float = 1.0,
              method_name: str = "fruit_nerf", optimizers: Optional[dict] = None, format: str = "nerfstudio",
              data: Optional[str] = None, dataparser: Optional[dict] = None, trainer_config=None,
-             schedulers: Optional[dict] = None) -> pathlib.Path:
+             schedulers: Optional[dict] = None, image_filenames=None, eval_cameras: Optional[Cameras] = None,
+             eval_image_filenames=None) -> pathlib.Path:
     """Write a run directory; returns the path of its config file (what ``--load-config`` takes).
     ``format="nerfstudio"``: config.yml + step-*.ckpt under nerfstudio's state-dict names (tcnn-packed when the model
     is a tcnn-layout one); ``format="json"``: this package's round-1 layout."""
@@ -89,7 +101,14 @@ def save_run(run_dir, model_config: FruitNerfModelConfig, cameras: Cameras, scen
             eval_num_rays_per_batch=getattr(getattr(getattr(tc, "pipeline", None), "datamanager", None),
                                             "eval_num_rays_per_batch", 4096),
             dataparser=dataparser)
-        (run_dir / "cameras.json").write_text(json.dumps(_cameras_dict(cameras)))
+        side = _cameras_dict(cameras)
+        if image_filenames is not None:  # what ``semantic_projection.py cameras`` names the frames by
+            side["image_filenames"] = [str(f) for f in image_filenames]
+        if eval_cameras is not None and len(eval_cameras) > 0:
+            side["eval"] = _cameras_dict(eval_cameras)
+            if eval_image_filenames is not None:
+                side["eval"]["image_filenames"] = [str(f) for f in eval_image_filenames]
+        (run_dir / "cameras.json").write_text(json.dumps(side))
         (run_dir / "dataparser_transforms.json").write_text(json.dumps({"transform": t, "scale": scale}))
         NIO.save_checkpoint(run_dir / "nerfstudio_models" / f"step-{step:09d}.ckpt", step, state, optimizers=optimizers,
                             schedulers=schedulers, buffers=NIO.field_buffers(model_config, scene_box.aabb))
@@ -100,6 +119,12 @@ def save_run(run_dir, model_config: FruitNerfModelConfig, cameras: Cameras, scen
         "method_name": method_name, "model": mc, "scene_box": scene_box.aabb.tolist(),
         "cameras": _cameras_dict(cameras),
     }
+    if image_filenames is not None:
+        raw["cameras"]["image_filenames"] = [str(f) for f in image_filenames]
+    if eval_cameras is not None and len(eval_cameras) > 0:
+        raw["cameras"]["eval"] = _cameras_dict(eval_cameras)
+        if eval_image_filenames is not None:
+            raw["cameras"]["eval"]["image_filenames"] = [str(f) for f in eval_image_filenames]
     (run_dir / "config.json").write_text(json.dumps(raw))
     (run_dir / "dataparser_transforms.json").write_text(json.dumps({"transform": t, "scale": scale}))
     ckpt = {"step": step, "params": {k: v.detach().cpu() for k, v in params.items()}}
@@ -145,6 +170,7 @@ def eval_setup(load_config, eval_num_rays_per_chunk: Optional[int] = None, test_
     pipe = FruitPipeline(FruitPipelineConfig(FruitDataManagerConfig(), model_cfg), device=device, cameras=cams,
                          scene_box=SceneBox(torch.tensor(raw["scene_box"], dtype=torch.float32)), test_mode=test_mode,
                          params=state["params"], world_size=world_size, local_rank=rank)
+    _attach_datasets(pipe, raw["cameras"])
     pipe.eval()
     return cfg, pipe, ckpts[-1], int(state["step"])
 
@@ -168,8 +194,10 @@ def _eval_setup_nerfstudio(load_config: pathlib.Path, eval_num_rays_per_chunk, t
     # cameras / scene box: the side file this package writes, else the capture named by the config
     side = load_config.parent / "cameras.json"
     semantics = None
+    side_dict, eval_out, train_names = {}, None, None
     if side.exists():
-        cams = _cameras_from_dict(json.loads(side.read_text()))
+        side_dict = json.loads(side.read_text())
+        cams = _cameras_from_dict(side_dict)
         aabb = state.get("field.aabb")
         scene_box = SceneBox(aabb.to(torch.float32) if aabb is not None else torch.tensor([[-1.0] * 3, [1.0] * 3]))
     else:
@@ -184,8 +212,11 @@ def _eval_setup_nerfstudio(load_config: pathlib.Path, eval_num_rays_per_chunk, t
             if hasattr(pc, k) and k not in ("data", "_target"):
                 setattr(pc, k, v)
         pc.data = pathlib.Path(str(data))
-        out = pc.setup().get_dataparser_outputs("train")
+        parser = pc.setup()
+        out = parser.get_dataparser_outputs("train")
         cams, scene_box, semantics = out.cameras, out.scene_box, out.metadata.get("semantics")
+        train_names = out.image_filenames
+        eval_out = parser.get_dataparser_outputs("val" if test_mode == "val" else "test")
     if len(cams) != num_images:
         raise ValueError(f"{load_config}: {len(cams)} training cameras but the appearance embedding has {num_images} rows")
     if is_tcnn_state_dict(state):
@@ -216,5 +247,12 @@ def _eval_setup_nerfstudio(load_config: pathlib.Path, eval_num_rays_per_chunk, t
     pipe = FruitPipeline(FruitPipelineConfig(FruitDataManagerConfig(), model_cfg), device=device, cameras=cams,
                          scene_box=scene_box, test_mode=test_mode, params=params, world_size=world_size,
                          local_rank=rank, semantics=semantics)
+    _attach_datasets(pipe, side_dict)
+    if train_names is not None:
+        from .data.fruit_datamanager import CameraDataset
+
+        pipe.datamanager.train_dataset = CameraDataset(pipe.datamanager.cameras, train_names, out.metadata)
+        if eval_out is not None and len(eval_out.image_filenames) > 0:
+            pipe.datamanager.eval_dataset = CameraDataset(eval_out.cameras, eval_out.image_filenames, eval_out.metadata)
     pipe.eval()
     return cfg, pipe, ckpt, step

@@ -56,6 +56,11 @@ class FruitDataset:
     def __len__(self) -> int:
         return len(self._dataparser_outputs.image_filenames)
 
+    @property
+    def image_filenames(self):
+        """nerfstudio ``InputDataset.image_filenames`` (read by ``collect_camera_poses_for_dataset``)."""
+        return self._dataparser_outputs.image_filenames
+
     def get_numpy_image(self, image_idx: int) -> np.ndarray:
         """nerfstudio ``InputDataset.get_numpy_image``: uint8 [H,W,3|4]."""
         pil_image = Image.open(self._dataparser_outputs.image_filenames[image_idx])

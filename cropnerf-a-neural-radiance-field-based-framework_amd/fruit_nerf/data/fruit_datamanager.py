@@ -52,6 +52,23 @@ def sample_surface_points(corners: Tensor, n: int, device, noise: bool = False) 
     return pts, plane
 
 
+class CameraDataset:
+    """What the exporters read from a nerfstudio ``InputDataset`` (``exporter_utils_nerfacto.py:308-309``,
+    ``fruit_nerf.py:263-264``): the split's cameras, its image file names and the metadata.  Stands in for the training /
+    eval dataset of a run that is opened for export only (no images decoded)."""
+
+    def __init__(self, cameras: Cameras, image_filenames=None, metadata: Optional[dict] = None):
+        names = list(image_filenames) if image_filenames is not None else [f"frame_{i:05d}" for i in range(len(cameras))]
+        if len(names) != len(cameras):
+            raise ValueError(f"{len(names)} image file names for {len(cameras)} cameras")
+        self.cameras = cameras
+        self.image_filenames = names
+        self.metadata = metadata if metadata is not None else {}
+
+    def __len__(self) -> int:
+        return len(self.image_filenames)
+
+
 class FruitDataManager:
     def __init__(self, config: FruitDataManagerConfig, cameras: Cameras, device="cuda", test_mode: str = "val",
                  world_size: int = 1, local_rank: int = 0, images: Optional[Tensor] = None,
@@ -66,6 +83,10 @@ class FruitDataManager:
         self.fruit_masks = fruit_masks  # [N,H,W,1] float (optional)
         self.train_count = 0
         self.eval_count = 0
+        # the datasets behind the rays (``:174-186``): what ``collect_camera_poses`` walks.  ``from_dataset`` / ``eval_setup``
+        # replace them with the capture's own (file names, eval split)
+        self.train_dataset = CameraDataset(self.cameras)
+        self.eval_dataset: Optional[CameraDataset] = None
         self._gen = torch.Generator(device="cpu").manual_seed(seed + 1000 * local_rank)
         self._device_generator: Optional[torch.Generator] = None
         self._seed = seed + 1000 * local_rank

@@ -12,7 +12,7 @@ applied only when open3d is importable."""
 from __future__ import annotations
 
 import sys
-from typing import Dict, Optional
+from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -147,3 +147,62 @@ def generate_point_cloud(pipeline, num_points: int = 1000000, remove_outliers: b
             result["normals"] = np.asarray(pcd.normals)
         result.update(points=np.asarray(pcd.points), colors=np.asarray(pcd.colors), view_directions=view_dirs)
     return result
+
+
+def render_trajectory(pipeline, cameras, rgb_output_name: str, depth_output_name: str,
+                      rendered_resolution_scaling_factor: float = 1.0, disable_distortion: bool = False,
+                      return_rgba_images: bool = False) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+    """``exporter_utils_nerfacto.py:230-287``: every camera's full image through ``get_outputs_for_camera_ray_bundle``;
+    rgb and depth images as numpy arrays.  ``disable_distortion`` is accepted and has nothing to disable (the cameras of
+    this path are undistorted pinholes).  ``return_rgba_images``: rgb with the accumulation as alpha (nerfstudio's
+    ``get_rgba_image``)."""
+    images, depths = [], []
+    cameras.rescale_output_resolution(rendered_resolution_scaling_factor)
+    cameras = cameras.to(pipeline.model.device)
+    for camera_idx in range(cameras.size):
+        camera_ray_bundle = cameras.generate_rays(camera_idx, keep_shape=True)
+        with torch.no_grad():
+            outputs = pipeline.model.get_outputs_for_camera_ray_bundle(camera_ray_bundle)
+        for flag, name in (("--rgb_output_name", rgb_output_name), ("--depth_output_name", depth_output_name)):
+            if name not in outputs:  # :269-278
+                print(f"Could not find {name} in the model outputs\nPlease set {flag} to one of: {list(outputs.keys())}",
+                      file=sys.stderr)
+                sys.exit(1)
+        image = outputs[rgb_output_name]
+        if return_rgba_images:
+            image = torch.cat([image, outputs["accumulation"]], dim=-1)
+        images.append(image.cpu().numpy())
+        depths.append(outputs[depth_output_name].cpu().numpy())
+    return images, depths
+
+
+def collect_camera_poses_for_dataset(dataset, camera_optimizer=None) -> List[Dict[str, Any]]:
+    """``exporter_utils_nerfacto.py:290-334``: one ``{"file_path", "transform"}`` per camera of ``dataset``; ``transform``
+    is the stored 3 x 4 camera-to-world, or -- with a camera optimiser -- ``camera_optimizer.apply_to_camera`` of it."""
+    if dataset is None:
+        return []
+    cameras = dataset.cameras
+    image_filenames = dataset.image_filenames
+    frames: List[Dict[str, Any]] = []
+    for idx in range(len(cameras)):
+        if camera_optimizer is None:
+            transform = cameras.camera_to_worlds[idx].tolist()
+        else:
+            camera = cameras[idx:idx + 1]
+            assert camera.metadata is not None
+            camera.metadata["cam_idx"] = idx
+            transform = camera_optimizer.apply_to_camera(camera).tolist()[0]
+        frames.append({"file_path": str(image_filenames[idx]), "transform": transform})
+    return frames
+
+
+def collect_camera_poses(pipeline) -> Tuple[List[Dict[str, Any]], List[Dict[str, Any]]]:
+    """``exporter_utils_nerfacto.py:337-357``: training frames with the optimised poses, eval frames with the original
+    ones."""
+    train_dataset = pipeline.datamanager.train_dataset
+    assert train_dataset is not None
+    eval_dataset = getattr(pipeline.datamanager, "eval_dataset", None)
+    camera_optimizer = getattr(pipeline.model, "camera_optimizer", None)
+    train_frames = collect_camera_poses_for_dataset(train_dataset, camera_optimizer)
+    eval_frames = collect_camera_poses_for_dataset(eval_dataset)
+    return train_frames, eval_frames

@@ -142,6 +142,14 @@ class FruitModel:
                              and fs.appearance_embedding_dim == 32)
         self.general_rays_per_call = 32768
 
+    @property
+    def camera_optimizer(self):
+        """``self.camera_optimizer`` of the reference (``fruit_nerf.py:114-116``) as the exporters use it: whole poses
+        (``apply_to_camera``).  Rays are corrected by ``cn_apply_pose_adjustment`` (``get_outputs``)."""
+        from .camera_optimizer import CameraOptimizer
+
+        return CameraOptimizer(self.params["camera_optimizer.pose_adjustment"], mode="SO3xR3")
+
     def state_dict(self) -> Dict[str, Tensor]:
         return dict(self.params)
 

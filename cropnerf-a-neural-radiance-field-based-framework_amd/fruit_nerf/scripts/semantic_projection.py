@@ -70,24 +70,25 @@ class ExportPointCloud(Exporter):
 
 @dataclass
 class ExportCameraPoses(Exporter):
-    """``scripts/semantic_projection.py:174-199``: dump the (pose-refined) training cameras."""
+    """``scripts/semantic_projection.py:174-199``: ``transforms_train.json`` (training cameras, pose-refined) and
+    ``transforms_eval.json`` (eval cameras, as stored); a split without frames is skipped with a message."""
 
     def main(self) -> None:
         from cropnerf_amd.fruit_nerf.checkpoint import eval_setup
+        from cropnerf_amd.fruit_nerf.export.exporter_utils_nerfacto import collect_camera_poses
 
         if not self.output_dir.exists():
             self.output_dir.mkdir(parents=True)
         _, pipeline, _, _ = eval_setup(self.load_config)
-        cams = pipeline.datamanager.cameras
-        adj = pipeline.model.params["camera_optimizer.pose_adjustment"].cpu()
-        frames = []
-        for i in range(len(cams)):
-            c2w = cams.camera_to_worlds[i].cpu()
-            frames.append({"file_path": f"frame_{i:05d}", "transform": c2w.tolist(), "pose_adjustment": adj[i].tolist()})
-        path = os.path.join(self.output_dir, "transforms_train.json")
-        with open(path, "w", encoding="UTF-8") as f:
-            json.dump(frames, f, indent=4)
-        print(f"Saved poses to {path}")
+        train_frames, eval_frames = collect_camera_poses(pipeline)
+        for file_name, frames in [("transforms_train.json", train_frames), ("transforms_eval.json", eval_frames)]:
+            if len(frames) == 0:
+                print(f"No frames found for {file_name}. Skipping.")
+                continue
+            output_file_path = os.path.join(self.output_dir, file_name)
+            with open(output_file_path, "w", encoding="UTF-8") as f:
+                json.dump(frames, f, indent=4)
+            print(f"Saved poses to {output_file_path}")
 
 
 def _add_common(p):

@@ -144,7 +144,9 @@ def train(method: str, data: Path, output_dir: Path = Path("outputs"), max_num_i
                             method_name=tc.method_name, data=str(Path(data).resolve()), dataparser=dp, trainer_config=tc,
                             optimizers=dict(trainer.state_dict(), rank_states=rank_states),
                             schedulers={g: {"last_epoch": trainer.step, "lr": grp.lr_at(trainer.step)}
-                                        for g, grp in trainer.groups.items()})
+                                        for g, grp in trainer.groups.items()},
+                            image_filenames=train_out.image_filenames, eval_cameras=eval_out.cameras,
+                            eval_image_filenames=eval_out.image_filenames)
         for old in sorted((run_dir / "nerfstudio_models").glob("step-*.ckpt"))[:-1]:
             old.unlink()  # nerfstudio's save_only_latest_checkpoint
         return cfg_path

@@ -125,16 +125,41 @@ class Cameras:
     cy: Tensor
     height: int
     width: int
+    metadata: Optional[dict] = None  # nerfstudio's Cameras.metadata ("cam_idx" for the pose optimiser's apply_to_camera)
 
     def __len__(self) -> int:
         return self.camera_to_worlds.shape[0]
 
-    def __getitem__(self, i: int) -> "Cameras":
-        return Cameras(self.camera_to_worlds[i:i + 1], self.fx[i:i + 1], self.fy[i:i + 1], self.cx[i:i + 1],
-                       self.cy[i:i + 1], self.height, self.width)
+    @property
+    def size(self) -> int:
+        return len(self)
+
+    @property
+    def device(self):
+        return self.camera_to_worlds.device
+
+    def __getitem__(self, i) -> "Cameras":
+        """An int or a slice -> a batch of cameras (``cameras[idx : idx + 1]`` at ``exporter_utils_nerfacto.py:321``); every
+        selection owns a fresh ``metadata`` dict, like nerfstudio's."""
+        if not isinstance(i, slice):
+            i = int(i)
+            if i < 0:
+                i += len(self)
+            i = slice(i, i + 1)
+        return Cameras(self.camera_to_worlds[i], self.fx[i], self.fy[i], self.cx[i], self.cy[i], self.height, self.width,
+                       dict(self.metadata or {}))
 
     def __iter__(self):
         return (self[i] for i in range(len(self)))
+
+    def rescale_output_resolution(self, scaling_factor: float) -> None:
+        """nerfstudio ``Cameras.rescale_output_resolution`` (in place, default ``floor`` rounding), as ``render_trajectory``
+        calls it (``exporter_utils_nerfacto.py:254``)."""
+        if float(scaling_factor) == 1.0:
+            return
+        f = float(scaling_factor)
+        self.fx, self.fy, self.cx, self.cy = self.fx * f, self.fy * f, self.cx * f, self.cy * f
+        self.height, self.width = int(self.height * f), int(self.width * f)
 
     @property
     def image_height(self):
@@ -149,7 +174,7 @@ class Cameras:
 
     def to(self, device) -> "Cameras":
         return Cameras(self.camera_to_worlds.to(device), self.fx.to(device), self.fy.to(device), self.cx.to(device),
-                       self.cy.to(device), self.height, self.width)
+                       self.cy.to(device), self.height, self.width, self.metadata)
 
     def generate_rays(self, camera_indices: Union[int, Tensor], keep_shape: Optional[bool] = None,
                       aabb_box: Optional[SceneBox] = None, coords: Optional[Tensor] = None) -> RayBundle:

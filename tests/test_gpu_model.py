@@ -319,7 +319,10 @@ def test_cli_end_to_end(scene, tmp_path):
     miss = np.asarray(Image.open(out / "projection" / "super_cluster_0" / "cam_0" / "wo_occ_cluster_1.png"))
     assert hit.shape == (20, 20, 3) and hit.max() > 0 and miss.max() == 0
     semantic_projection.entrypoint(["cameras", "--load-config", str(cfg_path), "--output-dir", str(out)])
-    assert len(json.loads((out / "transforms_train.json").read_text())) == 3
+    frames = json.loads((out / "transforms_train.json").read_text())  # scripts/semantic_projection.py:189-197
+    assert len(frames) == 3 and all(set(f) == {"file_path", "transform"} for f in frames)
+    assert np.asarray(frames[0]["transform"]).shape == (3, 4)
+    assert not (out / "transforms_eval.json").exists()  # this run has no eval split: skipped
 
 
 def test_big_method_shape_runs_through_the_generic_kernels():
