@@ -172,6 +172,7 @@ SIGNATURES = {
     "cn_zbuffer_update_large": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P, C.c_size_t, _P]),
     "cn_zbuffer_update": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, C.c_size_t, _P]),
     "cn_knn_mean_distance": (C.c_int, [_P, _P, _I32, _I32, _I32, _F, _F, _F, _F, _I64, _I32, _P, _P]),
+    "cn_estimate_normals": (C.c_int, [_P, _P, _I32, _I32, _I32, _F, _F, _F, _F, _I64, _I32, _P, _P, _P]),
     "cn_segment_mean": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "cn_dbscan_workspace_bytes": (C.c_size_t, [_I64]),
     "cn_dbscan": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _F, _I32, _P, _I64, _P, _P, _P, _P, C.c_size_t, _P]),
@@ -180,17 +181,30 @@ SIGNATURES = {
     "cn_kmeans_step": (C.c_int, [_P, _I64, _P, _I32, _P, _P, _P, _P, _I32, _P]),
     "cn_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _I32, C.c_double, C.c_double, C.c_double, C.c_double, _I32, _P]),
     "cn_radam_step": (C.c_int, [_P, _P, _P, _P, _I64, _I32, C.c_double, C.c_double, C.c_double, C.c_double, _I32, _P]),
+    "cn_deterministic_build": (C.c_int, []),
+    "cn_deterministic_register": (C.c_int, [_P, _I64, _P, _P]),
+    "cn_deterministic_clear": (C.c_int, []),
+    "cn_deterministic_flush": (C.c_int, [_P]),
 }
 
-_lib = None
+DET_LIB_PATH = _HERE / "libcropnerf_hip_det.so"
+_libs: dict = {}
+
+
+def deterministic() -> bool:
+    """``CN_DETERMINISTIC_SCATTER=1`` (read per call, so one test process can run both modes): calls go to the test build whose
+    training kernels accumulate order-independently (``csrc/cn_det.hpp``, ``include/cropnerf_hip.h``).  Never set by the
+    product path."""
+    return os.environ.get("CN_DETERMINISTIC_SCATTER", "0") not in ("", "0")
 
 
 def load() -> C.CDLL:
     """Load the shared library (built in-tree by build.py).  Raises if it is absent: no fallback path exists."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    path = Path(os.environ.get("CROPNERF_HIP_LIB", LIB_PATH))
+    det = deterministic()
+    lib = _libs.get(det)
+    if lib is not None:
+        return lib
+    path = DET_LIB_PATH if det else Path(os.environ.get("CROPNERF_HIP_LIB", LIB_PATH))
     if not path.exists():
         raise FileNotFoundError(
             f"{path} not found: build it with `python {(_HERE / 'build.py')}` (hipcc --offload-arch=gfx950). "
@@ -201,7 +215,9 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    if bool(lib.cn_deterministic_build()) != det:
+        raise RuntimeError(f"{path}: cn_deterministic_build() says {lib.cn_deterministic_build()}, expected {int(det)}")
+    _libs[det] = lib
     return lib
 
 

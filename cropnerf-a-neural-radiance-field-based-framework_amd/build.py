@@ -21,7 +21,10 @@ OUT = HERE / "libcropnerf_hip.so"
 BUILD = HERE / "build"
 ARCH = "gfx950"
 
-SOURCES = ["api_common.cpp", "raygen.hip", "sampler.hip", "field_simple.hip", "composite.hip", "render_fused.hip",
+OUT_DET = HERE / "libcropnerf_hip_det.so"  # the deterministic-accumulation test build (csrc/cn_det.hpp)
+DET_SOURCES = ["train_render.hip", "train_field.hip", "tcnn_grid.hip", "deterministic.hip"]  # compiled again with the macro
+
+SOURCES = ["api_common.cpp", "deterministic.hip", "raygen.hip", "sampler.hip", "field_simple.hip", "composite.hip", "render_fused.hip",
            "proposal.hip", "export.hip", "train_render.hip", "train_field.hip", "zbuffer.hip", "knn.hip", "cluster.hip", "tcnn_grid.hip", "contour.hip", "projection.hip", "png_writer.cpp"]
 
 
@@ -53,12 +56,21 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     flags += os.environ.get("CN_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DCN_FUSED_PIPELINE=0 for A/B builds
     jobs = []
     objs = []
+    det_objs = []  # the test library: the training units compiled with the macro, every other object shared
     for src in SOURCES:
         s = CSRC / src
         o = BUILD / (src.rsplit(".", 1)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s, *headers]):
             jobs.append([hipcc, *flags, "-c", str(s), "-o", str(o)])
+        if src in DET_SOURCES:
+            od = BUILD / (src.rsplit(".", 1)[0] + ".det.o")
+            det_objs.append(od)
+            if force or _stale(od, [s, *headers]):
+                jobs.append([hipcc, *flags, "-DCN_DETERMINISTIC_SCATTER=1", "-c", str(s), "-o", str(od)])
+        else:
+            det_objs.append(o)
+    jobs.sort(key=lambda c: -Path(c[-3]).stat().st_size)  # the long compiles first
 
     def run(cmd):
         if verbose:
@@ -67,10 +79,12 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed:\n{' '.join(cmd)}\n{p.stdout}\n{p.stderr}")
 
-    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, 8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(OUT, objs):
         run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(OUT), *map(str, objs), "-lz"])  # zlib: png_writer.cpp
+    if force or jobs or _stale(OUT_DET, det_objs):
+        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(OUT_DET), *map(str, det_objs), "-lz"])
     return OUT
 
 

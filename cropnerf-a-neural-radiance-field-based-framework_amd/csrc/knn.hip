@@ -75,7 +75,256 @@ knn_mean_distance_kernel(const float* __restrict__ pts /*sorted by cell*/, const
   }
 }
 
+// ---- normals of the exported cloud ---------------------------------------------------------------------------------------------
+// generate_point_cloud estimates normals with open3d's PointCloud::EstimateNormals() at its defaults
+// (fruit_nerf/export/exporter_utils_nerfacto.py:203-212; README.md:125 `--normal-method open3d`): per point the `knn` = 30
+// nearest points (KDTreeSearchParamKNN(30), the point itself included), their covariance through the nine cumulants
+// (sums of x, y, z, xx, xy, xz, yy, yz, zz over the neighbours, divided by their number, in double), and the eigenvector
+// of the smallest eigenvalue from the non-iterative solver for symmetric 3 x 3 matrices (Eberly, "A Robust Eigensolver for
+// 3 x 3 Symmetric Matrices": open3d's fast_normal_computation = true).  Fewer than three neighbours, or a zero vector from
+// the solver: (0, 0, 1), flagged.  Same uniform grid and ring search as the kernel above, keeping the neighbours' indices.
+struct Sym3 {
+  double a00, a01, a02, a11, a12, a22;
+};
+__device__ inline void cross3d(const double* u, const double* v, double* w) {
+  w[0] = u[1] * v[2] - u[2] * v[1];
+  w[1] = u[2] * v[0] - u[0] * v[2];
+  w[2] = u[0] * v[1] - u[1] * v[0];
+}
+// eigenvector of A for a simple eigenvalue e: (A - e I) has rank 2, its rows span the plane orthogonal to the eigenvector --
+// the longest of the three row cross products, normalised
+__device__ inline void eigvec_of_simple(const Sym3& A, double e, double* out) {
+  const double r0[3] = {A.a00 - e, A.a01, A.a02}, r1[3] = {A.a01, A.a11 - e, A.a12}, r2[3] = {A.a02, A.a12, A.a22 - e};
+  double c01[3], c02[3], c12[3];
+  cross3d(r0, r1, c01);
+  cross3d(r0, r2, c02);
+  cross3d(r1, r2, c12);
+  const double d01 = c01[0] * c01[0] + c01[1] * c01[1] + c01[2] * c01[2];
+  const double d02 = c02[0] * c02[0] + c02[1] * c02[1] + c02[2] * c02[2];
+  const double d12 = c12[0] * c12[0] + c12[1] * c12[1] + c12[2] * c12[2];
+  double dmax = d01;
+  const double* best = c01;
+  if (d02 > dmax) {
+    dmax = d02;
+    best = c02;
+  }
+  if (d12 > dmax) {
+    dmax = d12;
+    best = c12;
+  }
+  const double inv = 1.0 / sqrt(dmax);
+  out[0] = best[0] * inv;
+  out[1] = best[1] * inv;
+  out[2] = best[2] * inv;
+}
+// eigenvector for the eigenvalue e1 inside the plane orthogonal to the unit vector w (an eigenvector already found): with an
+// orthonormal basis (u, v) of that plane, the 2 x 2 matrix [u v]^T A [u v] - e1 I is singular and its kernel gives the
+// combination of u and v
+__device__ inline void eigvec_in_complement(const Sym3& A, const double* w, double e1, double* out) {
+  double u[3], v[3];
+  if (fabs(w[0]) > fabs(w[1])) {
+    const double inv = 1.0 / sqrt(w[0] * w[0] + w[2] * w[2]);
+    u[0] = -w[2] * inv;
+    u[1] = 0.0;
+    u[2] = w[0] * inv;
+  } else {
+    const double inv = 1.0 / sqrt(w[1] * w[1] + w[2] * w[2]);
+    u[0] = 0.0;
+    u[1] = w[2] * inv;
+    u[2] = -w[1] * inv;
+  }
+  cross3d(w, u, v);
+  const double au[3] = {A.a00 * u[0] + A.a01 * u[1] + A.a02 * u[2], A.a01 * u[0] + A.a11 * u[1] + A.a12 * u[2],
+                        A.a02 * u[0] + A.a12 * u[1] + A.a22 * u[2]};
+  const double av[3] = {A.a00 * v[0] + A.a01 * v[1] + A.a02 * v[2], A.a01 * v[0] + A.a11 * v[1] + A.a12 * v[2],
+                        A.a02 * v[0] + A.a12 * v[1] + A.a22 * v[2]};
+  double m00 = u[0] * au[0] + u[1] * au[1] + u[2] * au[2] - e1;
+  double m01 = u[0] * av[0] + u[1] * av[1] + u[2] * av[2];
+  double m11 = v[0] * av[0] + v[1] * av[1] + v[2] * av[2] - e1;
+  const double am00 = fabs(m00), am01 = fabs(m01), am11 = fabs(m11);
+  if (am00 >= am11) {
+    if (fmax(am00, am01) > 0.0) {
+      if (am00 >= am01) {
+        m01 /= m00;
+        m00 = 1.0 / sqrt(1.0 + m01 * m01);
+        m01 *= m00;
+      } else {
+        m00 /= m01;
+        m01 = 1.0 / sqrt(1.0 + m00 * m00);
+        m00 *= m01;
+      }
+      for (int k = 0; k < 3; ++k) out[k] = m01 * u[k] - m00 * v[k];
+    } else {
+      for (int k = 0; k < 3; ++k) out[k] = u[k];
+    }
+  } else {
+    if (fmax(am11, am01) > 0.0) {
+      if (am11 >= am01) {
+        m01 /= m11;
+        m11 = 1.0 / sqrt(1.0 + m01 * m01);
+        m01 *= m11;
+      } else {
+        m11 /= m01;
+        m01 = 1.0 / sqrt(1.0 + m11 * m11);
+        m11 *= m01;
+      }
+      for (int k = 0; k < 3; ++k) out[k] = m11 * u[k] - m01 * v[k];
+    } else {
+      for (int k = 0; k < 3; ++k) out[k] = u[k];
+    }
+  }
+}
+// unit eigenvector of the smallest eigenvalue of the covariance C (zero vector when C is zero)
+__device__ inline void smallest_eigenvector(Sym3 C, double* n) {
+  double mx = fmax(fmax(fmax(C.a00, C.a01), fmax(C.a02, C.a11)), fmax(C.a12, C.a22));
+  n[0] = n[1] = n[2] = 0.0;
+  if (mx == 0.0) return;
+  const double s = 1.0 / mx;
+  Sym3 A{C.a00 * s, C.a01 * s, C.a02 * s, C.a11 * s, C.a12 * s, C.a22 * s};
+  const double off = A.a01 * A.a01 + A.a02 * A.a02 + A.a12 * A.a12;
+  if (off > 0.0) {
+    const double q = (A.a00 + A.a11 + A.a22) / 3.0;
+    const double b00 = A.a00 - q, b11 = A.a11 - q, b22 = A.a22 - q;
+    const double p = sqrt((b00 * b00 + b11 * b11 + b22 * b22 + 2.0 * off) / 6.0);
+    const double c00 = b11 * b22 - A.a12 * A.a12, c01 = A.a01 * b22 - A.a12 * A.a02, c02 = A.a01 * A.a12 - b11 * A.a02;
+    const double det = (b00 * c00 - A.a01 * c01 + A.a02 * c02) / (p * p * p);
+    const double half = fmin(fmax(0.5 * det, -1.0), 1.0);
+    const double angle = acos(half) / 3.0;
+    const double beta2 = 2.0 * cos(angle), beta0 = 2.0 * cos(angle + 2.09439510239319549), beta1 = -(beta0 + beta2);
+    const double e0 = q + p * beta0, e1 = q + p * beta1, e2 = q + p * beta2;  // e0 <= e1 <= e2 up to rounding
+    double va[3], vb[3];
+    if (half >= 0.0) {  // e2 is the eigenvalue best separated from the others: start there
+      eigvec_of_simple(A, e2, va);
+      if (e2 < e0 && e2 < e1) {
+        n[0] = va[0], n[1] = va[1], n[2] = va[2];
+        return;
+      }
+      eigvec_in_complement(A, va, e1, vb);
+      if (e1 < e0 && e1 < e2) {
+        n[0] = vb[0], n[1] = vb[1], n[2] = vb[2];
+        return;
+      }
+      cross3d(vb, va, n);
+    } else {
+      eigvec_of_simple(A, e0, va);
+      if (e0 < e1 && e0 < e2) {
+        n[0] = va[0], n[1] = va[1], n[2] = va[2];
+        return;
+      }
+      eigvec_in_complement(A, va, e1, vb);
+      if (e1 < e0 && e1 < e2) {
+        n[0] = vb[0], n[1] = vb[1], n[2] = vb[2];
+        return;
+      }
+      cross3d(va, vb, n);
+    }
+  } else {  // diagonal already
+    if (C.a00 < C.a11 && C.a00 < C.a22) n[0] = 1.0;
+    else if (C.a11 < C.a00 && C.a11 < C.a22) n[1] = 1.0;
+    else n[2] = 1.0;
+  }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256)
+knn_normals_kernel(const float* __restrict__ pts /*sorted by cell*/, const int* __restrict__ cell_start, int gx, int gy, int gz,
+                   float ox, float oy, float oz, float inv_h, float h, long long n, int k_used, int max_ring,
+                   double* __restrict__ normals, int* __restrict__ flags) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+    const int cx = min(max((int)floorf((px - ox) * inv_h), 0), gx - 1);
+    const int cy = min(max((int)floorf((py - oy) * inv_h), 0), gy - 1);
+    const int cz = min(max((int)floorf((pz - oz) * inv_h), 0), gz - 1);
+    float best[K];
+    int bidx[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      best[j] = 3.0e38f;
+      bidx[j] = -1;
+    }
+    for (int ring = 0; ring <= max_ring; ++ring) {
+      for (int dz = -ring; dz <= ring; ++dz) {
+        const int z = cz + dz;
+        if (z < 0 || z >= gz) continue;
+        for (int dy = -ring; dy <= ring; ++dy) {
+          const int y = cy + dy;
+          if (y < 0 || y >= gy) continue;
+          const bool face = (dz == -ring || dz == ring || dy == -ring || dy == ring);
+          const int step = face ? 1 : max(2 * ring, 1);
+          for (int dx = -ring; dx <= ring; dx += step) {
+            const int x = cx + dx;
+            if (x < 0 || x >= gx) continue;
+            const long long c = ((long long)z * gy + y) * gx + x;
+            const int lo = cell_start[c], hi = cell_start[c + 1];
+            for (int q = lo; q < hi; ++q) {
+              const float ex = pts[3 * q] - px, ey = pts[3 * q + 1] - py, ez = pts[3 * q + 2] - pz;
+              float d = ex * ex + ey * ey + ez * ez;
+              if (d < best[K - 1]) {
+                int id = q;
+#pragma unroll
+                for (int j = 0; j < K; ++j) {  // sorted insertion of (d, id), fully unrolled
+                  const bool lt = d < best[j];
+                  const float keep = lt ? d : best[j];
+                  const int keep_id = lt ? id : bidx[j];
+                  d = lt ? best[j] : d;
+                  id = lt ? bidx[j] : id;
+                  best[j] = keep;
+                  bidx[j] = keep_id;
+                }
+              }
+            }
+          }
+        }
+      }
+      const float reach = (float)ring * h;
+      if (best[k_used - 1 < K ? k_used - 1 : K - 1] <= reach * reach && ring >= 1) break;
+    }
+    double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      if (j < k_used && bidx[j] >= 0) {
+        const double x = pts[3 * (long long)bidx[j]], y = pts[3 * (long long)bidx[j] + 1], z = pts[3 * (long long)bidx[j] + 2];
+        sx += x, sy += y, sz += z;
+        sxx += x * x, sxy += x * y, sxz += x * z, syy += y * y, syz += y * z, szz += z * z;
+        ++cnt;
+      }
+    }
+    double nv[3] = {0.0, 0.0, 0.0};
+    int flag = 0;
+    if (cnt >= 3) {
+      const double inv = 1.0 / (double)cnt;
+      sx *= inv, sy *= inv, sz *= inv;
+      Sym3 C{sxx * inv - sx * sx, sxy * inv - sx * sy, sxz * inv - sx * sz, syy * inv - sy * sy, syz * inv - sy * sz,
+             szz * inv - sz * sz};
+      smallest_eigenvector(C, nv);
+    }
+    if (nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2] == 0.0) {
+      nv[2] = 1.0;
+      flag = 1;
+    }
+    normals[3 * i] = nv[0];
+    normals[3 * i + 1] = nv[1];
+    normals[3 * i + 2] = nv[2];
+    if (flags) flags[i] = flag;
+  }
+}
+
 }  // namespace cn
+
+extern "C" int cn_estimate_normals(const float* points_sorted, const int32_t* cell_start, int32_t gx, int32_t gy, int32_t gz,
+                                   float origin_x, float origin_y, float origin_z, float cell_size, int64_t num_points,
+                                   int32_t knn, double* normals, int32_t* degenerate, cn_stream_t stream) {
+  CN_REQUIRE(gx > 0 && gy > 0 && gz > 0 && cell_size > 0.f, CN_ERR_INVALID, "cn_estimate_normals: bad grid");
+  CN_REQUIRE(knn >= 1 && knn <= cn::KNN_MAX_K, CN_ERR_UNSUPPORTED, "cn_estimate_normals: knn %d (max %d)", knn, cn::KNN_MAX_K);
+  if (num_points <= 0) return CN_OK;
+  CN_REQUIRE(points_sorted && cell_start && normals, CN_ERR_INVALID, "cn_estimate_normals: null argument");
+  const int max_ring = std::max(gx, std::max(gy, gz));
+  hipLaunchKernelGGL(cn::knn_normals_kernel<cn::KNN_MAX_K>, dim3(cn::grid_for(num_points, 256, 1 << 16)), dim3(256), 0,
+                     cn::as_stream(stream), points_sorted, cell_start, gx, gy, gz, origin_x, origin_y, origin_z, 1.f / cell_size,
+                     cell_size, (long long)num_points, knn, max_ring, normals, degenerate);
+  return cn::check_launch("cn_estimate_normals");
+}
 
 extern "C" int cn_knn_mean_distance(const float* points_sorted, const int32_t* cell_start, int32_t gx, int32_t gy,
                                     int32_t gz, float origin_x, float origin_y, float origin_z, float cell_size,

@@ -17,6 +17,7 @@
 //     reproduces that by filling every entry (x, y, z) in [0, res]^3 with the tcnn parameter at (x + y*res + z*res^2) mod size:
 //     several entries may alias one parameter; cn_tcnn_grid_tie_* keep them consistent during training.
 #include "cn_common.hpp"
+#include "cn_det.hpp"
 
 #include <cmath>
 #include <type_traits>
@@ -125,8 +126,8 @@ __global__ void __launch_bounds__(256) tcnn_tie_kernel(PlanDev P, float* __restr
     float* o = table + 2ull * ((unsigned long long)P.off[l] + owner);
     if (FOLD) {
       const float g0 = a[0], g1 = a[1];
-      if (g0 != 0.f) atomicAdd(o, g0);
-      if (g1 != 0.f) atomicAdd(o + 1, g1);
+      if (g0 != 0.f) cn_atomic_add(o, g0);
+      if (g1 != 0.f) cn_atomic_add(o + 1, g1);
       a[0] = 0.f;
       a[1] = 0.f;
     } else {
@@ -274,7 +275,9 @@ extern "C" int cn_tcnn_grid_tie_gradients(const cn_tcnn_grid_plan* plan, float* 
   Q.off[Q.num_levels] = end;
   hipLaunchKernelGGL(cn::tcnn_tie_kernel<true>, dim3(cn::grid_for(end, 256, 256 * 8)), dim3(256), 0,
                      cn::as_stream(stream), Q, grad_table);
-  return cn::check_launch("cn_tcnn_grid_tie_gradients");
+  if (int rc2 = cn::check_launch("cn_tcnn_grid_tie_gradients")) return rc2;
+  CN_DET_FLUSH(cn::as_stream(stream));
+  return CN_OK;
 }
 
 extern "C" int cn_tcnn_grid_tie_parameters(const cn_tcnn_grid_plan* plan, float* table, cn_stream_t stream) {

@@ -24,6 +24,7 @@
 #include <mutex>
 
 #include "cn_common.hpp"
+#include "cn_det.hpp"
 #include "wave_ops.hpp"
 
 namespace cn {
@@ -92,7 +93,7 @@ struct WGrad {
 #pragma unroll
     for (int i = 0; i < E; ++i) {
       int e = tid + TB * i;
-      if (e < N * K) atomicAdd(g + e, acc[i]);
+      if (e < N * K) cn_atomic_add(g + e, acc[i]);
     }
   }
 };
@@ -198,7 +199,7 @@ __device__ __forceinline__ void hash_level_backward(float* __restrict__ gtab, co
     const float a10 = dpp_f32<CTRL>(v0[1]), a11 = dpp_f32<CTRL>(v1[1]);                              \
     const unsigned es = (ql & 2) ? e1 : e0;                                                          \
     const float val = (ql & 2) ? ((ql & 1) ? a11 : a10) : ((ql & 1) ? a01 : a00);                    \
-    if (es != 0xffffffffu) atomicAdd(gtab + 2 * (size_t)es + (ql & 1), val);                         \
+    if (es != 0xffffffffu) cn_atomic_add(gtab + 2 * (size_t)es + (ql & 1), val);                         \
   }
     CN_QUAD_ROUND(0x00)  // quad_perm [0,0,0,0]
     CN_QUAD_ROUND(0x55)  // [1,1,1,1]
@@ -268,7 +269,7 @@ __device__ __forceinline__ void hash_level_backward_private(float* __restrict__ 
     const float a10 = dpp_f32<CTRL>(v0[1]), a11 = dpp_f32<CTRL>(v1[1]);                              \
     const unsigned es = (ql & 2) ? e1 : e0;                                                          \
     const float val = (ql & 2) ? ((ql & 1) ? a11 : a10) : ((ql & 1) ? a01 : a00);                    \
-    if (es != 0xffffffffu) atomicAdd(priv + 2 * (size_t)es + (ql & 1), val);                         \
+    if (es != 0xffffffffu) cn_atomic_add(priv + 2 * (size_t)es + (ql & 1), val);                         \
   }
     CN_QUAD_ROUND(0x00)
     CN_QUAD_ROUND(0x55)
@@ -336,7 +337,7 @@ __device__ __forceinline__ void hash_level_backward_cells(float* __restrict__ re
 #pragma unroll 4
   for (int k = 0; k < 16; ++k) {
     const unsigned cellk = __builtin_bit_cast(unsigned, tb[(row0 + k) * 17 + 16]);
-    if (cellk != 0xffffffffu) atomicAdd(rec + (size_t)cellk * 16 + row_lane, tb[(row0 + k) * 17 + row_lane]);
+    if (cellk != 0xffffffffu) cn_atomic_add(rec + (size_t)cellk * 16 + row_lane, tb[(row0 + k) * 17 + row_lane]);
   }
   __builtin_amdgcn_wave_barrier();
   if constexpr (POS) {
@@ -384,7 +385,7 @@ __device__ __forceinline__ void hash_level_backward_cells_rows(float* __restrict
     acc += tb[(row0 + k) * 17 + row_lane];
     const unsigned next = k < 15 ? __builtin_bit_cast(unsigned, tb[(row0 + k + 1) * 17 + 16]) : 0xfffffffdu;
     if (next != cur) {  // (uniform within the row)
-      if (cur != 0xffffffffu && acc != 0.f) atomicAdd(rec + (size_t)cur * 16 + row_lane, acc);
+      if (cur != 0xffffffffu && acc != 0.f) cn_atomic_add(rec + (size_t)cur * 16 + row_lane, acc);
       acc = 0.f;
     }
     cur = next;
@@ -444,8 +445,8 @@ __global__ void __launch_bounds__(256) cell_scatter_fold_kernel(CellFoldArgs F, 
   for (int c = 0; c < 8; ++c) {
     if (v[2 * c] == 0.f && v[2 * c + 1] == 0.f) continue;
     const unsigned e = (((x + (c & 1)) ^ ((y + ((c >> 1) & 1)) * lv.m1) ^ ((z + (c >> 2)) * lv.m2)) & lv.mask) + lv.off;
-    atomicAdd(gtab + 2 * (size_t)e, v[2 * c]);
-    atomicAdd(gtab + 2 * (size_t)e + 1, v[2 * c + 1]);
+    cn_atomic_add(gtab + 2 * (size_t)e, v[2 * c]);
+    cn_atomic_add(gtab + 2 * (size_t)e + 1, v[2 * c + 1]);
   }
 }
 // The same fold by BLOCKS of 8 x 8 x 8 cells (round 4).  The kernel above adds every touched record's 16 values to the table
@@ -524,13 +525,14 @@ __global__ void __launch_bounds__(256) cell_scatter_fold_blocks_kernel(CellFoldB
     if (val == 0.f) continue;
     const unsigned vtx = (unsigned)i >> 1, vx = vtx % 9, vy = (vtx / 9) % 9, vz = vtx / 81;
     const unsigned e = (((bx * 8 + vx) ^ ((by * 8 + vy) * lv.m1) ^ ((bz * 8 + vz) * lv.m2)) & lv.mask) + lv.off;
-    atomicAdd(gtab + 2 * (size_t)e + (i & 1), val);
+    cn_atomic_add(gtab + 2 * (size_t)e + (i & 1), val);
   }
 }
 inline void launch_cell_fold(const CellScatter& c, const GridDev& grid, float* gtab, hipStream_t stream) {
   if (!c.base || c.num_levels <= 0) return;
-  const char* form = getenv("CN_CELL_FOLD");  // "records": the first form, one thread per record (A/B runs)
-  if (!form || strcmp(form, "records") != 0) {
+  const char* form = getenv("CN_CELL_FOLD");  // "records": the first form, one thread per record (A/B runs; always in the
+  // deterministic test build: the block form sums in LDS with float atomics of four waves)
+  if (!CN_DETERMINISTIC_SCATTER && (!form || strcmp(form, "records") != 0)) {
     CellFoldBlocksArgs B{};
     B.c = c;
     unsigned blocks = 0;
@@ -586,8 +588,8 @@ __global__ void __launch_bounds__(256) coarse_scatter_reduce_kernel(CoarseScatte
   if (s0 == 0.f && s1 == 0.f) return;
   const unsigned x = v % c.n1, y = (v / c.n1) % c.n1, z = v / (c.n1 * c.n1);
   const unsigned e = ((x ^ (y * lv.m1) ^ (z * lv.m2)) & lv.mask) + lv.off;
-  atomicAdd(gtab + 2 * (size_t)e, s0);
-  atomicAdd(gtab + 2 * (size_t)e + 1, s1);
+  cn_atomic_add(gtab + 2 * (size_t)e, s0);
+  cn_atomic_add(gtab + 2 * (size_t)e + 1, s1);
 }
 inline void launch_coarse_reduce(const CoarseScatter& c, const GridDev& grid, float* gtab, hipStream_t stream) {
   if (!c.base) return;
@@ -810,7 +812,7 @@ __global__ void __launch_bounds__(TB) field_backward_kernel(FieldBwdArgs A) {
     bwd_rows<63, 64>(A.p.wc0, dA, dB, nullptr, A.d_dir ? 0 : 16, 63, wave, lane);  // dB rows 16..62
     __syncthreads();
     if (A.app_per_camera && valid && !(A.debug_skip & 2)) {
-      for (int k = wave; k < 32; k += 4) atomicAdd(A.g.emb + A.cam_idx[r] * 32 + k, dB[(31 + k) * LD + lane]);
+      for (int k = wave; k < 32; k += 4) cn_atomic_add(A.g.emb + A.cam_idx[r] * 32 + k, dB[(31 + k) * LD + lane]);
     }
     if (A.d_dir && wave == 3 && valid) {
       float gsh[16];
@@ -899,15 +901,15 @@ __global__ void __launch_bounds__(TB) field_backward_kernel(FieldBwdArgs A) {
   gW0.flush(A.g.w0, tid); gW1.flush(A.g.w1, tid); gWs0.flush(A.g.ws0, tid); gWs1.flush(A.g.ws1, tid);
   gWc0.flush(A.g.wc0, tid); gWc1.flush(A.g.wc1, tid); gWc2.flush(A.g.wc2, tid); gWh.flush(A.g.wh, tid);
   if (tid < 64) {
-    atomicAdd(A.g.b0 + tid, gb0);
-    atomicAdd(A.g.bs0 + tid, gbs0);
-    atomicAdd(A.g.bs1 + tid, gbs1);
-    atomicAdd(A.g.bc0 + tid, gbc0);
-    atomicAdd(A.g.bc1 + tid, gbc1);
+    cn_atomic_add(A.g.b0 + tid, gb0);
+    cn_atomic_add(A.g.bs0 + tid, gbs0);
+    cn_atomic_add(A.g.bs1 + tid, gbs1);
+    cn_atomic_add(A.g.bc0 + tid, gbc0);
+    cn_atomic_add(A.g.bc1 + tid, gbc1);
   }
-  if (tid < 16) atomicAdd(A.g.b1 + tid, gb1);
-  if (tid < 3) atomicAdd(A.g.bc2 + tid, gbc2);
-  if (tid < 1) atomicAdd(A.g.bh + tid, gbh);
+  if (tid < 16) cn_atomic_add(A.g.b1 + tid, gb1);
+  if (tid < 3) cn_atomic_add(A.g.bc2 + tid, gbc2);
+  if (tid < 1) cn_atomic_add(A.g.bh + tid, gbh);
 }
 
 }  // namespace cn
@@ -1067,8 +1069,8 @@ __global__ void __launch_bounds__(TB, 4) proposal_backward_kernel(PropBwdArgs A)
   }
   gW0.flush(A.g_w0, tid);
   gW1.flush(A.g_w1, tid);
-  if (tid < H) atomicAdd(A.g_b0 + tid, gb0);
-  if (tid < 1) atomicAdd(A.g_b1 + tid, gb1);
+  if (tid < H) cn_atomic_add(A.g_b0 + tid, gb0);
+  if (tid < 1) cn_atomic_add(A.g_b1 + tid, gb1);
 }
 
 }  // namespace cn
@@ -1182,10 +1184,13 @@ extern "C" int cn_field_backward(const cn_field_params* params, const cn_field_p
     }
     hipLaunchKernelGGL(cn::mf::field_backward_mfma_kernel, dim3(cn::grid_for(ntiles, 1, 256)), dim3(cn::mf::NT),
                        cn::mf::LDS_BYTES, cn::as_stream(stream), A);
+    CN_DET_FLUSH(cn::as_stream(stream));  // (deterministic test build: the scratch records are floats again before the folds)
     cn::launch_coarse_reduce(A.coarse, A.grid, A.g.table, cn::as_stream(stream));
     cn::launch_cell_fold(A.cells, A.grid, A.g.table, cn::as_stream(stream));
   }
-  return cn::check_launch("cn_field_backward");
+  if (int rc2 = cn::check_launch("cn_field_backward")) return rc2;
+  CN_DET_FLUSH(cn::as_stream(stream));
+  return CN_OK;
 }
 
 namespace cn {
@@ -1266,9 +1271,12 @@ extern "C" int cn_proposal_backward(const cn_density_params* params, const cn_de
     else
       hipLaunchKernelGGL(cn::pw::proposal_backward_wave_kernel<7>, grid, dim3(256), 0, cn::as_stream(stream), A);
   }
+  CN_DET_FLUSH(cn::as_stream(stream));
   cn::launch_coarse_reduce(A.coarse, A.grid, A.g_table, cn::as_stream(stream));
   cn::launch_cell_fold(A.cells, A.grid, A.g_table, cn::as_stream(stream));
-  return cn::check_launch("cn_proposal_backward");
+  if (int rc2 = cn::check_launch("cn_proposal_backward")) return rc2;
+  CN_DET_FLUSH(cn::as_stream(stream));
+  return CN_OK;
 }
 
 extern "C" size_t cn_grid_scatter_scratch_bytes(const cn_grid* grid) {
@@ -1454,10 +1462,12 @@ extern "C" int cn_field_backward_general(const cn_field_params* params, const cn
     if (A.cells.num_levels > 0) A.coarse.base = nullptr;
   }
   hipLaunchKernelGGL(cn::gb::field_backward_general_kernel, dim3(grid), dim3(cn::gb::NTG), lds, s, A);
+  CN_DET_FLUSH(s);
   cn::launch_coarse_reduce(A.coarse, A.grid, A.g_table, s);
   cn::launch_cell_fold(A.cells, A.grid, A.g_table, s);
   rc = cn::check_launch("cn_field_backward_general");
   if (rc) return rc;
+  CN_DET_FLUSH(s);
   for (int i = 0; i < nt; ++i)
     hipLaunchKernelGGL(cn::gb::field_backward_reduce_kernel, dim3(cn::grid_for(targets[i].n, 256, 64)), dim3(256), 0, s,
                        A.scratch, grid, ppb, targets[i].off, targets[i].n, targets[i].g);

@@ -330,8 +330,8 @@ __global__ void __launch_bounds__(NTG) field_backward_general_kernel(GenArgs A) 
         const bool last = row_run_reduce(valid ? (unsigned)r : 0xffffffffu, ga, gb, tid & 15);
         if (last && valid) {
           float* ge = A.g_emb + A.cam_idx[r] * (long long)A.app_dim;
-          if (ka < A.app_dim && ga != 0.f) atomicAdd(ge + ka, ga);
-          if (kb < A.app_dim && gb != 0.f) atomicAdd(ge + kb, gb);
+          if (ka < A.app_dim && ga != 0.f) cn_atomic_add(ge + ka, ga);
+          if (kb < A.app_dim && gb != 0.f) cn_atomic_add(ge + kb, gb);
         }
       }
     }

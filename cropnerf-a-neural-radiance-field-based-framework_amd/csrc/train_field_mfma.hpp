@@ -158,7 +158,7 @@ __device__ __forceinline__ void flush_dw(float* g, int N, int K, int n0, int k0,
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int n = n0 + 4 * q + r, k = k0 + i;
-    if (n < N && k < K && acc[r] != 0.f) atomicAdd(g + n * K + k, acc[r]);
+    if (n < N && k < K && acc[r] != 0.f) cn_atomic_add(g + n * K + k, acc[r]);
   }
 }
 
@@ -176,7 +176,7 @@ __device__ __forceinline__ void flush_bias(float* g, int n0, f32x4 gb, int lane)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const float s = row16_sum(gb[r]);
-    if (i == 15 && s != 0.f) atomicAdd(g + n0 + 4 * q + r, s);
+    if (i == 15 && s != 0.f) cn_atomic_add(g + n0 + 4 * q + r, s);
   }
 }
 
@@ -468,8 +468,8 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
         const bool last = row_run_reduce(valid ? (unsigned)r : 0xffffffffu, g0, g1, lane & 15);
         if (last && valid) {
           float* ge = A.g.emb + cam_row * 32 + 2 * lvl;
-          if (g0 != 0.f) atomicAdd(ge, g0);
-          if (g1 != 0.f) atomicAdd(ge + 1, g1);
+          if (g0 != 0.f) cn_atomic_add(ge, g0);
+          if (g1 != 0.f) cn_atomic_add(ge + 1, g1);
         }
       }
       if (A.d_dir && lvl == 2 && valid) {
@@ -560,15 +560,15 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
   {
     float v = row16_sum(b_o16);
     const float other = __shfl_up(v, 16, 32);
-    if (s == 31 && (v + other) != 0.f) atomicAdd(A.g.b1 + lvl, v + other);
+    if (s == 31 && (v + other) != 0.f) cn_atomic_add(A.g.b1 + lvl, v + other);
     v = row16_sum(b_sem);
     const float o2 = __shfl_up(v, 16, 32);
-    if (lvl == 0 && s == 31 && (v + o2) != 0.f) atomicAdd(A.g.bh, v + o2);
+    if (lvl == 0 && s == 31 && (v + o2) != 0.f) cn_atomic_add(A.g.bh, v + o2);
     if (wave < 2) {
 #pragma unroll
       for (int rr = 0; rr < 3; ++rr) {
         const float t = row16_sum(b_rgb[rr]);
-        if (lane == 15 && t != 0.f) atomicAdd(A.g.bc2 + rr, t);
+        if (lane == 15 && t != 0.f) cn_atomic_add(A.g.bc2 + rr, t);
       }
     }
   }

@@ -240,13 +240,13 @@ __global__ void __launch_bounds__(256, 4) proposal_backward_wave_kernel(PropBwdA
     const float s = red[tid] + red[256 + tid] + red[512 + tid] + red[768 + tid];
     const int n = tid >> 4, k = tid & 15;
     if (s != 0.f) {
-      if (k < K) atomicAdd(A.g_w0 + n * K + k, s);
-      else if (k == K) atomicAdd(A.g_b0 + n, s);
+      if (k < K) cn_atomic_add(A.g_w0 + n * K + k, s);
+      else if (k == K) cn_atomic_add(A.g_b0 + n, s);
     }
   }
   if (tid < 17) {
     const float s = red1[tid] + red1[17 + tid] + red1[34 + tid] + red1[51 + tid];
-    if (s != 0.f) atomicAdd(tid < 16 ? A.g_w1 + tid : A.g_b1, s);
+    if (s != 0.f) cn_atomic_add(tid < 16 ? A.g_w1 + tid : A.g_b1, s);
   }
 }
 

@@ -8,6 +8,7 @@
 //   cn_radam_step             : torch.optim.RAdam update (the _big / _huge methods, fruit_nerf_config.py:101-167).
 // Gradients w.r.t. per-sample field outputs leave as [R,S] arrays; train_field.hip turns them into parameter gradients.
 #include "composite_dev.hpp"
+#include "cn_det.hpp"
 
 namespace cn {
 
@@ -138,11 +139,11 @@ train_render_backward_kernel(const float* __restrict__ starts, const float* __re
   if (threadIdx.x == 0) {
     const float a = red[0][0] + red[1][0] + red[2][0] + red[3][0], b = red[0][1] + red[1][1] + red[2][1] + red[3][1];
     if (a != 0.f || b != 0.f) {
-      atomicAdd(loss_sums + 0, a);
-      atomicAdd(loss_sums + 1, b);
+      cn_atomic_add(loss_sums + 0, a);
+      cn_atomic_add(loss_sums + 1, b);
     }
     const float c = red[0][2] + red[1][2] + red[2][2] + red[3][2];
-    if (spacing_bins && c != 0.f) atomicAdd(loss_sums + 4, c);
+    if (spacing_bins && c != 0.f) cn_atomic_add(loss_sums + 4, c);
   }
 }
 
@@ -256,7 +257,7 @@ interlevel_backward_rays(float* lds, const float* __restrict__ c_bins, const flo
   __syncthreads();
   if (threadIdx.x == 0) {
     const float a = red[0] + red[1] + red[2] + red[3];
-    if (a != 0.f) atomicAdd(loss_sum, a);
+    if (a != 0.f) cn_atomic_add(loss_sum, a);
   }
 }
 __global__ void __launch_bounds__(256)
@@ -334,7 +335,7 @@ distortion_kernel(const float* __restrict__ bins, const float* __restrict__ weig
   __syncthreads();
   if (threadIdx.x == 0) {
     const float a = red[0] + red[1] + red[2] + red[3];
-    if (a != 0.f) atomicAdd(sum_out, a);
+    if (a != 0.f) cn_atomic_add(sum_out, a);
   }
 }
 
@@ -430,15 +431,21 @@ pose_backward_kernel(const float* __restrict__ adj, const int64_t* __restrict__ 
     float* dst = LDS ? pose_acc + 6 * c : grad_pose + 6 * c;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      atomicAdd(dst + k, d_origins[3 * r + k]);
-      atomicAdd(dst + 3 + k, f1 * dxg[k] + f2 * (t1[k] + t2[k]) + radial * w[k]);
+      const float go = d_origins[3 * r + k], gr = f1 * dxg[k] + f2 * (t1[k] + t2[k]) + radial * w[k];
+      if (LDS) {
+        atomicAdd(dst + k, go);
+        atomicAdd(dst + 3 + k, gr);
+      } else {
+        cn_atomic_add(dst + k, go);
+        cn_atomic_add(dst + 3 + k, gr);
+      }
     }
   }
   if (LDS) {
     __syncthreads();
     for (int e = threadIdx.x; e < 6 * C; e += blockDim.x) {
       const float v = pose_acc[e];
-      if (v != 0.f) atomicAdd(grad_pose + e, v);
+      if (v != 0.f) cn_atomic_add(grad_pose + e, v);
     }
   }
 }
@@ -462,7 +469,7 @@ pose_regularizer_kernel(const float* __restrict__ adj, int C, float trans, float
     }
   }
   local = wave_sum(local);
-  if (lane_id() == 0 && local != 0.f) atomicAdd(loss_out, local);
+  if (lane_id() == 0 && local != 0.f) cn_atomic_add(loss_out, local);
 }
 
 // get_loss_dict (fruit_nerf.py:601-615) and the scalar part of get_metrics_dict (:639-645) from the kernels' loss sums, in ONE
@@ -592,7 +599,9 @@ extern "C" int cn_train_render_backward(const float* starts, const float* ends, 
                      cn::as_stream(stream), starts, ends, density, rgb, semantics, image, fruit_mask,
                      (long long)num_rays, num_samples, semantic_loss_weight, out_rgb, out_semantics, out_accumulation,
                      out_weights, d_density, d_rgb, d_semantics, loss_sums, spacing_bins);
-  return cn::check_launch("cn_train_render_backward");
+  if (int rc = cn::check_launch("cn_train_render_backward")) return rc;
+  CN_DET_FLUSH(cn::as_stream(stream));
+  return CN_OK;
 }
 
 extern "C" int cn_interlevel_backward(const float* final_spacing_bins, const float* final_weights,
@@ -610,7 +619,9 @@ extern "C" int cn_interlevel_backward(const float* final_spacing_bins, const flo
   hipLaunchKernelGGL(cn::interlevel_backward_kernel, dim3(cn::grid_for(num_rays, 4, 4096)), dim3(256), lds,
                      cn::as_stream(stream), final_spacing_bins, final_weights, prop_spacing_bins, prop_starts, prop_ends,
                      prop_density, (long long)num_rays, s_final, s_prop, mult, d_prop_density, loss_sum);
-  return cn::check_launch("cn_interlevel_backward");
+  if (int rc = cn::check_launch("cn_interlevel_backward")) return rc;
+  CN_DET_FLUSH(cn::as_stream(stream));
+  return CN_OK;
 }
 
 extern "C" int cn_interlevel_backward_levels(const float* final_spacing_bins, const float* final_weights,
@@ -649,7 +660,9 @@ extern "C" int cn_interlevel_backward_levels(const float* final_spacing_bins, co
   const float mult = loss_mult / ((float)num_rays * (float)s_final);
   hipLaunchKernelGGL(cn::interlevel_backward_levels_kernel, dim3(cn::grid_for(num_rays, 4, 4096), num_levels), dim3(256), lds,
                      cn::as_stream(stream), final_spacing_bins, final_weights, L, (long long)num_rays, s_final, mult, loss_sum);
-  return cn::check_launch("cn_interlevel_backward_levels");
+  if (int rc = cn::check_launch("cn_interlevel_backward_levels")) return rc;
+  CN_DET_FLUSH(cn::as_stream(stream));
+  return CN_OK;
 }
 
 extern "C" int cn_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, int32_t step,
@@ -734,7 +747,9 @@ extern "C" int cn_distortion_metric(const float* spacing_bins, const float* weig
   size_t lds = (size_t)4 * 2 * num_samples * sizeof(float);
   hipLaunchKernelGGL(cn::distortion_kernel, dim3(cn::grid_for(num_rays, 4, 4096)), dim3(256), lds, cn::as_stream(stream),
                      spacing_bins, weights, (long long)num_rays, num_samples, sum_out);
-  return cn::check_launch("cn_distortion_metric");
+  if (int rc = cn::check_launch("cn_distortion_metric")) return rc;
+  CN_DET_FLUSH(cn::as_stream(stream));
+  return CN_OK;
 }
 
 extern "C" int cn_ray_backward(const float* d_positions, const float* d_dir_samples, const float* starts,
@@ -757,7 +772,8 @@ extern "C" int cn_pose_adjustment_backward(const float* pose_adjustment, const i
   CN_REQUIRE(pose_adjustment && camera_indices && directions_raw && d_origins && d_directions && grad_pose,
              CN_ERR_INVALID, "cn_pose_adjustment_backward: null argument");
   if (num_rays <= 0) return CN_OK;
-  if (num_cameras > 0 && num_cameras <= 2048)  // (48 KB of LDS at most; 0 = unknown: one atomic per ray and entry)
+  // (the deterministic test build takes the second form: the LDS sums of the first are float atomics of four waves)
+  if (!CN_DETERMINISTIC_SCATTER && num_cameras > 0 && num_cameras <= 2048)  // (48 KB of LDS at most; 0 = unknown: one atomic per ray and entry)
     hipLaunchKernelGGL(cn::pose_backward_kernel<true>, dim3(cn::grid_for(num_rays, 1024, 64)), dim3(256),
                        (size_t)6 * num_cameras * sizeof(float), cn::as_stream(stream), pose_adjustment, camera_indices,
                        directions_raw, d_origins, d_directions, (long long)num_rays, num_cameras, grad_pose);
@@ -765,7 +781,9 @@ extern "C" int cn_pose_adjustment_backward(const float* pose_adjustment, const i
     hipLaunchKernelGGL(cn::pose_backward_kernel<false>, dim3(cn::grid_for(num_rays, 256, 4096)), dim3(256), 0,
                        cn::as_stream(stream), pose_adjustment, camera_indices, directions_raw, d_origins, d_directions,
                        (long long)num_rays, 0, grad_pose);
-  return cn::check_launch("cn_pose_adjustment_backward");
+  if (int rc = cn::check_launch("cn_pose_adjustment_backward")) return rc;
+  CN_DET_FLUSH(cn::as_stream(stream));
+  return CN_OK;
 }
 
 extern "C" int cn_train_epilogue(const float* loss_sums, int32_t num_sums, int64_t num_rays, int32_t num_samples,
@@ -787,5 +805,7 @@ extern "C" int cn_pose_regularizer(const float* pose_adjustment, int32_t num_cam
   hipLaunchKernelGGL(cn::pose_regularizer_kernel, dim3(cn::grid_for(num_cameras, 256, 1024)), dim3(256), 0,
                      cn::as_stream(stream), pose_adjustment, num_cameras, trans_l2_penalty, rot_l2_penalty, grad_pose,
                      loss_out);
-  return cn::check_launch("cn_pose_regularizer");
+  if (int rc = cn::check_launch("cn_pose_regularizer")) return rc;
+  CN_DET_FLUSH(cn::as_stream(stream));
+  return CN_OK;
 }

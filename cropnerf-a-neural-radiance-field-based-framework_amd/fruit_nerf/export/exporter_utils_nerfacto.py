@@ -6,8 +6,9 @@ until ``num_points``.  Pixel draws (``cn_pixel_sample``), mask, point computatio
 (``cn_pointcloud_compact_calls``) run on the device, several of the reference's calls per launch; kept points leave the
 device once.  The statistical outlier removal (``:194-199``, open3d ``remove_statistical_outlier(nb_neighbors=20,
 std_ratio)``, on by default) runs on the device too (``ops.statistical_outlier_mask``: uniform-grid k-nearest search,
-``cn_knn_mean_distance``).  Normal estimation / re-orientation (``:200-225``) stays open3d CPU post-processing and is
-applied only when open3d is importable."""
+``cn_knn_mean_distance``), and so do the normals (``:200-225``): ``cn_estimate_normals`` restates open3d's
+``estimate_normals()`` defaults (30 nearest neighbours, covariance, smallest eigenvector), the re-orientation against the
+kept rays' view directions follows.  open3d is not imported anywhere on this path."""
 
 from __future__ import annotations
 
@@ -129,23 +130,23 @@ def generate_point_cloud(pipeline, num_points: int = 1000000, remove_outliers: b
         # threshold can flip)
         keep = ops.statistical_outlier_mask(pts.contiguous(), 20, std_ratio)
         pts, cols, dirs = pts[keep], cols[keep], dirs[keep]
-    points = pts.double().cpu().numpy()
-    colors = cols.double().cpu().numpy()
-    view_dirs = dirs.cpu().numpy()
-    result = {"points": points, "colors": colors, "view_directions": view_dirs}
-    if estimate_normals:
-        try:
-            import open3d as o3d  # noqa: F401
-        except ImportError:
-            result["note"] = "open3d not installed: normal estimation skipped"
-            return result
-        pcd = o3d.geometry.PointCloud()
-        pcd.points = o3d.utility.Vector3dVector(points)
-        pcd.colors = o3d.utility.Vector3dVector(colors)
-        if estimate_normals:
-            pcd.estimate_normals()
-            result["normals"] = np.asarray(pcd.normals)
-        result.update(points=np.asarray(pcd.points), colors=np.asarray(pcd.colors), view_directions=view_dirs)
+    result: Dict[str, np.ndarray] = {}
+    if estimate_normals:  # :203-212
+        if normal_output_name is not None:
+            print("Cannot estimate normals and use normal_output_name at the same time", file=sys.stderr)
+            sys.exit(1)
+        # open3d's estimate_normals() at its defaults, on the device (cn_estimate_normals: the 30 nearest points' covariance,
+        # eigenvector of its smallest eigenvalue), before the cloud leaves it
+        normals, degenerate = ops.estimate_normals(pts.contiguous(), 30)
+        if reorient_normals:  # :219-225 (the float32 round trip is the reference's)
+            normals, _ = ops.reorient_normals(normals, dirs)
+        result["normals"] = normals.cpu().numpy()
+        result["degenerate_normals"] = int(degenerate.sum())
+    elif normal_output_name is not None:
+        # the reference reads a "normals" model output here (:213-217); FruitModel predicts none (predict_normals is never set
+        # in its configs), so its own `outputs[normal_output_name]` raises KeyError as well
+        raise KeyError(f"the model has no output {normal_output_name!r}: use --normal-method open3d")
+    result.update(points=pts.double().cpu().numpy(), colors=cols.double().cpu().numpy(), view_directions=dirs.cpu().numpy())
     return result
 
 

@@ -209,9 +209,20 @@ class FruitTrainer:
         nears = rb.nears if rb.nears is not None else self._plane(R, cfg.near_plane)
         fars = rb.fars if rb.fars is not None else self._plane(R, cfg.far_plane)
         n_lvl = len(m.proposal_networks)
+        handles = [self.grad_field] + list(self.grad_props)
+        before = [h._scatter_scratch for h in handles]
         self.grad_field.enable_scatter_scratch(R * int(cfg.num_nerf_samples_per_ray))
         for i, gp in enumerate(self.grad_props):
             gp.enable_scatter_scratch(R * int(cfg.num_proposal_samples_per_ray[i]))
+        if any(h._scatter_scratch is not b for h, b in zip(handles, before)):
+            # a larger batch re-allocated a scratch: captured iterations of smaller batches hold the OLD buffer's address and
+            # layout as kernel arguments -- drop them (they are captured again on their next occurrence, against the new one)
+            self._drop_graphs()
+        if L.deterministic():
+            # the test build: every buffer the training kernels add to with float atomics accumulates through an integer shadow
+            # (the gradients, the scatter scratches, this iteration's accumulators and loss sums)
+            ops.deterministic_register([self.flat_grads] + list(self._zeroed.values()) + [h._scatter_scratch for h in handles],
+                                       owner=self)
         if jitter_rows is not None:  # [levels + 1, R] on the device already (the graph-replayed iteration's static buffer)
             jitter = [jitter_rows[i].reshape(R, 1) for i in range(n_lvl + 1)]
         elif jitter is None:
@@ -341,6 +352,16 @@ class FruitTrainer:
         return {"loss_dict": loss_dict, "rgb": rb_out["rgb"], "semantics": rb_out["semantics"],
                 "accumulation": rb_out["accumulation"]}
 
+    def _drop_graphs(self) -> None:
+        captured = [k for k, st in self._graphs.items() if "graph" in st]
+        if not captured:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the gradient scatter scratch was re-allocated inside a graph capture")
+        torch.cuda.synchronize()  # replays in flight still write the old scratch
+        for k in captured:
+            self._graphs[k] = {"seen": 1}
+
     def _plane(self, R: int, value: float) -> Tensor:
         key = (R, float(value))
         t = self._planes.get(key)
@@ -454,10 +475,15 @@ class FruitTrainer:
     def _graph_eligible(self) -> bool:
         import torch.distributed as dist
 
-        return (self.use_graph and not self.general and not self.concurrent_backward and self.model.device.type == "cuda"
+        m, cfg = self.model, self.model.config
+        n_lvl = len(m.proposal_networks)
+        # the captured iteration reads the annealing exponent from device memory, which only the one-launch sampler does: the
+        # materialising sampler calls take it as a host float that a capture would freeze at its value of iteration ~2
+        fused = self.fused_sampler and ops.proposal_sample_fused_supported(
+            m.proposal_networks, [int(v) for v in cfg.num_proposal_samples_per_ray[:n_lvl]], cfg.num_nerf_samples_per_ray)
+        return (fused and self.use_graph and not self.general and not self.concurrent_backward and self.model.device.type == "cuda"
                 and all(g.optimizer == "adam" for g in self.groups.values())
-                and not (dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_exchange))
-                and self.fused_sampler)
+                and not (dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or self.force_exchange)))
 
     def _train_iteration_graph(self, ray_bundle: RayBundle, batch: Dict[str, Tensor]) -> Optional[Dict[str, Tensor]]:
         """At the reference's batch size (4 096 rays) an iteration is ~45 launches of 5-700 us: the gaps between them are a tenth
@@ -470,7 +496,11 @@ class FruitTrainer:
         for (the distortion metric beside the field backward, the field group's HBM-bound Adam step beside the atomic-bound
         proposal backward) was built and measured -- 1.84-1.87 ms with it, 1.86-1.87 without at 4 096 rays, and the same on two
         streams without a graph -- and removed.  Returns None when the iteration has to run eagerly (first two occurrences of
-        a variant: warm-up, then capture)."""
+        a variant: warm-up, then capture).
+
+        The returned dictionary holds the graph's STATIC output tensors: they are valid until the next ``train_iteration`` of
+        the same variant overwrites them (an eager iteration returns fresh tensors) -- ``float(...)`` / ``.clone()`` what has to
+        outlive the call, as ``scripts/train.py`` does for its log line."""
         m, cfg, dev = self.model, self.model.config, self.model.device
         rb = ray_bundle.flatten()
         R = rb.origins.shape[0]
@@ -511,6 +541,7 @@ class FruitTrainer:
                 ops.adam_hyper(steps[g], grp.lr_at(self.step), eps=grp.eps, out=slot["scalars"][1 + gi])
             else:
                 slot["scalars"][1 + gi, 7] = 1.0  # no step for this group: cn_adam_step_groups_dev only zeroes its gradients
+        gen_state = self._gen.get_state() if "graph" not in st else None  # (a failed capture hands the draw back)
         torch.rand(n_lvl + 1, R, generator=self._gen, out=slot["jitter"])
         given = {"origins": rb.origins, "directions": rb.directions, "cam": rb.camera_indices, "nears": rb.nears, "fars": rb.fars,
                  "image": batch["image"], "mask": batch["fruit_mask"]}
@@ -560,6 +591,9 @@ class FruitTrainer:
                       file=sys.stderr)
                 self.use_graph = False
                 torch.cuda.synchronize()
+                self._gen.set_state(gen_state)  # the eager iteration that follows draws the same jitter an eager run would
+                self._g_ring_next -= 1
+                self._graphs[key] = {"seen": 1}
                 return None
             st["graph"] = graph
         else:
@@ -595,7 +629,10 @@ class FruitTrainer:
             else:
                 exchange = self.gradient_exchange(force=self.force_exchange)
                 exchange.begin_iteration()
-                out = self.forward_backward(ray_bundle, batch, update_proposals=updated, on_group_ready=exchange.start)
+                # (only the groups this iteration steps: a frozen group's gradients are zeroed, not averaged -- an exchange
+                #  nobody waits for would race with that fill)
+                out = self.forward_backward(ray_bundle, batch, update_proposals=updated, on_group_ready=lambda g: (
+                    exchange.start(g) if self._group_stepped(g, updated) else None))
         else:
             out = self.forward_backward(ray_bundle, batch, update_proposals=updated)
         if updated:

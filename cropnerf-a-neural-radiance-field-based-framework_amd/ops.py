@@ -211,6 +211,45 @@ class DensityHandle:
         return self
 
 
+# ---- deterministic accumulation (tests only: the CN_DETERMINISTIC_SCATTER=1 library, include/cropnerf_hip.h) --------------------
+_det_state: Dict[str, object] = {"key": None, "owner": None, "shadows": [], "misses": None}
+
+
+def deterministic_register(tensors: Sequence[Tensor], owner: object = None) -> None:
+    """Route the float atomics that land in ``tensors`` (float32, on the device) through 64-bit integer shadows.  The registry is
+    one per process: registering replaces what was registered before (the buffers of another trainer, a re-allocated scratch).
+    A no-op when the same buffers of the same ``owner`` are registered already; must not be called during a stream capture when
+    something changed."""
+    if not L.deterministic():
+        raise RuntimeError("deterministic_register: set CN_DETERMINISTIC_SCATTER=1 (the test build) first")
+    ts = [t for t in tensors if t is not None and t.numel() > 0]
+    key = tuple((t.data_ptr(), t.numel()) for t in ts)
+    if _det_state["key"] == key and _det_state["owner"] is owner:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("deterministic_register: the set of accumulation buffers changed inside a graph capture")
+    lib = L.load()
+    torch.cuda.synchronize()
+    L.check(lib.cn_deterministic_clear())
+    if _det_state["misses"] is None or _det_state["misses"].device != ts[0].device:
+        _det_state["misses"] = torch.zeros(1, dtype=torch.int64, device=ts[0].device)
+    shadows = []
+    for t in ts:
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise TypeError("deterministic_register: contiguous float32 buffers only")
+        sh = torch.zeros(t.numel(), dtype=torch.int64, device=t.device)
+        L.check(lib.cn_deterministic_register(_p(t), t.numel(), _p(sh), _p(_det_state["misses"])))
+        shadows.append(sh)
+    _det_state.update(key=key, owner=owner, shadows=shadows, tensors=ts)
+
+
+def deterministic_misses() -> int:
+    """Float atomics of the training kernels whose destination was in no registered range (they were summed the default,
+    order-dependent way) since the counter was created.  Tests assert 0."""
+    m = _det_state["misses"]
+    return 0 if m is None else int(m.item())
+
+
 def scene_struct(aabb: Tensor, contraction: bool) -> L.Scene:
     s = L.Scene()
     flat = [float(v) for v in aabb.reshape(-1).tolist()]
@@ -1002,6 +1041,59 @@ def zbuffer_update(z_buffer: Tensor, img: Tensor, xs: Tensor, ys: Tensor, zs: Te
 # --------------------------------------------------------------------------------------------------------------
 # statistical outlier removal (open3d remove_statistical_outlier as used by the point-cloud exporter)
 # --------------------------------------------------------------------------------------------------------------
+
+def _knn_grid(pts: Tensor, points_per_cell: float):
+    """The uniform grid of the k-nearest searches (torch plumbing: cell keys, sort, offsets), about ``points_per_cell`` points
+    per cell: (sorted points, cell_start int32, (gx, gy, gz), origin, cell size, order)."""
+    n = pts.shape[0]
+    lo, hi = pts.min(dim=0).values, pts.max(dim=0).values
+    ext = (hi - lo).clamp(min=1e-12).double()
+    h = float((ext.prod() * points_per_cell / n) ** (1.0 / 3.0))
+    h = max(h, float(ext.max()) / 1024.0)
+    dims = [max(1, min(1024, int(float(e) / h) + 1)) for e in ext]
+    while dims[0] * dims[1] * dims[2] > (1 << 27):
+        h *= 1.26
+        dims = [max(1, min(1024, int(float(e) / h) + 1)) for e in ext]
+    gx, gy, gz = dims
+    cell = ((pts - lo) / h).floor().to(torch.int64)
+    cell[:, 0].clamp_(0, gx - 1)
+    cell[:, 1].clamp_(0, gy - 1)
+    cell[:, 2].clamp_(0, gz - 1)
+    key = (cell[:, 2] * gy + cell[:, 1]) * gx + cell[:, 0]
+    key_sorted, order = torch.sort(key)
+    cell_start = torch.searchsorted(key_sorted, torch.arange(gx * gy * gz + 1, device=pts.device)).to(torch.int32).contiguous()
+    return pts[order].contiguous(), cell_start, (gx, gy, gz), lo, h, order
+
+
+def estimate_normals(points: Tensor, knn: int = 30, points_per_cell: float = 8.0) -> Tuple[Tensor, Tensor]:
+    """open3d ``PointCloud.estimate_normals()`` at its defaults (``KDTreeSearchParamKNN(30)``, fast 3 x 3 eigen-solver) on the
+    device: (normals [N,3] float64 -- unit vectors, sign as the solver leaves it --, degenerate [N] bool: fewer than three
+    neighbours or a zero covariance, normal (0, 0, 1) there).  ``cn_estimate_normals`` on the grid of the outlier pass."""
+    lib = L.load()
+    pts = _f32(points.contiguous(), "points")
+    n = pts.shape[0]
+    if n == 0:
+        return torch.empty(0, 3, dtype=torch.float64, device=pts.device), torch.empty(0, dtype=torch.bool, device=pts.device)
+    pts_sorted, cell_start, (gx, gy, gz), lo, h, order = _knn_grid(pts, points_per_cell)
+    nrm_sorted = torch.empty(n, 3, dtype=torch.float64, device=pts.device)
+    deg_sorted = torch.empty(n, dtype=torch.int32, device=pts.device)
+    L.check(lib.cn_estimate_normals(_p(pts_sorted), _p(cell_start), gx, gy, gz, float(lo[0]), float(lo[1]), float(lo[2]), h, n,
+                                    int(knn), _p(nrm_sorted), _p(deg_sorted), _stream(pts)))
+    normals = torch.empty_like(nrm_sorted)
+    normals[order] = nrm_sorted
+    degenerate = torch.empty(n, dtype=torch.bool, device=pts.device)
+    degenerate[order] = deg_sorted != 0
+    return normals, degenerate
+
+
+def reorient_normals(normals: Tensor, view_directions: Tensor) -> Tuple[Tensor, Tensor]:
+    """``exporter_utils_nerfacto.py:219-225``: in float32, flip every normal with ``sum(view_direction * normal) > 0`` (it
+    would point away from the camera that saw the point); back to float64.  Returns (normals, flipped mask)."""
+    nf = normals.to(torch.float32)
+    mask = torch.sum(view_directions.to(torch.float32) * nf, dim=-1) > 0
+    nf[mask] *= -1
+    return nf.double(), mask
+
 
 def knn_mean_distance(points: Tensor, nb_neighbors: int = 20, points_per_cell: float = 6.0) -> Tensor:
     """Mean distance of every point to its ``nb_neighbors`` nearest points (itself included), [N] float32, on a uniform

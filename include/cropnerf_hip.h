@@ -677,6 +677,16 @@ int cn_knn_mean_distance(const float* points_sorted, const int32_t* cell_start, 
                          float origin_x, float origin_y, float origin_z, float cell_size, int64_t num_points,
                          int32_t nb_neighbors, float* mean_distance, cn_stream_t stream);
 
+/* Normals of the exported cloud: open3d's PointCloud::EstimateNormals() at its defaults, as generate_point_cloud calls it
+ * for `ns-export pointcloud --normal-method open3d` (fruit_nerf/export/exporter_utils_nerfacto.py:203-212; README.md:125).
+ * Same grid as cn_knn_mean_distance.  normals [N,3] DOUBLE (sorted order): unit eigenvector of the smallest eigenvalue of
+ * the covariance of the point's `knn` nearest points (itself included; open3d: 30), sign as the solver leaves it -- the
+ * caller re-orients against the view directions (:219-225).  degenerate [N] (optional): 1 where fewer than three neighbours
+ * exist or the covariance is zero -- the normal is (0, 0, 1) there, as open3d's. */
+int cn_estimate_normals(const float* points_sorted, const int32_t* cell_start, int32_t gx, int32_t gy, int32_t gz,
+                        float origin_x, float origin_y, float origin_z, float cell_size, int64_t num_points, int32_t knn,
+                        double* normals, int32_t* degenerate, cn_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Super-cluster stage of the segmenter (segmentation/segmenter.py:69-86, get_super_clusters):
  * voxel_down_sample -> cluster_dbscan(eps, min_points) -> remove_statistical_outlier (cn_knn_mean_distance).
@@ -729,6 +739,31 @@ int cn_contour_largest(const uint8_t* gray, const int32_t* roi, int32_t num_imag
  * the host. points [N,3] float64 (centred as sklearn does), k <= 32. */
 int cn_kmeans_step(const double* points, int64_t num_points, const double* centers, int32_t k, int32_t* labels,
                    double* sums, int64_t* counts, int32_t* changed, int32_t accumulate, cn_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Deterministic gradient accumulation -- a TEST mode, a second library built from the same sources
+ * (libcropnerf_hip_det.so: build.py compiles the training units once more with -DCN_DETERMINISTIC_SCATTER=1).
+ * The reference has no counterpart (torch's float atomics are as order-dependent as these); the mode exists so that the
+ * tests of the training step (graph replay against eager launches, a resumed run against a straight one:
+ * fruit_nerf/fruit_nerf.py:543-615 through the trainer) can compare parameters and Adam moments BIT FOR BIT instead of
+ * within the per-cent noise of float-atomic summation orders.  In that library every global float atomic of the training
+ * kernels adds round(v * 2^44) to a 64-bit integer shadow of its destination, and a flush pass behind every such kernel adds
+ * the shadows to the floats in a fixed order (csrc/cn_det.hpp).  Not the default build's arithmetic (values below 5.7e-14
+ * vanish, |sum| < 5.2e5) and several times slower: never selected by the product path.
+ *   cn_deterministic_build()     1 in the test library, 0 in the default one.
+ *   cn_deterministic_register()  host call, not during a stream capture: the `count` floats at `base` (device) accumulate
+ *                                through `shadow` (device, `count` zeroed int64, caller-owned like every buffer); at most 16
+ *                                disjoint ranges.  `miss_counter` (device uint64, may be NULL; the last one given is
+ *                                used) counts atomics whose destination lies in no registered range -- those fall back to the
+ *                                float atomic.  Default build: CN_ERR_UNSUPPORTED.
+ *   cn_deterministic_clear()     forget every range (buffers were re-allocated).
+ *   cn_deterministic_flush()     the pass the library enqueues by itself behind each accumulating kernel; exported for
+ *                                callers that write shadows of their own.
+ * ------------------------------------------------------------------------------------------- */
+int cn_deterministic_build(void);
+int cn_deterministic_register(float* base, int64_t count, int64_t* shadow, uint64_t* miss_counter);
+int cn_deterministic_clear(void);
+int cn_deterministic_flush(cn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -270,6 +270,38 @@ def test_train_cli_resume_continues_the_same_run(tmp_path):
     assert abs(resumed["eval_psnr"] - full["eval_psnr"]) < 1.0
 
 
+@pytest.mark.gpu
+def test_train_cli_resume_is_bit_exact_in_deterministic_mode(tmp_path, monkeypatch):
+    """The same under ``CN_DETERMINISTIC_SCATTER=1`` (the test library whose training kernels accumulate through integer shadows,
+    ``csrc/cn_det.hpp``): with the summation order out of the picture, 13 + 11 resumed iterations must leave EXACTLY the
+    parameters and Adam moments of 24 uninterrupted ones -- a lost moment of one group, a schedule off by one step or a random
+    stream that did not come back shows as a failed ``torch.equal``, not as a few per cent inside a noise bound."""
+    from cropnerf_amd import ops
+    from cropnerf_amd.fruit_nerf.scripts import train
+
+    monkeypatch.setenv("CN_DETERMINISTIC_SCATTER", "1")
+    miss0 = ops.deterministic_misses()
+    cap = Path(synthetic.write_capture(tmp_path / "plant", num=12, res=40))
+    kw = dict(log_every=50, quiet=True, train_split_fraction=0.8, steps_per_save=1000)
+    full = train.train("fruit_nerf", cap, tmp_path / "a", max_num_iterations=24, timestamp="t", **kw)
+    first = train.train("fruit_nerf", cap, tmp_path / "b", max_num_iterations=13, timestamp="t", **kw)
+    resumed = train.train("fruit_nerf", cap, tmp_path / "c", max_num_iterations=24, timestamp="t",
+                          load_dir=Path(first["config"]).parent / "nerfstudio_models", **kw)
+    assert ops.deterministic_misses() == miss0
+
+    def ckpt(res):
+        ck = sorted((Path(res["config"]).parent / "nerfstudio_models").glob("step-*.ckpt"))[-1]
+        return torch.load(ck, map_location="cpu", weights_only=False)
+
+    a, c = ckpt(full), ckpt(resumed)
+    for k in a["pipeline"]:
+        assert torch.equal(torch.as_tensor(a["pipeline"][k]), torch.as_tensor(c["pipeline"][k])), k
+    for k in ("exp_avg", "exp_avg_sq"):
+        assert torch.equal(a["optimizers"][k], c["optimizers"][k]), k
+    assert a["optimizers"]["group_steps"] == c["optimizers"]["group_steps"] and a["optimizers"]["step"] == c["optimizers"]["step"] == 24
+    assert resumed["eval_psnr"] == full["eval_psnr"]
+
+
 def test_auto_downscale_picks_existing_folders(tmp_path):
     """``_get_fname`` (cotton_nerf_dataparser.py:307-331): with no explicit factor the images are halved while the longer side
     is >= 1200 px AND the ``images_<2^k>`` folder exists; masks follow into ``images_<k>/../semantics`` by the same rule."""

@@ -703,6 +703,153 @@ def test_graph_replayed_iteration_follows_the_eager_one(monkeypatch):
         assert rel < (1.5 if "camera_optimizer" in k else 0.25), (k, rel)
 
 
+def test_deterministic_mode_gives_identical_gradients_and_agrees_with_the_default_mode(monkeypatch):
+    """``CN_DETERMINISTIC_SCATTER=1`` (the test library, ``csrc/cn_det.hpp``): every float atomic of the training kernels goes
+    through a 64-bit integer shadow, so two runs of the same forward + backward give the same BITS in every gradient, loss sum
+    and scratch -- where the default build's float atomics differ from run to run -- with no atomic left outside the registered
+    buffers; and the mode computes the same gradients as the default one up to the rounding of the sums."""
+    from cropnerf_amd import _lib as L, ops
+    from cropnerf_amd.fruit_nerf.trainer import FruitTrainer
+
+    sc, idx, jitter, image, mask = _setup(seed=6, R=192)
+
+    def run():
+        model = _hip_model(sc)
+        model.training = True
+        tr = FruitTrainer(model)
+        out = tr.forward_backward(_hip_rays(sc, idx), {"image": image, "fruit_mask": mask}, jitter=jitter)
+        torch.cuda.synchronize()
+        return tr.flat_grads.clone(), {k: v.clone() for k, v in out["loss_dict"].items()}, tr
+
+    monkeypatch.setenv("CN_DETERMINISTIC_SCATTER", "1")
+    assert L.load().cn_deterministic_build() == 1
+    miss0 = ops.deterministic_misses()
+    g1, l1, tr1 = run()
+    assert all(float(h._scatter_scratch.abs().max()) == 0.0 for h in [tr1.grad_field] + tr1.grad_props)  # left zeroed
+    g2, l2, _ = run()
+    assert ops.deterministic_misses() == miss0, "a training kernel added to a buffer that is not registered"
+    assert torch.equal(g1, g2) and all(torch.equal(l1[k], l2[k]) for k in l1)
+    assert float(g1.abs().sum()) > 0
+    monkeypatch.setenv("CN_DETERMINISTIC_SCATTER", "0")
+    assert L.load().cn_deterministic_build() == 0
+    g0, l0, _ = run()
+    err = float((g1 - g0).norm() / g0.norm())
+    assert err < 2e-6, f"deterministic vs default accumulation: relative L2 {err:.3e}"
+    for k in l0:
+        assert abs(float(l1[k]) - float(l0[k])) <= 2e-6 * abs(float(l0[k])) + 1e-9, k
+
+
+def test_graph_replay_equals_eager_bit_for_bit_in_deterministic_mode(monkeypatch):
+    """The comparison ``test_graph_replayed_iteration_follows_the_eager_one`` can only bound loosely (float-atomic orders, Adam's
+    normalisation), made exact: under ``CN_DETERMINISTIC_SCATTER=1`` sixteen graph-replayed iterations and sixteen eager ones --
+    fresh batches, both proposal-update variants, the learning-rate and annealing schedules, the jitter stream -- leave the
+    SAME parameters and Adam moments, bit for bit.  A stale scalar, a lost moment of one group or a batch that was not
+    re-staged cannot hide in a tolerance."""
+    from cropnerf_amd import ops
+    from cropnerf_amd.fruit_nerf.trainer import FruitTrainer
+
+    monkeypatch.setenv("CN_DETERMINISTIC_SCATTER", "1")
+    miss0 = ops.deterministic_misses()
+
+    def run(graph: bool):
+        monkeypatch.setenv("CN_TRAIN_GRAPH", "1" if graph else "0")
+        sc, idx, _, image, mask = _setup(seed=8, R=160)
+        model = _hip_model(sc)
+        model.training = True
+        tr = FruitTrainer(model, seed=11)
+        rays = _hip_rays(sc, idx)
+        g = torch.Generator().manual_seed(5)
+        hist = []
+        for it in range(16):
+            noise = torch.rand(160, 3, generator=g) * 0.05
+            batch = {"image": (image * 0.9 + noise).cuda(), "fruit_mask": mask.cuda().clone()}
+            rb = rays._map(lambda t: t.clone()) if it % 3 == 0 else rays
+            out = tr.train_iteration(rb, batch)
+            hist.append(torch.stack([out["loss_dict"][k].reshape(()) for k in sorted(out["loss_dict"])] +
+                                    [out["metrics_dict"]["psnr"].reshape(())]).clone())
+        torch.cuda.synchronize()
+        return tr, torch.stack(hist)
+
+    tr_g, hist_g = run(True)
+    tr_e, hist_e = run(False)
+    assert sum("graph" in v for v in tr_g._graphs.values()) == 2 and not tr_e._graphs
+    assert ops.deterministic_misses() == miss0
+    assert torch.equal(hist_g, hist_e), (hist_g - hist_e).abs().max(dim=1).values
+    assert torch.equal(tr_g.flat_params, tr_e.flat_params)
+    assert torch.equal(tr_g.flat_exp_avg, tr_e.flat_exp_avg) and torch.equal(tr_g.flat_exp_avg_sq, tr_e.flat_exp_avg_sq)
+    assert tr_g.group_steps == tr_e.group_steps and tr_g.step == tr_e.step == 16
+    assert float(hist_g[-1, 2]) < float(hist_g[0, 2])  # (sorted keys: camera_opt_regularizer, interlevel, rgb, semantics)
+
+
+def test_graphs_of_a_smaller_batch_survive_a_larger_one(monkeypatch):
+    """A captured iteration holds the scatter scratch's address and layout as kernel arguments; a larger batch re-allocates
+    the scratch.  The trainer drops the captured iterations then (they are captured again on their next occurrence), so
+    R = 96 (captured), R = 256 (larger: new scratch), R = 96 again follows the eager run -- bit for bit under the deterministic
+    accumulation mode -- instead of scattering into freed memory."""
+    from cropnerf_amd.fruit_nerf.trainer import FruitTrainer
+
+    monkeypatch.setenv("CN_DETERMINISTIC_SCATTER", "1")
+    sizes = [96, 96, 96, 96, 256, 256, 256, 96, 96, 96, 256]
+
+    def run(graph: bool):
+        monkeypatch.setenv("CN_TRAIN_GRAPH", "1" if graph else "0")
+        sc, idx, _, image, mask = _setup(seed=9, R=256)
+        model = _hip_model(sc)
+        model.training = True
+        tr = FruitTrainer(model, seed=2)
+        rays = _hip_rays(sc, idx)
+        img, msk = image.cuda(), mask.cuda()
+        dropped = 0
+        for R in sizes:
+            before = sum("graph" in v for v in tr._graphs.values())
+            tr.train_iteration(rays[:R], {"image": img[:R].clone(), "fruit_mask": msk[:R].clone()})
+            dropped += sum("graph" in v for v in tr._graphs.values()) < before
+        torch.cuda.synchronize()
+        return tr, dropped
+
+    tr_g, dropped = run(True)
+    tr_e, _ = run(False)
+    assert dropped == 1, "the first 256-ray iteration re-allocates the scratch and must drop the captured 96-ray iteration"
+    assert any("graph" in v for k, v in tr_g._graphs.items() if k[0] == 96), "the 96-ray iteration was not captured again"
+    assert torch.equal(tr_g.flat_params, tr_e.flat_params) and torch.equal(tr_g.flat_exp_avg_sq, tr_e.flat_exp_avg_sq)
+
+
+def test_a_proposal_setup_without_the_fused_sampler_trains_eagerly(monkeypatch):
+    """The captured iteration reads the annealing exponent from device memory, which only the one-launch sampler
+    (``cn_proposal_sample_train``) does; a proposal setup it is not built for (here FOUR proposal networks) goes through the
+    materialising calls, whose exponent is a host float that a capture would freeze -- so such a model is not graph-eligible
+    and every iteration sees its own exponent (``fruit_nerf.py:206-216``)."""
+    from cropnerf_amd import ops
+    from cropnerf_amd.config import FruitNerfModelConfig
+    from cropnerf_amd.fruit_nerf.fruit_nerf import FruitModel, Semantics
+    from cropnerf_amd.fruit_nerf.trainer import FruitTrainer
+    from cropnerf_amd.rays import SceneBox
+
+    monkeypatch.setenv("CN_TRAIN_GRAPH", "1")
+    sc, idx, _, image, mask = _setup(seed=4, R=64)
+    pl = [{"hidden_dim": 16, "log2_hashmap_size": 10, "num_levels": 5, "max_res": 64 << min(i, 1)} for i in range(4)]
+    cfg = FruitNerfModelConfig(log2_hashmap_size=12, proposal_net_args_list=pl, num_proposal_iterations=4,
+                               num_proposal_samples_per_ray=(64, 48, 32, 32), num_nerf_samples_per_ray=S_FINAL)
+    model = FruitModel(cfg, SceneBox(sc.aabb), num_train_data=sc.c2w.shape[0], metadata={"semantics": Semantics()},
+                       device="cuda", test_mode="val", seed=3)
+    model.training = True
+    tr = FruitTrainer(model, seed=1)
+    assert len(model.proposal_networks) == 4
+    assert not ops.proposal_sample_fused_supported(model.proposal_networks, [64, 48, 32, 32], S_FINAL)
+    assert not tr._graph_eligible()
+    rays = _hip_rays(sc, idx)
+    anneals = []
+    for it in range(4):
+        out = tr.train_iteration(rays, {"image": image.cuda(), "fruit_mask": mask.cuda()})
+        anneals.append(model._anneal)
+        assert math.isfinite(float(out["loss_dict"]["rgb_loss"])) and math.isfinite(float(out["loss_dict"]["interlevel_loss"]))
+    assert not tr._graphs and len(set(anneals)) == 4  # never captured; the exponent moved every iteration
+    # the default setup is eligible
+    m2 = _hip_model(sc)
+    m2.training = True
+    assert FruitTrainer(m2)._graph_eligible()
+
+
 def test_graph_replay_takes_a_new_batch_that_lands_on_a_freed_address(monkeypatch):
     """The captured iteration reads the trainer's own copies of the batch and skips the copy for a tensor handed over again
     unchanged.  "Unchanged" must not be judged by the address: the caching allocator gives a new batch the block of the one
