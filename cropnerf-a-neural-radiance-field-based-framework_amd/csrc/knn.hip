@@ -293,10 +293,10 @@ knn_normals_kernel(const float* __restrict__ pts /*sorted by cell*/, const int* 
     double nv[3] = {0.0, 0.0, 0.0};
     int flag = 0;
     if (cnt >= 3) {
-      const double inv = 1.0 / (double)cnt;
-      sx *= inv, sy *= inv, sz *= inv;
-      Sym3 C{sxx * inv - sx * sx, sxy * inv - sx * sy, sxz * inv - sx * sz, syy * inv - sy * sy, syz * inv - sy * sz,
-             szz * inv - sz * sz};
+      const double m = (double)cnt;  // (divisions, as open3d's `cumulants /= n`: coincident points give an exactly zero matrix)
+      sx /= m, sy /= m, sz /= m;
+      Sym3 C{sxx / m - sx * sx, sxy / m - sx * sy, sxz / m - sx * sz, syy / m - sy * sy, syz / m - sy * sz,
+             szz / m - sz * sz};
       smallest_eigenvector(C, nv);
     }
     if (nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2] == 0.0) {

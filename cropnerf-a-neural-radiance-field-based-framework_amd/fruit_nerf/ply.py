@@ -37,7 +37,8 @@ def write_ply(path: str, points: np.ndarray, colors: Optional[np.ndarray] = None
         f.write(rec.tobytes())
 
 
-def read_ply(path: str) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+def read_ply(path: str, with_normals: bool = False):
+    """(points, colours or None); with ``with_normals`` a third entry: the normals [N,3] or None."""
     with open(path, "rb") as f:
         fields = []
         n = 0
@@ -55,4 +56,9 @@ def read_ply(path: str) -> Tuple[np.ndarray, Optional[np.ndarray]]:
     cols = None
     if "red" in rec.dtype.names:
         cols = np.stack([rec["red"], rec["green"], rec["blue"]], -1).astype(np.float64) / 255.0
-    return pts, cols
+    if not with_normals:
+        return pts, cols
+    nrm = None
+    if "nx" in rec.dtype.names:
+        nrm = np.stack([rec["nx"], rec["ny"], rec["nz"]], -1).astype(np.float64)
+    return pts, cols, nrm

@@ -73,6 +73,9 @@ class ExportPointCloud:
     obb_rotation: Optional[Tuple[float, float, float]] = None
     obb_scale: Optional[Tuple[float, float, float]] = None
     matrix_precision: str = "fp32"
+    reorient_normals: bool = True
+    normal_method: str = "open3d"  # "open3d" | "model_output" (debug/exporter_nerfacto.py:74-77)
+    normal_output_name: str = "normals"
 
     def main(self) -> None:
         from cropnerf_amd.fruit_nerf.checkpoint import eval_setup
@@ -88,7 +91,11 @@ class ExportPointCloud:
         crop_obb = None  # debug/exporter_nerfacto.py:119-121
         if self.obb_center is not None and self.obb_rotation is not None and self.obb_scale is not None:
             crop_obb = OrientedBox.from_params(self.obb_center, self.obb_rotation, self.obb_scale)
+        estimate_normals = self.normal_method == "open3d"  # debug/exporter_nerfacto.py:117 (the name is the reference's flag
+        # value: the estimate itself is cn_estimate_normals, open3d's algorithm on the device)
         pcd = generate_point_cloud(pipeline=pipeline, num_points=self.num_points, remove_outliers=self.remove_outliers,
+                                   reorient_normals=self.reorient_normals, estimate_normals=estimate_normals,
+                                   normal_output_name=self.normal_output_name if self.normal_method == "model_output" else None,
                                    std_ratio=self.std_ratio, crop_obb=crop_obb)
         if pipeline.local_rank != 0:
             return
@@ -119,7 +126,8 @@ def entrypoint(argv=None):
     sp.add_argument("--num-points-per-side", type=int, default=3000)
     pc.add_argument("--num-points", type=int, default=1000000)
     pc.add_argument("--remove-outliers", type=lambda s: s.lower() == "true", default=True)
-    pc.add_argument("--normal-method", default="open3d")
+    pc.add_argument("--normal-method", choices=["open3d", "model_output"], default="open3d")
+    pc.add_argument("--reorient-normals", type=lambda s: s.lower() == "true", default=True)
     pc.add_argument("--num-rays-per-batch", type=int, default=2048)
     pc.add_argument("--std-ratio", type=float, default=10.0)
     pc.add_argument("--save-world-frame", type=lambda s: s.lower() == "true", default=False)
@@ -131,7 +139,8 @@ def entrypoint(argv=None):
                                  a.bounding_box_max, a.num_rays_per_batch, a.num_points_per_side, a.matrix_precision).main()
     else:
         ExportPointCloud(a.load_config, a.output_dir, a.num_points, a.remove_outliers, a.num_rays_per_batch,
-                         a.std_ratio, a.save_world_frame, a.obb_center, a.obb_rotation, a.obb_scale, a.matrix_precision).main()
+                         a.std_ratio, a.save_world_frame, a.obb_center, a.obb_rotation, a.obb_scale, a.matrix_precision,
+                         a.reorient_normals, a.normal_method).main()
 
 
 if __name__ == "__main__":

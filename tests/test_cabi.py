@@ -110,13 +110,32 @@ def test_ops_refuse_cpu_tensors():
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from cropnerf_amd import _lib
 
-    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_libs", {})
     monkeypatch.setenv("CROPNERF_HIP_LIB", str(tmp_path / "nope.so"))
     with pytest.raises(FileNotFoundError, match="no CPU or PyTorch fallback"):
         _lib.load()
     monkeypatch.delenv("CROPNERF_HIP_LIB")
-    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_libs", {})
     _lib.load()
+
+
+def test_deterministic_test_library_exports_the_same_abi(monkeypatch):
+    """libcropnerf_hip_det.so (the deterministic-accumulation test build, csrc/cn_det.hpp): same symbols, says what it is;
+    the default library refuses a shadow registration instead of pretending."""
+    from cropnerf_amd import _lib
+
+    default = _lib.load()
+    assert default.cn_deterministic_build() == 0
+    assert default.cn_deterministic_register(None, 0, None, None) == _lib.CN_ERR_UNSUPPORTED
+    assert b"default build" in default.cn_last_error()
+    assert default.cn_deterministic_clear() == 0 and default.cn_deterministic_flush(None) == 0
+    monkeypatch.setenv("CN_DETERMINISTIC_SCATTER", "1")
+    det = _lib.load()
+    assert det is not default and det.cn_deterministic_build() == 1
+    for name in _lib.SIGNATURES:
+        assert hasattr(det, name), name
+    monkeypatch.setenv("CN_DETERMINISTIC_SCATTER", "0")
+    assert _lib.load() is default
 
 
 def test_scatter_scratch_size_is_a_host_computation(lib):

@@ -89,6 +89,51 @@ def test_forward_test_mode_matches_oracle(scene):
         m(rb)
 
 
+def test_c1_at_its_stated_shape_every_ray_against_the_oracle():
+    """BASELINE.json configs[0] literally: a 400 x 400 camera (f = 555.6), ONE 1 024-ray chunk, 64 samples per
+    ray, full-size tables (2^19 entries per level) -- the case the CPU-baseline leg of bench.py times -- on the HIP path, with
+    EVERY ray of the chunk held to the fp32 bars against the oracle: the inference wiring (uniform sampler, fruit_nerf.py:185-189,
+    497-541) strictly, the test-mode wiring (proposal sampler 256 / 96 -> 64, :543-599) with the bound its inverse-cdf steps
+    allow."""
+    from cropnerf_amd.rays import Cameras, SceneBox
+
+    sc = make_scene(seed=2, log2_T=19, num_images=6, height=400, width=400, focal=555.6, prop_log2_T=17)
+    cams = Cameras(sc.c2w, sc.intr[:, 0], sc.intr[:, 1], sc.intr[:, 2], sc.intr[:, 3], 400, 400).to("cuda")
+    first = 197 * 400 + 130  # a chunk across the middle of the image (two and a half rows through the plant)
+    rays = cams.generate_rays(camera_indices=1, keep_shape=False, aabb_box=SceneBox(sc.aabb))[first:first + 1024]
+    ref_rays = rays_with_box(sc, 1).slice(first, first + 1024)
+    assert len(rays) == 1024
+    assert_close(rays.origins, ref_rays.origins, 1e-6, 1e-6, "C1 origins")
+    assert_close(rays.directions, ref_rays.directions, 1e-6, 1e-6, "C1 directions")
+    # inference wiring: 64 uniform samples between the box planes, no contraction, mean appearance embedding
+    m = _model(sc, "inference", eval_num_rays_per_chunk=1024, num_nerf_samples_per_ray=64)
+    m.setup_inference(True, 64)
+    out = m(rays)
+    om = oracle_model(sc, "inference", eval_num_rays_per_chunk=1024)
+    om.setup_inference(True, 64)
+    ref = om.forward(ref_rays)
+    hit = float((ref["accumulation"] > 0.5).float().mean())
+    assert 0.2 < hit <= 1.0, f"the chunk must cross the scene ({hit:.2f} of its rays are opaque)"
+    assert_close(out["rgb"], ref["rgb"], RTOL, ATOL, "C1 rgb")  # every ray (frac_ok = 1)
+    assert_close(out["accumulation"], ref["accumulation"], RTOL, ATOL, "C1 accumulation")
+    assert_close(out["semantics"], ref["semantics"], RTOL, 5e-5, "C1 semantics")
+    ok = (out["depth"].cpu() - ref["depth"]).abs() <= 1e-5 + 1e-5 * ref["depth"].abs()  # the median's bin can tie
+    assert ok.float().mean().item() >= 0.995
+    clear = (ref["semantics"] - math.log(9.0)).abs().reshape(-1) > 1e-3
+    assert torch.equal(out["semantics_colormap"].cpu()[clear], ref["semantics_colormap"][clear])
+    # test-mode wiring: pose tweak, proposal sampler (256, 96) -> 64 final samples, contraction
+    m2 = _model(sc, "test", eval_num_rays_per_chunk=1024, num_nerf_samples_per_ray=64)
+    rb2 = cams.generate_rays(camera_indices=1, keep_shape=False)[first:first + 1024]
+    out2 = m2(rb2)
+    ref2 = oracle_model(sc, "test", num_nerf_samples_per_ray=64).forward(
+        ORY.image_rays(sc.c2w, sc.intr, 1, 400, 400).slice(first, first + 1024))
+    err = (out2["rgb"].cpu() - ref2["rgb"]).abs().max(dim=-1).values
+    tight = (err <= ATOL + RTOL).float().mean().item()
+    assert tight >= 0.90, f"C1 test mode: {100 * tight:.1f} % of rays inside the fp32 bars; worst {err.max().item():.3e}"
+    assert_close(out2["rgb"], ref2["rgb"], 2e-3, 2e-3, "C1 test-mode rgb", frac_ok=0.99)
+    assert_close(out2["accumulation"], ref2["accumulation"], 2e-3, 2e-3, "C1 test-mode accumulation", frac_ok=0.99)
+
+
 def test_full_image_render_and_chunking(scene, monkeypatch):
     m = _model(scene, "inference", eval_num_rays_per_chunk=100)
     m.setup_inference(True, 40)
@@ -303,8 +348,10 @@ def test_cli_end_to_end(scene, tmp_path):
     assert pts.shape[0] > 0 and cols.shape == pts.shape
     exporter.entrypoint(["pointcloud", "--load-config", str(cfg_path), "--output-dir", str(out), "--num-points", "200",
                          "--remove-outliers", "False", "--num-rays-per-batch", "256"])
-    pts, _ = read_ply(str(out / "semantics_pc.ply"))
+    pts, _, nrm = read_ply(str(out / "semantics_pc.ply"), with_normals=True)
     assert pts.shape[0] >= 200
+    # --normal-method open3d (the default, README.md:125): estimated on the device, re-oriented, written with the points
+    assert nrm is not None and nrm.shape == pts.shape and np.abs(np.linalg.norm(nrm, axis=1) - 1).max() < 1e-6
     # projection CLI: one super-cluster with two sub-cluster boxes (segmentation/segmenter.py:175-179 layout)
     npy = tmp_path / "clusters.npy"
     np.save(npy, np.array([{"aabb": np.array([[[-0.3, -0.3, -0.3], [0.3, 0.3, 0.3]], [[4, 4, 4], [5, 5, 5]]]), "pcd": {}}],
