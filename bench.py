@@ -695,6 +695,7 @@ def secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, o
 
         g = torch.Generator().manual_seed(0)
         train = {}
+        train_data: dict = {}
         from cropnerf_amd import synthetic
         from cropnerf_amd.rays import Cameras
 
@@ -736,6 +737,53 @@ def secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, o
                               "(~1 request per clock for 32 CUs) and its tile is a chain of 17 barrier-separated matrix phases at two "
                               "waves per SIMD -- 74-80 % of its own request floor at 48 samples per ray, the phase chain alone at 192; "
                               "the fraction priced here falls when requests are removed faster than time (DESIGN.md 4.17, 7)"}
+            # The figure above hands train_iteration the SAME resident tensors every time: the replayed graph then skips its
+            # input copies, and ray generation and the pixel gather sit outside the timed region -- a lower bound on a real
+            # iteration.  Here every iteration gets a fresh batch from the data manager (FruitDataManager.next_train: pixel
+            # draws on the host, one asynchronous index copy, cn_raygen_pinhole, the image / mask gathers from resident
+            # images) on a fresh trainer: iterations 0-1 warm up and capture, 2-9 are timed on the wall clock with no wait
+            # between them (all ten update the proposal networks, like the five timed above).
+            from cropnerf_amd.fruit_nerf.data.fruit_datamanager import FruitDataManager, FruitDataManagerConfig
+
+            if "images" not in train_data:
+                train_data["images"] = torch.rand(NUM_CAMERAS, H, W, 3, device=dev)
+                train_data["masks"] = (torch.rand(NUM_CAMERAS, H, W, 1, device=dev) > 0.5).float()
+            dm = FruitDataManager(FruitDataManagerConfig(train_num_rays_per_batch=nrays), cams, device=dev,
+                                  images=train_data["images"], fruit_masks=train_data["masks"], seed=3)
+            model2 = FruitModel(tcfg, SceneBox(torch.tensor([[-1.0, -1, -1], [1, 1, 1]])), NUM_CAMERAS,
+                                {"semantics": Semantics()}, device=dev, params={k: v.clone() for k, v in params.items()})
+            model2.training = True
+            tr2 = FruitTrainer(model2)
+            for i in range(2):
+                tr2.train_iteration(*dm.next_train(i))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(2, 10):
+                tr2.train_iteration(*dm.next_train(i))
+            torch.cuda.synchronize()
+            tf = (time.perf_counter() - t0) / 8
+            train[key]["fresh_batches"] = {
+                "ms_per_iter": round(tf * 1e3, 3), "rays_per_sec": nrays / tf,
+                "timing": "wall clock over 8 consecutive iterations, each on a new batch from FruitDataManager.next_train (host pixel "
+                          "draws, index copy, ray generation, image / mask gathers, the graph's input copies) -- what a training run "
+                          "pays; ms_per_iter above is the same iteration on one resident batch (device events)"}
+            del tr2, model2, dm
+            # The same iteration in the reference's training arithmetic (mixed_precision=True on tiny-cuda-nn's fp16 modules,
+            # fruit_nerf_config.py:35): matrix_precision="f16" -- fp16 operands in the field's forward and backward recompute,
+            # bf16 gradient products, fp32 sums and master parameters (cn_field_backward_mp).  Reported beside the exact-fp32
+            # figure, which stays the one the rooflines above are priced on.
+            tcfg16 = PC.FruitNerfModelConfig(num_nerf_samples_per_ray=spp, matrix_precision="f16")
+            model3 = FruitModel(tcfg16, SceneBox(torch.tensor([[-1.0, -1, -1], [1, 1, 1]])), NUM_CAMERAS,
+                                {"semantics": Semantics()}, device=dev, params={k: v.clone() for k, v in params.items()})
+            model3.training = True
+            tr3 = FruitTrainer(model3)
+            t16 = timed(lambda i: tr3.train_iteration(rb, batch), 5)
+            train[key]["mixed_precision"] = {
+                "ms_per_iter": round(t16 * 1e3, 3), "rays_per_sec": nrays / t16,
+                "arithmetic": "field forward and backward recompute: fp16 operands (v_mfma_f32_16x16x32_f16 / 16x16x16_f16); "
+                              "gradient products: bf16 operands; fp32 accumulation, fp32 master parameters, Adam in fp32; "
+                              "proposal networks fp32"}
+            del tr3, model3
             if spp == 48:
                 # The iterations above are the first seven of a run, where the reference updates the proposal networks every
                 # time.  The schedule (fruit_nerf.py:144-149: update_every = 5 once step >= proposal_warmup = 5 000) makes that
@@ -765,7 +813,7 @@ def subsystem_timings(args, params, device):
     builder probes under tools/).  Outside the headline's timed region; each with its algorithmic bytes and fraction of HBM
     peak.  Same synthetic scene (P-rand) with a density / fruit-logit offset so that the exporters keep points."""
     from cropnerf_amd import config as PC
-    from cropnerf_amd import synthetic
+    from cropnerf_amd import ops, synthetic
     from cropnerf_amd.fruit_nerf.data.fruit_datamanager import FruitDataManagerConfig
     from cropnerf_amd.fruit_nerf.export.exporter_utils import sample_volume
     from cropnerf_amd.fruit_nerf.export.exporter_utils_nerfacto import generate_point_cloud
@@ -845,6 +893,7 @@ def subsystem_timings(args, params, device):
         t_, pcd_ = wall(lambda: generate_point_cloud(pipe_x, num_points=num_points, remove_outliers=False, launch_rays=launch_rays,
                                                      stats=st))
         kept_ = int(pcd_["points"].shape[0])
+        last_cloud["points"] = pcd_["points"]
         return {"seconds": round(t_, 3), "kept_points": kept_, "calls": st["calls"], "rays_per_call": rays_per_call,
                 "calls_per_launch": st["calls_per_launch"], "rays_rendered": st["rays"], "kept_fraction": round(kept_ / st["rays"], 4),
                 "rays_per_sec": st["rays"] / t_, "points_per_sec": kept_ / t_, "seconds_to_10M_points": round(t_ * 1e7 / kept_, 2),
@@ -856,7 +905,19 @@ def subsystem_timings(args, params, device):
                                            "3 KB for the coherent rays of an image), i.e. the rate at which the memory side serves "
                                            "scattered 64-byte requests bounds it, as it bounds the training forward", pmc="export_c4")}
 
+    last_cloud: dict = {}
     c4 = export_case(2048, 1 << 16, 10_000_000)
+    # the two post-processing passes of `ns-export pointcloud` on that cloud (exporter_utils_nerfacto.py:194-225): statistical
+    # outlier removal (20 neighbours) and open3d-style normals (30 neighbours, covariance, smallest eigenvector) + re-orientation,
+    # both on the device (cn_knn_mean_distance / cn_estimate_normals)
+    pts_c4 = torch.from_numpy(last_cloud["points"]).to(device=device, dtype=torch.float32)
+    ops.estimate_normals(pts_c4[:100000], 30)
+    t_out, _ = wall(lambda: ops.statistical_outlier_mask(pts_c4, 20, 10.0))
+    t_nrm, nd = wall(lambda: ops.estimate_normals(pts_c4, 30))
+    c4["normals"] = {"points": int(pts_c4.shape[0]), "seconds": round(t_nrm, 3), "points_per_sec": pts_c4.shape[0] / t_nrm,
+                     "degenerate": int(nd[1].sum()), "outlier_pass_seconds": round(t_out, 3),
+                     "kernel": "knn_normals_kernel (uniform-grid 30-nearest search + fp64 covariance + closed-form 3x3 eigen-solve)"}
+    del pts_c4, nd
     c4["call_size_32768"] = export_case(32768, 1 << 16, 10_000_000)
     c4["one_call_per_launch_2048"] = export_case(2048, None, 1_000_000)  # the reference's loop shape, graph-replayed (round 3)
     c4["semantic_bias_for_3pct"] = round(bias, 4)

@@ -158,6 +158,8 @@ SIGNATURES = {
     "cn_interlevel_backward_levels": (C.c_int, [_P, _P, C.POINTER(InterlevelLevel), _I32, _I64, _I32, _F, _P, _P]),
     "cn_field_backward": (C.c_int, [C.POINTER(FieldParams), C.POINTER(FieldParams), C.POINTER(Scene), _I32, _I32, _P,
                                     _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P]),
+    "cn_field_backward_mp": (C.c_int, [C.POINTER(FieldParams), C.POINTER(FieldParams), C.POINTER(Scene), _I32, _I32, _P,
+                                       _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _I32, _P]),
     "cn_proposal_backward": (C.c_int, [C.POINTER(DensityParams), C.POINTER(DensityParams), C.POINTER(Scene), _P, _P,
                                        _P, _P, _P, _I64, _I32, _P, _P]),
     "cn_field_backward_general_workspace_bytes": (C.c_size_t, [C.POINTER(FieldParams)]),

@@ -1097,8 +1097,21 @@ extern "C" int cn_field_backward(const cn_field_params* params, const cn_field_p
                                  const float* ends, const float* d_density, const float* d_rgb, const float* d_semantics,
                                  int64_t num_rays, int32_t num_samples, float* d_positions, float* d_directions,
                                  cn_stream_t stream) {
+  return cn_field_backward_mp(params, grads, scene, app_mode, sh_unit_dir, app_mean, origins, directions, camera_indices, starts,
+                              ends, d_density, d_rgb, d_semantics, num_rays, num_samples, d_positions, d_directions,
+                              CN_MATRIX_FP32, stream);
+}
+
+extern "C" int cn_field_backward_mp(const cn_field_params* params, const cn_field_params* grads, const cn_scene* scene,
+                                    int32_t app_mode, int32_t sh_unit_dir, const float* app_mean, const float* origins,
+                                    const float* directions, const int64_t* camera_indices, const float* starts,
+                                    const float* ends, const float* d_density, const float* d_rgb, const float* d_semantics,
+                                    int64_t num_rays, int32_t num_samples, float* d_positions, float* d_directions,
+                                    int32_t matrix_precision, cn_stream_t stream) {
   CN_REQUIRE(params && grads && scene && origins && directions && starts && ends && d_density && d_rgb && d_semantics,
              CN_ERR_INVALID, "cn_field_backward: null argument");
+  CN_REQUIRE(matrix_precision == CN_MATRIX_FP32 || matrix_precision == CN_MATRIX_SPLIT_BF16 || matrix_precision == CN_MATRIX_F16,
+             CN_ERR_INVALID, "cn_field_backward: matrix_precision %d", matrix_precision);
   CN_REQUIRE(app_mode != CN_APP_PER_CAMERA || camera_indices, CN_ERR_INVALID, "Camera indices are not provided.");
   CN_REQUIRE(app_mode != CN_APP_MEAN || app_mean, CN_ERR_INVALID, "cn_field_backward: app_mean required for CN_APP_MEAN");
   int rc = cn::validate_field(*params);
@@ -1163,7 +1176,10 @@ extern "C" int cn_field_backward(const cn_field_params* params, const cn_field_p
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)((size_t)cn::FIELD_ROWS * cn::LD * sizeof(float)));
         if (e != hipSuccess) return e;
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(cn::mf::field_backward_mfma_kernel),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(cn::mf::field_backward_mfma_kernel<0>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)cn::mf::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(cn::mf::field_backward_mfma_kernel<1>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)cn::mf::LDS_BYTES);
       },
       nullptr, "cn_field_backward");
@@ -1182,8 +1198,13 @@ extern "C" int cn_field_backward(const cn_field_params* params, const cn_field_p
       if (ratio != 0.0) A.cells = cn::make_cell_scatter(grads->grid, (unsigned long long)(nsamp * ratio), (unsigned long long)nsamp);
       if (A.cells.num_levels > 0) A.coarse.base = nullptr;  // level 0 is cell-major then
     }
-    hipLaunchKernelGGL(cn::mf::field_backward_mfma_kernel, dim3(cn::grid_for(ntiles, 1, 256)), dim3(cn::mf::NT),
-                       cn::mf::LDS_BYTES, cn::as_stream(stream), A);
+    // (split-bf16 keeps ~fp32 products in the forward; its gradient is the exact-fp32 kernel's)
+    if (matrix_precision == CN_MATRIX_F16)
+      hipLaunchKernelGGL(cn::mf::field_backward_mfma_kernel<1>, dim3(cn::grid_for(ntiles, 1, 256)), dim3(cn::mf::NT),
+                         cn::mf::LDS_BYTES, cn::as_stream(stream), A);
+    else
+      hipLaunchKernelGGL(cn::mf::field_backward_mfma_kernel<0>, dim3(cn::grid_for(ntiles, 1, 256)), dim3(cn::mf::NT),
+                         cn::mf::LDS_BYTES, cn::as_stream(stream), A);
     CN_DET_FLUSH(cn::as_stream(stream));  // (deterministic test build: the scratch records are floats again before the folds)
     cn::launch_coarse_reduce(A.coarse, A.grid, A.g.table, cn::as_stream(stream));
     cn::launch_cell_fold(A.cells, A.grid, A.g.table, cn::as_stream(stream));

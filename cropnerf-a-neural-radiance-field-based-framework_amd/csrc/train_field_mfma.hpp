@@ -70,29 +70,96 @@ __device__ __forceinline__ int opaque(int v) {
 }
 #define CN_LANE_IQ const int lane_o = opaque(lane); const int i = lane_o & 15, q = lane_o >> 4;
 
+// Matrix modes of the kernel (template parameter MM): 0 = exact fp32 (v_mfma_f32_16x16x4_f32, the chains above), 1 = the
+// reference's mixed-precision class (cn_field_backward_mp, matrix_precision = CN_MATRIX_F16): the forward recompute on
+// v_mfma_f32_16x16x16_f16 -- weights and layer inputs rounded to fp16 as they leave LDS, fp32 accumulation, which is what the
+// fp16 render mode computes (render_f16.hpp) and tiny-cuda-nn's FullyFusedMLP under mixed_precision=True -- and the two
+// gradient products (dX, dW) on v_mfma_f32_16x16x16_bf16: deltas are ~1e-9 at 65 536 rays, below fp16's normal range, and
+// bf16 keeps fp32's exponent, so no loss scale runs through the kernel (tcnn scales its fp16 gradients by 128, nerfstudio's
+// GradScaler by 2^10 and up).  The LDS images stay fp32: a lane's four k-steps of the fp32 chain ARE the four-element operand
+// of the 16 x 16 x 16 instruction, so the reads are the same and one matrix instruction replaces four.
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma_f16x4(const f32x4& a, const f32x4& b, f32x4 acc) {
+  f16x4 ah, bh;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    ah[e] = (_Float16)a[e];
+    bh[e] = (_Float16)b[e];
+  }
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_bf16x4(const f32x4& a, const f32x4& b, f32x4 acc) {
+  bf16x4 ah, bh;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    ah[e] = (__bf16)a[e];
+    bh[e] = (__bf16)b[e];
+  }
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, ah), __builtin_bit_cast(s16x4, bh), acc, 0, 0, 0);
+}
+
 // (Two independent accumulation chains per block -- even / odd k blocks, summed at the end -- measured slower: 17.86 vs 17.61 ms
 //  per iteration at 65 536 rays; the second wave of the SIMD already fills the gaps of a dependent chain.)
-template <int K>
+// CN_ABL_QUARTER_MFMA (timing only, wrong results): the operand reads of four k-steps and ONE fp32 matrix instruction -- the
+// probe that priced the 16-bit mode before it was built.
+template <int K, int MM>
 __device__ __forceinline__ f32x4 blk_fwd(const float* W, int ws, int n0, const float* X, int s0, f32x4 acc, int lane) {
   CN_LANE_IQ
 #pragma unroll
   for (int kb = 0; kb < K / 16; ++kb) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(W + (n0 + i) * ws + 16 * kb + 4 * q);
+    if (MM == 1) {
+      f32x4 b;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b[e] = X[(16 * kb + 4 * q + e) * LDA + s0 + i];
+      acc = mfma_f16x4(a, b, acc);
+      continue;
+    }
+#ifdef CN_ABL_QUARTER_MFMA
+    float bsum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bsum += X[(16 * kb + 4 * q + e) * LDA + s0 + i];
+    acc = CN_MFMA(a[0] + a[1] + a[2] + a[3], bsum, acc);
+#else
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float av = a[e];
       const float b = X[(16 * kb + 4 * q + e) * LDA + s0 + i];
       acc = CN_MFMA(av, b, acc);
     }
+#endif
   }
   return acc;
 }
 
-template <int N>
+template <int N, int MM>
 __device__ __forceinline__ f32x4 blk_bwd(const float* W, int ws, int k0, const float* dY, int s0, f32x4 acc, int lane) {
   CN_LANE_IQ
 #pragma unroll
   for (int nb = 0; nb < N / 16; ++nb) {
+    if (MM == 1) {
+      f32x4 a, b;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int n = 16 * nb + 4 * q + e;
+        a[e] = W[n * ws + k0 + i];
+        b[e] = dY[n * LDA + s0 + i];
+      }
+      acc = mfma_bf16x4(a, b, acc);
+      continue;
+    }
+#ifdef CN_ABL_QUARTER_MFMA
+    float asum = 0.f, bsum = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = 16 * nb + 4 * q + e;
+      asum += W[n * ws + k0 + i];
+      bsum += dY[n * LDA + s0 + i];
+    }
+    acc = CN_MFMA(asum, bsum, acc);
+#else
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int n = 16 * nb + 4 * q + e;
@@ -100,21 +167,31 @@ __device__ __forceinline__ f32x4 blk_bwd(const float* W, int ws, int k0, const f
       const float b = dY[n * LDA + s0 + i];
       acc = CN_MFMA(a, b, acc);
     }
+#endif
   }
   return acc;
 }
 
+template <int MM>
 __device__ __forceinline__ f32x4 blk_dw(const float* dY, int n0, const float* X, int k0, f32x4 acc, int lane) {
   CN_LANE_IQ
 #pragma unroll
   for (int sb = 0; sb < TSM / 16; ++sb) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(dY + (n0 + i) * LDA + 16 * sb + 4 * q);
     const f32x4 b = *reinterpret_cast<const f32x4*>(X + (k0 + i) * LDA + 16 * sb + 4 * q);
+    if (MM == 1) {
+      acc = mfma_bf16x4(a, b, acc);
+      continue;
+    }
+#ifdef CN_ABL_QUARTER_MFMA
+    acc = CN_MFMA(a[0] + a[1] + a[2] + a[3], b[0] + b[1] + b[2] + b[3], acc);
+#else
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float av = a[e], bv = b[e];
       acc = CN_MFMA(av, bv, acc);
     }
+#endif
   }
   return acc;
 }
@@ -180,6 +257,7 @@ __device__ __forceinline__ void flush_bias(float* g, int n0, f32x4 gb, int lane)
   }
 }
 
+template <int MM>
 __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A) {
   extern __shared__ __align__(16) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -358,13 +436,13 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
     if (!live) break;
     __builtin_amdgcn_sched_barrier(0);
     // ---- h1 = relu(W0 enc + b0) -----------------------------------------------------------------------------------------
-    store_blk<true>(H1, n0, s0, blk_fwd<32>(Wb0, 36, n0, ENC, s0, bias4(lds + B_0, n0, lane), lane), lane);
+    store_blk<true>(H1, n0, s0, blk_fwd<32, MM>(Wb0, 36, n0, ENC, s0, bias4(lds + B_0, n0, lane), lane), lane);
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     // ---- o16 = W1 h1 + b1; geo rows also into the colour input ---------------------------------------------------------
     if (wave < 2) {
       const int c0 = 16 * wave;
-      const f32x4 v = blk_fwd<64>(Wb1, 68, 0, H1, c0, bias4(lds + B_1, 0, lane), lane);
+      const f32x4 v = blk_fwd<64, MM>(Wb1, 68, 0, H1, c0, bias4(lds + B_1, 0, lane), lane);
       CN_LANE_IQ
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
@@ -377,38 +455,38 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
     __builtin_amdgcn_sched_barrier(0);
     // ---- semantic branch (its input is the DETACHED geo: nothing flows back to the base MLP) ---------------------------
     if (!(A.debug_skip & 32)) {  // (bit 32, timing only: the semantic branch's four phases skipped)
-    store_blk<true>(A1, n0, s0, blk_fwd<16>(Ws0, 20, n0, O16 + LDA, s0, bias4(lds + B_S0, n0, lane), lane), lane);
+    store_blk<true>(A1, n0, s0, blk_fwd<16, MM>(Ws0, 20, n0, O16 + LDA, s0, bias4(lds + B_S0, n0, lane), lane), lane);
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    store_blk<false>(A2, n0, s0, blk_fwd<64>(Ws1, 68, n0, A1, s0, bias4(lds + B_S1, n0, lane), lane), lane);
+    store_blk<false>(A2, n0, s0, blk_fwd<64, MM>(Ws1, 68, n0, A1, s0, bias4(lds + B_S1, n0, lane), lane), lane);
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    store_delta(D2, nullptr, n0, s0, blk_bwd<16>(Wsem, 68, n0, DSEM, s0, zero4, lane), bS1, lane);  // d_s2
-    if (wave >= 4) gY = blk_dw(DSEM, 0, A2, 16 * (wave - 4), gY, lane);                             // dW head
+    store_delta(D2, nullptr, n0, s0, blk_bwd<16, MM>(Wsem, 68, n0, DSEM, s0, zero4, lane), bS1, lane);  // d_s2
+    if (wave >= 4) gY = blk_dw<MM>(DSEM, 0, A2, 16 * (wave - 4), gY, lane);                             // dW head
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    store_delta(D1, A1, n0, s0, blk_bwd<64>(Ws1, 68, n0, D2, s0, zero4, lane), bS0, lane);          // d_s1
+    store_delta(D1, A1, n0, s0, blk_bwd<64, MM>(Ws1, 68, n0, D2, s0, zero4, lane), bS0, lane);          // d_s1
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const int blk = 2 * wave + b;
       __builtin_amdgcn_sched_barrier(0);
-      gS1[b] = blk_dw(D2, 16 * (blk >> 2), A1, 16 * (blk & 3), gS1[b], lane);                        // dW sem1
+      gS1[b] = blk_dw<MM>(D2, 16 * (blk >> 2), A1, 16 * (blk & 3), gS1[b], lane);                        // dW sem1
     }
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     }
     // ---- colour branch -----------------------------------------------------------------------------------------------------
-    if (wave < 4) gX = blk_dw(D1, 16 * wave, O16 + LDA, 0, gX, lane);                               // dW sem0
-    store_blk<true>(A1, n0, s0, blk_fwd<64>(Wc0, 68, n0, CIN, s0, bias4(lds + B_C0, n0, lane), lane), lane);  // c1
+    if (wave < 4) gX = blk_dw<MM>(D1, 16 * wave, O16 + LDA, 0, gX, lane);                               // dW sem0
+    store_blk<true>(A1, n0, s0, blk_fwd<64, MM>(Wc0, 68, n0, CIN, s0, bias4(lds + B_C0, n0, lane), lane), lane);  // c1
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    store_blk<true>(A2, n0, s0, blk_fwd<64>(Wc1, 68, n0, A1, s0, bias4(lds + B_C1, n0, lane), lane), lane);
+    store_blk<true>(A2, n0, s0, blk_fwd<64, MM>(Wc1, 68, n0, A1, s0, bias4(lds + B_C1, n0, lane), lane), lane);
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     if (wave < 2) {  // rgb = sigmoid(Wc2 c2 + bc2); delta_pre = d_rgb * rgb * (1 - rgb)
       const int c0 = 16 * wave;
-      const f32x4 v = blk_fwd<64>(Wrgb, 68, 0, A2, c0, bias4(lds + B_RGB, 0, lane), lane);
+      const f32x4 v = blk_fwd<64, MM>(Wrgb, 68, 0, A2, c0, bias4(lds + B_RGB, 0, lane), lane);
       CN_LANE_IQ
       if (q == 0) {
 #pragma unroll
@@ -422,27 +500,27 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
     }
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    store_delta(D2, A2, n0, s0, blk_bwd<16>(Wrgb, 68, n0, DRGB, s0, zero4, lane), bC1, lane);       // d_c2
-    if (wave < 4) gY = blk_dw(DRGB, 0, A2, 16 * wave, gY, lane);                                    // dW rgb head
+    store_delta(D2, A2, n0, s0, blk_bwd<16, MM>(Wrgb, 68, n0, DRGB, s0, zero4, lane), bC1, lane);       // d_c2
+    if (wave < 4) gY = blk_dw<MM>(DRGB, 0, A2, 16 * wave, gY, lane);                                    // dW rgb head
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    store_delta(D1, A1, n0, s0, blk_bwd<64>(Wc1, 68, n0, D2, s0, zero4, lane), bC0, lane);          // d_c1
+    store_delta(D1, A1, n0, s0, blk_bwd<64, MM>(Wc1, 68, n0, D2, s0, zero4, lane), bC0, lane);          // d_c1
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const int blk = 2 * wave + b;
       __builtin_amdgcn_sched_barrier(0);
-      gC1[b] = blk_dw(D2, 16 * (blk >> 2), A1, 16 * (blk & 3), gC1[b], lane);                        // dW col1
+      gC1[b] = blk_dw<MM>(D2, 16 * (blk >> 2), A1, 16 * (blk & 3), gC1[b], lane);                        // dW col1
     }
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    store_blk<false>(DCIN, n0, s0, blk_bwd<64>(Wc0, 68, n0, D1, s0, zero4, lane), lane);            // d_cin
+    store_blk<false>(DCIN, n0, s0, blk_bwd<64, MM>(Wc0, 68, n0, D1, s0, zero4, lane), lane);            // d_cin
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const int blk = 2 * wave + b;
       __builtin_amdgcn_sched_barrier(0);
-      gC0[b] = blk_dw(D1, 16 * (blk >> 2), CIN, 16 * (blk & 3), gC0[b], lane);                       // dW col0
+      gC0[b] = blk_dw<MM>(D1, 16 * (blk >> 2), CIN, 16 * (blk & 3), gC0[b], lane);                       // dW col0
     }
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
@@ -493,18 +571,18 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     // ---- base MLP backward ------------------------------------------------------------------------------------------------
-    store_delta(D2, H1, n0, s0, blk_bwd<16>(Wb1, 68, n0, DO16, s0, zero4, lane), bH1, lane);        // d_h1
+    store_delta(D2, H1, n0, s0, blk_bwd<16, MM>(Wb1, 68, n0, DO16, s0, zero4, lane), bH1, lane);        // d_h1
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     if (wave < 4) {
       store_blk<false>(D1, 16 * (wave >> 1), 16 * (wave & 1),
-                       blk_bwd<64>(Wb0, 36, 16 * (wave >> 1), D2, 16 * (wave & 1), zero4, lane), lane);  // d_enc
+                       blk_bwd<64, MM>(Wb0, 36, 16 * (wave >> 1), D2, 16 * (wave & 1), zero4, lane), lane);  // d_enc
     } else {
-      gX = blk_dw(DO16, 0, H1, 16 * (wave - 4), gX, lane) /* dW base1 */;
+      gX = blk_dw<MM>(DO16, 0, H1, 16 * (wave - 4), gX, lane) /* dW base1 */;
     }
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    gB0 = blk_dw(D2, 16 * (wave >> 1), ENC, 16 * (wave & 1), gB0, lane);                            // dW base0
+    gB0 = blk_dw<MM>(D2, 16 * (wave >> 1), ENC, 16 * (wave & 1), gB0, lane);                            // dW base0
     {
       const bool lvl_off = (A.debug_skip >> (8 + lvl)) & 1;  // bits 8..23: skip the scatter of level l (profiling)
       p_g0 = valid && !lvl_off ? D1[(2 * lvl) * LDA + s] : 0.f;

@@ -250,12 +250,30 @@ class FruitModel:
             return None
         return rb.camera_indices.reshape(-1).to(torch.int64).contiguous()
 
-    def _matrix_precision(self) -> int:
+    def _matrix_mode(self) -> str:
         mode = getattr(self.config, "matrix_precision", "fp32")
         mode = {"fp16": "f16", "bf16": "split_bf16"}.get(mode, mode)  # the spellings a user of 'fp32' tries first
         if mode not in ("fp32", "split_bf16", "f16"):
             raise ValueError(f"matrix_precision {mode!r}: 'fp32', 'split_bf16' or 'f16' (alias 'fp16')")
+        return mode
+
+    def _matrix_precision(self) -> int:
+        """The matrix mode of the eval / export renders (a model in training mode that is rendered through these paths, e.g.
+        an eval image during a run, stays exact fp32)."""
+        mode = self._matrix_mode()
         if self.training or mode == "fp32":
+            return L.MATRIX_FP32
+        return L.MATRIX_SPLIT_BF16 if mode == "split_bf16" else L.MATRIX_F16
+
+    def train_matrix_precision(self) -> int:
+        """The matrix mode of the TRAINING iteration (``FruitTrainer.forward_backward``): ``matrix_precision="f16"`` is the
+        reference's own training arithmetic -- ``mixed_precision=True`` on tiny-cuda-nn's fp16 modules
+        (``fruit_nerf_config.py:35``, ``fruit_field.py:95,125-167``): the field's forward and its backward recompute with fp16
+        operands, gradient products in bf16, fp32 sums, fp32 master parameters and Adam (``cn_field_backward_mp``).  The field
+        shapes of the ``_big`` / ``_huge`` methods (shape-generic kernels) and the proposal networks train in fp32 whatever the
+        setting."""
+        mode = self._matrix_mode()
+        if mode == "fp32" or not self._fused_shape:
             return L.MATRIX_FP32
         return L.MATRIX_SPLIT_BF16 if mode == "split_bf16" else L.MATRIX_F16
 

@@ -11,7 +11,9 @@ kernels return d loss / d sample position (and the SH-input gradient of the colo
 them per ray and ``cn_pose_adjustment_backward`` chains through exp_map_SO3xR3; ``camera_opt_regularizer``
 (``fruit_nerf.py:614``) is added by ``cn_pose_regularizer``.  The proposal networks follow the reference's update
 schedule (``fruit_nerf.py:144-149``): evaluated without gradient unless ``steps_since_update > update_sched(step) or
-step < 10``.  No GradScaler / autocast (everything is fp32).
+step < 10``.  No GradScaler: exact fp32 by default; ``config.matrix_precision = "f16"`` selects the reference's
+mixed-precision class for the field (fp16 forward operands, bf16 gradient products, fp32 sums and master parameters:
+``FruitModel.train_matrix_precision``), whose bf16 deltas need no loss scale.
 
 An optimiser group is stepped only when the iteration produced a gradient for it: on the iterations where the proposal
 networks are evaluated under ``no_grad`` their parameters have ``grad is None`` in the reference, ``torch.optim.Adam``
@@ -258,11 +260,13 @@ class FruitTrainer:
                 starts, ends = eu[:, :-1].contiguous(), eu[:, 1:].contiguous()
         # ---- field forward (fused kernel, per-sample outputs) --------------------------------------------------------
         S = cfg.num_nerf_samples_per_ray
+        mp = m.train_matrix_precision()  # fp32, or the reference's mixed-precision class (config.matrix_precision = "f16")
         if self.general:
             fo = ops.field_eval(m.field, scene, o, d, cam, starts, ends, app_mode=L.APP_PER_CAMERA,
                                 sh_unit_dir=cfg.sh_input == "unit")
         else:
-            opts = ops.render_opts(S, app_mode=L.APP_PER_CAMERA, sh_unit_dir=cfg.sh_input == "unit", eval_clamp=False)
+            opts = ops.render_opts(S, app_mode=L.APP_PER_CAMERA, sh_unit_dir=cfg.sh_input == "unit", eval_clamp=False,
+                                   matrix_precision=mp)
             fo = ops.render_samples(m.field, scene, opts, o, d, nears, fars, camera_indices=cam, bins=eu.contiguous())
         # ---- renderer + losses + their backward ------------------------------------------------------------------------
         image = batch["image"].to(dev)[:, :3].to(torch.float32).contiguous()
@@ -285,7 +289,8 @@ class FruitTrainer:
             else:
                 ops.field_backward(m.field, self.grad_field, scene, o, d, cam, starts, ends, rb_out["d_density"],
                                    rb_out["d_rgb"], rb_out["d_semantics"], app_mode=L.APP_PER_CAMERA,
-                                   sh_unit_dir=cfg.sh_input == "unit", d_positions=dpos, d_directions=ddir)
+                                   sh_unit_dir=cfg.sh_input == "unit", d_positions=dpos, d_directions=ddir,
+                                   matrix_precision=mp)
             if self.train_pose:
                 ops.ray_backward(dpos, ddir, starts, ends, d_o_acc, d_d_acc)
 

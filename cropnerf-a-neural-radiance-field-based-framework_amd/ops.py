@@ -835,21 +835,22 @@ def field_backward(fh: FieldHandle, gh: FieldHandle, scene: L.Scene, origins: Te
                    camera_indices: Optional[Tensor], starts: Tensor, ends: Tensor, d_density: Tensor, d_rgb: Tensor,
                    d_semantics: Tensor, app_mode: int = L.APP_PER_CAMERA, sh_unit_dir: bool = True,
                    app_mean: Optional[Tensor] = None, d_positions: Optional[Tensor] = None,
-                   d_directions: Optional[Tensor] = None) -> None:
+                   d_directions: Optional[Tensor] = None, matrix_precision: int = L.MATRIX_FP32) -> None:
     """Accumulates parameter gradients into the tensors behind ``gh`` (a FieldHandle over the gradient dict).
     ``d_positions`` / ``d_directions`` [R,S,3] (optional) are overwritten with the per-sample position / SH-direction
-    gradients that feed the camera pose refinement."""
+    gradients that feed the camera pose refinement.  ``matrix_precision``: ``MATRIX_F16`` = the reference's mixed-precision
+    class (fp16 forward recompute, bf16 gradient products, fp32 sums: ``cn_field_backward_mp``)."""
     lib = L.load()
     R, S = starts.shape
     for t, nm in ((d_positions, "d_positions"), (d_directions, "d_directions")):
         if t is not None and tuple(t.shape) != (R, S, 3):
             raise ValueError(f"{nm} must be [{R},{S},3]")
-    L.check(lib.cn_field_backward(
+    L.check(lib.cn_field_backward_mp(
         C.byref(fh.struct), C.byref(gh.struct), C.byref(scene), app_mode, 1 if sh_unit_dir else 0,
         _p(_f32(app_mean, "app_mean")), _p(_f32(origins, "origins")), _p(_f32(directions, "directions")),
         _p(_i64(camera_indices, "camera_indices")), _p(_f32(starts, "starts")), _p(_f32(ends, "ends")),
         _p(_f32(d_density, "d_density")), _p(_f32(d_rgb, "d_rgb")), _p(_f32(d_semantics, "d_semantics")), R, S,
-        _p(_f32(d_positions, "d_positions")), _p(_f32(d_directions, "d_directions")), _stream(starts)))
+        _p(_f32(d_positions, "d_positions")), _p(_f32(d_directions, "d_directions")), int(matrix_precision), _stream(starts)))
 
 
 def field_backward_general(fh: FieldHandle, gh: FieldHandle, scene: L.Scene, origins: Tensor, directions: Tensor,

@@ -561,6 +561,18 @@ int cn_field_backward(const cn_field_params* params, const cn_field_params* grad
                       const float* ends, const float* d_density, const float* d_rgb, const float* d_semantics,
                       int64_t num_rays, int32_t num_samples, float* d_positions /*[R,S,3] or NULL*/,
                       float* d_directions /*[R,S,3] or NULL*/, cn_stream_t stream);
+/* The same with the matrix arithmetic of the caller's choice (cn_field_backward = CN_MATRIX_FP32).  CN_MATRIX_F16: the
+ * reference's training arithmetic class -- it trains under mixed_precision=True on tiny-cuda-nn's fp16 modules
+ * (fruit_nerf/fruit_nerf_config.py:35, fruit_field.py:95,125-167): the forward recompute with fp16 weights and layer inputs
+ * (what cn_render_samples computes in that mode), the gradient products dX and dW with bf16 operands (fp32's exponent range:
+ * no loss scale), fp32 accumulation throughout, fp32 master gradients out.  CN_MATRIX_SPLIT_BF16 (a ~fp32 forward): the
+ * exact-fp32 kernel. */
+int cn_field_backward_mp(const cn_field_params* params, const cn_field_params* grads, const cn_scene* scene,
+                         int32_t app_mode, int32_t sh_unit_dir, const float* app_mean, const float* origins,
+                         const float* directions, const int64_t* camera_indices, const float* starts,
+                         const float* ends, const float* d_density, const float* d_rgb, const float* d_semantics,
+                         int64_t num_rays, int32_t num_samples, float* d_positions, float* d_directions,
+                         int32_t matrix_precision, cn_stream_t stream);
 
 /* The same for the other field shapes of the reference's method configs (fruit_nerf_method_big / _huge:
  * fruit_nerf/fruit_nerf_config.py:66-172): base MLP 2 layers, semantic MLP 2-3 layers, colour MLP 3 layers, widths

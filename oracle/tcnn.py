@@ -117,8 +117,17 @@ def grid_index(pos_grid: np.ndarray, resolution: int, hashmap_size: int) -> np.n
     return (index % np.uint32(hashmap_size)).astype(np.int64)
 
 
+def round_f16(t: Tensor) -> Tensor:
+    """Round to fp16 values (kept as float32).  Under autograd the rounding is a straight-through step: the gradient passes
+    unchanged, in float32 -- a plain ``.to(float16)`` would also round the GRADIENT to fp16 on the way back and flush the
+    ~1e-9 deltas of a 65 536-ray batch to zero (tiny-cuda-nn avoids that with its loss scale; the checker has no need to)."""
+    t = t.to(torch.float32)
+    r = t.detach().to(torch.float16).to(torch.float32)
+    return t + (r - t.detach()) if t.requires_grad else r
+
+
 def _as_compute(params: Tensor, half_params: bool) -> Tensor:
-    return params.to(torch.float16).to(torch.float32) if half_params else params.to(torch.float32)
+    return round_f16(params) if half_params else params.to(torch.float32)
 
 
 def hash_grid(x: Tensor, params: Tensor, spec: TcnnGridSpec, half_params: bool = True,
@@ -152,7 +161,7 @@ def hash_grid(x: Tensor, params: Tensor, spec: TcnnGridSpec, half_params: bool =
             index = torch.from_numpy(grid_index(corner, res, size) + offs[l])
             acc = acc + table[index] * w[:, None]
             if half_activations:  # tcnn accumulates `result` in the parameter type
-                acc = acc.to(torch.float16).to(torch.float32)
+                acc = round_f16(acc)
         outs.append(acc)
     return torch.cat(outs, dim=-1)
 
@@ -221,14 +230,14 @@ def fully_fused_mlp(x_padded: Tensor, params: Tensor, n_in: int, n_out: int, wid
     h = x_padded
     for i, w in enumerate(mats):
         if half_activations:
-            h = h.to(torch.float16).to(torch.float32)
+            h = round_f16(h)
         h = h @ w.t()
         if i < len(mats) - 1:
             h = torch.relu(h)
     if out_activation == "sigmoid":
         h = torch.sigmoid(h)
     if half_activations:
-        h = h.to(torch.float16).to(torch.float32)
+        h = round_f16(h)
     return h[:, :n_out]
 
 

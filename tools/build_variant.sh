@@ -10,6 +10,6 @@ OUT=$ROOT/tools/scratch/variants
 mkdir -p $OUT
 SRC=${VARIANT_SRC:-render_fused}
 hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -x hip -Wno-unused-result "$@" -c $PKG/csrc/$SRC.hip -o $OUT/${SRC}_$NAME.o
-OBJS=$(ls $PKG/build/*.o | grep -v "/$SRC.o")
+OBJS=$(ls $PKG/build/*.o | grep -v "/$SRC.o" | grep -v "\.det\.o")
 hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libcropnerf_$NAME.so $OBJS $OUT/${SRC}_$NAME.o
 echo $OUT/libcropnerf_$NAME.so
