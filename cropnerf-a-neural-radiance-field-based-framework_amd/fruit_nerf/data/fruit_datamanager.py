@@ -91,7 +91,8 @@ class FruitDataManager:
         self._device_generator: Optional[torch.Generator] = None
         self._seed = seed + 1000 * local_rank
         self.orthographic_ray_generator: Optional[OrthographicRayGenerator] = None
-        self._idx_ring: Dict[tuple, dict] = {}  # pinned staging of next_train / next_eval's pixel indices, per batch shape
+        self._idx_ring: Dict[int, dict] = {}  # pinned staging of next_train / next_eval's pixel draws, per batch shape
+        self._dims_dev: Optional[Tensor] = None
 
     @classmethod
     def from_dataset(cls, config: FruitDataManagerConfig, dataset, device="cuda", **kwargs) -> "FruitDataManager":
@@ -113,39 +114,48 @@ class FruitDataManager:
         return dm
 
     # PixelSampler.sample + train_ray_generator (:188-197)
-    def _indices_to_device(self, idx: Tensor) -> Tensor:
-        """The batch's pixel indices on the device through ONE asynchronous copy from a pinned staging slot (a ring of four,
-        each guarded by an event: the host may run four batches ahead of the GPU).  Indexing resident images with host index
-        tensors made three synchronous pageable copies per image tensor -- at 4 096 rays per batch the host side of
-        ``next_train`` was longer than half a training iteration."""
+    def _uniforms_to_device(self, num_rays: int) -> Tensor:
+        """[num_rays, 3] uniforms of the data manager's host stream, on the device: drawn straight into a pinned staging slot
+        (a ring of four, each guarded by an event: the host may run four batches ahead of the GPU) and sent with ONE
+        asynchronous copy.  Indexing resident images with host index tensors made three synchronous pageable copies per image
+        tensor -- at 4 096 rays per batch the host side of ``next_train`` was longer than half a training iteration."""
         if self.device.type != "cuda":
-            return idx.to(self.device)
-        ring = self._idx_ring.get(tuple(idx.shape))
+            return torch.rand(num_rays, 3, generator=self._gen).to(self.device)
+        ring = self._idx_ring.get(num_rays)
         if ring is None:
-            ring = self._idx_ring[tuple(idx.shape)] = {"slots": [torch.empty_like(idx).pin_memory() for _ in range(4)],
-                                                       "events": [None] * 4, "next": 0}
+            ring = self._idx_ring[num_rays] = {"slots": [torch.empty(num_rays, 3).pin_memory() for _ in range(4)],
+                                               "events": [None] * 4, "next": 0}
         k = ring["next"] % 4
         ring["next"] += 1
         if ring["events"][k] is not None:
             ring["events"][k].synchronize()
-        ring["slots"][k].copy_(idx)
+        torch.rand(num_rays, 3, generator=self._gen, out=ring["slots"][k])
         dev = ring["slots"][k].to(self.device, non_blocking=True)
         ring["events"][k] = torch.cuda.Event()
         ring["events"][k].record()
         return dev
 
     def _sample(self, num_rays: int) -> Tuple[RayBundle, Dict]:
+        """nerfstudio's ``PixelSampler.sample_method``: ``floor(rand(B, 3) * (images, height, width))``.  The uniforms are drawn
+        on the host (the data manager's seeded stream), staged through the pinned ring and turned into indices ON THE DEVICE:
+        at 65 536 rays three ``torch.randint`` calls on a CPU generator took 13-48 ms per batch -- their OpenMP regions wake
+        the worker threads for 65 536 elements each time -- which is longer than the iteration they feed (15.8 ms); the
+        arithmetic on 196 608 floats is two small launches instead."""
         n, h, w = len(self.cameras), self.cameras.height, self.cameras.width
-        idx = torch.stack([torch.randint(0, n, (num_rays,), generator=self._gen),
-                           torch.randint(0, h, (num_rays,), generator=self._gen),
-                           torch.randint(0, w, (num_rays,), generator=self._gen)], dim=-1)
-        batch: Dict[str, Tensor] = {"indices": idx}
-        idx_d = self._indices_to_device(idx)
+        u_d = self._uniforms_to_device(num_rays)
+        if u_d.is_cuda:
+            dims = self._dims_dev
+            if dims is None or dims.device != u_d.device:
+                dims = self._dims_dev = torch.tensor([n, h, w], dtype=torch.float32, device=u_d.device)
+            idx_d = torch.floor(u_d * dims).to(torch.int64)
+        else:
+            idx_d = torch.floor(u_d * torch.tensor([n, h, w], dtype=torch.float32)).to(torch.int64)
+        batch: Dict[str, Tensor] = {"indices": idx_d}
         if self.images is not None:
-            ii = idx_d if self.images.device == idx_d.device else idx
+            ii = idx_d.to(self.images.device)
             batch["image"] = self.images[ii[:, 0], ii[:, 1], ii[:, 2]]
         if self.fruit_masks is not None:
-            ii = idx_d if self.fruit_masks.device == idx_d.device else idx
+            ii = idx_d.to(self.fruit_masks.device)
             batch["fruit_mask"] = self.fruit_masks[ii[:, 0], ii[:, 1], ii[:, 2]]
         return self.cameras.generate_rays(idx_d), batch
 
