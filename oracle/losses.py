@@ -100,15 +100,24 @@ def train_forward(
             "weights_list": weights_list, "ray_samples_list": samples_list, "_field": fo}
 
 
-def loss_dict(outputs: Dict[str, Tensor], image: Tensor, fruit_mask: Tensor, semantic_loss_weight: float = 1.0,
-              interlevel_loss_mult: float = 1.0) -> Dict[str, Tensor]:
-    """``get_loss_dict`` (``fruit_nerf.py:601-615``)."""
+def data_losses(outputs: Dict[str, Tensor], image: Tensor, fruit_mask: Tensor, semantic_loss_weight: float = 1.0
+                ) -> Dict[str, Tensor]:
+    """The two data terms of ``get_loss_dict`` (``fruit_nerf.py:603-608``): ``MSELoss()(image[:, :3], rgb)`` and
+    ``semantic_loss_weight * BCEWithLogitsLoss(reduction="mean")(semantics, fruit_mask)`` (``:177-178``).  Pinned by the
+    reference's own statements (``tests/golden/make_golden_reference.py: loss_cases``)."""
     return {
         "rgb_loss": torch.nn.functional.mse_loss(image[:, :3], outputs["rgb"]),
         "semantics_loss": semantic_loss_weight * torch.nn.functional.binary_cross_entropy_with_logits(
             outputs["semantics"], fruit_mask),
-        "interlevel_loss": interlevel_loss_mult * interlevel_loss(outputs["weights_list"], outputs["ray_samples_list"]),
     }
+
+
+def loss_dict(outputs: Dict[str, Tensor], image: Tensor, fruit_mask: Tensor, semantic_loss_weight: float = 1.0,
+              interlevel_loss_mult: float = 1.0) -> Dict[str, Tensor]:
+    """``get_loss_dict`` (``fruit_nerf.py:601-615``)."""
+    ld = data_losses(outputs, image, fruit_mask, semantic_loss_weight)
+    ld["interlevel_loss"] = interlevel_loss_mult * interlevel_loss(outputs["weights_list"], outputs["ray_samples_list"])
+    return ld
 
 
 def camera_opt_regularizer(pose_adjustment: Tensor, trans_l2_penalty: float = 1e-2,

@@ -26,6 +26,22 @@ that holds only the libraries they use, and runs them on seeded inputs:
                                                             nested closures of the hot path that are the reference's own code, executed
                                                             on an object that holds the config fields they read
 
+    (round 5) STATEMENT BLOCKS of functions that cannot run as a whole (they need a trained pipeline, progress bars, open3d):
+    the torch / numpy statements between two source lines, compiled from the function's own AST and executed on seeded
+    tensors in a namespace that holds only what they name --
+    fruit_nerf/data/cotton_nerf_dataparser.py               :248-254   the class list and colour table of `Semantics`
+    fruit_nerf/fruit_nerf.py                                :594-597   get_outputs: sigmoid -> heaviside(. - 0.9, 0) -> colormap
+                                                            :488-492   get_export_outputs: the per-sample label
+                                                            :178, :603-608  the BCE loss object and get_loss_dict's two terms
+                                                                        (`self.rgb_loss` = upstream's alias of torch.nn.MSELoss)
+    fruit_nerf/export/exporter_utils.py                     :96-153    sample_volume's per-call masks, gathers and colours, with
+                                                                        a pipeline object that hands back seeded model outputs
+    fruit_nerf/export/exporter_utils_nerfacto.py            :156-180   generate_point_cloud: point = o + d * depth, fruit mask
+                                                            :221-225   the re-orientation of the normals (o3d's Vector3dVector is
+                                                                        a container: the identity here)
+    segmentation/segmenter.py                               cluster_kmeans :28-45 (scikit-learn IS installed), on an object with
+                                                            a `points` array
+
 Nothing of the reference is copied into the repository: the fixture holds inputs and outputs only.  The oracle
 (``oracle/zbuffer.py``, ``oracle/rays.py``), the host mirrors (``cropnerf_amd/segmentation/merger.py``,
 ``fruit_nerf/data/fruit_datamanager.py``) and the HIP kernels (``cn_depth_project``, ``cn_zbuffer_update*``,
@@ -300,6 +316,146 @@ def schedule_cases(out):
     out["anneal_config"] = np.array([cfg.proposal_weights_anneal_slope, cfg.proposal_weights_anneal_max_num_iters], dtype=np.float64)
 
 
+def statement_block(path, first, last):
+    """A code object of the statements of the module at `path` that lie between source lines `first` and `last` (inclusive),
+    taken from the innermost statement list that holds them -- the reference's own AST nodes, nothing edited."""
+    with open(path, encoding="utf-8") as f:
+        tree = ast.parse(f.read(), filename=path)
+
+    def pick(body):
+        sel = [n for n in body if first <= n.lineno and n.end_lineno <= last]
+        if sel:
+            return sel
+        for n in body:
+            if n.lineno <= first and last <= n.end_lineno:
+                for field in ("body", "orelse", "finalbody"):
+                    sub = getattr(n, field, None)
+                    if isinstance(sub, list) and sub and isinstance(sub[0], ast.stmt):
+                        got = pick(sub)
+                        if got:
+                            return got
+        return []
+
+    sel = pick(tree.body)
+    if not sel:
+        raise RuntimeError(f"{path}: no statements between lines {first} and {last}")
+    return compile(ast.Module(body=sel, type_ignores=[]), path, "exec")
+
+
+def colormap_cases(out):
+    """a13: `Semantics.colors` as the dataparser builds it (:248-254) and the colormap statements of get_outputs (:594-597) and
+    get_export_outputs (:488-492) on seeded logits -- including the threshold logit ln 9 itself and its float32 neighbours."""
+    ns = {"torch": torch}
+    exec(statement_block(f"{REF}/fruit_nerf/data/cotton_nerf_dataparser.py", 248, 254), ns)
+    colors = ns["colors"]
+    g = torch.Generator().manual_seed(31)
+    ln9 = torch.tensor(9.0).log()
+    edge = torch.stack([ln9, torch.nextafter(ln9, torch.tensor(10.0)), torch.nextafter(ln9, torch.tensor(0.0)),
+                        ln9 + 1e-4, ln9 - 1e-4, torch.tensor(0.0), torch.tensor(-30.0), torch.tensor(30.0)])
+    logits = torch.cat([edge, torch.randn(248, generator=g) * 3.0 + 2.0])[:, None]
+    ns2 = {"torch": torch, "outputs": {"semantics": logits.clone()}, "self": Record(colormap=colors.clone(), device="cpu")}
+    exec(statement_block(f"{REF}/fruit_nerf/fruit_nerf.py", 594, 597), ns2)
+    out["cm_classes"] = np.array(ns["classes"])
+    out["cm_colors"] = colors.numpy()
+    out["cm_logits"] = logits.numpy()
+    out["cm_colormap"] = ns2["outputs"]["semantics_colormap"].numpy()
+    ns3 = {"torch": torch, "outputs": {"semantics": torch.randn(16, 24, generator=g) * 3.0 + 2.0}}
+    out["cm_export_logits"] = ns3["outputs"]["semantics"].numpy().copy()
+    exec(statement_block(f"{REF}/fruit_nerf/fruit_nerf.py", 488, 492), ns3)
+    out["cm_export_labels"] = ns3["outputs"]["semantics_colormap"].numpy()
+
+
+def loss_cases(out):
+    """a18: the loss object the reference constructs itself (:178) and the two data terms of get_loss_dict (:603-608; the
+    interlevel term and the camera optimiser's are upstream code).  The image carries an alpha channel: `image[:, :3]`."""
+    g = torch.Generator().manual_seed(32)
+    R = 192
+    fake = Record(config=Record(semantic_loss_weight=1.0), device="cpu", rgb_loss=torch.nn.MSELoss())
+    exec(statement_block(f"{REF}/fruit_nerf/fruit_nerf.py", 178, 178), {"torch": torch, "self": fake})
+    batch = {"image": torch.rand(R, 4, generator=g), "fruit_mask": (torch.rand(R, 1, generator=g) > 0.6).float()}
+    outputs = {"rgb": torch.rand(R, 3, generator=g), "semantics": torch.randn(R, 1, generator=g) * 4.0}
+    ns = {"torch": torch, "self": fake, "batch": batch, "outputs": outputs, "loss_dict": {}}
+    exec(statement_block(f"{REF}/fruit_nerf/fruit_nerf.py", 603, 608), ns)
+    out["loss_image"], out["loss_mask"] = batch["image"].numpy(), batch["fruit_mask"].numpy()
+    out["loss_rgb"], out["loss_sem"] = outputs["rgb"].numpy(), outputs["semantics"].numpy()
+    out["loss_values"] = np.array([float(ns["loss_dict"]["rgb_loss"]), float(ns["loss_dict"]["semantics_loss"])], dtype=np.float64)
+
+
+def sample_volume_cases(out):
+    """a16: one pass of sample_volume's loop body (:96-153) -- thresholds `semantic >= 3`, `density >= 70`,
+    `semantics_colormap >= 0.999`, the three point sets and their four-channel colours -- on seeded model outputs with values ON
+    the thresholds."""
+    g = torch.Generator().manual_seed(33)
+    R, S = 24, 40
+    sem = torch.randn(R, S, generator=g) * 3.0 + 1.5
+    den = torch.rand(R, S, generator=g) * 140.0
+    sem[0, :4] = torch.tensor([3.0, 2.9999998, 3.0000002, 3.0])
+    den[0, :4] = torch.tensor([70.0, 70.0, 69.99999, 70.00001])
+    lab = torch.heaviside(torch.sigmoid(sem) - 0.9, torch.tensor(0.0)).to(torch.long)  # (what get_export_outputs hands on)
+    outputs = {"point_location": torch.rand(R, S, 3, generator=g) * 2 - 1, "semantics": sem, "semantics_colormap": lab,
+               "density": den, "rgb": torch.rand(R, S, 3, generator=g)}
+    pipeline = Record(datamanager=Record(next_sample_volume=lambda step: (Record(), None)), model=lambda rb: outputs)
+    lists = {k: [] for k in ("points_sem", "points_only_sem", "points_den", "points_sem_colormap", "color_semantics",
+                             "color_only_semantics", "color_semantics_colormap", "densities")}
+    ns = {"torch": torch, "pipeline": pipeline, "rgb_flag": True, **lists}
+    exec(statement_block(f"{REF}/fruit_nerf/export/exporter_utils.py", 96, 153), ns)
+    for k in ("point_location", "semantics", "semantics_colormap", "density", "rgb"):
+        out[f"sv_in_{k}"] = outputs[k].numpy()
+    for name, pk, ck in (("semantic_colormap", "points_sem_colormap", "color_semantics_colormap"),
+                         ("semantic", "points_sem", "color_semantics"), ("density", "points_den", "densities")):
+        assert len(ns[pk]) == 1 and len(ns[ck]) == 1
+        out[f"sv_{name}_points"] = ns[pk][0].numpy()
+        out[f"sv_{name}_colors"] = ns[ck][0].numpy()
+
+
+def pointcloud_cases(out):
+    """a17: generate_point_cloud's per-call statements (:156-180: point = origin + direction * depth, kept where
+    `semantics_colormap[:, 0] > 0`; no crop box, no model normals) and the re-orientation of the normals (:221-225)."""
+    g = torch.Generator().manual_seed(34)
+    R = 300
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=-1)
+    rb = Record(origins=torch.randn(R, 3, generator=g) * 0.3, directions=d)
+    depth = torch.rand(R, 1, generator=g) * 2.0 + 0.1
+    cmap = (torch.rand(R, 1, generator=g) > 0.7).float().repeat(1, 3)
+    rgba = torch.rand(R, 4, generator=g)
+    lists = {"points": [], "rgbs": [], "view_directions": [], "normals": []}
+    ns = {"torch": torch, "ray_bundle": rb, "depth": depth, "outputs": {"semantics_colormap": cmap}, "rgba": rgba,
+          "only_semantics": True, "normal": None, "crop_obb": None, "progress": Record(advance=lambda *a: None), "task": 0, **lists}
+    exec(statement_block(f"{REF}/fruit_nerf/export/exporter_utils_nerfacto.py", 156, 180), ns)
+    out["pc_origins"], out["pc_directions"], out["pc_depth"] = rb.origins.numpy(), d.numpy(), depth.numpy()
+    out["pc_colormap"], out["pc_rgba"] = cmap.numpy(), rgba.numpy()
+    out["pc_points"], out["pc_rgbs"] = ns["points"][0].numpy(), ns["rgbs"][0].numpy()
+    out["pc_view_directions"] = ns["view_directions"][0].numpy()
+    # re-orientation: unit normals (float64, as open3d holds them) against the kept view directions
+    n = ns["points"][0].shape[0]
+    nrm = torch.nn.functional.normalize(torch.randn(n, 3, generator=g, dtype=torch.float64), dim=-1).numpy()
+    nrm[:3] = ns["view_directions"][0][:3].double().numpy() * np.array([[1.0], [-1.0], [0.0]])  # along, against, zero
+    pcd = Record(normals=nrm.copy())
+    o3d = Record(utility=Record(Vector3dVector=lambda a: a))
+    ns2 = {"torch": torch, "np": np, "o3d": o3d, "pcd": pcd, "reorient_normals": True,
+           "view_directions": ns["view_directions"][0].clone()}
+    exec(statement_block(f"{REF}/fruit_nerf/export/exporter_utils_nerfacto.py", 221, 225), ns2)
+    out["pc_normals_in"] = nrm
+    out["pc_normals_out"] = np.asarray(pcd.normals)
+
+
+def kmeans_cases(out):
+    """f2: cluster_kmeans (segmentation/segmenter.py:28-45; consider_normals=False) -- the KMeans configuration the segmenter
+    splits every super-cluster with -- on three seeded clouds."""
+    from sklearn.cluster import KMeans
+
+    ns = extract(f"{REF}/segmentation/segmenter.py", {"cluster_kmeans"}, {"np": np, "KMeans": KMeans})
+    rng = np.random.default_rng(35)
+    case = 0
+    for k, n in ((2, 400), (3, 900), (5, 2500)):
+        centres = rng.uniform(-0.5, 0.5, size=(k, 3))
+        pts = np.concatenate([c + rng.normal(scale=0.04 + 0.02 * j, size=(n // k, 3)) for j, c in enumerate(centres)])
+        labels = ns["cluster_kmeans"](Record(points=pts), k=k)
+        out[f"km_{case}_points"], out[f"km_{case}_k"], out[f"km_{case}_labels"] = pts, np.array(k), np.asarray(labels)
+        case += 1
+    out["num_km"] = np.array(case)
+
+
 def main():
     out = {}
     projection_cases(out)
@@ -308,6 +464,11 @@ def main():
     sampler_cases(out)
     ortho_cases(out)
     schedule_cases(out)
+    colormap_cases(out)
+    loss_cases(out)
+    sample_volume_cases(out)
+    pointcloud_cases(out)
+    kmeans_cases(out)
     path = os.path.join(HERE, "reference_functions.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path), "bytes", len(out), "arrays")

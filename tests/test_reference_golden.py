@@ -11,6 +11,13 @@
   ``UniformSamplerWithNoise.generate_ray_samples`` (``fruit_nerf/components/ray_samplers.py:54-104``) in eval and with both
   kinds of training jitter -- and ``oracle/rays.py: ortho_rays`` / ``cn_raygen_ortho`` against the reference's
   ``OrthographicRayGenerator`` (``fruit_nerf/components/ray_generators.py:22-66``).
+* (round 5) STATEMENT BLOCKS of the hot path's own functions, executed from the reference's AST on seeded tensors: the
+  semantics colormap of ``get_outputs`` / ``get_export_outputs`` and the dataparser's colour table (a13:
+  ``fruit_nerf.py:594-597,488-492``, ``data/cotton_nerf_dataparser.py:248-254``), ``get_loss_dict``'s two data terms (a18:
+  ``:178,603-608``), ``sample_volume``'s masks and point sets (a16: ``export/exporter_utils.py:96-153``),
+  ``generate_point_cloud``'s point / mask step and the re-orientation of the normals (a17:
+  ``export/exporter_utils_nerfacto.py:156-180,221-225``), and ``cluster_kmeans`` (f2: ``segmentation/segmenter.py:28-45``) --
+  against the oracle on the CPU and against the HIP kernels on the device.
 """
 
 import os
@@ -276,3 +283,151 @@ def test_trainer_and_sampler_follow_the_references_schedules(gold):
                                   (64, 32), 24, anneal=a)
         ref_eu = torch.cat([ref[0].starts[..., 0], ref[0].ends[:, -1:, 0]], -1)
         assert_close(got["euclidean_bins"], ref_eu, 2e-3, 2e-4, f"final bins at anneal {a:.4f}", frac_ok=0.99)
+
+
+# ------------------------------------------------------------------------------------------ round 5: statement blocks
+def _rows_sorted(a):
+    a = np.asarray(a)
+    return a[np.lexsort(a.T[::-1])]
+
+
+def test_oracle_colormap_reproduces_the_reference(gold):
+    from oracle import render as OR
+
+    colors = torch.from_numpy(gold["cm_colors"])
+    assert list(gold["cm_classes"]) == ["apple", "stuff"] and colors.tolist() == [0.0, 1.0]
+    got = OR.semantics_colormap(torch.from_numpy(gold["cm_logits"]), colors)
+    assert np.array_equal(got.numpy(), gold["cm_colormap"])  # every logit, the threshold ln 9 and its neighbours included
+    assert set(np.unique(gold["cm_colormap"])) == {0.0, 1.0}
+    lab = OR.semantics_colormap(torch.from_numpy(gold["cm_export_logits"])[..., None], repeat3=False)[..., 0]
+    assert np.array_equal(lab.numpy().astype(np.int64), gold["cm_export_labels"])
+    # the product's Semantics carries the same table (data/cotton_nerf_dataparser.py:248-254)
+    from cropnerf_amd.fruit_nerf.fruit_nerf import Semantics
+
+    sm = Semantics()
+    assert list(sm.classes) == ["apple", "stuff"] and sm.colors.tolist() == colors.tolist()
+
+
+def test_oracle_data_losses_reproduce_the_reference(gold):
+    from oracle import losses as OL
+
+    ld = OL.data_losses({"rgb": torch.from_numpy(gold["loss_rgb"]), "semantics": torch.from_numpy(gold["loss_sem"])},
+                        torch.from_numpy(gold["loss_image"]), torch.from_numpy(gold["loss_mask"]), 1.0)
+    assert float(ld["rgb_loss"]) == gold["loss_values"][0] and float(ld["semantics_loss"]) == gold["loss_values"][1]
+
+
+def test_oracle_export_masks_reproduce_the_reference(gold):
+    from oracle import model as OM
+
+    outputs = {k: torch.from_numpy(gold[f"sv_in_{k}"]) for k in ("point_location", "semantics", "semantics_colormap", "density", "rgb")}
+    res = OM.sample_volume_masks(outputs)
+    for name in ("semantic_colormap", "semantic", "density"):
+        assert np.array_equal(res[name]["points"].numpy(), gold[f"sv_{name}_points"]), name
+        assert np.array_equal(res[name]["colors"].numpy(), gold[f"sv_{name}_colors"]), name
+    assert gold["sv_semantic_points"].shape[0] > 0 and gold["sv_density_points"].shape[0] > gold["sv_semantic_points"].shape[0]
+
+
+def test_oracle_pointcloud_step_and_reorientation_reproduce_the_reference(gold):
+    from oracle import model as OM
+    from oracle import normals as ON
+    from oracle import rays as ORY
+
+    R = gold["pc_origins"].shape[0]
+    rb = ORY.RayBundle(torch.from_numpy(gold["pc_origins"]), torch.from_numpy(gold["pc_directions"]), torch.zeros(R, 1), None)
+    pts, rgb, dirs = OM.pointcloud_from_outputs(rb, {"depth": torch.from_numpy(gold["pc_depth"]),
+                                                    "semantics_colormap": torch.from_numpy(gold["pc_colormap"]),
+                                                    "rgb": torch.from_numpy(gold["pc_rgba"])[:, :3]})
+    assert np.array_equal(pts.numpy(), gold["pc_points"]) and np.array_equal(rgb.numpy(), gold["pc_rgbs"])
+    assert np.array_equal(dirs.numpy(), gold["pc_view_directions"])
+    out, flipped = ON.reorient_normals(gold["pc_normals_in"], gold["pc_view_directions"])
+    assert np.array_equal(out, gold["pc_normals_out"])
+    assert flipped[0] and not flipped[1] and not flipped[2]  # along the view: flipped; against it, or zero: kept
+
+
+@pytest.mark.gpu
+def test_hip_colormap_reproduces_the_reference(gold):
+    """The composite epilogue's colormap (``cn_composite``) on the reference's own logits: one sample per ray with weight exactly 1
+    (density 1000 over a unit interval), so the rendered semantic logit IS the input logit."""
+    from cropnerf_amd import ops
+
+    logits = torch.from_numpy(gold["cm_logits"]).cuda()
+    R = logits.shape[0]
+    out = ops.composite(torch.zeros(R, 1, device="cuda"), torch.ones(R, 1, device="cuda"), torch.full((R, 1), 1000.0, device="cuda"),
+                        rgb=torch.zeros(R, 1, 3, device="cuda"), semantics=logits.reshape(R, 1, 1).contiguous())
+    assert torch.equal(out["semantics"].cpu(), torch.from_numpy(gold["cm_logits"]))
+    got, want = out["semantics_colormap"].cpu().numpy(), gold["cm_colormap"]
+    # the device's exp is not torch's to the last bit: a logit within 2 ulp of the threshold may fall on the other side
+    ln9 = float(np.log(9.0))
+    clear = np.abs(gold["cm_logits"][:, 0] - ln9) > 1e-6
+    assert clear.sum() >= 250 and np.array_equal(got[clear], want[clear])
+    assert set(np.unique(got)) <= {0.0, 1.0}
+
+
+@pytest.mark.gpu
+def test_hip_export_compaction_reproduces_the_reference(gold):
+    """``cn_export_compact`` on the reference's own seeded model outputs: the three point sets of ``sample_volume``
+    (``exporter_utils.py:96-153``), values ON the thresholds included, as sets (the device appends in its own order)."""
+    from cropnerf_amd import ops
+
+    t = {k: torch.from_numpy(gold[f"sv_in_{k}"]).cuda() for k in ("point_location", "semantics", "density", "rgb")}
+    n = t["semantics"].numel()
+    pts, cols, counts = ops.export_compact(t["point_location"].reshape(n, 3).contiguous(), t["rgb"].reshape(n, 3).contiguous(),
+                                           t["semantics"].reshape(n).contiguous(), t["density"].reshape(n).contiguous(), capacity=n)
+    counts = counts.cpu().tolist()
+    for i, name in enumerate(("semantic_colormap", "semantic", "density")):
+        want_p, want_c = gold[f"sv_{name}_points"], gold[f"sv_{name}_colors"]
+        assert counts[i] == want_p.shape[0], (name, counts[i], want_p.shape[0])
+        got = np.concatenate([pts[i][:counts[i]].cpu().numpy(), cols[i][:counts[i]].cpu().numpy()], axis=1)
+        want = np.concatenate([want_p, want_c], axis=1)
+        got, want = _rows_sorted(got), _rows_sorted(want)
+        assert np.array_equal(got[:, :6], want[:, :6]), name          # positions and rgb: copies
+        assert np.abs(got[:, 6] - want[:, 6]).max() <= 2e-7, name      # the sigmoid channel: the device's exp
+
+
+@pytest.mark.gpu
+def test_hip_pointcloud_step_and_reorientation_reproduce_the_reference(gold):
+    from cropnerf_amd import ops
+
+    o, d, depth = (torch.from_numpy(gold[k]).cuda() for k in ("pc_origins", "pc_directions", "pc_depth"))
+    rgb = torch.from_numpy(gold["pc_rgba"])[:, :3].contiguous().cuda()
+    cmap = torch.from_numpy(gold["pc_colormap"]).cuda()
+    pts, cols, dirs, count = ops.pointcloud_compact(o, d, depth, rgb, cmap, capacity=o.shape[0])
+    n = int(count.item())
+    assert n == gold["pc_points"].shape[0]
+    got = _rows_sorted(np.concatenate([pts[:n].cpu().numpy(), cols[:n].cpu().numpy(), dirs[:n].cpu().numpy()], axis=1))
+    want = _rows_sorted(np.concatenate([gold["pc_points"], gold["pc_rgbs"], gold["pc_view_directions"]], axis=1))
+    assert np.abs(got[:, :3] - want[:, :3]).max() <= 2.4e-7  # o + d * depth: an fma on the device, mul + add in torch
+    assert np.array_equal(got[:, 3:], want[:, 3:])
+    out, flipped = ops.reorient_normals(torch.from_numpy(gold["pc_normals_in"]).cuda(), torch.from_numpy(gold["pc_view_directions"]).cuda())
+    assert np.array_equal(out.cpu().numpy(), gold["pc_normals_out"])
+
+
+@pytest.mark.gpu
+def test_hip_data_losses_reproduce_the_reference(gold):
+    """``cn_train_render_backward`` + ``cn_train_epilogue`` on the reference's own loss inputs: one sample per ray with weight
+    exactly 1, so the rendered colour and logit are the inputs and the two loss values are ``get_loss_dict``'s."""
+    from cropnerf_amd import ops
+
+    rgb, sem = torch.from_numpy(gold["loss_rgb"]).cuda(), torch.from_numpy(gold["loss_sem"]).cuda()
+    image = torch.from_numpy(gold["loss_image"])[:, :3].contiguous().cuda()
+    mask = torch.from_numpy(gold["loss_mask"]).cuda()
+    R = rgb.shape[0]
+    sums = torch.zeros(5, device="cuda")
+    out = ops.train_render_backward(torch.zeros(R, 1, device="cuda"), torch.ones(R, 1, device="cuda"),
+                                    torch.full((R, 1), 1000.0, device="cuda"), rgb.reshape(R, 1, 3).contiguous(),
+                                    sem.reshape(R, 1, 1).contiguous(), image, mask, 1.0, sums)
+    assert torch.equal(out["rgb"], rgb) and torch.equal(out["semantics"], sem)
+    ep = ops.train_epilogue(sums[:4], R, 1, 1.0, 1.0, None).cpu()
+    assert abs(float(ep[0]) - gold["loss_values"][0]) <= 2e-6 * gold["loss_values"][0]
+    assert abs(float(ep[1]) - gold["loss_values"][1]) <= 2e-6 * gold["loss_values"][1]
+
+
+@pytest.mark.gpu
+def test_device_kmeans_reproduces_the_references_cluster_kmeans(gold):
+    """``segmentation/segmenter.py:28-45`` executed from source (scikit-learn's KMeans with the reference's arguments) against
+    the product's ``cluster_kmeans`` (scikit-learn's seeding on the host, Lloyd iterations on the device): the same labels."""
+    from cropnerf_amd.segmentation.segmenter import cluster_kmeans
+
+    for c in range(int(gold["num_km"])):
+        labels = cluster_kmeans(gold[f"km_{c}_points"], k=int(gold[f"km_{c}_k"]))
+        assert np.array_equal(np.asarray(labels), gold[f"km_{c}_labels"]), c
