@@ -1136,6 +1136,43 @@ def subsystem_timings(args, params, device):
     out["eval_image_800"]["tcnn_f16_mode"] = {
         "ms_per_image": round(t16 * 1e3, 3), "spread_ms": {"min": round(ts16[0] * 1e3, 3), "max": round(ts16[-1] * 1e3, 3), "images": len(ts16)},
         "note": "tcnn layout, fp16 tables (random values), matrix_precision = f16: what an imported reference checkpoint renders as"}
+    del m16
+    # ---- the other two method specifications of the plugin (fruit_nerf_config.py:66-172) on the shape-generic kernels ---------------
+    # fruit_nerf_method_big: geo 30, 3 x 128 semantic layers, 2^21-entry levels, (512, 256) proposal + 128 field samples per ray,
+    # 8 192-ray training batches; fruit_nerf_method_huge: the 7-level second proposal network, 16 384-ray batches, no pose group.
+    from cropnerf_amd.fruit_nerf import fruit_nerf_config as FC
+    from cropnerf_amd.fruit_nerf.trainer import FruitTrainer, groups_from_spec
+
+    gs = {}
+    g2 = torch.Generator().manual_seed(5)
+    cams8 = Cameras(c2w[:8], intr[:8, 0], intr[:8, 1], intr[:8, 2], intr[:8, 3], H, W).to(device)
+    for short, spec_name in (("big", "fruit_nerf_big"), ("huge", "fruit_nerf_huge")):
+        tc_ = FC.NATIVE_METHODS[spec_name].config
+        mcfg = tc_.pipeline.model
+        mg = FruitModel(mcfg, box, 8, {"semantics": Semantics()}, device=device, test_mode="inference")
+        for k_, v_ in mg.params.items():
+            if k_.endswith("hash_table"):
+                v_.mul_(100.0)  # (the 1e-3 initialisation is an empty volume)
+        rb_ = cams8.generate_rays(0, keep_shape=False, aabb_box=box)[:65536]
+        mg(rb_)
+        tr_, _ = wall(lambda: [mg(rb_) for _ in range(3)])
+        mg.training = True
+        trn = FruitTrainer(mg, groups_from_spec(tc_.optimizers))
+        Rt = int(tc_.pipeline.datamanager.train_num_rays_per_batch)
+        idx_ = torch.floor(torch.rand(Rt, 3, generator=g2) * torch.tensor([8.0, H, W])).long().to(device)
+        rays_t = cams8.generate_rays(idx_)
+        batch_t = {"image": torch.rand(Rt, 3, generator=g2).to(device), "fruit_mask": (torch.rand(Rt, 1, generator=g2) > 0.5).float().to(device)}
+        for _ in range(2):
+            trn.train_iteration(rays_t, batch_t)
+        tt_, _ = wall(lambda: [trn.train_iteration(rays_t, batch_t) for _ in range(5)])
+        gs[f"{short}_render_ms"] = round(tr_ / 3 * 1e3, 3)
+        gs[f"{short}_train_ms"] = round(tt_ / 5 * 1e3, 3)
+        gs[f"{short}_train_rays"] = Rt
+        gs[f"{short}_samples_per_ray"] = {"proposal": list(mcfg.num_proposal_samples_per_ray), "field": mcfg.num_nerf_samples_per_ray}
+        del trn, mg
+    gs["workload"] = ("one 65 536-ray inference call and one training iteration at the method's own batch size, shape-generic "
+                      "kernels (cn_field_eval / cn_field_backward_general), random-init model with the tables scaled x100")
+    out["generic_shapes"] = gs
     return out
 
 
