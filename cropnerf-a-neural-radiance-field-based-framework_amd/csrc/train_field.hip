@@ -199,25 +199,13 @@ __device__ __forceinline__ void hash_level_backward(float* __restrict__ gtab, co
     const float a10 = dpp_f32<CTRL>(v0[1]), a11 = dpp_f32<CTRL>(v1[1]);                              \
     const unsigned es = (ql & 2) ? e1 : e0;                                                          \
     const float val = (ql & 2) ? ((ql & 1) ? a11 : a10) : ((ql & 1) ? a01 : a00);                    \
-    CN_QUAD_ADD(es, ql, val)                                                                         \
+    if (es != 0xffffffffu) cn_atomic_add(gtab + 2 * (size_t)es + (ql & 1), val);                         \
   }
-#ifdef CN_ABL_U64_SCATTER  // timing only (wrong results): the x-edge as 64-bit INTEGER atomics (two lanes x 8 bytes), with the
-  // float -> fixed-point conversion a real 64-bit accumulator would pay (tools/atomic_kinds_microbench.hip: 23.7e9 against
-  // 21.1e9 requests/s) -- the probe behind DESIGN.md 4.18's "integer accumulator" paragraph
-#define CN_QUAD_ADD(es, ql, val)                                                                                       \
-  if ((es) != 0xffffffffu && !((ql) & 1))                                                                              \
-    atomicAdd(reinterpret_cast<unsigned long long*>(gtab + 2 * (size_t)(es)),                                           \
-              (unsigned long long)__double2ll_rn((double)(val) * 1152921504606846976.0));
-#else
-#define CN_QUAD_ADD(es, ql, val) \
-  if ((es) != 0xffffffffu) cn_atomic_add(gtab + 2 * (size_t)(es) + ((ql) & 1), (val));
-#endif
     CN_QUAD_ROUND(0x00)  // quad_perm [0,0,0,0]
     CN_QUAD_ROUND(0x55)  // [1,1,1,1]
     CN_QUAD_ROUND(0xAA)  // [2,2,2,2]
     CN_QUAD_ROUND(0xFF)  // [3,3,3,3]
 #undef CN_QUAD_ROUND
-#undef CN_QUAD_ADD
   }
   // (History, measured at 4096 rays: one atomic per float from the owning lane 2.73 ms; the two features of an entry from
   // two adjacent lanes of one instruction 1.73 ms; this x-edge form 1.30 ms.  The earlier forms were removed.)
