@@ -89,6 +89,12 @@ class ProjectionJob(C.Structure):
                 ("camera_index", C.c_int32), ("reserved", C.c_int32), ("slot_offset", C.c_int64)]
 
 
+class PointGrid(C.Structure):
+    """``cn_point_grid``: the two-level grid of the k-nearest passes"""
+    _fields_ = [("top", C.c_int32 * 3), ("sub", C.c_int32), ("fine_rings", C.c_int32), ("origin", C.c_float * 3),
+                ("top_cell_size", C.c_float), ("top_rank", C.c_void_p), ("cell_start", C.c_void_p)]
+
+
 class InterlevelLevel(C.Structure):
     """``cn_interlevel_level`` (a host array read by ``cn_interlevel_backward_levels`` at call time)"""
     _fields_ = [("spacing_bins", C.c_void_p), ("starts", C.c_void_p), ("ends", C.c_void_p), ("density", C.c_void_p),
@@ -175,6 +181,8 @@ SIGNATURES = {
     "cn_zbuffer_update": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, _P, _P, _P, _P, C.c_size_t, _P]),
     "cn_knn_mean_distance": (C.c_int, [_P, _P, _I32, _I32, _I32, _F, _F, _F, _F, _I64, _I32, _P, _P]),
     "cn_estimate_normals": (C.c_int, [_P, _P, _I32, _I32, _I32, _F, _F, _F, _F, _I64, _I32, _P, _P, _P]),
+    "cn_knn_mean_distance_grid": (C.c_int, [_P, C.POINTER(PointGrid), _I64, _I32, _P, _P]),
+    "cn_estimate_normals_grid": (C.c_int, [_P, C.POINTER(PointGrid), _I64, _I32, _P, _P, _P]),
     "cn_segment_mean": (C.c_int, [_P, _P, _I64, _I32, _P, _P]),
     "cn_dbscan_workspace_bytes": (C.c_size_t, [_I64]),
     "cn_dbscan": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _F, _F, _I32, _P, _I64, _P, _P, _P, _P, C.c_size_t, _P]),

@@ -14,6 +14,140 @@ namespace cn {
 
 constexpr int KNN_MAX_K = 32;
 
+// ---- the two-level grid (cn_point_grid; round 5) -----------------------------------------------------------------------------------
+// An exported cloud is not a volume: 10^7 kept points are surfaces, or -- the C4 bench's synthetic cloud -- a few hundred clumps
+// with 27 000 points to a cell of any dense grid that fits memory (3.7 s for the outlier pass, 8.1 s for the normals).  Two levels:
+// a dense TOP grid (<= 128 cells per axis) whose occupied cells are numbered (top_rank), and sub^3 FINE cells inside every
+// occupied top cell, so that fine cells exist only where points are: fine cell (fx, fy, fz) = top cell (f / sub), sub cell
+// (f % sub), its points [cell_start[rank * sub^3 + sub index], cell_start[... + 1]).  The points are sorted by that key, so a
+// top cell's points are contiguous too -- which is what the search falls back on where the fine rings run out of points: after
+// `fine_rings` rings it starts over on the top grid (an isolated point would otherwise walk 2 048^3 empty fine cells).
+struct PointGrid {
+  int tx, ty, tz, sub, sub3, fine_rings;
+  float ox, oy, oz, H, h, inv_h, inv_H;
+  const int* __restrict__ top_rank;
+  const int* __restrict__ cell_start;
+};
+
+// Insert candidate (d, id) into the sorted lists (ascending d); WITH_IDX = false keeps distances only.
+template <int K, bool WITH_IDX>
+__device__ __forceinline__ void knn_insert(float (&best)[K], int (&bidx)[WITH_IDX ? K : 1], float d, int id) {
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const bool lt = d < best[j];
+    const float keep = lt ? d : best[j];
+    d = lt ? best[j] : d;
+    best[j] = keep;
+    if (WITH_IDX) {
+      const int keep_id = lt ? id : bidx[j];
+      id = lt ? bidx[j] : id;
+      bidx[j] = keep_id;
+    }
+  }
+}
+
+template <int K, bool WITH_IDX>
+__device__ __forceinline__ void knn_scan(const float* __restrict__ pts, int lo, int hi, float px, float py, float pz,
+                                         float (&best)[K], int (&bidx)[WITH_IDX ? K : 1]) {
+  for (int q = lo; q < hi; ++q) {
+    const float ex = pts[3 * (long long)q] - px, ey = pts[3 * (long long)q + 1] - py, ez = pts[3 * (long long)q + 2] - pz;
+    const float d = ex * ex + ey * ey + ez * ez;
+    if (d < best[K - 1]) knn_insert<K, WITH_IDX>(best, bidx, d, q);
+  }
+}
+
+// the k_used nearest points of (px, py, pz) (squared distances ascending in best[]; indices in bidx[] with WITH_IDX)
+template <int K, bool WITH_IDX>
+__device__ __forceinline__ void knn_search(const PointGrid& g, const float* __restrict__ pts, float px, float py, float pz, int k_used,
+                                           float (&best)[K], int (&bidx)[WITH_IDX ? K : 1]) {
+  const int kk = k_used - 1 < K ? k_used - 1 : K - 1;
+  auto reset = [&]() {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      best[j] = 3.0e38f;
+      if (WITH_IDX) bidx[j] = -1;
+    }
+  };
+  reset();
+  const int fx_n = g.tx * g.sub, fy_n = g.ty * g.sub, fz_n = g.tz * g.sub;
+  const int cx = min(max((int)floorf((px - g.ox) * g.inv_h), 0), fx_n - 1);
+  const int cy = min(max((int)floorf((py - g.oy) * g.inv_h), 0), fy_n - 1);
+  const int cz = min(max((int)floorf((pz - g.oz) * g.inv_h), 0), fz_n - 1);
+  bool done = false;
+  for (int ring = 0; ring <= g.fine_rings && !done; ++ring) {
+    // the shell of fine cells at Chebyshev distance `ring` from the query's cell
+    for (int dz = -ring; dz <= ring; ++dz) {
+      const int z = cz + dz;
+      if (z < 0 || z >= fz_n) continue;
+      for (int dy = -ring; dy <= ring; ++dy) {
+        const int y = cy + dy;
+        if (y < 0 || y >= fy_n) continue;
+        const bool face = (dz == -ring || dz == ring || dy == -ring || dy == ring);
+        const int step = face ? 1 : max(2 * ring, 1);  // interior rows of the shell: only the two end cells
+        const int tzy = ((z / g.sub) * g.ty + (y / g.sub)) * g.tx;
+        const int szy = ((z % g.sub) * g.sub + (y % g.sub)) * g.sub;
+        for (int dx = -ring; dx <= ring; dx += step) {
+          const int x = cx + dx;
+          if (x < 0 || x >= fx_n) continue;
+          const int r = g.top_rank[tzy + x / g.sub];
+          if (r < 0) continue;
+          const long long c = (long long)r * g.sub3 + szy + x % g.sub;
+          knn_scan<K, WITH_IDX>(pts, g.cell_start[c], g.cell_start[c + 1], px, py, pz, best, bidx);
+        }
+      }
+    }
+    // everything outside the (2 ring + 1)^3 block is at least ring * h away (the point lies inside the centre cell)
+    const float reach = (float)ring * g.h;
+    done = ring >= 1 && best[kk] <= reach * reach;
+  }
+  if (done) return;
+  // not enough points within the fine rings: the same search on the top grid (whole top cells, contiguous point ranges)
+  reset();
+  const int tcx = cx / g.sub, tcy = cy / g.sub, tcz = cz / g.sub;
+  const int max_ring = max(g.tx, max(g.ty, g.tz));
+  for (int ring = 0; ring <= max_ring; ++ring) {
+    for (int dz = -ring; dz <= ring; ++dz) {
+      const int z = tcz + dz;
+      if (z < 0 || z >= g.tz) continue;
+      for (int dy = -ring; dy <= ring; ++dy) {
+        const int y = tcy + dy;
+        if (y < 0 || y >= g.ty) continue;
+        const bool face = (dz == -ring || dz == ring || dy == -ring || dy == ring);
+        const int step = face ? 1 : max(2 * ring, 1);
+        for (int dx = -ring; dx <= ring; dx += step) {
+          const int x = tcx + dx;
+          if (x < 0 || x >= g.tx) continue;
+          const int r = g.top_rank[(z * g.ty + y) * g.tx + x];
+          if (r < 0) continue;
+          knn_scan<K, WITH_IDX>(pts, g.cell_start[(long long)r * g.sub3], g.cell_start[(long long)(r + 1) * g.sub3], px, py, pz, best, bidx);
+        }
+      }
+    }
+    const float reach = (float)ring * g.H;
+    if (ring >= 1 && best[kk] <= reach * reach) break;
+  }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256)
+knn_mean_distance_grid_kernel(PointGrid g, const float* __restrict__ pts, long long n, int k_used, float* __restrict__ mean_out) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float best[K];
+    int none[1];
+    knn_search<K, false>(g, pts, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], k_used, best, none);
+    float sum = 0.f;
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      if (j < k_used && best[j] < 3.0e38f) {
+        sum += sqrtf(best[j]);
+        ++cnt;
+      }
+    }
+    mean_out[i] = cnt > 0 ? sum / (float)cnt : -1.f;
+  }
+}
+
 template <int K>
 __global__ void __launch_bounds__(256)
 knn_mean_distance_kernel(const float* __restrict__ pts /*sorted by cell*/, const int* __restrict__ cell_start,
@@ -225,6 +359,37 @@ __device__ inline void smallest_eigenvector(Sym3 C, double* n) {
   }
 }
 
+// covariance of the neighbours listed in bidx (cumulants in double, as open3d) and its smallest eigenvector; returns 1 where
+// fewer than three neighbours exist or the solver gives no direction (the normal is (0, 0, 1) then)
+template <int K>
+__device__ __forceinline__ int normal_of_neighbours(const float* __restrict__ pts, const int (&bidx)[K], int k_used, double* nv) {
+  double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+  int cnt = 0;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    if (j < k_used && bidx[j] >= 0) {
+      const double x = pts[3 * (long long)bidx[j]], y = pts[3 * (long long)bidx[j] + 1], z = pts[3 * (long long)bidx[j] + 2];
+      sx += x, sy += y, sz += z;
+      sxx += x * x, sxy += x * y, sxz += x * z, syy += y * y, syz += y * z, szz += z * z;
+      ++cnt;
+    }
+  }
+  nv[0] = nv[1] = nv[2] = 0.0;
+  int flag = 0;
+  if (cnt >= 3) {
+    const double m = (double)cnt;  // (divisions, as open3d's `cumulants /= n`: coincident points give an exactly zero matrix)
+    sx /= m, sy /= m, sz /= m;
+    Sym3 C{sxx / m - sx * sx, sxy / m - sx * sy, sxz / m - sx * sz, syy / m - sy * sy, syz / m - sy * sz,
+           szz / m - sz * sz};
+    smallest_eigenvector(C, nv);
+  }
+  if (nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2] == 0.0) {
+    nv[2] = 1.0;
+    flag = 1;
+  }
+  return flag;
+}
+
 template <int K>
 __global__ void __launch_bounds__(256)
 knn_normals_kernel(const float* __restrict__ pts /*sorted by cell*/, const int* __restrict__ cell_start, int gx, int gy, int gz,
@@ -279,30 +444,8 @@ knn_normals_kernel(const float* __restrict__ pts /*sorted by cell*/, const int* 
       const float reach = (float)ring * h;
       if (best[k_used - 1 < K ? k_used - 1 : K - 1] <= reach * reach && ring >= 1) break;
     }
-    double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
-    int cnt = 0;
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-      if (j < k_used && bidx[j] >= 0) {
-        const double x = pts[3 * (long long)bidx[j]], y = pts[3 * (long long)bidx[j] + 1], z = pts[3 * (long long)bidx[j] + 2];
-        sx += x, sy += y, sz += z;
-        sxx += x * x, sxy += x * y, sxz += x * z, syy += y * y, syz += y * z, szz += z * z;
-        ++cnt;
-      }
-    }
-    double nv[3] = {0.0, 0.0, 0.0};
-    int flag = 0;
-    if (cnt >= 3) {
-      const double m = (double)cnt;  // (divisions, as open3d's `cumulants /= n`: coincident points give an exactly zero matrix)
-      sx /= m, sy /= m, sz /= m;
-      Sym3 C{sxx / m - sx * sx, sxy / m - sx * sy, sxz / m - sx * sz, syy / m - sy * sy, syz / m - sy * sz,
-             szz / m - sz * sz};
-      smallest_eigenvector(C, nv);
-    }
-    if (nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2] == 0.0) {
-      nv[2] = 1.0;
-      flag = 1;
-    }
+    double nv[3];
+    const int flag = normal_of_neighbours<K>(pts, bidx, k_used, nv);
     normals[3 * i] = nv[0];
     normals[3 * i + 1] = nv[1];
     normals[3 * i + 2] = nv[2];
@@ -310,7 +453,75 @@ knn_normals_kernel(const float* __restrict__ pts /*sorted by cell*/, const int* 
   }
 }
 
+template <int K>
+__global__ void __launch_bounds__(256)
+knn_normals_grid_kernel(PointGrid g, const float* __restrict__ pts, long long n, int k_used, double* __restrict__ normals,
+                        int* __restrict__ flags) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float best[K];
+    int bidx[K];
+    knn_search<K, true>(g, pts, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], k_used, best, bidx);
+    double nv[3];
+    const int flag = normal_of_neighbours<K>(pts, bidx, k_used, nv);
+    normals[3 * i] = nv[0];
+    normals[3 * i + 1] = nv[1];
+    normals[3 * i + 2] = nv[2];
+    if (flags) flags[i] = flag;
+  }
+}
+
+static int make_point_grid(const cn_point_grid* grid, PointGrid* out, const char* who) {
+  CN_REQUIRE(grid && grid->top_rank && grid->cell_start, CN_ERR_INVALID, "%s: null grid", who);
+  CN_REQUIRE(grid->top[0] > 0 && grid->top[1] > 0 && grid->top[2] > 0 && grid->top[0] <= 1024 && grid->top[1] <= 1024 &&
+                 grid->top[2] <= 1024 && grid->sub >= 1 && grid->sub <= 64 && grid->top_cell_size > 0.f && grid->fine_rings >= 1,
+             CN_ERR_INVALID, "%s: bad grid (top %d x %d x %d, sub %d, top cell %g, fine rings %d)", who, grid->top[0], grid->top[1],
+             grid->top[2], grid->sub, (double)grid->top_cell_size, grid->fine_rings);
+  PointGrid g;
+  g.tx = grid->top[0];
+  g.ty = grid->top[1];
+  g.tz = grid->top[2];
+  g.sub = grid->sub;
+  g.sub3 = grid->sub * grid->sub * grid->sub;
+  g.fine_rings = grid->fine_rings;
+  g.ox = grid->origin[0];
+  g.oy = grid->origin[1];
+  g.oz = grid->origin[2];
+  g.H = grid->top_cell_size;
+  g.h = grid->top_cell_size / (float)grid->sub;
+  g.inv_h = 1.f / g.h;
+  g.inv_H = 1.f / g.H;
+  g.top_rank = grid->top_rank;
+  g.cell_start = grid->cell_start;
+  *out = g;
+  return CN_OK;
+}
+
 }  // namespace cn
+
+extern "C" int cn_knn_mean_distance_grid(const float* points_sorted, const cn_point_grid* grid, int64_t num_points,
+                                         int32_t nb_neighbors, float* mean_distance, cn_stream_t stream) {
+  CN_REQUIRE(nb_neighbors >= 1 && nb_neighbors <= cn::KNN_MAX_K, CN_ERR_UNSUPPORTED,
+             "cn_knn_mean_distance_grid: nb_neighbors %d (max %d)", nb_neighbors, cn::KNN_MAX_K);
+  if (num_points <= 0) return CN_OK;
+  CN_REQUIRE(points_sorted && mean_distance, CN_ERR_INVALID, "cn_knn_mean_distance_grid: null argument");
+  cn::PointGrid g;
+  if (int rc = cn::make_point_grid(grid, &g, "cn_knn_mean_distance_grid")) return rc;
+  hipLaunchKernelGGL(cn::knn_mean_distance_grid_kernel<cn::KNN_MAX_K>, dim3(cn::grid_for(num_points, 256, 1 << 16)), dim3(256), 0,
+                     cn::as_stream(stream), g, points_sorted, (long long)num_points, nb_neighbors, mean_distance);
+  return cn::check_launch("cn_knn_mean_distance_grid");
+}
+
+extern "C" int cn_estimate_normals_grid(const float* points_sorted, const cn_point_grid* grid, int64_t num_points, int32_t knn,
+                                        double* normals, int32_t* degenerate, cn_stream_t stream) {
+  CN_REQUIRE(knn >= 1 && knn <= cn::KNN_MAX_K, CN_ERR_UNSUPPORTED, "cn_estimate_normals_grid: knn %d (max %d)", knn, cn::KNN_MAX_K);
+  if (num_points <= 0) return CN_OK;
+  CN_REQUIRE(points_sorted && normals, CN_ERR_INVALID, "cn_estimate_normals_grid: null argument");
+  cn::PointGrid g;
+  if (int rc = cn::make_point_grid(grid, &g, "cn_estimate_normals_grid")) return rc;
+  hipLaunchKernelGGL(cn::knn_normals_grid_kernel<cn::KNN_MAX_K>, dim3(cn::grid_for(num_points, 256, 1 << 16)), dim3(256), 0,
+                     cn::as_stream(stream), g, points_sorted, (long long)num_points, knn, normals, degenerate);
+  return cn::check_launch("cn_estimate_normals_grid");
+}
 
 extern "C" int cn_estimate_normals(const float* points_sorted, const int32_t* cell_start, int32_t gx, int32_t gy, int32_t gz,
                                    float origin_x, float origin_y, float origin_z, float cell_size, int64_t num_points,

@@ -1043,74 +1043,76 @@ def zbuffer_update(z_buffer: Tensor, img: Tensor, xs: Tensor, ys: Tensor, zs: Te
 # statistical outlier removal (open3d remove_statistical_outlier as used by the point-cloud exporter)
 # --------------------------------------------------------------------------------------------------------------
 
-def _knn_grid(pts: Tensor, points_per_cell: float):
-    """The uniform grid of the k-nearest searches (torch plumbing: cell keys, sort, offsets): (sorted points, cell_start int32,
-    (gx, gy, gz), origin, cell size, order).
-
-    The cell size starts from the cloud's bounding volume (``points_per_cell`` points per cell if the points filled it) and is
-    then ADAPTED to the points per OCCUPIED cell: an exported cloud is surfaces, not a volume -- 10^7 kept points of the C4
-    bench lie on thin shells, 57 to an occupied cell of the volume-sized grid, ~1 500 candidates per query, 3.7 s for the
-    outlier pass and 8.1 s for the normals.  With n / occupied above twice the target the cell shrinks by
-    sqrt(target / occupancy) (points on a surface: occupancy ~ h^2) and the cloud is binned again, at most three times.  The
-    adapted grid keeps at most 320 cells per axis: a query's search widens ring by ring until its k-th neighbour is closer than
-    the ring, so an ISOLATED point (what the outlier pass exists for) visits up to every cell of the grid -- 3.3e7 at 320 per
-    axis, a tenth of a second for that one wave; a finer grid would trade the common case's time for that tail."""
+def _knn_grid(pts: Tensor, points_per_cell: float = 8.0, top_cells: int = 128):
+    """The two-level grid of the k-nearest passes (``cn_point_grid``; torch plumbing: cell keys, one sort, offsets).  A dense TOP
+    grid of at most ``top_cells`` cells per axis over the cloud's bounding box, its occupied cells numbered, and ``sub``^3 fine
+    cells inside each occupied one, ``sub`` chosen so that an occupied FINE cell holds about ``points_per_cell`` points: an
+    exported cloud is surfaces or clumps, not a volume -- the 10^7 kept points of the C4 bench sit in a few hundred cells of any
+    dense grid that fits memory, 27 000 to a cell.  Returns (sorted points, the ``L.PointGrid`` struct, order, keep-alive tensors)."""
     n = pts.shape[0]
     lo, hi = pts.min(dim=0).values, pts.max(dim=0).values
     ext = (hi - lo).clamp(min=1e-12).double()
-    h = float((ext.prod() * points_per_cell / n) ** (1.0 / 3.0))
-    h = max(h, float(ext.max()) / 1024.0)
-
-    def dims_for(h_):
-        return [max(1, min(1024, int(float(e) / h_) + 1)) for e in ext]
-
-    def widen(h_):
-        d = dims_for(h_)
-        while d[0] * d[1] * d[2] > (1 << 26):
-            h_ *= 1.26
-            d = dims_for(h_)
-        return h_, d
-
-    def bin_points(h_, d):
-        gx_, gy_, gz_ = d
-        cell = ((pts - lo) / h_).floor().to(torch.int64)
-        cell[:, 0].clamp_(0, gx_ - 1)
-        cell[:, 1].clamp_(0, gy_ - 1)
-        cell[:, 2].clamp_(0, gz_ - 1)
-        key = (cell[:, 2] * gy_ + cell[:, 1]) * gx_ + cell[:, 0]
-        key_sorted, order_ = torch.sort(key)
-        start = torch.searchsorted(key_sorted, torch.arange(gx_ * gy_ * gz_ + 1, device=pts.device)).to(torch.int32).contiguous()
-        return start, order_
-
-    h, dims = widen(h)
-    cell_start, order = bin_points(h, dims)
-    for _ in range(3):
-        occupied = int((cell_start[1:] > cell_start[:-1]).sum())
-        occupancy = n / max(occupied, 1)
-        if occupancy <= 2.0 * points_per_cell:
-            break
-        h_new, dims_new = widen(max(h * (points_per_cell / occupancy) ** 0.5, float(ext.max()) / 320.0))
-        if h_new >= 0.95 * h:
-            break
-        h, dims = h_new, dims_new
-        cell_start, order = bin_points(h, dims)
-    return pts[order].contiguous(), cell_start, tuple(dims), lo, h, order
+    # top cell: sized for points_per_cell points per cell if the cloud filled its box, at most top_cells per axis
+    H = float((ext.prod() * points_per_cell / n) ** (1.0 / 3.0))
+    H = max(H, float(ext.max()) / top_cells)
+    top = [max(1, min(top_cells, int(float(e) / H) + 1)) for e in ext]
+    tcell = ((pts - lo) / H).floor().to(torch.int64)
+    for a_ in range(3):
+        tcell[:, a_].clamp_(0, top[a_] - 1)
+    tkey = (tcell[:, 2] * top[1] + tcell[:, 1]) * top[0] + tcell[:, 0]
+    occ_keys, counts = torch.unique(tkey, return_counts=True)
+    occupied = int(occ_keys.numel())
+    # fine cells: points on a surface thin out with the SQUARE of the cell size; never more than 2^26 fine cells in all
+    occupancy = n / occupied
+    sub = 1
+    while sub < 64 and occupancy / (sub * sub) > 1.5 * points_per_cell and occupied * (2 * sub) ** 3 <= (1 << 26):
+        sub *= 2
+    top_rank = torch.full((top[0] * top[1] * top[2],), -1, dtype=torch.int32, device=pts.device)
+    top_rank[occ_keys] = torch.arange(occupied, dtype=torch.int32, device=pts.device)
+    h = H / sub
+    fcell = ((pts - lo) / h).floor().to(torch.int64)
+    for a_ in range(3):
+        fcell[:, a_].clamp_(0, top[a_] * sub - 1)
+    sub_idx = ((fcell[:, 2] % sub) * sub + (fcell[:, 1] % sub)) * sub + (fcell[:, 0] % sub)
+    # (the top cell of the FINE coordinates, so that both levels agree on points that sit on a cell face)
+    tkey2 = ((fcell[:, 2] // sub) * top[1] + (fcell[:, 1] // sub)) * top[0] + (fcell[:, 0] // sub)
+    rank = top_rank[tkey2].to(torch.int64)
+    if bool((rank < 0).any()):  # a point whose fine cell lies in a top cell the coarse binning found empty (rounding at a face)
+        extra = torch.unique(tkey2[rank < 0])
+        top_rank[extra] = torch.arange(occupied, occupied + extra.numel(), dtype=torch.int32, device=pts.device)
+        occupied += int(extra.numel())
+        rank = top_rank[tkey2].to(torch.int64)
+    key = rank * (sub ** 3) + sub_idx
+    key_sorted, order = torch.sort(key)
+    cell_start = torch.searchsorted(key_sorted, torch.arange(occupied * sub ** 3 + 1, device=pts.device)).to(torch.int32).contiguous()
+    pts_sorted = pts[order].contiguous()
+    g = L.PointGrid()
+    for a_ in range(3):
+        g.top[a_] = top[a_]
+        g.origin[a_] = float(lo[a_])
+    g.sub = sub
+    g.fine_rings = max(2, sub)
+    g.top_cell_size = H
+    g.top_rank = top_rank.data_ptr()
+    g.cell_start = cell_start.data_ptr()
+    return pts_sorted, g, order, (top_rank, cell_start)
 
 
 def estimate_normals(points: Tensor, knn: int = 30, points_per_cell: float = 8.0) -> Tuple[Tensor, Tensor]:
     """open3d ``PointCloud.estimate_normals()`` at its defaults (``KDTreeSearchParamKNN(30)``, fast 3 x 3 eigen-solver) on the
     device: (normals [N,3] float64 -- unit vectors, sign as the solver leaves it --, degenerate [N] bool: fewer than three
-    neighbours or a zero covariance, normal (0, 0, 1) there).  ``cn_estimate_normals`` on the grid of the outlier pass."""
+    neighbours or a zero covariance, normal (0, 0, 1) there).  ``cn_estimate_normals_grid`` on the two-level grid of the outlier
+    pass."""
     lib = L.load()
     pts = _f32(points.contiguous(), "points")
     n = pts.shape[0]
     if n == 0:
         return torch.empty(0, 3, dtype=torch.float64, device=pts.device), torch.empty(0, dtype=torch.bool, device=pts.device)
-    pts_sorted, cell_start, (gx, gy, gz), lo, h, order = _knn_grid(pts, points_per_cell)
+    pts_sorted, grid, order, keep = _knn_grid(pts, points_per_cell)
     nrm_sorted = torch.empty(n, 3, dtype=torch.float64, device=pts.device)
     deg_sorted = torch.empty(n, dtype=torch.int32, device=pts.device)
-    L.check(lib.cn_estimate_normals(_p(pts_sorted), _p(cell_start), gx, gy, gz, float(lo[0]), float(lo[1]), float(lo[2]), h, n,
-                                    int(knn), _p(nrm_sorted), _p(deg_sorted), _stream(pts)))
+    L.check(lib.cn_estimate_normals_grid(_p(pts_sorted), C.byref(grid), n, int(knn), _p(nrm_sorted), _p(deg_sorted), _stream(pts)))
+    del keep
     normals = torch.empty_like(nrm_sorted)
     normals[order] = nrm_sorted
     degenerate = torch.empty(n, dtype=torch.bool, device=pts.device)
@@ -1129,17 +1131,17 @@ def reorient_normals(normals: Tensor, view_directions: Tensor) -> Tuple[Tensor, 
 
 def knn_mean_distance(points: Tensor, nb_neighbors: int = 20, points_per_cell: float = 6.0) -> Tensor:
     """Mean distance of every point to its ``nb_neighbors`` nearest points (itself included), [N] float32, on a uniform
-    grid sized for about ``points_per_cell`` points per occupied cell (``_knn_grid``).  The binning (cell keys, sort, offsets) is
-    torch plumbing; the search is ``cn_knn_mean_distance``."""
+    two-level grid with about ``points_per_cell`` points per occupied fine cell (``_knn_grid``).  The binning (cell keys, sort,
+    offsets) is torch plumbing; the search is ``cn_knn_mean_distance_grid``."""
     lib = L.load()
     pts = _f32(points.contiguous(), "points")
     n = pts.shape[0]
     if n == 0:
         return torch.empty(0, device=pts.device)
-    pts_sorted, cell_start, (gx, gy, gz), lo, h, order = _knn_grid(pts, points_per_cell)
+    pts_sorted, grid, order, keep = _knn_grid(pts, points_per_cell)
     mean_sorted = torch.empty(n, device=pts.device)
-    L.check(lib.cn_knn_mean_distance(_p(pts_sorted), _p(cell_start), gx, gy, gz, float(lo[0]), float(lo[1]), float(lo[2]),
-                                     h, n, int(nb_neighbors), _p(mean_sorted), _stream(pts)))
+    L.check(lib.cn_knn_mean_distance_grid(_p(pts_sorted), C.byref(grid), n, int(nb_neighbors), _p(mean_sorted), _stream(pts)))
+    del keep
     out = torch.empty_like(mean_sorted)
     out[order] = mean_sorted
     return out

@@ -689,6 +689,27 @@ int cn_knn_mean_distance(const float* points_sorted, const int32_t* cell_start, 
                          float origin_x, float origin_y, float origin_z, float cell_size, int64_t num_points,
                          int32_t nb_neighbors, float* mean_distance, cn_stream_t stream);
 
+/* The same two passes on a TWO-LEVEL grid (round 5).  An exported cloud is surfaces -- or clumps: the cells of any dense grid
+ * that fits memory then hold thousands of points each.  cn_point_grid: a dense TOP grid (top[0] x top[1] x top[2] cells of
+ * top_cell_size, at most 1024 per axis) whose occupied cells are numbered in top_rank [top[2]*top[1]*top[0]] (linear index
+ * (z*top[1] + y)*top[0] + x; -1 = empty), and sub^3 FINE cells of top_cell_size / sub inside every occupied top cell: the points
+ * are sorted by (rank of their top cell) * sub^3 + ((z % sub)*sub + y % sub)*sub + x % sub of their fine cell, and cell_start
+ * [occupied * sub^3 + 1] holds the offsets.  A query searches fine rings (at most fine_rings of them), then -- an isolated
+ * point -- whole top cells.  Same results as the dense-grid entry points (the exact k nearest). */
+typedef struct cn_point_grid {
+  int32_t top[3];
+  int32_t sub;
+  int32_t fine_rings;
+  float origin[3];
+  float top_cell_size;
+  const int32_t* top_rank;
+  const int32_t* cell_start;
+} cn_point_grid;
+int cn_knn_mean_distance_grid(const float* points_sorted, const cn_point_grid* grid, int64_t num_points, int32_t nb_neighbors,
+                              float* mean_distance, cn_stream_t stream);
+int cn_estimate_normals_grid(const float* points_sorted, const cn_point_grid* grid, int64_t num_points, int32_t knn,
+                             double* normals, int32_t* degenerate, cn_stream_t stream);
+
 /* Normals of the exported cloud: open3d's PointCloud::EstimateNormals() at its defaults, as generate_point_cloud calls it
  * for `ns-export pointcloud --normal-method open3d` (fruit_nerf/export/exporter_utils_nerfacto.py:203-212; README.md:125).
  * Same grid as cn_knn_mean_distance.  normals [N,3] DOUBLE (sorted order): unit eigenvector of the smallest eigenvalue of

@@ -50,11 +50,11 @@ def test_binding_covers_every_declared_symbol(lib):
 BY_POINTER_STRUCTS = {"Grid": "cn_grid", "TcnnGridPlan": "cn_tcnn_grid_plan", "Mlp": "cn_mlp", "FieldParams": "cn_field_params",
                       "DensityParams": "cn_density_params", "ProposalLevelOut": "cn_proposal_level_out",
                       "Scene": "cn_scene", "RenderOpts": "cn_render_opts", "ProjectionJob": "cn_projection_job",
-                      "InterlevelLevel": "cn_interlevel_level"}
+                      "InterlevelLevel": "cn_interlevel_level", "PointGrid": "cn_point_grid"}
 
 
 def test_struct_layout_matches_header():
-    """sizeof AND the offset of every field of all ten by-pointer structs, as the C compiler lays out the header, against
+    """sizeof AND the offset of every field of all eleven by-pointer structs, as the C compiler lays out the header, against
     the ctypes mirrors of ``_lib.py`` -- the C program is generated from the mirrors' ``_fields_``, so a field that is
     missing, renamed or reordered on either side fails to compile or to compare."""
     import subprocess

@@ -15,8 +15,8 @@ pts[:1000] = torch.rand(1000, 3, device="cuda", generator=g) * 4 - 2  # some iso
 for name, fn in (("outlier mask (20 nn)", lambda: ops.statistical_outlier_mask(pts, 20, 10.0)), ("normals (30 nn)", lambda: ops.estimate_normals(pts, 30))):
     fn(); torch.cuda.synchronize(); t = time.perf_counter(); r = fn(); torch.cuda.synchronize()
     print(f"{name}: {N} points in {time.perf_counter() - t:.3f} s")
-_, _, dims, _, h, _ = ops._knn_grid(pts, 8.0)
-print("grid", dims, "cell", round(h, 5))
+_, g, _, _ = ops._knn_grid(pts, 8.0)
+print("top grid", list(g.top), "top cell", round(g.top_cell_size, 5), "sub", g.sub)
 # exactness on a subsample: the mean neighbour distance against scipy
 import numpy as np
 from scipy.spatial import cKDTree
