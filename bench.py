@@ -916,7 +916,8 @@ def subsystem_timings(args, params, device):
     t_nrm, nd = wall(lambda: ops.estimate_normals(pts_c4, 30))
     c4["normals"] = {"points": int(pts_c4.shape[0]), "seconds": round(t_nrm, 3), "points_per_sec": pts_c4.shape[0] / t_nrm,
                      "degenerate": int(nd[1].sum()), "outlier_pass_seconds": round(t_out, 3),
-                     "kernel": "knn_normals_kernel (uniform-grid 30-nearest search + fp64 covariance + closed-form 3x3 eigen-solve)"}
+                     "kernel": "knn_mean_distance_grid_kernel / knn_normals_grid_kernel on the two-level grid (binning included: torch sort, "
+                               "unique, offsets), 30-nearest search + fp64 covariance + closed-form 3x3 eigen-solve"}
     del pts_c4, nd
     c4["call_size_32768"] = export_case(32768, 1 << 16, 10_000_000)
     c4["one_call_per_launch_2048"] = export_case(2048, None, 1_000_000)  # the reference's loop shape, graph-replayed (round 3)
