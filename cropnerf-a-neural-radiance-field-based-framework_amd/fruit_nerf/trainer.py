@@ -503,9 +503,9 @@ class FruitTrainer:
         streams without a graph -- and removed.  Returns None when the iteration has to run eagerly (first two occurrences of
         a variant: warm-up, then capture).
 
-        The returned dictionary holds the graph's STATIC output tensors: they are valid until the next ``train_iteration`` of
-        the same variant overwrites them (an eager iteration returns fresh tensors) -- ``float(...)`` / ``.clone()`` what has to
-        outlive the call, as ``scripts/train.py`` does for its log line."""
+        The losses and metrics of the returned dictionary are a per-iteration copy; its per-ray tensors (``rgb``, ``semantics``,
+        ``accumulation``) are the graph's STATIC outputs, valid until the next ``train_iteration`` of the same variant overwrites
+        them (an eager iteration returns fresh tensors) -- ``.clone()`` what has to outlive the call."""
         m, cfg, dev = self.model, self.model.config, self.model.device
         rb = ray_bundle.flatten()
         R = rb.origins.shape[0]
@@ -589,6 +589,7 @@ class FruitTrainer:
             try:
                 with torch.cuda.graph(graph):
                     st["out"] = body()
+                    st["ep"] = self._epilogue  # this variant's static epilogue tensor (another variant captures its own)
             except Exception as e:  # capture is an optimisation: fall back to eager launches, loudly, for good
                 import sys
 
@@ -604,6 +605,18 @@ class FruitTrainer:
         else:
             stage_inputs()
         st["graph"].replay()
+        # the scalars a caller is most likely to keep (losses, metrics: views of the 8-float epilogue) are handed out as a COPY per
+        # iteration -- one 32-byte device copy -- so that a list of past iterations' losses stays what it was; the per-ray outputs
+        # (rgb, semantics, accumulation) are the graph's static tensors, valid until the next replay of this variant
+        ep = st["ep"].clone()
+        out = dict(st["out"])
+        out["loss_dict"] = {k: ep[i] for i, k in enumerate(("rgb_loss", "semantics_loss", "interlevel_loss")) if k in st["out"]["loss_dict"]}
+        if "camera_opt_regularizer" in st["out"]["loss_dict"]:
+            out["loss_dict"]["camera_opt_regularizer"] = ep[3]
+        md = {"psnr": ep[4], "distortion": ep[7]}
+        if self.train_pose:
+            md["camera_opt_translation"], md["camera_opt_rotation"] = ep[5], ep[6]
+        out["metrics_dict"] = md
         # ---- the host-side counters of optimizer_step / train_iteration ------------------------------------------------------------
         it = self.step
         self.step += 1
@@ -612,7 +625,7 @@ class FruitTrainer:
             self._steps_since_update = 0
         self._sampler_step = it
         self._steps_since_update += 1
-        return st["out"]
+        return out
 
     def train_iteration(self, ray_bundle: RayBundle, batch: Dict[str, Tensor]) -> Dict[str, Tensor]:
         if self._graph_eligible():

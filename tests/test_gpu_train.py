@@ -781,6 +781,31 @@ def test_graph_replay_equals_eager_bit_for_bit_in_deterministic_mode(monkeypatch
     assert float(hist_g[-1, 2]) < float(hist_g[0, 2])  # (sorted keys: camera_opt_regularizer, interlevel, rgb, semantics)
 
 
+def test_graph_replay_hands_out_its_losses_as_copies(monkeypatch):
+    """a replayed iteration wrote its losses into the graph's static tensors, so a caller that kept the dictionaries of
+    earlier iterations (to average or log them later) read the newest values in every one of them.  The losses and metrics are
+    now a per-iteration copy: what iteration i returned still holds iteration i's numbers after iteration i + 3."""
+    from cropnerf_amd.fruit_nerf.trainer import FruitTrainer
+
+    monkeypatch.setenv("CN_TRAIN_GRAPH", "1")
+    sc, idx, _, image, mask = _setup(seed=8, R=128)
+    model = _hip_model(sc)
+    model.training = True
+    tr = FruitTrainer(model, seed=4)
+    rays = _hip_rays(sc, idx)
+    batch = {"image": image.cuda(), "fruit_mask": mask.cuda()}
+    kept, at_the_time = [], []
+    for it in range(8):
+        out = tr.train_iteration(rays, batch)
+        kept.append(out)
+        at_the_time.append({k: float(v) for k, v in out["loss_dict"].items()} | {"psnr": float(out["metrics_dict"]["psnr"])})
+    assert any("graph" in st for st in tr._graphs.values())
+    for out, then in zip(kept, at_the_time):
+        now = {k: float(v) for k, v in out["loss_dict"].items()} | {"psnr": float(out["metrics_dict"]["psnr"])}
+        assert now == then
+    assert at_the_time[3]["rgb_loss"] != at_the_time[6]["rgb_loss"]
+
+
 def test_graphs_of_a_smaller_batch_survive_a_larger_one(monkeypatch):
     """A captured iteration holds the scatter scratch's address and layout as kernel arguments; a larger batch re-allocates
     the scratch.  The trainer drops the captured iterations then (they are captured again on their next occurrence), so
