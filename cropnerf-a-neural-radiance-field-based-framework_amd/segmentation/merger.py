@@ -37,12 +37,15 @@ def quantise_projection(img) -> "torch.Tensor":
 
 
 def process_super_cluster(wo_occ, visible, label_frames, binary_thresh: int = 100, frame_sampling_interval: int = 10,
-                          area_normalize: bool = False, device="cuda") -> Dict[int, Dict[str, np.ndarray]]:
+                          area_normalize: bool = False, device="cuda", plain_reliability: str = "ones"
+                          ) -> Dict[int, Dict[str, np.ndarray]]:
     """``process_super_cluster`` (``:273-333``) on arrays: ``wo_occ`` / ``visible`` [n_cams, k, H, W] (uint8 gray, or the
     float projection images, quantised as the PNG round trip does), ``label_frames`` [n_cams, H, W] uint8 instance labels.
     Every ``frame_sampling_interval``-th camera is used (the reference samples its directory listing the same way).  Returns
     the reference's ``cluster_prop``: per sub-cluster ``visible_area``, ``wo_occ_area``, ``wo_occ_area_norm``, ``label``,
-    ``label_overlap_area``, ``reliability`` (arrays over the cameras, ``eps`` / 0 where nothing was seen)."""
+    ``label_overlap_area``, ``reliability`` (arrays over the cameras, ``eps`` / 0 where nothing was seen).
+    ``plain_reliability``: the reliability without ``area_normalize`` -- ``"ones"`` (``merger.py:320``) or ``"overlap"``
+    = label-overlap area / un-occluded area (``depth_projection_based_merger.py:263``)."""
     import torch
 
     from .. import ops
@@ -76,7 +79,7 @@ def process_super_cluster(wo_occ, visible, label_frames, binary_thresh: int = 10
         va, wa, oa, ol = EPS * np.ones(n_cams), EPS * np.ones(n_cams), EPS * np.ones(n_cams), np.zeros(n_cams)
         va[ci], wa[ci], oa[ci], ol[ci] = vis_area[:, cid], wo_area[:, cid], overlap[:, cid], label[:, cid]
         wn = wa / wa.max()
-        rel = wn * (oa / wa) if area_normalize else np.ones_like(wa)
+        rel = wn * (oa / wa) if area_normalize else (oa / wa if plain_reliability == "overlap" else np.ones_like(wa))
         prop[cid] = {"visible_area": va, "wo_occ_area": wa, "wo_occ_area_norm": wn, "label": ol, "label_overlap_area": oa,
                      "reliability": rel}
     return prop

@@ -41,6 +41,7 @@ that holds only the libraries they use, and runs them on seeded inputs:
                                                                         a container: the identity here)
     segmentation/segmenter.py                               cluster_kmeans :28-45 (scikit-learn IS installed), on an object with
                                                             a `points` array
+    segmentation/depth_projection_based_merger.py           get_component :23-61, calc_affinity :275-297 (whole functions)
 
 Nothing of the reference is copied into the repository: the fixture holds inputs and outputs only.  The oracle
 (``oracle/zbuffer.py``, ``oracle/rays.py``), the host mirrors (``cropnerf_amd/segmentation/merger.py``,
@@ -456,6 +457,38 @@ def kmeans_cases(out):
     out["num_km"] = np.array(case)
 
 
+def depth_merger_cases(out):
+    """f3/f4: get_component of the depth-projection merger (segmentation/depth_projection_based_merger.py:23-61 -- unlike
+    merger.py's it keeps the edge WEIGHTS for the clique / bridge partitions and uses networkx's own label propagation) on
+    row-normalised affinities as its main() builds them (:330), and calc_affinity (:275-297) on seeded cluster properties."""
+    path = f"{REF}/segmentation/depth_projection_based_merger.py"
+    ns = extract(path, {"get_component", "calc_affinity"}, {"np": np, "nx": nx})
+    rng = np.random.default_rng(36)
+    case = 0
+    for n in (3, 5, 8):
+        for rep in range(3):
+            # sub-clusters of two or three fruits: every sub-cluster mostly carries its fruit's label, sometimes a neighbour's or
+            # background (0), so that every row of the affinity has a positive maximum, as real projections give
+            fruit = rng.integers(1, 4, size=n)
+            fruit[:2] = (1, 1)
+            labels = np.where(rng.uniform(size=(n, 12)) < 0.75, fruit[:, None], rng.integers(0, 4, size=(n, 12))).astype(np.float64)
+            rel = rng.uniform(0.2, 1.0, size=(n, 12))
+            prop = {i: {"label": labels[i], "reliability": rel[i]} for i in range(n)}
+            aff = ns["calc_affinity"](prop)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                norm = aff / np.abs(aff.max(axis=1, keepdims=True))
+            if not np.isfinite(norm).all():
+                continue
+            out[f"dpm{case}/labels"], out[f"dpm{case}/reliability"], out[f"dpm{case}/affinity"] = labels, rel, aff
+            for algo in ("clique", "bridge", "community"):
+                random.seed(100 + case)
+                k, lab = ns["get_component"](norm.copy(), algo)
+                out[f"dpm{case}/{algo}_count"] = np.array(k)
+                out[f"dpm{case}/{algo}_labels"] = np.asarray(lab)
+            case += 1
+    out["num_dpm"] = np.array(case)
+
+
 def main():
     out = {}
     projection_cases(out)
@@ -469,6 +502,7 @@ def main():
     sample_volume_cases(out)
     pointcloud_cases(out)
     kmeans_cases(out)
+    depth_merger_cases(out)
     path = os.path.join(HERE, "reference_functions.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path), "bytes", len(out), "arrays")

@@ -182,6 +182,13 @@ def test_device_process_super_cluster_matches_the_restated_reference(area_normal
     aff = merger.calc_affinity(got)
     n, labels = merger.get_component(aff, "clique")
     assert aff.shape == (k, k) and 1 <= n <= k and len(labels) == k
+    if not area_normalize:
+        # the depth-projection merger's reliability (depth_projection_based_merger.py:263): label overlap / un-occluded area
+        alt = merger.process_super_cluster(torch.from_numpy(wo), torch.from_numpy(vis), lab, 100, 4, False, plain_reliability="overlap")
+        for cid in range(k):
+            want = np.asarray(ref[cid]["label_overlap_area"], dtype=np.float64) / np.asarray(ref[cid]["wo_occ_area"], dtype=np.float64)
+            assert np.array_equal(alt[cid]["reliability"], want), cid
+            assert np.array_equal(got[cid]["reliability"], np.ones_like(want))
 
 
 @pytest.mark.gpu

@@ -74,3 +74,32 @@ def test_get_component_partitions():
         MG.get_component(a, "spectral")
     total, all_labels = MG.count_fruit([_props([[1, 1], [1, 1]]), _props([[1, 2], [2, 1], [0, 0]])], "clique")
     assert total == 1 + 3 and all_labels[1].min() == 2     # second super-cluster's labels are shifted past the first's
+
+
+def test_depth_projection_merger_graph_stage_reproduces_the_reference():
+    """``segmentation/depth_projection_based_merger.py``: its ``calc_affinity`` (``:275-297``) and its own ``get_component``
+    (``:23-61``: edge weights kept for clique / bridge, networkx's label propagation for community), executed from the
+    reference's source on seeded cluster properties (``tests/golden/make_golden_reference.py: depth_merger_cases``) -- the
+    mirror gives the same affinities and, on the row-normalised affinity of its ``main`` (``:330``), the same partitions."""
+    from cropnerf_amd.segmentation import depth_projection_based_merger as DM
+
+    gold = np.load(os.path.join(os.path.dirname(GOLD), "reference_functions.npz"))
+    n_cases = int(gold["num_dpm"])
+    assert n_cases >= 4
+    for c in range(n_cases):
+        labels, rel = gold[f"dpm{c}/labels"], gold[f"dpm{c}/reliability"]
+        prop = {i: {"label": labels[i], "reliability": rel[i]} for i in range(len(labels))}
+        aff = DM.calc_affinity(prop)
+        assert np.array_equal(aff, gold[f"dpm{c}/affinity"]), c
+        norm = DM.normalise_affinity(aff)
+        assert np.isfinite(norm).all()
+        for algo in ("clique", "bridge", "community"):
+            random.seed(100 + c)
+            k, lab = DM.get_component(norm.copy(), algo)
+            assert k == int(gold[f"dpm{c}/{algo}_count"]), (c, algo)
+            assert np.array_equal(np.asarray(lab), gold[f"dpm{c}/{algo}_labels"]), (c, algo)
+    # a row whose maximum is 0 divides by zero, as in the reference (its own comment: "buggy!!! handle case when max 0")
+    bad = DM.normalise_affinity(np.array([[0.0, -1.0], [-1.0, 0.0]]))
+    assert not np.isfinite(bad).all()
+    with pytest.raises(ValueError):
+        DM.get_component(np.eye(2), "spectral")
