@@ -34,7 +34,8 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[3]))
 
 def train(method: str, data: Path, output_dir: Path = Path("outputs"), max_num_iterations=None, steps_per_save=None,
           downscale_factor=None, experiment_name=None, timestamp=None, seed: int = 0, log_every: int = 100,
-          train_split_fraction=None, device: str = "cuda", quiet: bool = False, load_dir=None, implementation=None):
+          train_split_fraction=None, device: str = "cuda", quiet: bool = False, load_dir=None, implementation=None,
+          matrix_precision=None):
     from cropnerf_amd.fruit_nerf import fruit_nerf_config as FC
     from cropnerf_amd.fruit_nerf.checkpoint import save_run
     from cropnerf_amd.fruit_nerf.data.cotton_dataset import FruitDataset
@@ -51,6 +52,11 @@ def train(method: str, data: Path, output_dir: Path = Path("outputs"), max_num_i
     tc = _copy.deepcopy(specs[method].config)
     if implementation is not None:  # "tcnn" (the reference's default module implementation) or "torch"
         tc.pipeline.model.implementation = implementation
+    if matrix_precision is not None:
+        # "f16": the arithmetic the reference trains in (TrainerConfig.mixed_precision=True on tiny-cuda-nn's fp16 modules,
+        # fruit_nerf_config.py:35) -- fp16 operands in the field's forward / backward recompute, bf16 gradient products, fp32
+        # sums and master parameters (cn_field_backward_mp); default: exact fp32
+        tc.pipeline.model.matrix_precision = matrix_precision
     iters = max_num_iterations if max_num_iterations is not None else tc.max_num_iterations
     save_every = steps_per_save if steps_per_save is not None else tc.steps_per_save
     from cropnerf_amd.distributed import init_from_env
@@ -221,10 +227,13 @@ def entrypoint(argv=None):
                     help="module implementation of the field / proposal networks (nerfacto's `implementation`): tcnn = "
                          "tiny-cuda-nn's grid geometry and bias-free MLPs, the reference's default; torch = nerfstudio's "
                          "torch modules.  Default: the method specification's")
+    ap.add_argument("--matrix-precision", choices=["fp32", "f16", "split_bf16"], default=None,
+                    help="matrix arithmetic of the field in training: fp32 (default, exact), f16 = the reference's mixed-precision "
+                         "class (fp16 forward operands, bf16 gradient products, fp32 sums and masters), split_bf16 (forward only)")
     a = ap.parse_args(argv)
     return train(a.method, a.data, a.output_dir, a.max_num_iterations, a.steps_per_save, a.downscale_factor,
                  a.experiment_name, a.timestamp, a.seed, a.log_every, a.train_split_fraction, load_dir=a.load_dir,
-                 implementation=a.implementation)
+                 implementation=a.implementation, matrix_precision=a.matrix_precision)
 
 
 if __name__ == "__main__":

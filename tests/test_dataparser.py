@@ -271,6 +271,27 @@ def test_train_cli_resume_continues_the_same_run(tmp_path):
 
 
 @pytest.mark.gpu
+def test_train_cli_in_the_references_mixed_precision(tmp_path):
+    """``train.py --matrix-precision f16``: the reference's training arithmetic (``mixed_precision=True``,
+    ``fruit_nerf_config.py:35``) end to end -- the run trains (PSNR of the eval split close to the exact-fp32 run's), records
+    the mode in its config.yml, and ``eval_setup`` renders it in that mode."""
+    from cropnerf_amd import _lib as L
+    from cropnerf_amd.fruit_nerf.checkpoint import eval_setup
+    from cropnerf_amd.fruit_nerf.scripts import train
+
+    cap = Path(synthetic.write_capture(tmp_path / "plant", num=12, res=40))
+    kw = dict(log_every=50, quiet=True, train_split_fraction=0.8, steps_per_save=1000, max_num_iterations=60, timestamp="t")
+    mixed = train.train("fruit_nerf", cap, tmp_path / "m", matrix_precision="f16", **kw)
+    exact = train.train("fruit_nerf", cap, tmp_path / "e", **kw)
+    assert math.isfinite(mixed["eval_psnr"]) and mixed["eval_psnr"] > 5.0
+    assert abs(mixed["eval_psnr"] - exact["eval_psnr"]) < 1.0, (mixed["eval_psnr"], exact["eval_psnr"])
+    _, pipe, _, step = eval_setup(mixed["config"])
+    assert step == 59 and pipe.model.config.matrix_precision == "f16" and pipe.model._matrix_precision() == L.MATRIX_F16
+    _, pipe_e, _, _ = eval_setup(exact["config"])
+    assert pipe_e.model._matrix_precision() == L.MATRIX_FP32
+
+
+@pytest.mark.gpu
 def test_train_cli_resume_is_bit_exact_in_deterministic_mode(tmp_path, monkeypatch):
     """The same under ``CN_DETERMINISTIC_SCATTER=1`` (the test library whose training kernels accumulate through integer shadows,
     ``csrc/cn_det.hpp``): with the summation order out of the picture, 13 + 11 resumed iterations must leave EXACTLY the
