@@ -900,13 +900,13 @@ def subsystem_timings(args, params, device):
                 "roofline": mixed_roofline(st["rays"], t_, "pixel_sample + raygen + proposal_sample_kernel + render kernel + "
                                            "pointcloud_compact_calls per launch",
                                            f"{st['calls_per_launch']} call(s) of {rays_per_call} rays per launch sequence"
-                                           + (" (HIP-graph replay)" if st.get("graph") else "") + "; RANDOM pixels of random cameras: "
-                                           "the field's gathers miss the L2 (profiled: ~108 KB of memory-side traffic per ray against "
-                                           "3 KB for the coherent rays of an image), i.e. the rate at which the memory side serves "
-                                           "scattered 64-byte requests bounds it, as it bounds the training forward", pmc="export_c4")}
+                                           + (" (HIP-graph replay)" if st.get("graph") else "") + "; RANDOM pixels of random cameras, "
+                                           "rendered sorted by camera and pixel inside a launch: what is left of the field's L2 misses "
+                                           "(draw order: ~108 KB of memory-side traffic per ray against 3 KB for an image's coherent rays) "
+                                           "bounds it", pmc="export_c4")}
 
     last_cloud: dict = {}
-    c4 = export_case(2048, 1 << 16, 10_000_000)
+    c4 = export_case(2048, 1 << 20, 10_000_000)
     # the two post-processing passes of `ns-export pointcloud` on that cloud (exporter_utils_nerfacto.py:194-225): statistical
     # outlier removal (20 neighbours) and open3d-style normals (30 neighbours, covariance, smallest eigenvector) + re-orientation,
     # both on the device (cn_knn_mean_distance / cn_estimate_normals)
@@ -919,12 +919,14 @@ def subsystem_timings(args, params, device):
                      "kernel": "knn_mean_distance_grid_kernel / knn_normals_grid_kernel on the two-level grid (binning included: torch sort, "
                                "unique, offsets), 30-nearest search + fp64 covariance + closed-form 3x3 eigen-solve"}
     del pts_c4, nd
-    c4["call_size_32768"] = export_case(32768, 1 << 16, 10_000_000)
+    c4["call_size_32768"] = export_case(32768, 1 << 20, 10_000_000)
     c4["one_call_per_launch_2048"] = export_case(2048, None, 1_000_000)  # the reference's loop shape, graph-replayed (round 3)
     c4["semantic_bias_for_3pct"] = round(bias, 4)
     c4["workload"] = ("ns-export pointcloud --num-points 10000000 on the synthetic scene with ~3 % of the rays kept, default method (48 "
-                      "field + 352 proposal samples per ray); 2 048-ray calls (debug/exporter_nerfacto.py:91) grouped 32 per launch, "
-                      "32 768-ray calls (upstream ns-export) 2 per launch, and the one-call-per-launch loop on 1 M points beside them; "
+                      "field + 352 proposal samples per ray); 2 048-ray calls (debug/exporter_nerfacto.py:91) grouped 512 per launch and rendered "
+                      "in (camera, pixel Morton) order, the outputs put back in draw order before the compaction (round 5; 32 per "
+                      "launch in draw order until then); 32 768-ray calls (upstream ns-export) 32 per launch; the one-call-per-launch "
+                      "loop on 1 M points beside them; "
                       "reference: exporter_utils_nerfacto.py:125-183")
     out["export_pointcloud_c4"] = c4
     pipe = FruitPipeline(FruitPipelineConfig(FruitDataManagerConfig(2048, 2048), cfg), device, cams, box, test_mode="test", params=p2)

@@ -21,7 +21,7 @@ import torch
 from ... import ops
 
 
-DEFAULT_LAUNCH_RAYS = 1 << 16  # one C2-sized batch per launch sequence
+DEFAULT_LAUNCH_RAYS = 1 << 20  # calls per launch sequence = this // the call size (512 of the reference's 2 048-ray calls)
 
 
 def generate_point_cloud(pipeline, num_points: int = 1000000, remove_outliers: bool = True,
@@ -29,14 +29,19 @@ def generate_point_cloud(pipeline, num_points: int = 1000000, remove_outliers: b
                          depth_output_name: str = "depth", normal_output_name: Optional[str] = None, crop_obb=None,
                          std_ratio: float = 10.0, only_semantics: bool = True, max_batches: Optional[int] = None,
                          use_graph: bool = True, launch_rays: Optional[int] = DEFAULT_LAUNCH_RAYS,
-                         stats: Optional[dict] = None) -> Dict[str, np.ndarray]:
+                         stats: Optional[dict] = None, sort_rays: bool = True) -> Dict[str, np.ndarray]:
     """``launch_rays`` (extension): the reference's call size (``train_num_rays_per_batch``: 2 048 in its own exporter, 32 768
     upstream) bounds ITS memory and fixes its stopping rule -- the cloud is every kept point of calls 0 .. c*, c* = the first
     call at which the count reaches ``num_points``.  Here K = ``launch_rays // rays_per_call`` calls' pixel draws go through ONE
     sampler + render + compaction launch sequence; the draws come from a counter-based stream (``cn_pixel_sample``) and the
     append stops at the same call boundary (``cn_pointcloud_compact_calls``), so the cloud does not depend on K (tested).
     ``launch_rays=None`` (or below the call size): one call per launch, as the reference loops.  ``stats``: filled with the
-    calls / rays rendered."""
+    calls / rays rendered.
+
+    ``sort_rays`` (extension, with several calls per launch): the launch's rays are rendered in (camera, pixel Morton) order and
+    their outputs put back in draw order before the compaction.  The draws are random pixels of random cameras, whose field
+    gathers miss the L2 (1.77 ms per 65 536 rays against 0.73 ms for an image's); inside a 2^20-ray launch the sorted rays are
+    neighbours again (0.93 ms).  A ray's result does not depend on its neighbours: the cloud is the same, point for point."""
     model, dm = pipeline.model, pipeline.datamanager
     # several ranks (one per GPU): every rank collects its share of the target from its own random rays; the shares are
     # concatenated with one variable-length all-gather (counts, then padded rows) before the outlier pass
@@ -60,9 +65,12 @@ def generate_point_cloud(pipeline, num_points: int = 1000000, remove_outliers: b
     call_no = torch.zeros(1, dtype=torch.int64, device=dev)  # first call of the next launch (device: a graph advances it)
     state = {"buffers": None}
 
+    sort_launch = bool(sort_rays) and K > 1
+
     def one_launch():
         idx = ops.pixel_sample(dm.export_seed, call_no, K, rays_per_call, n_cam, H, W)
-        ray_bundle = cams.generate_rays(idx)  # data/fruit_datamanager.py:188-197 -> train_ray_generator(ray_indices)
+        perm = ops.ray_sort_permutation(idx, H, W) if sort_launch else None
+        ray_bundle = cams.generate_rays(idx if perm is None else idx[perm])  # data/fruit_datamanager.py:188-197
         outputs = model(ray_bundle)
         for name in (rgb_output_name, depth_output_name):
             if name not in outputs:  # :133-142
@@ -72,8 +80,11 @@ def generate_point_cloud(pipeline, num_points: int = 1000000, remove_outliers: b
         if crop_obb is not None:  # :168-174: cropped points do not count towards num_points
             inside = crop_obb.within(ray_bundle.origins + ray_bundle.directions * outputs[depth_output_name])
             cmap = cmap * inside[:, None].to(cmap.dtype)
-        state["buffers"] = ops.pointcloud_compact_calls(ray_bundle.origins, ray_bundle.directions, outputs[depth_output_name],
-                                                        outputs[rgb_output_name], cmap.contiguous(), rays_per_call, num_points,
+        per_ray = [ray_bundle.origins, ray_bundle.directions, outputs[depth_output_name], outputs[rgb_output_name], cmap]
+        if perm is not None:  # back into draw order: the compaction cuts the cloud at a CALL boundary
+            per_ray = [torch.empty_like(t).index_copy_(0, perm, t) for t in per_ray]
+        o_, d_, depth_, rgb_, cmap_ = per_ray
+        state["buffers"] = ops.pointcloud_compact_calls(o_, d_, depth_, rgb_, cmap_.contiguous(), rays_per_call, num_points,
                                                         cap, state["buffers"])
         call_no.add_(K)
 
@@ -85,7 +96,9 @@ def generate_point_cloud(pipeline, num_points: int = 1000000, remove_outliers: b
         # device memory, every intermediate lives in the graph's memory pool -- and replayed.
         graph = None
         replay = None
-        if use_graph and max_batches is None:
+        # (a launch of 2^18 rays or more is tens of milliseconds of device work: nothing to gain from a replay, and the sort's
+        #  temporaries stay out of a graph pool)
+        if use_graph and max_batches is None and K * rays_per_call < (1 << 18):
             for j in range(3):
                 one_launch()
             launches = 3

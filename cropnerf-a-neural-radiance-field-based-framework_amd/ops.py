@@ -742,6 +742,27 @@ def pixel_sample(seed: int, first_call: Tensor, num_calls: int, rays_per_call: i
     return out
 
 
+def ray_sort_permutation(ray_indices: Tensor, height: int, width: int) -> Tensor:
+    """Permutation that orders (camera, row, col) ray indices by camera and, inside a camera, along the Morton curve of the pixel
+    (torch plumbing: bit spreads and one sort).  Random pixels of random cameras read the hash tables at random: the field pass
+    of 65 536 such rays takes 1.77 ms against 0.73 ms for an image's coherent rays (its gathers miss the L2).  Sorted, the rays
+    of a large launch are neighbours again -- 0.93 ms per 65 536 rays inside a 2^20-ray launch, 0.82 ms inside a 2^22-ray one
+    (``tools/sorted_ray_probe.py``) -- and a ray's result does not depend on its neighbours, so un-permuting the outputs gives
+    the same numbers in the same order."""
+    idx = _i64(ray_indices, "ray_indices")
+
+    def spread(v):
+        v = (v | (v << 8)) & 0x00FF00FF
+        v = (v | (v << 4)) & 0x0F0F0F0F
+        v = (v | (v << 2)) & 0x33333333
+        return (v | (v << 1)) & 0x55555555
+
+    if height > (1 << 16) or width > (1 << 16):  # (host integers: nothing here waits for the device, so a graph can capture it)
+        raise ValueError("ray_sort_permutation: images of at most 65 536 pixels a side")
+    key = (idx[:, 0] << 32) | spread(idx[:, 1]) | (spread(idx[:, 2]) << 1)
+    return torch.argsort(key)
+
+
 def pointcloud_compact_calls(origins: Tensor, directions: Tensor, depth: Tensor, rgb: Tensor, semantics_colormap: Tensor,
                              rays_per_call: int, target_points: int, capacity: int,
                              buffers: Optional[Tuple[Tensor, ...]] = None) -> Tuple[Tensor, ...]:

@@ -634,14 +634,17 @@ def test_point_cloud_export_does_not_depend_on_calls_per_launch(monkeypatch):
     sc.params["field.field_head_semantics.net.bias"] += 0.5 * (lo + hi)
     pipe = _pipeline(sc, "test")
     clouds, stats = [], []
-    for launch_rays, use_graph in ((None, False), (None, True), (2048, True), (1 << 15, False)):
+    # (K > 1 launches render their rays sorted by camera and pixel and put the outputs back in draw order: the last case
+    #  switches that off -- the same cloud either way)
+    for launch_rays, use_graph, sort_rays in ((None, False, True), (None, True, True), (2048, True, True), (1 << 15, False, True),
+                                              (1 << 15, False, False)):
         st = {}
         pcd = generate_point_cloud(pipe, num_points=3000, remove_outliers=False, use_graph=use_graph, launch_rays=launch_rays,
-                                   stats=st)
+                                   stats=st, sort_rays=sort_rays)
         rows = np.concatenate([pcd["points"], pcd["colors"], pcd["view_directions"]], axis=1)
         clouds.append(rows[np.lexsort(rows.T[::-1])])
         stats.append(st)
-    assert [s["calls_per_launch"] for s in stats] == [1, 1, 4, 64] and stats[1]["graph"] and not stats[0]["graph"]
+    assert [s["calls_per_launch"] for s in stats] == [1, 1, 4, 64, 64] and stats[1]["graph"] and not stats[0]["graph"]
     n = clouds[0].shape[0]
     assert 3000 <= n < 3000 + 512
     assert n % 512 != 0 and stats[0]["calls"] >= 3000 / (0.3 * 512)  # a cloud of whole calls would mean nothing was rejected
