@@ -26,12 +26,13 @@ def morton(r, c):
 
 def run(order_name, ids):
     ts_s, ts_f = [], []
-    for k in range(0, min(N, 16 * CH), CH):
+    for k in range(0, max(min(ids.shape[0], 16 * CH) - CH + 1, 1), CH):
         sub = ids[k:k + CH].contiguous()
+        CHn = sub.shape[0]
         r = ops.raygen_pinhole(c2w, intr, ray_indices=sub)
         o, d = r["origins"], r["directions"]
-        n = torch.full((CH, 1), 0.05, device=dev)
-        f = torch.full((CH, 1), 1000.0, device=dev)
+        n = torch.full((CHn, 1), 0.05, device=dev)
+        f = torch.full((CHn, 1), 1000.0, device=dev)
         for rep in range(3):
             e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             e[0].record()
@@ -48,7 +49,7 @@ def run(order_name, ids):
 run("draw order", idx)
 key = idx[:, 0] * (1 << 22) + morton(idx[:, 1], idx[:, 2])
 run(f"sorted, launch of {N} rays", idx[torch.argsort(key)])
-for n_small in (1 << 20, 1 << 18):
+for n_small in (1 << 20, 1 << 18, 1 << 16):
     sub = idx[:n_small]
     k2 = sub[:, 0] * (1 << 22) + morton(sub[:, 1], sub[:, 2])
     run(f"sorted, launch of {n_small} rays", sub[torch.argsort(k2)])

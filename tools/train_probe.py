@@ -20,7 +20,10 @@ cams = Cameras(c2w, intr[:,0], intr[:,1], intr[:,2], intr[:,3], 800, 800).to(dev
 g = torch.Generator().manual_seed(0)
 R = int(os.environ.get("TRAIN_RAYS", "4096"))
 idx = torch.stack([torch.randint(0,100,(R,),generator=g), torch.randint(0,800,(R,),generator=g), torch.randint(0,800,(R,),generator=g)],-1)
-rb = cams.generate_rays(idx.to(dev))
+idx = idx.to(dev)
+if os.environ.get("SORT_BATCH", "0") != "0":  # SORT_BATCH=1: the batch sorted by camera and pixel (faster forward, slower backward: DESIGN.md 4.18)
+    idx = idx[ops.ray_sort_permutation(idx, 800, 800)]
+rb = cams.generate_rays(idx)
 batch = {"image": torch.rand(R,3,generator=g).to(dev), "fruit_mask": (torch.rand(R,1,generator=g)>0.5).float().to(dev)}
 WARM, ITERS = int(os.environ.get("WARM", "2")), int(os.environ.get("ITERS", "20"))
 if os.environ.get("PER_ITER") == "1":  # one line per iteration, each waited for (which variant ran, and how long it took)
