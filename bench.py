@@ -107,7 +107,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", choices=["uniform", "proposal"], default="uniform",
                     help="uniform: 192 field evals/ray (headline); proposal: + (256,96) proposal-net evals/ray")
-    ap.add_argument("--variant", choices=["headline", "tcnn_f16", "tcnn_f16_mfma", "split_bf16"], default="headline",
+    ap.add_argument("--variant", choices=["headline", "exact_fp32", "tcnn_f16", "tcnn_f16_mfma", "split_bf16"], default="headline",
                     help="profiling aid (rocprofv3 -- python3 bench.py --variant ... --no-secondary --no-cpu-baseline): the "
                          "timed loop renders the M-uniform workload through another table / matrix mode; the JSON line "
                          "then names the variant and is NOT the headline")
@@ -211,10 +211,19 @@ def main():
     batches = make_batches(ops, c2w, intr, rank, world)
     scene_u = ops.scene_struct(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), contraction=False)
     scene_c = ops.scene_struct(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), contraction=True)
-    def opts_for(start):
-        return ops.render_opts(S) if args.no_image_hint else ops.render_opts(S, image_width=W, pixel_start=start)
+    # The headline runs in the product's default arithmetic (FruitNerfModelConfig.matrix_precision, "split_bf16" since round 5:
+    # bf16 hi + lo operands on the bf16 matrix pipe, fp32 accumulation -- the same parity bars against the fp32 oracle as the
+    # exact kernels, tests/test_gpu_parity.py); the exact-fp32 products of rounds 1-4 are timed as `uniform_mode_exact_fp32`.
+    from cropnerf_amd import config as _PC
 
-    opts = ops.render_opts(S)
+    mp_name = _PC.FruitNerfModelConfig().matrix_precision
+    mp = {"fp32": L.MATRIX_FP32, "split_bf16": L.MATRIX_SPLIT_BF16, "f16": L.MATRIX_F16}[mp_name]
+
+    def opts_for(start):
+        return (ops.render_opts(S, matrix_precision=mp) if args.no_image_hint
+                else ops.render_opts(S, image_width=W, pixel_start=start, matrix_precision=mp))
+
+    opts = ops.render_opts(S, matrix_precision=mp)
     fh_run, variant_kw = fh, {}
     if args.variant != "headline":
         fh_run, variant_kw = variant_field(args.variant, params, fspec, fh, device)
@@ -297,26 +306,35 @@ def main():
         pmc = pmc_summary()
         kernel_name = ("render_fused_kernel<false,false>" if os.environ.get("CN_FUSED_SPLIT", "1") == "0"
                        else "render_split_kernel")
-        mlp_tflops = R * S * 2 * MLP_MAC_PER_SAMPLE / avg / 1e12
+        split = mp == L.MATRIX_SPLIT_BF16
+        # matrix work executed: the split mode issues three bf16 products per fp32 product (hi.hi + hi.lo + lo.hi)
+        mlp_tflops = R * S * 2 * MLP_MAC_PER_SAMPLE * (3 if split else 1) / avg / 1e12
+        mfma_peak = MFMA_F16_PEAK_TFLOPS if split else MFMA_FP32_PEAK_TFLOPS
+        limited = ("SIMD issue: VALU cycles (hashing, blending, the operand splits, compositing) + bf16 MFMA cycles, and the L1's "
+                   "line-lookup rate of the corner gathers; not HBM" if split else
+                   "SIMD issue: fp32 MFMA cycles + VALU cycles (they add on a SIMD); not HBM")
         # `frac` = ALGORITHMIC bytes (1024 B per field sample + 68 B per ray) / launch time / HBM peak, the
         # figure the target is stated in.  The kernel is not limited by HBM: the 64 MB table is cache-resident (measured
-        # traffic below is a small fraction of the algorithmic bytes).  What limits it is SIMD issue: the fp32 MFMA passes
-        # of the MLPs and the VALU instructions of hashing / blending / compositing do not overlap on a SIMD, their cycles
-        # add -- `limited_by` says so and `roofline_mfma` prices the matrix half of it.
+        # traffic below is a small fraction of the algorithmic bytes).  What limits it is SIMD issue:
+        # `limited_by` says so and `roofline_mfma` prices the matrix half of it.
         # `bound` keeps the key the contract names; the kernel is NOT HBM-bound: `limited_by` / `bound_measured` say what it is
-        roofline = {"bound": "hbm", "bound_measured": "simd-issue (fp32 MFMA + VALU cycles add on a SIMD)", "kernel": kernel_name,
+        roofline = {"bound": "hbm", "bound_measured": "simd-issue + L1 line lookups" if split else
+                    "simd-issue (fp32 MFMA + VALU cycles add on a SIMD)", "kernel": kernel_name,
+                    "matrix_precision": mp_name,
                     "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                     "traffic": pmc.get("traffic"), "traffic_source": pmc.get("source"),
                     "hbm_measured_frac": (round(pmc["traffic"] / avg / 1e9 / HBM_PEAK_GBPS, 4) if pmc.get("traffic") else None),
-                    "limited_by": "SIMD issue: fp32 MFMA cycles + VALU cycles (they add on a SIMD); not HBM",
+                    "limited_by": limited,
                     "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_sample": BYTES_PER_SAMPLE,
-                    "avg_launch_ms": round(avg * 1e3, 4), "mfma_frac": round(mlp_tflops / MFMA_FP32_PEAK_TFLOPS, 4)}
+                    "avg_launch_ms": round(avg * 1e3, 4), "mfma_frac": round(mlp_tflops / mfma_peak, 4)}
         extra["roofline_mfma"] = {"bound": "mfma", "kernel": kernel_name, "achieved": round(mlp_tflops, 2),
-                                  "peak": MFMA_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(mlp_tflops / MFMA_FP32_PEAK_TFLOPS, 4), "traffic": None,
-                                  "flops_per_sample": 2 * MLP_MAC_PER_SAMPLE,
-                                  "note": "exact-fp32 matrix products (v_mfma_f32_16x16x4_f32); dense fp32 matrix peak"}
+                                  "peak": mfma_peak, "unit": "TFLOP/s",
+                                  "frac": round(mlp_tflops / mfma_peak, 4), "traffic": None,
+                                  "flops_per_sample": 2 * MLP_MAC_PER_SAMPLE * (3 if split else 1),
+                                  "note": ("three bf16 products per fp32 product (v_mfma_f32_16x16x32_bf16, operands hi + lo); "
+                                           "dense bf16 matrix peak" if split else
+                                           "exact-fp32 matrix products (v_mfma_f32_16x16x4_f32); dense fp32 matrix peak")}
         extra["uniform_samples_per_sec_single_launch"] = R * S / avg
 
     # ---- secondary numbers (rank 0, N=1): proposal-mode render and training iterations --------------------------------
@@ -346,11 +364,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": {"fp32": "f32", "f16": "f16 products, f32 accumulate"}.get(
+                mp_name, "f32 (matrix products: bf16 hi+lo operand split, f32 accumulate)"),
             "data": "synthetic",
             "config": {"workload": "plant_1-shaped synthetic scene (P-rand), 800x800, 192 samples/ray, 65536-ray batch"
                                    f", mode M-{args.mode}, fused cn_render_rays, eval (no jitter)",
                        "rays_per_batch": R, "samples_per_ray": S, "image": [H, W], "mode": args.mode,
+                       "matrix_precision": mp_name + " (FruitNerfModelConfig default; exact fp32: secondary.exact_fp32_ms)",
                        **({"variant": args.variant + " (profiling aid, not the headline)"} if args.variant != "headline" else {}),
                        "sharding": "ray batches per rank + RCCL all-gather of per-ray outputs" if world > 1 else "none"},
             "rays_per_sec": world * R * args.steps / elapsed,
@@ -389,8 +409,10 @@ def flat_secondary(extra: dict) -> dict:
         if isinstance(d, (int, float)):
             f[key] = _num(d * scale)
 
-    put("mfma_fp32_tflops", "roofline_mfma", "achieved")
-    put("split_bf16_ms", "uniform_mode_split_bf16_matrix", "ms_per_batch")
+    put("mfma_tflops", "roofline_mfma", "achieved")
+    put("exact_fp32_ms", "uniform_mode_exact_fp32", "ms_per_batch")
+    put("exact_fp32_frac", "uniform_mode_exact_fp32", "roofline", "frac")
+    put("psnr_vs_exact_fp32_db", "uniform_mode_exact_fp32", "psnr_of_the_headline_vs_this_render_db")
     put("tcnn_f16_table_ms", "uniform_mode_tcnn_f16_table", "ms_per_batch")
     put("f16_mode_ms", "uniform_mode_tcnn_f16_mfma", "ms_per_batch")
     put("f16_mode_samples_per_s", "uniform_mode_tcnn_f16_mfma", "samples_per_sec")
@@ -429,7 +451,11 @@ def compact_line(line: dict, extra: dict) -> dict:
     if rf:
         out["roofline"] = {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel",
                                               "avg_launch_ms", "mfma_frac", "hbm_measured_frac") if k in rf}
-        out["roofline"]["limited_by"] = "SIMD issue (fp32 MFMA + VALU), not HBM: the table is cache-resident"
+        out["roofline"]["limited_by"] = ("SIMD issue (VALU + bf16 MFMA) and L1 line lookups, not HBM: the table is cache-resident"
+                                         if rf.get("matrix_precision") == "split_bf16" else
+                                         "SIMD issue (fp32 MFMA + VALU), not HBM: the table is cache-resident")
+        if "matrix_precision" in rf:
+            out["roofline"]["matrix_precision"] = rf["matrix_precision"]
     cb = line.get("cpu_baseline")
     if cb:
         out["cpu_baseline"] = {"value": _num(cb["value"], 6), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
@@ -481,8 +507,10 @@ def tcnn_f16_field(params, device):
 def variant_field(variant, params, fspec, fh, device):
     from cropnerf_amd import _lib as L
 
-    if variant == "split_bf16":
+    if variant == "split_bf16":  # (= the headline since round 5)
         return fh, {"matrix_precision": L.MATRIX_SPLIT_BF16}
+    if variant == "exact_fp32":  # the headline of rounds 1-4: v_mfma_f32_16x16x4_f32 products
+        return fh, {"matrix_precision": L.MATRIX_FP32}
     fht, _ = tcnn_f16_field(params, device)
     if variant == "tcnn_f16_mfma":
         return fht, {"matrix_precision": L.MATRIX_F16}
@@ -552,7 +580,7 @@ def pmc_variant_summary(tag_part: str) -> dict:
         return {"source": f"unreadable: {e}"}
 
 
-def pmc_summary() -> dict:
+def pmc_summary(pattern: str = "r*_pmc_render*.json") -> dict:
     """Memory-side bytes per launch of the render kernel from the committed rocprofv3 PMC passes of this same command
     (``profiles/r*_pmc_render*.json``, written by tools/collect_pmc.sh + tools/summarise_pmc.py: FETCH_SIZE and WRITE_SIZE,
     KiB, separate passes; the summary records the commit it was measured on).  Counters cannot be read from inside this
@@ -561,7 +589,7 @@ def pmc_summary() -> dict:
     the same run agrees with the raw value.  Infinity-Cache hits are included (an upper bound on HBM bytes)."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_render*.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     if not files:
         return {"traffic": None, "source": "no PMC summary under profiles/"}
     try:
@@ -601,13 +629,21 @@ def secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, o
         return round(-10.0 * math.log10(max(mse, 1e-30)), 1)
 
     flops = R * S * 2 * MLP_MAC_PER_SAMPLE
-    # ---- split-bf16 matrix products on the headline table (cn_render_opts.matrix_precision = 1; NOT the headline) ----------
-    st = launch_stats(render(fh, matrix_precision=L.MATRIX_SPLIT_BF16))
+    # ---- exact fp32 matrix products on the headline table (cn_render_opts.matrix_precision = 0: the headline of rounds 1-4) ----
+    st = launch_stats(render(fh, matrix_precision=L.MATRIX_FP32))
     t = st["median"]
-    out["uniform_mode_split_bf16_matrix"] = {
+    alg32 = R * (S * BYTES_PER_SAMPLE + BYTES_PER_RAY_IO)
+    pm32 = pmc_summary("r05_pmc_render_fused.json")
+    out["uniform_mode_exact_fp32"] = {
         **_ms(st), "samples_per_sec": R * S / t, "rays_per_sec": R / t,
-        "psnr_vs_fp32_render_db": psnr(render(fh, matrix_precision=L.MATRIX_SPLIT_BF16)(0)["rgb"], render(fh)(0)["rgb"]),
-        "note": "optional arithmetic (operands split into bf16 hi + lo, fp32 accumulation); the headline value is exact fp32"}
+        "psnr_of_the_headline_vs_this_render_db": psnr(render(fh, matrix_precision=L.MATRIX_SPLIT_BF16)(0)["rgb"],
+                                                       render(fh, matrix_precision=L.MATRIX_FP32)(0)["rgb"]),
+        "roofline": {"bound": "hbm", "kernel": "render_split_kernel<.,fp32,float,generic>", "achieved": round(alg32 / t / 1e9, 1),
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(alg32 / t / 1e9 / HBM_PEAK_GBPS, 4),
+                     "traffic": pm32.get("traffic"), "traffic_source": pm32.get("source"),
+                     "bytes_per_sample": BYTES_PER_SAMPLE, "mfma_frac": round(flops / t / 1e12 / MFMA_FP32_PEAK_TFLOPS, 4),
+                     "limited_by": "SIMD issue: fp32 MFMA cycles + VALU cycles (they add on a SIMD); not HBM"},
+        "note": "v_mfma_f32_16x16x4_f32 products: what small batches and training always use, and config matrix_precision='fp32'"}
 
     # ---- the reference's default module implementation: tcnn grid geometry, half2 table entries (512 B per sample) ------
     fht, tspec = tcnn_f16_field(params, batches[0][0].device)

@@ -156,11 +156,14 @@ class FruitNerfModelConfig:
     # extension (not in the reference, which composites every sample): > 0 stops a ray in eval renders once its
     # transmittance falls below this value; 0 keeps the reference's behaviour
     early_stop_transmittance: float = 0.0
-    # extension: "fp32" = exact fp32 matrix products (default); "split_bf16" = operands as bf16 hi + lo on the bf16 matrix
-    # pipe with fp32 accumulation in the eval renders that fill the device (cn_render_opts.matrix_precision); "f16" = the
-    # reference's own arithmetic class (tcnn FullyFusedMLP under mixed_precision=True, fruit_field.py:95,
-    # fruit_nerf_config.py:35): fp16 weights and layer inputs, fp32 accumulation, in every eval render
-    matrix_precision: str = "fp32"
+    # extension: the matrix arithmetic of the eval / export renders that fill the device (cn_render_opts.matrix_precision).
+    # "split_bf16" (default since round 5): every operand of the MLP products as bf16 hi + bf16 lo (16 mantissa bits) on the
+    # bf16 matrix pipe, fp32 accumulation -- held to the SAME parity bars against the fp32 oracle as the exact kernels
+    # (tests/test_gpu_parity.py) and 1.5x faster; "fp32" = exact fp32 matrix products (v_mfma_f32_16x16x4_f32; what small
+    # batches and TRAINING always use); "f16" = the reference's own arithmetic class (tcnn FullyFusedMLP under
+    # mixed_precision=True, fruit_field.py:95, fruit_nerf_config.py:35): fp16 weights and layer inputs, fp32 accumulation, in
+    # every eval render and -- with fp32 masters -- in the training iteration
+    matrix_precision: str = "split_bf16"
     # Which of the reference's two implementations the parameters follow (nerfacto's ``implementation``; FruitField's own
     # default is "tcnn", fruit_field.py:95).  "torch": nerfstudio's torch HashEncoding / MLP (all levels hashed, biases).
     # "tcnn": tiny-cuda-nn's grid geometry (dense coarse levels, +0.5 offset), bias-free MLPs (tcnn_params.py) -- the

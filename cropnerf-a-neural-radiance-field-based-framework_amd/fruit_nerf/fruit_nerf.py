@@ -251,7 +251,7 @@ class FruitModel:
         return rb.camera_indices.reshape(-1).to(torch.int64).contiguous()
 
     def _matrix_mode(self) -> str:
-        mode = getattr(self.config, "matrix_precision", "fp32")
+        mode = getattr(self.config, "matrix_precision", "split_bf16")
         mode = {"fp16": "f16", "bf16": "split_bf16"}.get(mode, mode)  # the spellings a user of 'fp32' tries first
         if mode not in ("fp32", "split_bf16", "f16"):
             raise ValueError(f"matrix_precision {mode!r}: 'fp32', 'split_bf16' or 'f16' (alias 'fp16')")
@@ -273,9 +273,9 @@ class FruitModel:
         shapes of the ``_big`` / ``_huge`` methods (shape-generic kernels) and the proposal networks train in fp32 whatever the
         setting."""
         mode = self._matrix_mode()
-        if mode == "fp32" or not self._fused_shape:
-            return L.MATRIX_FP32
-        return L.MATRIX_SPLIT_BF16 if mode == "split_bf16" else L.MATRIX_F16
+        if mode != "f16" or not self._fused_shape:
+            return L.MATRIX_FP32  # "split_bf16" is an arithmetic of the eval renders: training stays exact fp32
+        return L.MATRIX_F16
 
     def _opts(self, num_samples: int, density_only: bool = False) -> L.RenderOpts:
         bg_mode, bg = self._background()

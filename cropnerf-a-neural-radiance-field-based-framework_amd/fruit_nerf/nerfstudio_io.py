@@ -106,7 +106,7 @@ def write_config_yml(path, *, method_name: str, model_config: FruitNerfModelConf
                      optimizers: Optional[Dict[str, Any]] = None) -> None:
     """A ``TrainerConfig`` dump with the reference's class paths (``fruit_nerf_config.py:29-65``)."""
     mc = asdict(model_config)
-    if mc.get("matrix_precision") == "fp32":
+    if mc.get("matrix_precision") == FruitNerfModelConfig().matrix_precision:
         # this package's extension field at its default makes no statement (a reference config has no such key): eval_setup
         # then picks the arithmetic from the checkpoint -- fp16 products for a tcnn-packed mixed-precision run
         del mc["matrix_precision"]

@@ -30,7 +30,9 @@ class ExportSemanticPointCloud:
     bounding_box_max: Tuple[float, float, float] = (1, 1, 1 + 0.318)
     num_rays_per_batch: int = 512
     num_points_per_side: int = 3000
-    matrix_precision: str = "fp32"  # extension: "split_bf16" = bf16 hi + lo matrix products in the render kernel
+    # extension: None = what the run's config says (default "split_bf16": bf16 hi + lo matrix products, the fp32 parity bars);
+    # "fp32" = exact fp32 products; "f16" = tiny-cuda-nn's class
+    matrix_precision: Optional[str] = None
 
     def main(self) -> None:
         from cropnerf_amd.fruit_nerf.checkpoint import eval_setup
@@ -38,9 +40,8 @@ class ExportSemanticPointCloud:
         from cropnerf_amd.fruit_nerf.ply import write_ply
 
         if not self.output_dir.exists():
-            self.output_dir.mkdir(parents=True)
-        config, pipeline, _, _ = eval_setup(self.load_config, test_mode="export")
-        pipeline.model.config.matrix_precision = self.matrix_precision
+            self.output_dir.mkdir(parents=True, exist_ok=True)  # (several ranks get here at once)
+        config, pipeline, _, _ = eval_setup(self.load_config, test_mode="export", matrix_precision=self.matrix_precision)
         pipeline.datamanager.config.eval_num_rays_per_batch = self.num_rays_per_batch
         pipeline.model.setup_inference(render_rgb=True, num_inference_samples=self.num_points_per_side)
         num_points = pipeline.datamanager.setup_inference(num_points=self.num_points_per_side,
@@ -72,7 +73,7 @@ class ExportPointCloud:
     obb_center: Optional[Tuple[float, float, float]] = None
     obb_rotation: Optional[Tuple[float, float, float]] = None
     obb_scale: Optional[Tuple[float, float, float]] = None
-    matrix_precision: str = "fp32"
+    matrix_precision: Optional[str] = None
     reorient_normals: bool = True
     normal_method: str = "open3d"  # "open3d" | "model_output" (debug/exporter_nerfacto.py:74-77)
     normal_output_name: str = "normals"
@@ -84,9 +85,8 @@ class ExportPointCloud:
         from cropnerf_amd.fruit_nerf.ply import write_ply
 
         if not self.output_dir.exists():
-            self.output_dir.mkdir(parents=True)
-        _, pipeline, _, _ = eval_setup(self.load_config, test_mode="test")
-        pipeline.model.config.matrix_precision = self.matrix_precision
+            self.output_dir.mkdir(parents=True, exist_ok=True)  # (several ranks get here at once)
+        _, pipeline, _, _ = eval_setup(self.load_config, test_mode="test", matrix_precision=self.matrix_precision)
         pipeline.datamanager.config.train_num_rays_per_batch = self.num_rays_per_batch
         crop_obb = None  # debug/exporter_nerfacto.py:119-121
         if self.obb_center is not None and self.obb_rotation is not None and self.obb_scale is not None:
@@ -118,7 +118,7 @@ def entrypoint(argv=None):
     for p in (sp, pc):
         p.add_argument("--load-config", type=Path, required=True)
         p.add_argument("--output-dir", type=Path, required=True)
-        p.add_argument("--matrix-precision", choices=["fp32", "split_bf16"], default="fp32")
+        p.add_argument("--matrix-precision", choices=["fp32", "split_bf16", "f16"], default=None)
     sp.add_argument("--use-bounding-box", type=lambda s: s.lower() == "true", default=True)
     sp.add_argument("--bounding-box-min", type=_floats3, default=ExportSemanticPointCloud.bounding_box_min)
     sp.add_argument("--bounding-box-max", type=_floats3, default=ExportSemanticPointCloud.bounding_box_max)

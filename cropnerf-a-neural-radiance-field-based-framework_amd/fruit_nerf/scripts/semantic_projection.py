@@ -52,7 +52,7 @@ class ExportPointCloud(Exporter):
         from cropnerf_amd.fruit_nerf.fruit_nerf import Semantics, background_color_override_context
 
         if not self.output_dir.exists():
-            self.output_dir.mkdir(parents=True)
+            self.output_dir.mkdir(parents=True, exist_ok=True)  # (several ranks get here at once)
         config, pipeline, _, step = eval_setup(self.load_config, eval_num_rays_per_chunk=self.num_rays_per_batch,
                                                test_mode="test")
         pipeline.model.eval()
@@ -78,7 +78,7 @@ class ExportCameraPoses(Exporter):
         from cropnerf_amd.fruit_nerf.export.exporter_utils_nerfacto import collect_camera_poses
 
         if not self.output_dir.exists():
-            self.output_dir.mkdir(parents=True)
+            self.output_dir.mkdir(parents=True, exist_ok=True)  # (several ranks get here at once)
         _, pipeline, _, _ = eval_setup(self.load_config)
         train_frames, eval_frames = collect_camera_poses(pipeline)
         for file_name, frames in [("transforms_train.json", train_frames), ("transforms_eval.json", eval_frames)]:

@@ -288,7 +288,9 @@ def test_train_cli_in_the_references_mixed_precision(tmp_path):
     _, pipe, _, step = eval_setup(mixed["config"])
     assert step == 59 and pipe.model.config.matrix_precision == "f16" and pipe.model._matrix_precision() == L.MATRIX_F16
     _, pipe_e, _, _ = eval_setup(exact["config"])
-    assert pipe_e.model._matrix_precision() == L.MATRIX_FP32
+    assert pipe_e.model._matrix_precision() == L.MATRIX_SPLIT_BF16 and pipe_e.model.train_matrix_precision() == L.MATRIX_FP32
+    _, pipe_x, _, _ = eval_setup(exact["config"], matrix_precision="fp32")
+    assert pipe_x.model._matrix_precision() == L.MATRIX_FP32
 
 
 @pytest.mark.gpu

@@ -449,27 +449,31 @@ def test_point_cloud_export_graph_replay_matches_eager_semantics():
 
 
 def test_model_matrix_precision_option(scene):
-    """FruitNerfModelConfig.matrix_precision = "split_bf16": a whole-image eval render through the model differs from the
-    exact-fp32 one by less than the parity bar; an unknown value is refused."""
+    """FruitNerfModelConfig.matrix_precision: the default is "split_bf16" (bf16 hi + lo operands, fp32 sums) in the eval renders
+    that fill the device; a whole-image render through the model differs from the exact-fp32 one ("fp32") by less than the
+    parity bar and is not the same arithmetic; training stays exact whatever the setting; an unknown value is refused."""
+    from cropnerf_amd import _lib as L
+    from cropnerf_amd import config as PC
+
+    assert PC.FruitNerfModelConfig().matrix_precision == "split_bf16"
     pipe = _pipeline(scene, "test")
     m = pipe.model
+    assert m.config.matrix_precision == "split_bf16" and m._matrix_precision() == L.MATRIX_SPLIT_BF16
+    assert m.train_matrix_precision() == L.MATRIX_FP32
     rb = _cameras(scene).to("cuda").generate_rays(0, keep_shape=True)
-    exact = m.get_outputs_for_camera_ray_bundle(rb)
-    m.config.matrix_precision = "split_bf16"
+    fast = m.get_outputs_for_camera_ray_bundle(rb)
     try:
-        fast = m.get_outputs_for_camera_ray_bundle(rb)
-    finally:
         m.config.matrix_precision = "fp32"
-    for k in ("rgb", "accumulation", "semantics"):
-        assert_close(fast[k], exact[k], 2e-4, 5e-5, k)
-    m.config.matrix_precision = "fp8"
-    with pytest.raises(ValueError):
-        m.get_outputs_for_camera_ray_bundle(rb)
-    m.config.matrix_precision = "fp16"  # alias of "f16" (fp32 tables here: the fp16 products on float entries)
-    try:
+        exact = m.get_outputs_for_camera_ray_bundle(rb)
+        for k in ("rgb", "accumulation", "semantics"):
+            assert_close(fast[k], exact[k], 2e-4, 5e-5, k)
+        m.config.matrix_precision = "fp8"
+        with pytest.raises(ValueError):
+            m.get_outputs_for_camera_ray_bundle(rb)
+        m.config.matrix_precision = "fp16"  # alias of "f16" (fp32 tables here: the fp16 products on float entries)
         half = m.get_outputs_for_camera_ray_bundle(rb)
     finally:
-        m.config.matrix_precision = "fp32"
+        m.config.matrix_precision = "split_bf16"
     assert_close(half["rgb"], exact["rgb"], 0.0, 2e-3, "rgb in fp16 matrix mode")
 
 
@@ -525,8 +529,10 @@ def test_bench_line_contract():
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 5 and d["higher_is_better"] is True and d["vs_baseline"] is None
-    assert d["unit"] == "samples/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["unit"] == "samples/s" and d["dtype"].startswith("f32") and "bf16 hi+lo" in d["dtype"] and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["config"]["matrix_precision"].startswith("split_bf16") and d["secondary"]["exact_fp32_ms"] > d["ms_per_step"]
     r = d["roofline"]
+    assert r["matrix_precision"] == "split_bf16"
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and 0 < r["frac"] <= 1.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["peak"] == 8000.0
     assert "limited_by" in r and "traffic_source" in r and "traffic" in r
