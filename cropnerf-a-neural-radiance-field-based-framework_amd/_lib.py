@@ -131,6 +131,8 @@ SIGNATURES = {
     "cn_proposal_density": (C.c_int, [C.POINTER(DensityParams), C.POINTER(Scene), _P, _P, _P, _P, _I64, _I32, _P, _P]),
     "cn_field_eval": (C.c_int, [C.POINTER(FieldParams), C.POINTER(Scene), _I32, _I32, _P, _P, _P, _P, _P, _I64, _I32,
                                 _P, _P, _P, _P, _P]),
+    "cn_field_eval_mp": (C.c_int, [C.POINTER(FieldParams), C.POINTER(Scene), _I32, _I32, _P, _P, _P, _P, _P, _I64, _I32,
+                                   _P, _P, _P, _P, _I32, _P]),
     "cn_composite": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, C.POINTER(_F), _I32, _P, _P, _P, _P, _P, _P, _P]),
     "cn_render_workspace_bytes": (C.c_size_t, [C.POINTER(FieldParams)]),
     "cn_render_rays": (C.c_int, [C.POINTER(FieldParams), C.POINTER(Scene), C.POINTER(RenderOpts), _P, _P, _P, _P, _P,

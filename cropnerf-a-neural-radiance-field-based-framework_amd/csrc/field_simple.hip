@@ -438,6 +438,7 @@ static bool mfma_generic_ok(const cn_field_params& p) {
 
 }  // namespace cn
 #include "field_regw.hpp"
+#include "field_regw_split.hpp"
 namespace cn {
 
 int validate_field(const cn_field_params& p) {
@@ -475,7 +476,18 @@ extern "C" int cn_field_eval(const cn_field_params* params, const cn_scene* scen
                              const int64_t* camera_indices, const float* starts, const float* ends, int64_t num_rays,
                              int32_t num_samples, float* density, float* rgb, float* semantics, float* positions,
                              cn_stream_t stream) {
+  return cn_field_eval_mp(params, scene, app_mode, sh_unit_dir, origins, directions, camera_indices, starts, ends, num_rays,
+                          num_samples, density, rgb, semantics, positions, CN_MATRIX_FP32, stream);
+}
+
+extern "C" int cn_field_eval_mp(const cn_field_params* params, const cn_scene* scene, int32_t app_mode,
+                                int32_t sh_unit_dir, const float* origins, const float* directions,
+                                const int64_t* camera_indices, const float* starts, const float* ends, int64_t num_rays,
+                                int32_t num_samples, float* density, float* rgb, float* semantics, float* positions,
+                                int32_t matrix_precision, cn_stream_t stream) {
   CN_REQUIRE(params && scene && origins && directions && starts && ends, CN_ERR_INVALID, "cn_field_eval: null input");
+  CN_REQUIRE(matrix_precision == CN_MATRIX_FP32 || matrix_precision == CN_MATRIX_SPLIT_BF16 || matrix_precision == CN_MATRIX_F16,
+             CN_ERR_INVALID, "cn_field_eval: matrix_precision %d", matrix_precision);
   CN_REQUIRE(num_samples > 0, CN_ERR_INVALID, "cn_field_eval: num_samples must be > 0");
   CN_REQUIRE(app_mode >= CN_APP_ZEROS && app_mode <= CN_APP_PER_CAMERA, CN_ERR_INVALID, "cn_field_eval: app_mode %d",
              app_mode);
@@ -499,8 +511,14 @@ extern "C" int cn_field_eval(const cn_field_params* params, const cn_scene* scen
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(cn::rw::field_eval_regw_kernel<15, 2, 64>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)cn::rw::LDS_BYTES);
         if (e != hipSuccess) return e;
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(cn::rw::field_eval_regw_kernel<30, 3, 128>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)cn::rw::LDS_BYTES);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(cn::rw::field_eval_regw_kernel<30, 3, 128>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)cn::rw::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(cn::rws::field_eval_regw_split_kernel<15, 2, 64>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)cn::rws::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(cn::rws::field_eval_regw_split_kernel<30, 3, 128>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)cn::rws::LDS_BYTES);
       },
       nullptr, "cn_field_eval");
   if (rc) return rc;
@@ -512,6 +530,24 @@ extern "C" int cn_field_eval(const cn_field_params* params, const cn_scene* scen
   const bool want = impl != nullptr;
   if (!want || std::strcmp(impl, "regw") == 0) {
     const bool def = cn::rw::regw_shape_matches<15, 2, 64>(*params), big = cn::rw::regw_shape_matches<30, 3, 128>(*params);
+    // The 16-bit matrix modes (the model's default for the renders that fill the device is split-bf16): the two shapes of the
+    // reference's configs in field_regw_split.hpp.  CN_MATRIX_F16 has no shape-generic kernel of its own and takes the same
+    // one (bf16 hi + lo operands: more precise than fp16 operands, and the faster of the two); other shapes stay exact fp32.
+    if ((def || big) && matrix_precision != CN_MATRIX_FP32) {
+      const long long ntiles = (num_rays * (long long)num_samples + cn::rws::TS - 1) / cn::rws::TS;
+      const dim3 grid(cn::grid_for(ntiles, 1, 256)), block(cn::rws::NT);
+      if (def)
+        hipLaunchKernelGGL((cn::rws::field_eval_regw_split_kernel<15, 2, 64>), grid, block, cn::rws::LDS_BYTES,
+                           cn::as_stream(stream), cn::make_field_dev(*params), cn::make_scene_dev(*scene), app_mode,
+                           sh_unit_dir, origins, directions, camera_indices, starts, ends, (long long)num_rays,
+                           num_samples, density, rgb, semantics, positions);
+      else
+        hipLaunchKernelGGL((cn::rws::field_eval_regw_split_kernel<30, 3, 128>), grid, block, cn::rws::LDS_BYTES,
+                           cn::as_stream(stream), cn::make_field_dev(*params), cn::make_scene_dev(*scene), app_mode,
+                           sh_unit_dir, origins, directions, camera_indices, starts, ends, (long long)num_rays,
+                           num_samples, density, rgb, semantics, positions);
+      return cn::check_launch("cn_field_eval_mp");
+    }
     if (def || big) {
       const long long ntiles = (num_rays * (long long)num_samples + cn::rw::TS - 1) / cn::rw::TS;
       const dim3 grid(cn::grid_for(ntiles, 1, 256)), block(cn::rw::NT);

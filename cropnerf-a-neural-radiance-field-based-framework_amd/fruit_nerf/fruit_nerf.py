@@ -331,7 +331,8 @@ class FruitModel:
             starts, ends = self._general_samples(n[sl], f[sl], S, None if bins is None else bins[sl])
             fo = ops.field_eval(self.field, scene, o[sl].contiguous(), d[sl].contiguous(),
                                 None if cam is None else cam[sl].contiguous(), starts, ends,
-                                app_mode=self._app_mode(), sh_unit_dir=self.config.sh_input == "unit")
+                                app_mode=self._app_mode(), sh_unit_dir=self.config.sh_input == "unit",
+                                matrix_precision=self._matrix_precision())
             if density_only:
                 comp = ops.composite(starts, ends, fo["density"], None, None, bg_mode, bg, eval_clamp=not self.training)
                 comp = {"accumulation": comp["accumulation"]}
@@ -467,7 +468,8 @@ class FruitModel:
             starts, ends = self._general_samples(rb.nears, rb.fars, self._uniform_samples, None)
             fo = ops.field_eval(self.field, self._scene(self._field_contraction), rb.origins, rb.directions,
                                 self._cam_idx(rb), starts, ends, app_mode=self._app_mode(),
-                                sh_unit_dir=self.config.sh_input == "unit", want_positions=True)
+                                sh_unit_dir=self.config.sh_input == "unit", want_positions=True,
+                                matrix_precision=self._matrix_precision())
             label = (torch.sigmoid(fo["semantics"]) - 0.9 > 0).to(torch.int64)  # fruit_nerf.py:488-492
             return {"rgb": fo["rgb"], "point_location": fo["positions"], "semantics": fo["semantics"],
                     "density": fo["density"], "semantics_colormap": label}

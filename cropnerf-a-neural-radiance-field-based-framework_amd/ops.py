@@ -597,18 +597,20 @@ def proposal_density(prop: DensityHandle, scene: L.Scene, origins: Tensor, direc
 
 def field_eval(fh: FieldHandle, scene: L.Scene, origins: Tensor, directions: Tensor, camera_indices: Optional[Tensor],
                starts: Tensor, ends: Tensor, app_mode: int = L.APP_MEAN, sh_unit_dir: bool = True,
-               want_positions: bool = False) -> Dict[str, Tensor]:
+               want_positions: bool = False, matrix_precision: int = L.MATRIX_FP32) -> Dict[str, Tensor]:
+    """``cn_field_eval_mp``: ``matrix_precision`` as ``cn_render_opts.matrix_precision`` (the two field shapes of the
+    reference's configs have a split-bf16 form; other shapes are evaluated in exact fp32 whatever it says)."""
     lib = L.load()
     R, S = starts.shape
     dev = starts.device
     out = {"density": torch.empty(R, S, device=dev), "rgb": torch.empty(R, S, 3, device=dev),
            "semantics": torch.empty(R, S, device=dev)}
     pos = torch.empty(R, S, 3, device=dev) if want_positions else None
-    L.check(lib.cn_field_eval(C.byref(fh.struct), C.byref(scene), app_mode, 1 if sh_unit_dir else 0,
-                              _p(_f32(origins, "origins")), _p(_f32(directions, "directions")),
-                              _p(_i64(camera_indices, "camera_indices")), _p(_f32(starts, "starts")),
-                              _p(_f32(ends, "ends")), R, S, _p(out["density"]), _p(out["rgb"]), _p(out["semantics"]),
-                              _p(pos), _stream(starts)))
+    L.check(lib.cn_field_eval_mp(C.byref(fh.struct), C.byref(scene), app_mode, 1 if sh_unit_dir else 0,
+                                 _p(_f32(origins, "origins")), _p(_f32(directions, "directions")),
+                                 _p(_i64(camera_indices, "camera_indices")), _p(_f32(starts, "starts")),
+                                 _p(_f32(ends, "ends")), R, S, _p(out["density"]), _p(out["rgb"]), _p(out["semantics"]),
+                                 _p(pos), int(matrix_precision), _stream(starts)))
     if pos is not None:
         out["positions"] = pos
     return out

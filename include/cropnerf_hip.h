@@ -369,6 +369,16 @@ int cn_field_eval(const cn_field_params* params, const cn_scene* scene, int32_t 
                   const float* origins, const float* directions, const int64_t* camera_indices,
                   const float* starts, const float* ends, int64_t num_rays, int32_t num_samples,
                   float* density, float* rgb, float* semantics, float* positions, cn_stream_t stream);
+/* The same with the matrix arithmetic of the caller's choice (cn_field_eval = CN_MATRIX_FP32), as cn_render_opts.matrix_precision
+ * chooses it for the fused renderers: CN_MATRIX_SPLIT_BF16 evaluates the two field shapes of the reference's method configs
+ * (fruit_nerf_method and fruit_nerf_method_big / _huge, fruit_nerf/fruit_nerf_config.py:29-172) with every matrix operand as
+ * bf16 hi + lo and fp32 accumulation -- the path the _big / _huge models render and export through; CN_MATRIX_F16 takes the same
+ * kernel (there is no fp16-operand form of the shape-generic evaluation); any other shape is evaluated in exact fp32. */
+int cn_field_eval_mp(const cn_field_params* params, const cn_scene* scene, int32_t app_mode, int32_t sh_unit_dir,
+                     const float* origins, const float* directions, const int64_t* camera_indices,
+                     const float* starts, const float* ends, int64_t num_rays, int32_t num_samples,
+                     float* density, float* rgb, float* semantics, float* positions, int32_t matrix_precision,
+                     cn_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Compositing

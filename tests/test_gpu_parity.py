@@ -850,3 +850,26 @@ def test_generic_field_kernels_agree(scene, ops, monkeypatch):
         for impl in ("regw", "mfma"):
             for k in outs[impl]:
                 assert_close(outs[impl][k], outs["scalar"][k], 2e-5, 2e-6, f"{impl} {'big' if big else 'default'} {k}")
+        # the split-bf16 form of the register-resident kernel (cn_field_eval_mp, field_regw_split.hpp): bf16 hi + lo operands,
+        # fp32 sums -- the bars the split-bf16 mode of the fused renderer is held to per sample (densities are exp(logit):
+        # relative); all three app modes, the density-only and semantics-less calls, a ragged tail (333 x 37 is not a
+        # multiple of the 64-sample tile)
+        from cropnerf_amd import _lib as L
+
+        monkeypatch.delenv("CN_FIELD_EVAL_IMPL")
+        name = "big" if big else "default"
+        for app_mode in (0, 1, 2):
+            exact = ops.field_eval(fh, ops.scene_struct(scene.aabb, True), o, d, cam, sm["starts"], sm["ends"],
+                                   app_mode=app_mode, want_positions=True)
+            fast = ops.field_eval(fh, ops.scene_struct(scene.aabb, True), o, d, cam, sm["starts"], sm["ends"],
+                                  app_mode=app_mode, want_positions=True, matrix_precision=L.MATRIX_SPLIT_BF16)
+            assert torch.equal(fast["positions"], exact["positions"])
+            assert_close(fast["density"], exact["density"], 2e-4, 1e-6, f"split-bf16 {name} density, app mode {app_mode}")
+            assert_close(fast["rgb"], exact["rgb"], 5e-5, 5e-5, f"split-bf16 {name} rgb, app mode {app_mode}")
+            assert_close(fast["semantics"], exact["semantics"], 2e-4, 5e-5, f"split-bf16 {name} semantics, app mode {app_mode}")
+            assert not torch.equal(fast["rgb"], exact["rgb"])  # it really is the other arithmetic
+        f16 = ops.field_eval(fh, ops.scene_struct(scene.aabb, True), o, d, cam, sm["starts"], sm["ends"], app_mode=2,
+                             want_positions=True, matrix_precision=L.MATRIX_F16)  # no fp16 form: the split-bf16 kernel
+        assert torch.equal(f16["rgb"], fast["rgb"])
+        with pytest.raises(L.CropNerfHipError, match="matrix_precision"):
+            ops.field_eval(fh, ops.scene_struct(scene.aabb, True), o, d, cam, sm["starts"], sm["ends"], matrix_precision=7)
