@@ -14,20 +14,24 @@ m = FruitModel(cfg, SceneBox(torch.tensor(synthetic.SCENE_AABB)), 8, {"semantics
 for k, v in m.params.items():
     if k.endswith("hash_table"):
         v.mul_(100.0)  # the 1e-3 init is an empty volume
+PROBE = os.environ.get("PROBE", "both")  # render | train | both
 rb = cams.generate_rays(0, keep_shape=False, aabb_box=SceneBox(torch.tensor(synthetic.SCENE_AABB)))
 rb = rb[:65536] if hasattr(rb, "__getitem__") else rb
-out = m(rb)
-torch.cuda.synchronize()
-t = time.perf_counter()
-for _ in range(3):
+if PROBE != "train":
+  out = m(rb)
+  torch.cuda.synchronize()
+  t = time.perf_counter()
+  for _ in range(3):
     out = m(rb)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t) / 3
-R = out["rgb"].shape[0]
-S = cfg.num_nerf_samples_per_ray
-print(json.dumps({"rays": R, "field_samples_per_ray": S, "proposal_samples_per_ray": list(cfg.num_proposal_samples_per_ray),
+  torch.cuda.synchronize()
+  dt = (time.perf_counter() - t) / 3
+  R = out["rgb"].shape[0]
+  S = cfg.num_nerf_samples_per_ray
+  print(json.dumps({"matrix_precision": m.config.matrix_precision, "rays": R, "field_samples_per_ray": S, "proposal_samples_per_ray": list(cfg.num_proposal_samples_per_ray),
                   "ms_per_call": round(dt * 1e3, 2), "rays_per_sec": R / dt, "field_samples_per_sec": R * S / dt,
                   "finite": bool(torch.isfinite(out["rgb"]).all())}))
+if PROBE == "render":
+    sys.exit(0)
 
 # training iteration of the big method: 8192 rays (train_num_rays_per_batch = 4096 * 2, fruit_nerf_config.py)
 from cropnerf_amd.fruit_nerf.trainer import FruitTrainer
