@@ -1482,6 +1482,10 @@ extern "C" int cn_field_backward_general(const cn_field_params* params, const cn
                                       (unsigned long long)num_rays * (unsigned long long)num_samples);
     if (A.cells.num_levels > 0) A.coarse.base = nullptr;
   }
+  {
+    const char* e = getenv("CN_DEBUG_SKIP");  // profiling aid (results are wrong by construction)
+    A.debug_skip = e ? atoi(e) : 0;
+  }
   hipLaunchKernelGGL(cn::gb::field_backward_general_kernel, dim3(grid), dim3(cn::gb::NTG), lds, s, A);
   CN_DET_FLUSH(s);
   cn::launch_coarse_reduce(A.coarse, A.grid, A.g_table, s);

@@ -51,6 +51,7 @@ struct GenArgs {
   int S;
   CoarseScatter coarse;  // private copies for level 0's gradient (cn_grid.scatter_scratch of the gradient grid)
   CellScatter cells;     // cell-major records of the coarse levels (take precedence for the levels they cover)
+  int debug_skip;        // CN_DEBUG_SKIP, timing only: 1 no hash scatter, 4 no weight-gradient products, 64 no forward gathers
 };
 
 __device__ __forceinline__ int opaque_i(int v) {
@@ -134,6 +135,7 @@ __device__ __forceinline__ void gen_bwd(const GenLayer& L, const float* dy, floa
 
 // scratch dW[n][k] += sum_s dy[n][s] x[k][s];  scratch db[n] += sum_s dy[n][s]   (workgroup-private, no atomics)
 __device__ __forceinline__ void gen_dw(const GenLayer& L, const float* dy, const float* x, float* scratch, int tid) {
+  if (!scratch) return;  // (CN_DEBUG_SKIP bit 4)
   const int lane = opaque_i(tid) & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
   const int Kp = (L.K + 15) & ~15, Np = (L.N + 15) & ~15;
   const int nkt = Kp >> 4;
@@ -183,7 +185,7 @@ __global__ void __launch_bounds__(NTG) field_backward_general_kernel(GenArgs A) 
   float* DG = lds + A.r_dg * LDG;
   float* DRGB = lds + A.r_drgb * LDG;
   float* DSEM = lds + A.r_dsem * LDG;
-  float* scratch = A.scratch + (size_t)blockIdx.x * A.params_per_block;
+  float* scratch = (A.debug_skip & 4) ? nullptr : A.scratch + (size_t)blockIdx.x * A.params_per_block;
   const int s = tid & 31, grp = tid >> 5;  // 16 groups of 32 samples
   const int lane = tid & 63;
   const int cin_dim = 16 + A.geo + A.app_dim;
@@ -203,7 +205,8 @@ __global__ void __launch_bounds__(NTG) field_backward_general_kernel(GenArgs A) 
     const float self = normalize_position(A.scene, px, py, pz) ? 1.f : 0.f;
     // ---- inputs ---------------------------------------------------------------------------------------------------------
     for (int l = grp; l < A.num_levels; l += 16) {
-      const float2 f = hash_level(A.table, lds_level_rec(SCL, l), A.grid.pos_offset, px, py, pz);
+      const float2 f = (A.debug_skip & 64) ? make_float2(px * 0.01f, py * 0.01f)
+                                           : hash_level(A.table, lds_level_rec(SCL, l), A.grid.pos_offset, px, py, pz);
       ENC[(2 * l) * LDG + s] = f.x;
       ENC[(2 * l + 1) * LDG + s] = f.y;
     }
@@ -252,12 +255,12 @@ __global__ void __launch_bounds__(NTG) field_backward_general_kernel(GenArgs A) 
       const int ht = lastsem.N;
       // head: d_sout[k][s] = wh[k] d_sem[s];  dWh[k] += sum_s d_sem[s] sout[k][s];  dbh += sum_s d_sem[s]
       for (int k = grp; k < ((ht + 15) & ~15); k += 16) DA[k * LDG + s] = k < ht ? A.wh[k] * DSEM[s] : 0.f;
-      for (int k = tid; k < ht; k += NTG) {
+      for (int k = tid; k < ht && scratch; k += NTG) {
         float sum = 0.f;
         for (int j = 0; j < TSG; ++j) sum += DSEM[j] * sout[k * LDG + j];
         scratch[A.off_wh + k] += sum;
       }
-      if (tid == 0) {
+      if (tid == 0 && scratch) {
         float sum = 0.f;
         for (int j = 0; j < TSG; ++j) sum += DSEM[j];
         scratch[A.off_bh] += sum;
@@ -348,7 +351,8 @@ __global__ void __launch_bounds__(NTG) field_backward_general_kernel(GenArgs A) 
       const int l = l0 + grp;
       const bool on = l < A.num_levels;
       const int lc = on ? l : 0;
-      const float g0 = on && valid ? DB[(2 * lc) * LDG + s] : 0.f, g1 = on && valid ? DB[(2 * lc + 1) * LDG + s] : 0.f;
+      const bool sc_on = on && valid && !(A.debug_skip & 1);
+      const float g0 = sc_on ? DB[(2 * lc) * LDG + s] : 0.f, g1 = sc_on ? DB[(2 * lc + 1) * LDG + s] : 0.f;
       // (a wave holds two levels, 32 lanes each; the branch splits it along whole 16-lane rows)
       if (on && lc < A.cells.num_levels) {
         // cell-major level: C1 / C2 / CIN / DCIN are dead by now and host the 16-lane hand-over of two waves each (the host
