@@ -17,6 +17,9 @@ namespace gb {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int TSG = 32, LDG = 36, NTG = 512;
+#ifndef CN_GEN_DW_PREFETCH
+#define CN_GEN_DW_PREFETCH 4
+#endif
 
 struct GenLayer {
   const float* W;
@@ -75,10 +78,21 @@ __device__ __forceinline__ void gen_fwd(const GenLayer& L, const float* in, floa
     // all A operands of the block (one weight row per lane, <= 128 columns) are requested up front: the L2 latency is
     // paid once per 16x16 block instead of once per MFMA
     float areg[32];
+    if ((L.K & 3) == 0) {  // 16-byte row loads: a quarter of the load instructions and of the L1's line lookups
 #pragma unroll
-    for (int j = 0; j < 32; ++j) {
-      const int k = 16 * (j >> 2) + 4 * q + (j & 3);
-      areg[j] = (nrow < L.N && k < L.K) ? L.W[(size_t)nrow * L.K + k] : 0.f;
+      for (int kb = 0; kb < 8; ++kb) {
+        const int k = 16 * kb + 4 * q;
+        f32x4 w = {0.f, 0.f, 0.f, 0.f};
+        if (nrow < L.N && k < L.K) w = *reinterpret_cast<const f32x4*>(L.W + (size_t)nrow * L.K + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) areg[4 * kb + e] = w[e];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        const int k = 16 * (j >> 2) + 4 * q + (j & 3);
+        areg[j] = (nrow < L.N && k < L.K) ? L.W[(size_t)nrow * L.K + k] : 0.f;
+      }
     }
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
@@ -138,9 +152,12 @@ __device__ __forceinline__ void gen_dw(const GenLayer& L, const float* dy, const
   if (!scratch) return;  // (CN_DEBUG_SKIP bit 4)
   const int lane = opaque_i(tid) & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
   const int Kp = (L.K + 15) & ~15, Np = (L.N + 15) & ~15;
-  const int nkt = Kp >> 4;
-  for (int blk = wave; blk < (Np >> 4) * nkt; blk += NTG / 64) {
-    const int n0 = (blk / nkt) * 16, k0 = (blk % nkt) * 16;
+  const int nkt = Kp >> 4, nblocks = (Np >> 4) * nkt;
+  // The workgroup's slice of the scratch (206 KB for the big shape, 32 slices to an XCD) does not stay in the L2: a block's
+  // read-modify-write waits for the Infinity Cache.  All of a wave's blocks of the layer (<= 8 for widths <= 128) are
+  // therefore REQUESTED PF at a time, and added to as their products come out -- PF misses in flight per wave instead of one.
+  constexpr int PF = CN_GEN_DW_PREFETCH;
+  auto product = [&](int n0, int k0) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int sb = 0; sb < TSG; sb += 16) {
@@ -152,10 +169,36 @@ __device__ __forceinline__ void gen_dw(const GenLayer& L, const float* dy, const
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
       }
     }
+    return acc;
+  };
+#pragma unroll 1
+  for (int b0 = wave; b0 < nblocks; b0 += (NTG / 64) * PF) {
+    f32x4 pre[PF];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = n0 + 4 * q + r, k = k0 + i;
-      if (n < L.N && k < L.K) scratch[L.off_w + n * L.K + k] += acc[r];
+    for (int j = 0; j < PF; ++j) {
+      const int blk = b0 + (NTG / 64) * j;
+      pre[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (blk < nblocks) {
+        const int n0 = (blk / nkt) * 16, k0 = (blk % nkt) * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + 4 * q + r, k = k0 + i;
+          if (n < L.N && k < L.K) pre[j][r] = scratch[L.off_w + n * L.K + k];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      const int blk = b0 + (NTG / 64) * j;
+      if (blk < nblocks) {
+        const int n0 = (blk / nkt) * 16, k0 = (blk % nkt) * 16;
+        const f32x4 acc = product(n0, k0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + 4 * q + r, k = k0 + i;
+          if (n < L.N && k < L.K) scratch[L.off_w + n * L.K + k] = pre[j][r] + acc[r];
+        }
+      }
     }
   }
   for (int n = tid; n < L.N; n += NTG) {
