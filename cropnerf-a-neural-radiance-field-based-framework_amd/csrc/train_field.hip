@@ -1493,8 +1493,13 @@ extern "C" int cn_field_backward_general(const cn_field_params* params, const cn
   rc = cn::check_launch("cn_field_backward_general");
   if (rc) return rc;
   CN_DET_FLUSH(s);
-  for (int i = 0; i < nt; ++i)
-    hipLaunchKernelGGL(cn::gb::field_backward_reduce_kernel, dim3(cn::grid_for(targets[i].n, 256, 64)), dim3(256), 0, s,
-                       A.scratch, grid, ppb, targets[i].off, targets[i].n, targets[i].g);
+  cn::gb::ReduceTargets T;
+  T.count = nt;
+  for (int i = 0; i < nt; ++i) {
+    T.g[i] = targets[i].g;
+    T.off[i] = targets[i].off;
+    T.n[i] = targets[i].n;
+  }
+  hipLaunchKernelGGL(cn::gb::field_backward_reduce_all_kernel, dim3((ppb + 31) / 32), dim3(256), 0, s, A.scratch, grid, ppb, T);
   return cn::check_launch("cn_field_backward_general reduce");
 }

@@ -62,18 +62,22 @@ __device__ __forceinline__ int opaque_i(int v) {
   return v;
 }
 
-// out[n][s] = act(b[n] + sum_k W[n][k] in[k][s]) for all n < pad16(N); rows >= N come out as zeros
-__device__ __forceinline__ void gen_fwd(const GenLayer& L, const float* in, float* out, bool relu, int tid) {
-  const int lane = opaque_i(tid) & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
-  const int Kp = (L.K + 15) & ~15, Np = (L.N + 15) & ~15;
-  for (int blk = wave; blk < (Np >> 4) * 2; blk += NTG / 64) {
-    const int n0 = (blk >> 1) * 16, s0 = (blk & 1) * 16;
-    f32x4 acc;
+// A layer has T = pad16(rows) / 16 row tiles and two 16-sample halves.  With T >= 8 (the 128-wide layers) a wave takes row
+// tile `wave` and BOTH halves: its 32 A operands are loaded once and feed two accumulation chains (half the weight loads, half
+// the L1 line lookups, one exposed L2 latency per phase instead of two, and two independent matrix chains).  With fewer row
+// tiles the 2 T blocks are spread over the waves one (row tile, half) each, as before.
+template <bool BOTH>
+__device__ __forceinline__ void gen_fwd_blocks(const GenLayer& L, const float* in, float* out, bool relu, int first, int step,
+                                               int count, int i, int q, int Kp) {
+  for (int blk = first; blk < count; blk += step) {
+    const int n0 = (BOTH ? blk : blk >> 1) * 16, s0 = BOTH ? 0 : (blk & 1) * 16;
+    f32x4 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = n0 + 4 * q + r;
-      acc[r] = n < L.N ? L.b[n] : 0.f;
+      acc0[r] = n < L.N ? L.b[n] : 0.f;
     }
+    acc1 = acc0;
     const int nrow = n0 + i;
     // all A operands of the block (one weight row per lane, <= 128 columns) are requested up front: the L2 latency is
     // paid once per 16x16 block instead of once per MFMA
@@ -99,27 +103,41 @@ __device__ __forceinline__ void gen_fwd(const GenLayer& L, const float* in, floa
       if (16 * kb < Kp) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float b = in[(16 * kb + 4 * q + e) * LDG + s0 + i];
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[4 * kb + e], b, acc, 0, 0, 0);
+          const float* row = in + (16 * kb + 4 * q + e) * LDG + s0 + i;
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[4 * kb + e], row[0], acc0, 0, 0, 0);
+          if (BOTH) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[4 * kb + e], row[16], acc1, 0, 0, 0);
         }
       }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float v = acc[r];
-      if (relu) v = fmaxf(v, 0.f);
-      out[(n0 + 4 * q + r) * LDG + s0 + i] = v;
+      float v0 = acc0[r], v1 = acc1[r];
+      if (relu) {
+        v0 = fmaxf(v0, 0.f);
+        v1 = fmaxf(v1, 0.f);
+      }
+      out[(n0 + 4 * q + r) * LDG + s0 + i] = v0;
+      if (BOTH) out[(n0 + 4 * q + r) * LDG + 16 + i] = v1;
     }
   }
 }
 
-// dx[k][s] = (sum_n W[n][k] dy[n][s]) * (mask ? mask[k][s] > 0 : 1) for all k < pad16(K)
-__device__ __forceinline__ void gen_bwd(const GenLayer& L, const float* dy, float* dx, const float* mask, int tid) {
+// out[n][s] = act(b[n] + sum_k W[n][k] in[k][s]) for all n < pad16(N); rows >= N come out as zeros
+__device__ __forceinline__ void gen_fwd(const GenLayer& L, const float* in, float* out, bool relu, int tid) {
   const int lane = opaque_i(tid) & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
-  const int Kp = (L.K + 15) & ~15, Np = (L.N + 15) & ~15;
-  for (int blk = wave; blk < (Kp >> 4) * 2; blk += NTG / 64) {
-    const int k0 = (blk >> 1) * 16, s0 = (blk & 1) * 16;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int Kp = (L.K + 15) & ~15, tiles = ((L.N + 15) & ~15) >> 4;
+  if (tiles >= NTG / 64)
+    gen_fwd_blocks<true>(L, in, out, relu, wave, NTG / 64, tiles, i, q, Kp);
+  else
+    gen_fwd_blocks<false>(L, in, out, relu, wave, NTG / 64, 2 * tiles, i, q, Kp);
+}
+
+template <bool BOTH>
+__device__ __forceinline__ void gen_bwd_blocks(const GenLayer& L, const float* dy, float* dx, const float* mask, int first,
+                                               int step, int count, int i, int q, int Np) {
+  for (int blk = first; blk < count; blk += step) {
+    const int k0 = (BOTH ? blk : blk >> 1) * 16, s0 = BOTH ? 0 : (blk & 1) * 16;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const int kcol = k0 + i;
     float areg[32];
 #pragma unroll
@@ -132,19 +150,34 @@ __device__ __forceinline__ void gen_bwd(const GenLayer& L, const float* dy, floa
       if (16 * nb < Np) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float b = dy[(16 * nb + 4 * q + e) * LDG + s0 + i];
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[4 * nb + e], b, acc, 0, 0, 0);
+          const float* row = dy + (16 * nb + 4 * q + e) * LDG + s0 + i;
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[4 * nb + e], row[0], acc0, 0, 0, 0);
+          if (BOTH) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[4 * nb + e], row[16], acc1, 0, 0, 0);
         }
       }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int k = k0 + 4 * q + r;
-      float v = acc[r];
-      if (mask) v = mask[k * LDG + s0 + i] > 0.f ? v : 0.f;
-      dx[k * LDG + s0 + i] = v;
+      float v0 = acc0[r], v1 = acc1[r];
+      if (mask) {
+        v0 = mask[k * LDG + s0 + i] > 0.f ? v0 : 0.f;
+        if (BOTH) v1 = mask[k * LDG + 16 + i] > 0.f ? v1 : 0.f;
+      }
+      dx[k * LDG + s0 + i] = v0;
+      if (BOTH) dx[k * LDG + 16 + i] = v1;
     }
   }
+}
+
+// dx[k][s] = (sum_n W[n][k] dy[n][s]) * (mask ? mask[k][s] > 0 : 1) for all k < pad16(K)
+__device__ __forceinline__ void gen_bwd(const GenLayer& L, const float* dy, float* dx, const float* mask, int tid) {
+  const int lane = opaque_i(tid) & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+  const int tiles = ((L.K + 15) & ~15) >> 4, Np = (L.N + 15) & ~15;
+  if (tiles >= NTG / 64)
+    gen_bwd_blocks<true>(L, dy, dx, mask, wave, NTG / 64, tiles, i, q, Np);
+  else
+    gen_bwd_blocks<false>(L, dy, dx, mask, wave, NTG / 64, 2 * tiles, i, q, Np);
 }
 
 // scratch dW[n][k] += sum_s dy[n][s] x[k][s];  scratch db[n] += sum_s dy[n][s]   (workgroup-private, no atomics)
@@ -458,6 +491,32 @@ field_backward_reduce_kernel(const float* __restrict__ scratch, int nblocks, int
     float sum = 0.f;
     for (int b = 0; b < nblocks; ++b) sum += scratch[(size_t)b * params_per_block + off + e];
     grad[e] += sum;
+  }
+}
+
+// The same for EVERY parameter tensor in one launch (18 launches of the kernel above were 1.5 ms of a _big iteration: a thread
+// walked all the workgroups' slices by itself).  A workgroup takes 32 consecutive scratch elements; its 8 groups of 32 threads
+// take every 8th slice each (128-byte rows, coalesced) and the partial sums meet in LDS in a fixed order.
+struct ReduceTargets {
+  float* g[24];
+  int off[24], n[24];
+  int count;
+};
+__global__ void __launch_bounds__(256)
+field_backward_reduce_all_kernel(const float* __restrict__ scratch, int nblocks, int params_per_block, ReduceTargets T) {
+  __shared__ float part[8][32];
+  const int e = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+  float sum = 0.f;
+  if (e < params_per_block)
+    for (int b = g; b < nblocks; b += 8) sum += scratch[(size_t)b * params_per_block + e];
+  part[g][threadIdx.x & 31] = sum;
+  __syncthreads();
+  if (g == 0 && e < params_per_block) {
+    float total = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) total += part[k][threadIdx.x];
+    for (int t = 0; t < T.count; ++t)
+      if (e >= T.off[t] && e < T.off[t] + T.n[t]) T.g[t][e - T.off[t]] += total;
   }
 }
 
