@@ -12,7 +12,7 @@ from cropnerf_amd.rays import Cameras, SceneBox
 # tables, random values) rendered in tcnn's own arithmetic class
 impl = os.environ.get("IMPLEMENTATION", "torch")
 cfg = PC.FruitNerfModelConfig(implementation=impl, hash_table_dtype=os.environ.get("TABLE_DTYPE", "float32"),
-                              matrix_precision=os.environ.get("MATRIX_PRECISION", "fp32"))
+                              matrix_precision=os.environ.get("MATRIX_PRECISION", PC.FruitNerfModelConfig().matrix_precision))
 params = synthetic.p_rand(cfg.field_spec(100), cfg.proposal_specs(), seed=0, device="cuda") if impl == "torch" else None
 c2w, intr = synthetic.orbit_cameras(100)
 cams = Cameras(c2w, intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], 800, 800).to("cuda")
