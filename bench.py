@@ -733,6 +733,7 @@ def secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, o
         train = {}
         train_data: dict = {}
         from cropnerf_amd import synthetic
+        from cropnerf_amd.fruit_nerf.data.fruit_datamanager import FruitDataManager
         from cropnerf_amd.rays import Cameras
 
         dev = batches[0][0].device
@@ -749,7 +750,10 @@ def secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, o
             # training batches are random pixels over all images (PixelSampler), not a block of one image
             idx = torch.stack([torch.randint(0, NUM_CAMERAS, (nrays,), generator=g), torch.randint(0, H, (nrays,), generator=g),
                                torch.randint(0, W, (nrays,), generator=g)], -1)
-            rb = cams.generate_rays(idx.to(dev))
+            idx = idx.to(dev)
+            if nrays >= FruitDataManager.SORT_BATCHES_FROM:  # as the data manager hands such a batch out (round 5): by camera and pixel
+                idx = idx[ops.ray_sort_permutation(idx, H, W)]
+            rb = cams.generate_rays(idx)
             batch = {"image": torch.rand(nrays, 3, generator=g), "fruit_mask": (torch.rand(nrays, 1, generator=g) > 0.5).float()}
             batch = {k: v.to(dev) for k, v in batch.items()}
             t = timed(lambda i: tr.train_iteration(rb, batch), 5)

@@ -723,7 +723,10 @@ __global__ void __launch_bounds__(TB) field_backward_kernel(FieldBwdArgs A) {
 
   const long long total = A.R * (long long)A.S;
   const long long ntiles = (total + TS - 1) / TS;
-  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // (one contiguous run of tiles per workgroup: train_field_mfma.hpp on batches sorted by camera and pixel)
+  const long long tiles_per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
+  const long long tile_end = ((long long)blockIdx.x + 1) * tiles_per_wg < ntiles ? ((long long)blockIdx.x + 1) * tiles_per_wg : ntiles;
+  for (long long tile = blockIdx.x * tiles_per_wg; tile < tile_end; ++tile) {
     const long long i = tile * TS + lane;
     const bool valid = i < total;
     const long long ic = valid ? i : total - 1;
@@ -957,7 +960,10 @@ __global__ void __launch_bounds__(TB, 4) proposal_backward_kernel(PropBwdArgs A)
   float gb0 = 0.f, gb1 = 0.f;
   const long long total = A.R * (long long)A.S;
   const long long ntiles = (total + TS - 1) / TS;
-  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // (one contiguous run of tiles per workgroup: train_field_mfma.hpp on batches sorted by camera and pixel)
+  const long long tiles_per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
+  const long long tile_end = ((long long)blockIdx.x + 1) * tiles_per_wg < ntiles ? ((long long)blockIdx.x + 1) * tiles_per_wg : ntiles;
+  for (long long tile = blockIdx.x * tiles_per_wg; tile < tile_end; ++tile) {
     const long long i = tile * TS + lane;
     const bool valid = i < total;
     const long long ic = valid ? i : total - 1;

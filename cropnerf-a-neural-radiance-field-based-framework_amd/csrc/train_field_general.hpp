@@ -268,7 +268,10 @@ __global__ void __launch_bounds__(NTG) field_backward_general_kernel(GenArgs A) 
   const long long total = A.R * (long long)A.S;
   const long long ntiles = (total + TSG - 1) / TSG;
   const GenLayer& lastsem = A.sem[A.ns - 1];
-  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // (one contiguous run of tiles per workgroup: train_field_mfma.hpp on batches sorted by camera and pixel)
+  const long long tiles_per_wg = (ntiles + gridDim.x - 1) / gridDim.x;
+  const long long tile_end = ((long long)blockIdx.x + 1) * tiles_per_wg < ntiles ? ((long long)blockIdx.x + 1) * tiles_per_wg : ntiles;
+  for (long long tile = blockIdx.x * tiles_per_wg; tile < tile_end; ++tile) {
     const long long ismp = tile * TSG + s;
     const bool valid = ismp < total;
     const long long ic = valid ? ismp : total - 1;

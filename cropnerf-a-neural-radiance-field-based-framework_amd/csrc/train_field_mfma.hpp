@@ -331,8 +331,15 @@ __global__ void __launch_bounds__(NT) field_backward_mfma_kernel(FieldBwdArgs A)
   bool p_valid = false;
   // (the loop makes one trip more than the workgroup has tiles: that trip only issues the last tile's scatter -- written
   //  once in the loop rather than as a lambda called twice, which hipcc keeps as a closure in scratch memory)
-  for (long long tile = blockIdx.x;; tile += gridDim.x) {
-    const bool live = tile < ntiles;  // workgroup-uniform
+  // Tile -> workgroup: one contiguous run of tiles per workgroup (round 5; before: tile = blockIdx.x + k gridDim.x).  The tiles
+  // in flight at one moment are then far apart in the batch, a workgroup's own consecutive tiles are neighbours.  For a batch in
+  // draw order nothing changes (15.58 against 15.59 ms per 65 536-ray iteration); for a batch sorted by camera and pixel
+  // (FruitDataManager.sort_batches) the interleaved form had every workgroup adding to its neighbours' table lines at the same
+  // moment (22.99 ms), this one keeps the gathers' locality without the atomics' contention (14.94 ms).
+  const long long per = (ntiles + gridDim.x - 1) / gridDim.x;
+  const long long t_end = ((long long)blockIdx.x + 1) * per < ntiles ? ((long long)blockIdx.x + 1) * per : ntiles;
+  for (long long tile = blockIdx.x * per;; ++tile) {
+    const bool live = tile < t_end;  // workgroup-uniform
     if (!live && !have_prev) break;
     // ---- gather ------------------------------------------------------------------------------------------------------
     const long long ismp = tile * TSM + s;

@@ -96,7 +96,10 @@ __global__ void __launch_bounds__(256, 4) proposal_backward_wave_kernel(PropBwdA
   const long long total = A.R * (long long)A.S;
   const long long ntiles = (total + TS - 1) / TS;
   const bool small = total < (1ll << 31);  // (32-bit ray index division where it is exact)
-  for (long long tile = blockIdx.x * 4ll + wave; tile < ntiles; tile += gridDim.x * 4ll) {
+  // one contiguous run of tiles per wave (see field_backward_mfma_kernel: batches sorted by camera and pixel)
+  const long long nwaves = gridDim.x * 4ll, gw = blockIdx.x * 4ll + wave, per = (ntiles + nwaves - 1) / nwaves;
+  const long long t_end = (gw + 1) * per < ntiles ? (gw + 1) * per : ntiles;
+  for (long long tile = gw * per; tile < t_end; ++tile) {
     const long long i = tile * TS + lane;
     const bool valid = i < total;
     const long long ic = valid ? i : total - 1;

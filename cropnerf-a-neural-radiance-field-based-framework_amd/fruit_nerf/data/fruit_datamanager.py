@@ -70,6 +70,8 @@ class CameraDataset:
 
 
 class FruitDataManager:
+    SORT_BATCHES_FROM = 16384  # rays: smaller batches keep their draw order (see _sample)
+
     def __init__(self, config: FruitDataManagerConfig, cameras: Cameras, device="cuda", test_mode: str = "val",
                  world_size: int = 1, local_rank: int = 0, images: Optional[Tensor] = None,
                  fruit_masks: Optional[Tensor] = None, seed: int = 0, **kwargs):
@@ -93,7 +95,7 @@ class FruitDataManager:
         self.orthographic_ray_generator: Optional[OrthographicRayGenerator] = None
         self._idx_ring: Dict[int, dict] = {}  # pinned staging of next_train / next_eval's pixel draws, per batch shape
         self._dims_dev: Optional[Tensor] = None
-        self.sort_batches = False  # True: rays handed out sorted by (camera, pixel Morton) -- faster forward, SLOWER training: see _sample
+        self.sort_batches = True  # batches of SORT_BATCHES_FROM rays and more are handed out sorted by (camera, pixel Morton): see _sample
 
     @classmethod
     def from_dataset(cls, config: FruitDataManagerConfig, dataset, device="cuda", **kwargs) -> "FruitDataManager":
@@ -151,13 +153,15 @@ class FruitDataManager:
             idx_d = torch.floor(u_d * dims).to(torch.int64)
         else:
             idx_d = torch.floor(u_d * torch.tensor([n, h, w], dtype=torch.float32)).to(torch.int64)
-        if self.sort_batches and u_d.is_cuda:
+        if self.sort_batches and u_d.is_cuda and idx_d.shape[0] >= self.SORT_BATCHES_FROM:
             # The ORDER of a batch's rays means nothing to the losses (means over the batch).  Sorted by camera and, inside a
-            # camera, along the pixel's Morton curve, the FORWARD field pass gains (1.77 -> 1.28 ms per 65 536 rays,
-            # tools/sorted_ray_probe.py) -- but a TRAINING iteration loses far more: neighbouring rays then send their gradient
-            # atomics to the same table lines at the same moment and the memory side serialises them (65 536 rays, 48 samples:
-            # 15.5 -> 22.2 ms; 192 samples: 44.2 -> 67.4 ms; 4096 rays: 1.72 -> 2.02 ms).  Off by default for that reason; an
-            # evaluation-only consumer (no backward) may switch it on.
+            # camera, along the pixel's Morton curve, neighbouring rays share table lines: the forward field pass of a 65 536-ray
+            # batch 1.77 -> 1.28 ms (tools/sorted_ray_probe.py), the backward's recompute gathers likewise.  With the backward
+            # kernels' OLD tile order (workgroup w took tiles w, w + 256, ...) this lost far more than it gained -- neighbouring
+            # workgroups added to the same lines at the same moment and the memory side serialised them: 15.6 -> 23.0 ms; since
+            # a workgroup takes one contiguous run of tiles (train_field_mfma.hpp) the iteration gains: 15.6 -> 14.9 ms at
+            # 65 536 rays.  At 4 096 rays (41 rays to a camera) the argsort costs what the order gains: batches below
+            # SORT_BATCHES_FROM rays keep their draw order.
             idx_d = idx_d[ops.ray_sort_permutation(idx_d, h, w)]
         batch: Dict[str, Tensor] = {"indices": idx_d}
         if self.images is not None:
@@ -192,7 +196,7 @@ class FruitDataManager:
         idx = torch.stack([torch.randint(0, n, (num_rays,), device=dev, generator=g),
                            torch.randint(0, h, (num_rays,), device=dev, generator=g),
                            torch.randint(0, w, (num_rays,), device=dev, generator=g)], dim=-1)
-        if self.sort_batches:
+        if self.sort_batches and num_rays >= self.SORT_BATCHES_FROM:
             idx = idx[ops.ray_sort_permutation(idx, h, w)]
         return self.cameras.generate_rays(idx), {"indices": idx}
 
