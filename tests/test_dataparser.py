@@ -401,3 +401,51 @@ def test_dataparser_on_the_references_real_capture(tmp_path):
     # auto_scale_poses off: positions keep the capture's metric scale
     raw = CottonNerfDataParserConfig(data=tmp_path, downscale_factor=1, auto_scale_poses=False).setup().get_dataparser_outputs("train")
     assert raw.dataparser_scale == 1.0
+
+
+@pytest.mark.gpu
+def test_large_training_batches_are_sorted_by_camera_and_pixel():
+    """``FruitDataManager.next_train``: a batch of ``SORT_BATCHES_FROM`` rays and more comes sorted by camera and, inside a camera,
+    along the pixel's Morton curve (the order means nothing to the losses and much to the hash-grid gathers) -- and
+    image, mask and rays follow the SAME permutation; smaller batches and ``sort_batches = False`` keep the draw order, and the
+    drawn SET of pixels does not depend on the switch."""
+    from cropnerf_amd.fruit_nerf.data.fruit_datamanager import FruitDataManager, FruitDataManagerConfig
+    from cropnerf_amd.rays import Cameras
+
+    n, h, w = 6, 48, 64
+    c2w, intr = synthetic.orbit_cameras(n, height=h, width=w)
+    cams = Cameras(c2w, intr[:, 0], intr[:, 1], intr[:, 2], intr[:, 3], h, w)
+    g = torch.Generator().manual_seed(0)
+    images, masks = torch.rand(n, h, w, 3, generator=g), (torch.rand(n, h, w, 1, generator=g) > 0.5).float()
+    R = FruitDataManager.SORT_BATCHES_FROM
+
+    def manager(rays, sort=True):
+        dm = FruitDataManager(FruitDataManagerConfig(train_num_rays_per_batch=rays), cams, device="cuda", images=images.cuda(),
+                              fruit_masks=masks.cuda(), seed=5)
+        dm.sort_batches = sort
+        return dm
+
+    def key(idx):
+        idx = idx.cpu()
+        spread = lambda v: sum(((v >> b) & 1) << (2 * b) for b in range(16))  # noqa: E731
+        return (idx[:, 0] << 32) | spread(idx[:, 1]) | (spread(idx[:, 2]) << 1)
+
+    rb, batch = manager(R).next_train(0)
+    idx = batch["indices"]
+    k = key(idx)
+    assert bool((k[1:] >= k[:-1]).all()) and int(idx[0, 0]) == 0 and int(idx[-1, 0]) == n - 1
+    ic = idx.cpu()
+    assert torch.equal(batch["image"].cpu(), images[ic[:, 0], ic[:, 1], ic[:, 2]])
+    assert torch.equal(batch["fruit_mask"].cpu(), masks[ic[:, 0], ic[:, 1], ic[:, 2]])
+    ref = cams.to("cuda").generate_rays(idx)
+    assert torch.equal(rb.origins, ref.origins) and torch.equal(rb.directions, ref.directions)
+    assert torch.equal(rb.camera_indices.reshape(-1).cpu(), ic[:, 0])
+    # the same draws in draw order: the same multiset of pixels
+    _, plain = manager(R, sort=False).next_train(0)
+    kp = key(plain["indices"])
+    assert not bool((kp[1:] >= kp[:-1]).all())
+    assert torch.equal(torch.sort(kp).values, k)
+    # below the threshold: draw order
+    _, small = manager(R // 4).next_train(0)
+    ks = key(small["indices"])
+    assert not bool((ks[1:] >= ks[:-1]).all())
