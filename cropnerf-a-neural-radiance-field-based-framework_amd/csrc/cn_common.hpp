@@ -387,9 +387,45 @@ __device__ __forceinline__ XpLoads<HALF> hash_level_xpair_issue(const void* __re
   }
   return L;
 }
+#ifndef CN_XPAIR_WEIGHT_SWAP
+#define CN_XPAIR_WEIGHT_SWAP 1
+#endif
 template <bool HALF = false>
 __device__ __forceinline__ float2 hash_level_xpair_blend(const XpLoads<HALF>& L) {
   const bool odd = (L.bits & 16u) != 0u;
+#if CN_XPAIR_WEIGHT_SWAP
+  // Which entry of an aligned pair is the lower-x corner depends on the row's hash parity; instead of SELECTING the values (six
+  // conditional moves per row: lo / hi of two features, and the separately loaded upper corner of odd cells) the x WEIGHTS are
+  // selected -- row value = a wa + b wb + u ox with (wa, wb) = (mx, ox') or (ox', mx), ox' = 0 for odd cells (their upper corner
+  // is u; u is zero for even cells): two conditional moves per row and one more packed multiply-add.
+  {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const float ox = L.ox, oy = L.oy, oz = L.oz;
+    const float mx = 1.f - ox, my = 1.f - oy, mz = 1.f - oz;
+    const float oxe = odd ? 0.f : ox;
+    v2f row[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool second = ((L.bits >> r) & 1u) != 0u;
+      const float wa = second ? oxe : mx, wb = second ? mx : oxe;
+      v2f a, b, u;
+      a.x = (float)L.pr[r].x;
+      a.y = (float)L.pr[r].y;
+      b.x = (float)L.pr[r].z;
+      b.y = (float)L.pr[r].w;
+      u.x = (float)L.up[r].x;
+      u.y = (float)L.up[r].y;
+      row[r] = u * ox + (b * wb + a * wa);
+    }
+    const v2f a2 = row[3] * oy + row[2] * my, b2 = row[1] * oy + row[0] * my;
+    const v2f rv = a2 * oz + b2 * mz;
+    float2 r;
+    r.x = rv.x;
+    r.y = rv.y;
+    asm volatile("" : "+v"(r.x), "+v"(r.y));
+    return r;
+  }
+#endif
   float2 lo[4], hi[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
