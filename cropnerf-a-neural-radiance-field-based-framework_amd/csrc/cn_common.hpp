@@ -249,9 +249,12 @@ __device__ __forceinline__ Cell hash_cell(const Lvl& lv, float pos_offset, float
   const unsigned ix = (unsigned)(int)fx, iy = (unsigned)(int)fy, iz = (unsigned)(int)fz;
   c.hx0 = ix;
   c.hx1 = ix + 1u;
-  c.hy0 = iy * lv.m1;
+  // 24-bit multiplies (v_mul_u32_u24, full rate; a 32-bit v_mul_lo_u32 is a quarter-rate instruction): cell indices are far
+  // below 2^24, a dense level's strides too (exact product), and of a hash prime only the low 24 bits matter -- the index is
+  // masked to at most 24 bits (check_grid) and the low 24 bits of a product depend on the low 24 bits of its factors only.
+  c.hy0 = __umul24(iy, lv.m1);
   c.hy1 = c.hy0 + lv.m1;
-  c.hz0 = iz * lv.m2;
+  c.hz0 = __umul24(iz, lv.m2);
   c.hz1 = c.hz0 + lv.m2;
   return c;
 }
