@@ -686,7 +686,8 @@ def secondary_timings(args, cfg, params, fspec, batches, ops, fh, dh, scene_c, o
     def prop(i):
         o, d, n, f, cam, start = batches[i % DISTINCT_BATCHES]
         ps = ops.proposal_sample(dh, scene_c, o, d, n, f, cfg.num_proposal_samples_per_ray, S)
-        ops.render_rays(fh, scene_c, ops.render_opts(S, **hint(start)), o, d, n, f, bins=ps["euclidean_bins"])
+        ops.render_rays(fh, scene_c, ops.render_opts(S, matrix_precision=opts.matrix_precision, **hint(start)), o, d, n, f,
+                        bins=ps["euclidean_bins"])  # (the product default's arithmetic, as the headline)
 
     st = launch_stats(prop, 20)
     t = st["median"]
